@@ -154,18 +154,28 @@ def main():
         ctl = DiffIK(physics=ph, joints=joints, actuators=None, eef_site="site", k_pos=0.9, k_ori=0.9,
                      damping=1.0e-4, k_null=k_null, q0=homes[a].copy(), max_angvel=3.14,
                      integration_dt=0.04, iterations=10)
-        o = {"q": qs, "target_pos": tpos, "target_quat_wxyz": tquat, "k_null": k_null, "q0": homes[a]}
+        # the float32-rounded target matrix the reference computes internally (transform_utils.py:66)
+        tmat = np.stack([np.asarray(T.quat2mat(T.wxyz_to_xyzw(x)), dtype=np.float64) for x in tquat])
+        o = {"q": qs, "target_pos": tpos, "target_quat_wxyz": tquat, "target_mat": tmat, "k_null": k_null, "q0": homes[a]}
         o["q_out"] = np.stack([ctl.run(qs[i].copy(), tpos[i].copy(), tquat[i].copy()) for i in range(M)])
         np.savez_compressed(os.path.join(HERE, f"diffik_{names[a]}.npz"), **o)
 
         if a < 2:
-            g = GradIK(physics=ph, joints=joints, actuators=None, eef_site="site", step_size=0.0001,
-                       min_cost_delta=1.0e-12, max_iterations=50, position_weight=500.0, rotation_weight=100.0,
-                       joint_center_weight=np.array([10.0, 10.0, 1.0, 50.0, 1.0, 1.0]),
-                       joint_displacement_weight=np.array(6 * [50.0]), position_threshold=0.001,
-                       rotation_threshold=0.001, max_pos_diff=0.1, max_rot_diff=0.3, joint_p=0.9)
-            o = {"q": qs, "target_pos": tpos, "target_quat_wxyz": tquat}
-            o["q_out"] = np.stack([g.run(qs[i].copy(), tpos[i].copy(), tquat[i].copy()) for i in range(M)])
+            def mk(max_it):
+                return GradIK(physics=ph, joints=joints, actuators=None, eef_site="site", step_size=0.0001,
+                              min_cost_delta=1.0e-12, max_iterations=max_it, position_weight=500.0,
+                              rotation_weight=100.0, joint_center_weight=np.array([10.0, 10.0, 1.0, 50.0, 1.0, 1.0]),
+                              joint_displacement_weight=np.array(6 * [50.0]), position_threshold=0.001,
+                              rotation_threshold=0.001, max_pos_diff=0.1, max_rot_diff=0.3, joint_p=0.9)
+            o = {"q": qs, "target_pos": tpos, "target_quat_wxyz": tquat, "target_mat": tmat}
+            # the secant descent amplifies rounding noise ~x3-10 per iteration (it is chaotic by iteration
+            # ~30), so the algorithm is pinned on truncated runs and the full 50-iteration run is kept
+            # for a statistical check only
+            for max_it in (1, 4, 8, 50):
+                g = mk(max_it)
+                o[f"q_out_it{max_it}"] = np.stack(
+                    [g.run(qs[i].copy(), tpos[i].copy(), tquat[i].copy()) for i in range(M)])
+            o["q_out"] = o["q_out_it50"]
             np.savez_compressed(os.path.join(HERE, f"gradik_{names[a]}.npz"), **o)
 
     # ---- reward truth tables (env.py get_reward x5) ----
