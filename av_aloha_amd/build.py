@@ -1,0 +1,43 @@
+"""Build the native pieces in-tree: libavsim.so (HIP, gfx950) and, for tests/bench only, the CPU oracle."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libavsim.so")
+SRC = os.path.join(HERE, "csrc")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_hip(force=False, verbose=False):
+    srcs = [os.path.join(SRC, f) for f in sorted(os.listdir(SRC))] + [os.path.join(ROOT, "include", "avsim.h")]
+    if not force and not _stale(LIB, srcs):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+           "-o", LIB, os.path.join(SRC, "avsim_api.hip")]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_oracle(force=False):
+    d = os.path.join(ROOT, "oracle")
+    so = os.path.join(d, "liborc.so")
+    srcs = [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".c", ".h"))]
+    if force or _stale(so, srcs):
+        subprocess.check_call(["make", "-C", d, "-B", "liborc.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+if __name__ == "__main__":
+    print(build_hip(force="--force" in sys.argv, verbose=True))
+    print(build_oracle(force="--force" in sys.argv))

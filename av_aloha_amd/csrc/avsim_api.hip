@@ -1,0 +1,629 @@
+// avsim_api.hip -- the C-ABI of libavsim.so (include/avsim.h) and the kernel launches behind it.
+// gfx950 only; there is no CPU path in this library.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/avsim.h"
+#include "avsim_ik.hip.h"
+#include "avsim_model.h"
+#include "avsim_phys.hip.h"
+
+using namespace avs;
+
+static thread_local std::string g_create_error;
+
+#define HIPCHK(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (h)->set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return AVSIM_EHIP;                                                                       \
+        }                                                                                            \
+    } while (0)
+
+struct avsim {
+    int device = 0;
+    uint32_t flags = 0;
+    int N = 0;
+    bool io_device = false, f64 = false;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[16] = {};
+    std::string err;
+    // model
+    int nq = 0, nv = 0, nu = 0, nj = 0, nobj = 0, task_id = 0, num_arms = 3, max_reward = 0;
+    IkParams ik;
+    std::vector<int> obj_qadr, obs_qadr;
+    std::vector<double> qpos_home, ctrl_home;
+    PhysHost phys;  // device model image + launch configuration (avsim_phys.hip.h)
+    // device state (real = float, or double with AVSIM_F64_PHYSICS)
+    void *d_qpos = nullptr, *d_qvel = nullptr, *d_ctrl = nullptr, *d_warm = nullptr;
+    int* d_latch = nullptr;
+    // device scratch for host-pointer I/O
+    void* d_io[8] = {};
+    size_t d_io_sz[8] = {};
+    // kernel timing
+    bool ktiming = false;
+    double k_ms = 0;
+    int64_t k_launches = 0;
+    hipEvent_t kev[2] = {};
+
+    void set_error(const char* fmt, ...) {
+        char buf[1024];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+    }
+    size_t rsz() const { return f64 ? 8 : 4; }
+    int io_buf(int slot, size_t bytes, void** out) {
+        if (d_io_sz[slot] < bytes) {
+            if (d_io[slot]) (void)hipFree(d_io[slot]);
+            d_io[slot] = nullptr;
+            d_io_sz[slot] = 0;
+            hipError_t e = hipMalloc(&d_io[slot], bytes);
+            if (e != hipSuccess) {
+                set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+                return AVSIM_EHIP;
+            }
+            d_io_sz[slot] = bytes;
+        }
+        *out = d_io[slot];
+        return 0;
+    }
+    // stage an input: returns device pointer holding `bytes` of `p` (host or device according to io mode)
+    int in(int slot, const void* p, size_t bytes, const void** out) {
+        if (io_device) { *out = p; return 0; }
+        void* d;
+        int rc = io_buf(slot, bytes, &d);
+        if (rc) return rc;
+        hipError_t e = hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) { set_error("H2D copy failed: %s", hipGetErrorString(e)); return AVSIM_EHIP; }
+        *out = d;
+        return 0;
+    }
+    int out_begin(int slot, void* p, size_t bytes, void** dev) {
+        if (io_device) { *dev = p; return 0; }
+        return io_buf(slot, bytes, dev);
+    }
+    int out_end(int slot, void* p, size_t bytes) {
+        if (io_device || !p) return 0;
+        hipError_t e = hipMemcpyAsync(p, d_io[slot], bytes, hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) { set_error("D2H copy failed: %s", hipGetErrorString(e)); return AVSIM_EHIP; }
+        return 0;
+    }
+    int finish() {  // host-pointer mode is synchronous
+        if (io_device) return 0;
+        hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { set_error("stream sync failed: %s", hipGetErrorString(e)); return AVSIM_EHIP; }
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// IK kernels: one problem per lane; blockIdx.y selects the arm so a wave never mixes 6- and 7-DoF code
+// ------------------------------------------------------------------------------------------------
+template <int NJ>
+__global__ void __launch_bounds__(64) k_fk_jac(IkParams P, int arm, int n, const double* __restrict__ q, double* __restrict__ Tout,
+                                               double* __restrict__ Jout) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double th[NJ];
+#pragma unroll
+    for (int k = 0; k < NJ; k++) th[k] = q[(size_t)i * NJ + k];
+    if (Tout) {
+        double R[9], p[3];
+        fk<double, NJ>(P.arm[arm], th, R, p);
+        double* T = Tout + (size_t)i * 16;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) T[4 * r + c] = R[3 * r + c];
+            T[4 * r + 3] = p[r];
+        }
+        T[12] = T[13] = T[14] = 0;
+        T[15] = 1;
+    }
+    if (Jout) {
+        double J[6][NJ];
+        jac<double, NJ>(P.arm[arm], th, J);
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int k = 0; k < NJ; k++) Jout[((size_t)i * 6 + r) * NJ + k] = J[r][k];
+    }
+}
+
+template <int NJ>
+__global__ void __launch_bounds__(64) k_ik(IkParams P, int arm, int controller, int iters, int n, const double* __restrict__ q,
+                                           const double* __restrict__ pos, const double* __restrict__ quat,
+                                           double* __restrict__ qout) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double th[NJ], out[NJ], tp[3], qx[4], Rt[9];
+#pragma unroll
+    for (int k = 0; k < NJ; k++) th[k] = q[(size_t)i * NJ + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) tp[k] = pos[(size_t)i * 3 + k];
+    qx[0] = quat[(size_t)i * 4 + 1]; qx[1] = quat[(size_t)i * 4 + 2]; qx[2] = quat[(size_t)i * 4 + 3];
+    qx[3] = quat[(size_t)i * 4 + 0];  // wxyz_to_xyzw (diff_ik.py:59)
+    quat2mat_xyzw(qx, Rt);
+    if (controller == 0) {
+        diffik<double, NJ>(P, arm, th, tp, Rt, iters, out);
+    } else {
+        if constexpr (NJ == 6) gradik<double>(P, arm, th, tp, Rt, iters, out);
+    }
+#pragma unroll
+    for (int k = 0; k < NJ; k++) qout[(size_t)i * NJ + k] = out[k];
+}
+
+// sim_env.py:277-301: Cartesian action -> ctrl, IK seeded with the MEASURED qpos
+template <typename real>
+__global__ void __launch_bounds__(64) k_cart_ctrl(IkParams P, int mode, int N, int nq, int nu, const double* __restrict__ act,
+                                                  const real* __restrict__ qpos, real* __restrict__ ctrl) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int arm = blockIdx.y;
+    if (i >= N) return;
+    const double* a = act + (size_t)i * 23 + (arm == 0 ? 0 : (arm == 1 ? 8 : 16));
+    double tp[3] = {a[0], a[1], a[2]}, qx[4] = {a[4], a[5], a[6], a[3]}, Rt[9];
+    quat2mat_xyzw(qx, Rt);
+    const real* qp = qpos + (size_t)i * nq;
+    real* c = ctrl + (size_t)i * nu + (arm == 0 ? 0 : (arm == 1 ? 7 : 14));
+    const IkArm& A = P.arm[arm];
+    if (arm == 2) {
+        double th[7], out[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) th[k] = (double)qp[A.qadr[k]];
+        diffik<double, 7>(P, 2, th, tp, Rt, P.diff_iters, out);
+#pragma unroll
+        for (int k = 0; k < 7; k++) c[k] = (real)out[k];
+    } else {
+        double th[6], out[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) th[k] = (double)qp[A.qadr[k]];
+        if (mode == AVSIM_IK_DLS) diffik<double, 6>(P, arm, th, tp, Rt, P.diff_iters, out);
+        else gradik<double>(P, arm, th, tp, Rt, P.grad_iters, out);
+#pragma unroll
+        for (int k = 0; k < 6; k++) c[k] = (real)out[k];
+        double trig = a[7];  // sim_env.py:300-301: unnorm(1 - trigger)
+        c[6] = (real)((1.0 - trig) * (P.grip_hi - P.grip_lo) + P.grip_lo);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small state kernels
+// ------------------------------------------------------------------------------------------------
+template <typename real>
+__global__ void k_reset(int N, int nq, int nv, int nu, int nobj, const unsigned char* __restrict__ mask,
+                        const double* __restrict__ obj, const double* __restrict__ qhome, const double* __restrict__ chome,
+                        const int* __restrict__ objadr, real* qpos, real* qvel, real* ctrl, real* warm, int* latch) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (mask && !mask[i]) return;
+    for (int k = 0; k < nq; k++) qpos[(size_t)i * nq + k] = (real)qhome[k];
+    for (int o = 0; o < nobj; o++)
+        for (int k = 0; k < 7; k++) qpos[(size_t)i * nq + objadr[o] + k] = (real)obj[((size_t)i * nobj + o) * 7 + k];
+    for (int k = 0; k < nv; k++) { qvel[(size_t)i * nv + k] = 0; warm[(size_t)i * nv + k] = 0; }
+    for (int k = 0; k < nu; k++) ctrl[(size_t)i * nu + k] = (real)chome[k];
+    latch[i] = 0;
+}
+
+template <typename A, typename B>
+__global__ void k_convert(size_t n, const A* __restrict__ a, B* __restrict__ b) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = (B)a[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* avsim_last_error(const avsim_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+static void fill_ik(const Blob& b, IkParams& P) {
+    std::memset(&P, 0, sizeof P);
+    auto n = b.i("ik_n");
+    auto w0 = b.f("ik_w0"), p0 = b.f("ik_p0"), s0 = b.f("ik_site0"), rg = b.f("ik_range");
+    auto qa = b.i("ik_qadr");
+    auto home = b.f("qpos_home");
+    for (int a = 0; a < 3; a++) {
+        IkArm& A = P.arm[a];
+        A.n = n[a];
+        for (int i = 0; i < 7; i++) {
+            const double* w = &w0[(a * 7 + i) * 3];
+            const double* p = &p0[(a * 7 + i) * 3];
+            for (int k = 0; k < 3; k++) A.w[i][k] = w[k];
+            // kinematics.py:12  v0 = -cross(w0, p0)
+            A.v[i][0] = -(w[1] * p[2] - w[2] * p[1]);
+            A.v[i][1] = -(w[2] * p[0] - w[0] * p[2]);
+            A.v[i][2] = -(w[0] * p[1] - w[1] * p[0]);
+            A.lo[i] = rg[(a * 7 + i) * 2];
+            A.hi[i] = rg[(a * 7 + i) * 2 + 1];
+            A.qadr[i] = qa[a * 7 + i];
+        }
+        for (int k = 0; k < 12; k++) A.site0[k] = s0[a * 16 + k];
+    }
+    // DiffIK parameters: sim_env.py:125-138 (middle arm); manipulators reuse the gains with q0 = home pose
+    P.k_pos = 0.9; P.k_ori = 0.9; P.damping = 1.0e-4; P.max_angvel = 3.14; P.dt = 0.04; P.diff_iters = 10;
+    const double kn[7] = {10.0, 10.0, 10.0, 10.0, 5.0, 5.0, 5.0};
+    for (int a = 0; a < 3; a++)
+        for (int i = 0; i < P.arm[a].n; i++) {
+            P.k_null[a][i] = kn[i];
+            P.q0[a][i] = home[P.arm[a].qadr[i]];
+        }
+    // GradIK parameters: sim_env.py:89-122
+    P.g_step = 1e-4; P.g_min_delta = 1e-12; P.grad_iters = 50; P.g_pw = 500.0; P.g_rw = 100.0;
+    P.g_pthr = 1e-3; P.g_rthr = 1e-3; P.g_maxp = 0.1; P.g_maxr = 0.3; P.g_joint_p = 0.9;
+    const double jc[6] = {10.0, 10.0, 1.0, 50.0, 1.0, 1.0};
+    for (int i = 0; i < 6; i++) { P.g_jcw[i] = jc[i]; P.g_jdw[i] = 50.0; }
+    auto gr = b.f("grip_range");
+    P.grip_lo = gr[0];
+    P.grip_hi = gr[1];
+}
+
+int avsim_create(const void* blob, size_t nbytes, int num_envs, int device, uint32_t flags, avsim_t** out) {
+    if (!out) return AVSIM_EINVAL;
+    *out = nullptr;
+    if (!blob || num_envs <= 0) { g_create_error = "avsim_create: bad arguments"; return AVSIM_EINVAL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_create_error = "avsim_create: no usable HIP device (this library has no CPU path)";
+        return AVSIM_ENODEV;
+    }
+    std::unique_ptr<avsim> h(new avsim);
+    h->device = device;
+    h->flags = flags;
+    h->N = num_envs;
+    h->io_device = flags & AVSIM_IO_DEVICE;
+    h->f64 = flags & AVSIM_F64_PHYSICS;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return AVSIM_EHIP; }
+    try {
+        Blob b(blob, nbytes);
+        h->nq = b.scalar("nq"); h->nv = b.scalar("nv"); h->nu = b.scalar("nu");
+        h->task_id = b.scalar("task_id"); h->num_arms = b.scalar("num_arms");
+        h->nj = h->num_arms == 3 ? 21 : 14;
+        static const int mx[5] = {4, 4, 5, 3, 4};  // env.py:423, 509, 598, 699, 788
+        h->max_reward = mx[h->task_id];
+        h->obj_qadr = b.i("objects_qposadr");
+        h->nobj = (int)h->obj_qadr.size();
+        h->obs_qadr = b.i("obs_qposadr");
+        h->qpos_home = b.f("qpos_home");
+        h->ctrl_home = b.f("ctrl_home");
+        fill_ik(b, h->ik);
+        std::string perr;
+        if (!h->phys.init(b, num_envs, h->f64, perr)) { g_create_error = perr; return AVSIM_EMODEL; }
+    } catch (const std::exception& ex) {
+        g_create_error = std::string("avsim_create: ") + ex.what();
+        return AVSIM_EMODEL;
+    }
+    e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); return AVSIM_EHIP; }
+    h->own_stream = true;
+    for (auto& ev : h->ev) (void)hipEventCreate(&ev);
+    (void)hipEventCreate(&h->kev[0]);
+    (void)hipEventCreate(&h->kev[1]);
+    size_t N = num_envs, r = h->rsz();
+    if (hipMalloc(&h->d_qpos, N * h->nq * r) != hipSuccess || hipMalloc(&h->d_qvel, N * h->nv * r) != hipSuccess ||
+        hipMalloc(&h->d_ctrl, N * h->nu * r) != hipSuccess || hipMalloc(&h->d_warm, N * h->nv * r) != hipSuccess ||
+        hipMalloc((void**)&h->d_latch, N * sizeof(int)) != hipSuccess) {
+        g_create_error = "avsim_create: hipMalloc of the state arrays failed";
+        avsim_destroy(h.release());
+        return AVSIM_EHIP;
+    }
+    *out = h.release();
+    // bring every env to the home pose with objects at their model default pose
+    std::vector<double> obj((size_t)num_envs * (*out)->nobj * 7);
+    for (int i = 0; i < num_envs; i++)
+        for (int o = 0; o < (*out)->nobj; o++)
+            for (int k = 0; k < 7; k++) obj[((size_t)i * (*out)->nobj + o) * 7 + k] = (*out)->qpos_home[(*out)->obj_qadr[o] + k];
+    bool save = (*out)->io_device;
+    (*out)->io_device = false;
+    int rc = avsim_reset(*out, nullptr, obj.data());
+    (*out)->io_device = save;
+    if (rc) {
+        g_create_error = (*out)->err;
+        avsim_destroy(*out);
+        *out = nullptr;
+        return rc;
+    }
+    return AVSIM_OK;
+}
+
+void avsim_destroy(avsim_t* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->phys.destroy();
+    for (void* p : {h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, (void*)h->d_latch})
+        if (p) (void)hipFree(p);
+    for (void* p : h->d_io)
+        if (p) (void)hipFree(p);
+    for (auto& ev : h->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : h->kev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int avsim_dims(const avsim_t* h, int32_t d[AVSIM_NDIMS]) {
+    if (!h || !d) return AVSIM_EINVAL;
+    d[0] = h->nq; d[1] = h->nv; d[2] = h->nu; d[3] = h->nj; d[4] = h->nobj; d[5] = h->max_reward; d[6] = h->N;
+    d[7] = h->task_id; d[8] = h->phys.maxcon; d[9] = h->phys.maxefc;
+    return AVSIM_OK;
+}
+
+int avsim_set_option(avsim_t* h, const char* name, double value) {
+    if (!h || !name) return AVSIM_EINVAL;
+    if (!std::strcmp(name, "kernel_timing")) { h->ktiming = value != 0; return AVSIM_OK; }
+    if (!std::strcmp(name, "diffik_iters")) { h->ik.diff_iters = (int)value; return AVSIM_OK; }
+    if (!std::strcmp(name, "gradik_iters")) { h->ik.grad_iters = (int)value; return AVSIM_OK; }
+    if (h->phys.set_option(name, value)) return AVSIM_OK;
+    h->set_error("avsim_set_option: unknown option '%s'", name);
+    return AVSIM_EINVAL;
+}
+
+int avsim_sync(avsim_t* h) {
+    if (!h) return AVSIM_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return AVSIM_OK;
+}
+
+int avsim_set_stream(avsim_t* h, void* s) {
+    if (!h) return AVSIM_EINVAL;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)s;
+    h->own_stream = false;
+    return AVSIM_OK;
+}
+
+int avsim_event_record(avsim_t* h, int slot) {
+    if (!h || slot < 0 || slot >= 16) return AVSIM_EINVAL;
+    HIPCHK(h, hipEventRecord(h->ev[slot], h->stream));
+    return AVSIM_OK;
+}
+
+int avsim_event_elapsed_ms(avsim_t* h, int a, int b, float* ms) {
+    if (!h || !ms || a < 0 || a >= 16 || b < 0 || b >= 16) return AVSIM_EINVAL;
+    HIPCHK(h, hipEventSynchronize(h->ev[b]));
+    HIPCHK(h, hipEventElapsedTime(ms, h->ev[a], h->ev[b]));
+    return AVSIM_OK;
+}
+
+int avsim_kernel_time(avsim_t* h, int reset, double* total_ms, int64_t* launches) {
+    if (!h) return AVSIM_EINVAL;
+    if (total_ms) *total_ms = h->k_ms;
+    if (launches) *launches = h->k_launches;
+    if (reset) { h->k_ms = 0; h->k_launches = 0; }
+    return AVSIM_OK;
+}
+
+int avsim_fk_jac(avsim_t* h, int arm, int n, const double* q, double* T, double* J) {
+    if (!h || arm < 0 || arm > 2 || n <= 0 || !q) { if (h) h->set_error("avsim_fk_jac: bad arguments"); return AVSIM_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int nj = h->ik.arm[arm].n, rc;
+    const void* dq;
+    void *dT = nullptr, *dJ = nullptr;
+    if ((rc = h->in(0, q, sizeof(double) * n * nj, &dq))) return rc;
+    if (T && (rc = h->out_begin(1, T, sizeof(double) * n * 16, &dT))) return rc;
+    if (J && (rc = h->out_begin(2, J, sizeof(double) * n * 6 * nj, &dJ))) return rc;
+    dim3 grid((n + 63) / 64);
+    if (nj == 6) hipLaunchKernelGGL(k_fk_jac<6>, grid, dim3(64), 0, h->stream, h->ik, arm, n, (const double*)dq, (double*)dT, (double*)dJ);
+    else hipLaunchKernelGGL(k_fk_jac<7>, grid, dim3(64), 0, h->stream, h->ik, arm, n, (const double*)dq, (double*)dT, (double*)dJ);
+    HIPCHK(h, hipGetLastError());
+    if ((rc = h->out_end(1, T, sizeof(double) * n * 16))) return rc;
+    if ((rc = h->out_end(2, J, sizeof(double) * n * 6 * nj))) return rc;
+    return h->finish();
+}
+
+int avsim_ik(avsim_t* h, int arm, int controller, int max_iters, int n, const double* q, const double* pos,
+             const double* quat, double* qout) {
+    if (!h || arm < 0 || arm > 2 || n <= 0 || !q || !pos || !quat || !qout || controller < 0 || controller > 1) {
+        if (h) h->set_error("avsim_ik: bad arguments");
+        return AVSIM_EINVAL;
+    }
+    if (controller == 1 && arm == 2) { h->set_error("avsim_ik: GradIK is defined for the 6-DoF manipulators only"); return AVSIM_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int nj = h->ik.arm[arm].n, rc;
+    int iters = max_iters > 0 ? max_iters : (controller == 0 ? h->ik.diff_iters : h->ik.grad_iters);
+    const void *dq, *dp, *dqt;
+    void* dout;
+    if ((rc = h->in(0, q, sizeof(double) * n * nj, &dq))) return rc;
+    if ((rc = h->in(1, pos, sizeof(double) * n * 3, &dp))) return rc;
+    if ((rc = h->in(2, quat, sizeof(double) * n * 4, &dqt))) return rc;
+    if ((rc = h->out_begin(3, qout, sizeof(double) * n * nj, &dout))) return rc;
+    dim3 grid((n + 63) / 64);
+    if (nj == 6)
+        hipLaunchKernelGGL(k_ik<6>, grid, dim3(64), 0, h->stream, h->ik, arm, controller, iters, n, (const double*)dq, (const double*)dp,
+                           (const double*)dqt, (double*)dout);
+    else
+        hipLaunchKernelGGL(k_ik<7>, grid, dim3(64), 0, h->stream, h->ik, arm, controller, iters, n, (const double*)dq, (const double*)dp,
+                           (const double*)dqt, (double*)dout);
+    HIPCHK(h, hipGetLastError());
+    if ((rc = h->out_end(3, qout, sizeof(double) * n * nj))) return rc;
+    return h->finish();
+}
+
+}  // extern "C"
+
+template <typename real>
+static int reset_impl(avsim_t* h, const uint8_t* mask, const double* obj) {
+    int rc;
+    const void *dm = nullptr, *dobj;
+    if (mask && (rc = h->in(0, mask, h->N, &dm))) return rc;
+    if ((rc = h->in(1, obj, sizeof(double) * h->N * h->nobj * 7, &dobj))) return rc;
+    hipLaunchKernelGGL(k_reset<real>, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->N, h->nq, h->nv, h->nu, h->nobj,
+                       (const unsigned char*)dm, (const double*)dobj, h->phys.d_qpos_home, h->phys.d_ctrl_home, h->phys.d_obj_qadr,
+                       (real*)h->d_qpos, (real*)h->d_qvel, (real*)h->d_ctrl, (real*)h->d_warm, h->d_latch);
+    HIPCHK(h, hipGetLastError());
+    // mj_forward (env.py:244, 538): refresh kinematics + contacts of the new state, no time stepping
+    if ((rc = h->phys.launch(h->stream, h->N, 0, nullptr, h->nj, h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, h->d_latch, nullptr, nullptr,
+                             nullptr, h->err)))
+        return rc;
+    return h->finish();
+}
+
+extern "C" {
+
+int avsim_reset(avsim_t* h, const uint8_t* mask, const double* obj_qpos) {
+    if (!h || !obj_qpos) { if (h) h->set_error("avsim_reset: obj_qpos is required"); return AVSIM_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device));
+    return h->f64 ? reset_impl<double>(h, mask, obj_qpos) : reset_impl<float>(h, mask, obj_qpos);
+}
+
+static int step_common(avsim_t* h, const float* d_action, int nsub, double* agent_pos, int32_t* reward, uint8_t* success) {
+    int rc;
+    void *dap = nullptr, *drw = nullptr, *dsu = nullptr;
+    size_t N = h->N;
+    if (agent_pos && (rc = h->out_begin(4, agent_pos, sizeof(double) * N * h->nj, &dap))) return rc;
+    if (reward && (rc = h->out_begin(5, reward, sizeof(int32_t) * N, &drw))) return rc;
+    if (success && (rc = h->out_begin(6, success, N, &dsu))) return rc;
+    if (h->ktiming) HIPCHK(h, hipEventRecord(h->kev[0], h->stream));
+    if ((rc = h->phys.launch(h->stream, h->N, nsub, d_action, h->nj, h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, h->d_latch, (double*)dap,
+                             (int32_t*)drw, (uint8_t*)dsu, h->err)))
+        return rc;
+    if (h->ktiming) {
+        HIPCHK(h, hipEventRecord(h->kev[1], h->stream));
+        HIPCHK(h, hipEventSynchronize(h->kev[1]));
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->kev[0], h->kev[1]));
+        h->k_ms += ms;
+        h->k_launches++;
+    }
+    if ((rc = h->out_end(4, agent_pos, sizeof(double) * N * h->nj))) return rc;
+    if ((rc = h->out_end(5, reward, sizeof(int32_t) * N))) return rc;
+    if ((rc = h->out_end(6, success, N))) return rc;
+    return h->finish();
+}
+
+int avsim_step(avsim_t* h, const float* action, int nsub, double* agent_pos, int32_t* reward, uint8_t* success) {
+    if (!h || !action || nsub < 0) { if (h) h->set_error("avsim_step: bad arguments"); return AVSIM_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const void* da;
+    int rc;
+    if ((rc = h->in(0, action, sizeof(float) * h->N * h->nj, &da))) return rc;
+    return step_common(h, (const float*)da, nsub, agent_pos, reward, success);
+}
+
+int avsim_step_cartesian(avsim_t* h, const double* action23, int ik_mode, int nsub, double* agent_pos, int32_t* reward,
+                         uint8_t* success) {
+    if (!h || !action23 || nsub < 0 || (ik_mode != AVSIM_IK_REFERENCE && ik_mode != AVSIM_IK_DLS)) {
+        if (h) h->set_error("avsim_step_cartesian: bad arguments");
+        return AVSIM_EINVAL;
+    }
+    if (h->num_arms != 3) { h->set_error("avsim_step_cartesian: the 23-D Cartesian action drives three arms (sim_env.py:277-282)"); return AVSIM_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const void* da;
+    int rc;
+    if ((rc = h->in(0, action23, sizeof(double) * h->N * 23, &da))) return rc;
+    dim3 grid((h->N + 63) / 64, 3);
+    if (h->f64)
+        hipLaunchKernelGGL(k_cart_ctrl<double>, grid, dim3(64), 0, h->stream, h->ik, ik_mode, h->N, h->nq, h->nu, (const double*)da,
+                           (const double*)h->d_qpos, (double*)h->d_ctrl);
+    else
+        hipLaunchKernelGGL(k_cart_ctrl<float>, grid, dim3(64), 0, h->stream, h->ik, ik_mode, h->N, h->nq, h->nu, (const double*)da,
+                           (const float*)h->d_qpos, (float*)h->d_ctrl);
+    HIPCHK(h, hipGetLastError());
+    return step_common(h, nullptr, nsub, agent_pos, reward, success);
+}
+
+// ---- state access --------------------------------------------------------------------------------
+static int put(avsim_t* h, int slot, const double* src, void* dst, size_t n) {
+    if (!src) return 0;
+    const void* d;
+    int rc;
+    if ((rc = h->in(slot, src, sizeof(double) * n, &d))) return rc;
+    unsigned g = (unsigned)((n + 255) / 256);
+    if (h->f64) hipLaunchKernelGGL((k_convert<double, double>), dim3(g), dim3(256), 0, h->stream, n, (const double*)d, (double*)dst);
+    else hipLaunchKernelGGL((k_convert<double, float>), dim3(g), dim3(256), 0, h->stream, n, (const double*)d, (float*)dst);
+    return 0;
+}
+static int get(avsim_t* h, int slot, double* dst, const void* src, size_t n) {
+    if (!dst) return 0;
+    void* d;
+    int rc;
+    if ((rc = h->out_begin(slot, dst, sizeof(double) * n, &d))) return rc;
+    unsigned g = (unsigned)((n + 255) / 256);
+    if (h->f64) hipLaunchKernelGGL((k_convert<double, double>), dim3(g), dim3(256), 0, h->stream, n, (const double*)src, (double*)d);
+    else hipLaunchKernelGGL((k_convert<float, double>), dim3(g), dim3(256), 0, h->stream, n, (const float*)src, (double*)d);
+    return h->out_end(slot, dst, sizeof(double) * n);
+}
+
+int avsim_get_state(avsim_t* h, double* qpos, double* qvel, double* ctrl, double* warm) {
+    if (!h) return AVSIM_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    size_t N = h->N;
+    int rc;
+    if ((rc = get(h, 0, qpos, h->d_qpos, N * h->nq))) return rc;
+    if ((rc = get(h, 1, qvel, h->d_qvel, N * h->nv))) return rc;
+    if ((rc = get(h, 2, ctrl, h->d_ctrl, N * h->nu))) return rc;
+    if ((rc = get(h, 3, warm, h->d_warm, N * h->nv))) return rc;
+    HIPCHK(h, hipGetLastError());
+    return h->finish();
+}
+
+int avsim_set_state(avsim_t* h, const double* qpos, const double* qvel, const double* ctrl, const double* warm) {
+    if (!h) return AVSIM_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    size_t N = h->N;
+    int rc;
+    if ((rc = put(h, 0, qpos, h->d_qpos, N * h->nq))) return rc;
+    if ((rc = put(h, 1, qvel, h->d_qvel, N * h->nv))) return rc;
+    if ((rc = put(h, 2, ctrl, h->d_ctrl, N * h->nu))) return rc;
+    if ((rc = put(h, 3, warm, h->d_warm, N * h->nv))) return rc;
+    HIPCHK(h, hipGetLastError());
+    if ((rc = h->phys.launch(h->stream, h->N, 0, nullptr, h->nj, h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, h->d_latch, nullptr, nullptr,
+                             nullptr, h->err)))
+        return rc;
+    return h->finish();
+}
+
+int avsim_set_qpos(avsim_t* h, const double* qpos) {
+    if (!h || !qpos) return AVSIM_EINVAL;
+    return avsim_set_state(h, qpos, nullptr, nullptr, nullptr);
+}
+
+int avsim_get_contacts(avsim_t* h, int32_t* ncon, int32_t* pairs, double* dist) {
+    if (!h) return AVSIM_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    size_t N = h->N, cap = h->phys.maxcon;
+    if (h->io_device) {
+        if (ncon) HIPCHK(h, hipMemcpyAsync(ncon, h->phys.d_ncon, N * 4, hipMemcpyDeviceToDevice, h->stream));
+        if (pairs) HIPCHK(h, hipMemcpyAsync(pairs, h->phys.d_cpairs, N * cap * 8, hipMemcpyDeviceToDevice, h->stream));
+        if (dist) HIPCHK(h, hipMemcpyAsync(dist, h->phys.d_cdist, N * cap * 8, hipMemcpyDeviceToDevice, h->stream));
+        return AVSIM_OK;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ncon) HIPCHK(h, hipMemcpy(ncon, h->phys.d_ncon, N * 4, hipMemcpyDeviceToHost));
+    if (pairs) HIPCHK(h, hipMemcpy(pairs, h->phys.d_cpairs, N * cap * 8, hipMemcpyDeviceToHost));
+    if (dist) HIPCHK(h, hipMemcpy(dist, h->phys.d_cdist, N * cap * 8, hipMemcpyDeviceToHost));
+    return AVSIM_OK;
+}
+
+int avsim_get_diag(avsim_t* h, int32_t* diag) {
+    if (!h || !diag) return AVSIM_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    size_t N = h->N;
+    if (h->io_device) {
+        HIPCHK(h, hipMemcpyAsync(diag, h->phys.d_diag, N * 16, hipMemcpyDeviceToDevice, h->stream));
+        return AVSIM_OK;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(diag, h->phys.d_diag, N * 16, hipMemcpyDeviceToHost));
+    return AVSIM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,375 @@
+// avsim_ik.hip.h -- device IK: one (env, arm) problem per lane, everything in registers.
+// Mirrors data_collection_scripts/{kinematics.py:17-50, diff_ik.py:51-85, grad_ik.py:8-99,
+// transform_utils.py:52-79,183-301}.  NJ is a template constant so every loop unrolls.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "avsim_model.h"
+
+namespace avs {
+
+template <typename T>
+struct M3 {
+    T m[9];
+};
+
+template <typename T>
+__device__ __forceinline__ void mat3mul(const T* A, const T* B, T* C) {
+    T t[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) C[i] = t[i];
+}
+
+// transform_utils.py:52-79 incl. the float32 cast at :66
+template <typename T>
+__device__ __forceinline__ void quat2mat_xyzw(const T qx[4], T R[9]) {
+    float q[4] = {(float)qx[3], (float)qx[0], (float)qx[1], (float)qx[2]};
+    float n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (n < 8.8817841970012523e-16f) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? T(1) : T(0);
+        return;
+    }
+    float s = (float)sqrt((double)(2.0f / n));
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] *= s;
+    float q2[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) q2[i][j] = q[i] * q[j];
+    R[0] = 1.0f - q2[2][2] - q2[3][3]; R[1] = q2[1][2] - q2[3][0]; R[2] = q2[1][3] + q2[2][0];
+    R[3] = q2[1][2] + q2[3][0]; R[4] = 1.0f - q2[1][1] - q2[3][3]; R[5] = q2[2][3] - q2[1][0];
+    R[6] = q2[1][3] - q2[2][0]; R[7] = q2[2][3] + q2[1][0]; R[8] = 1.0f - q2[1][1] - q2[2][2];
+}
+
+// transform_utils.py:183-194
+template <typename T>
+__device__ __forceinline__ void angular_error(const T* D, const T* C, T e[3]) {
+    e[0] = e[1] = e[2] = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        T c0 = C[k], c1 = C[3 + k], c2 = C[6 + k], d0 = D[k], d1 = D[3 + k], d2 = D[6 + k];
+        e[0] += c1 * d2 - c2 * d1;
+        e[1] += c2 * d0 - c0 * d2;
+        e[2] += c0 * d1 - c1 * d0;
+    }
+    e[0] *= T(0.5); e[1] *= T(0.5); e[2] *= T(0.5);
+}
+
+// exp([S] th) for a unit revolute screw (transform_utils.py:212-261): R (row-major 9) and p
+template <typename T>
+__device__ __forceinline__ void exp_screw(const double w_[3], const double v_[3], T th, T R[9], T p[3]) {
+    T w[3] = {(T)w_[0], (T)w_[1], (T)w_[2]}, v[3] = {(T)v_[0], (T)v_[1], (T)v_[2]};
+    T S[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0}, S2[9];
+    mat3mul(S, S, S2);
+    T s = sin(th), c = cos(th);
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = ((i % 4 == 0) ? T(1) : T(0)) + s * S[i] + (1 - c) * S2[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        T a = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) a += (((i == j) ? th : T(0)) + (1 - c) * S[3 * i + j] + (th - s) * S2[3 * i + j]) * v[j];
+        p[i] = a;
+    }
+}
+
+// kinematics.py:17-24: T(theta) = exp(S1 th1) ... exp(Sn thn) site0, built from the last joint to the first
+template <typename T, int NJ>
+__device__ __forceinline__ void fk(const IkArm& A, const T* q, T R[9], T p[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) R[3 * i + j] = (T)A.site0[4 * i + j];
+        p[i] = (T)A.site0[4 * i + 3];
+    }
+#pragma unroll
+    for (int i = NJ - 1; i >= 0; i--) {
+        T Re[9], pe[3], np[3];
+        exp_screw<T>(A.w[i], A.v[i], q[i], Re, pe);
+#pragma unroll
+        for (int r = 0; r < 3; r++) np[r] = Re[3 * r] * p[0] + Re[3 * r + 1] * p[1] + Re[3 * r + 2] * p[2] + pe[r];
+        mat3mul(Re, R, R);
+        p[0] = np[0]; p[1] = np[1]; p[2] = np[2];
+    }
+}
+
+// kinematics.py:35-50: space Jacobian, rows [linear(3); angular(3)], J[r][i]
+template <typename T, int NJ>
+__device__ __forceinline__ void jac(const IkArm& A, const T* q, T J[6][NJ]) {
+    T R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+        T w[3] = {(T)A.w[i][0], (T)A.w[i][1], (T)A.w[i][2]}, v[3] = {(T)A.v[i][0], (T)A.v[i][1], (T)A.v[i][2]};
+        T Rw[3], Rv[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            Rw[r] = R[3 * r] * w[0] + R[3 * r + 1] * w[1] + R[3 * r + 2] * w[2];
+            Rv[r] = R[3 * r] * v[0] + R[3 * r + 1] * v[1] + R[3 * r + 2] * v[2];
+        }
+        // Ad(T) [w; v] = [R w; p x (R w) + R v]; rows swapped to linear first (kinematics.py:48)
+        J[3][i] = Rw[0]; J[4][i] = Rw[1]; J[5][i] = Rw[2];
+        J[0][i] = p[1] * Rw[2] - p[2] * Rw[1] + Rv[0];
+        J[1][i] = p[2] * Rw[0] - p[0] * Rw[2] + Rv[1];
+        J[2][i] = p[0] * Rw[1] - p[1] * Rw[0] + Rv[2];
+        T Re[9], pe[3], np[3];
+        exp_screw<T>(A.w[i], A.v[i], q[i], Re, pe);
+#pragma unroll
+        for (int r = 0; r < 3; r++) np[r] = R[3 * r] * pe[0] + R[3 * r + 1] * pe[1] + R[3 * r + 2] * pe[2] + p[r];
+        mat3mul(R, Re, R);
+        p[0] = np[0]; p[1] = np[1]; p[2] = np[2];
+    }
+}
+
+// in-register Cholesky solve of a 6x6 SPD system A x = b (lower triangle of A used). `guard`: pivots
+// below guard*max_diag are treated as singular directions (their solution component is dropped).
+template <typename T>
+__device__ __forceinline__ void chol6_solve(T A[6][6], T b[6], T guard) {
+    T dmax = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) dmax = A[i][i] > dmax ? A[i][i] : dmax;
+    T inv[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        T d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
+        bool ok = d > guard * dmax;
+        T l = ok ? sqrt(d) : T(1);
+        inv[j] = ok ? T(1) / l : T(0);
+        A[j][j] = l;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            T s = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k];
+            A[i][j] = s * inv[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        T s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= A[i][k] * b[k];
+        b[i] = s * inv[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        T s = b[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) s -= A[k][i] * b[k];
+        b[i] = s * inv[i];
+    }
+}
+
+// diff_ik.py:51-85.  The 6x6 solves use Cholesky (J J^T + lambda I is SPD); the null-space projector
+// I - pinv(J) J is evaluated as z - J^T (J J^T)^-1 J z, equal to the reference's SVD pinv whenever J has
+// full row rank with a pivot guard for rank-deficient poses.
+template <typename T, int NJ>
+__device__ void diffik(const IkParams& P, int arm, const T* qin, const T pos[3], const T Rt[9], int iters, T* q) {
+    const IkArm& A = P.arm[arm];
+#pragma unroll
+    for (int i = 0; i < NJ; i++) q[i] = qin[i];
+    const T k_pos = (T)P.k_pos, k_ori = (T)P.k_ori, dt = (T)P.dt, vmax = (T)P.max_angvel;
+    for (int it = 0; it < iters; it++) {
+        T Rc[9], pc[3], tw[6], dr[3];
+        fk<T, NJ>(A, q, Rc, pc);
+#pragma unroll
+        for (int i = 0; i < 3; i++) tw[i] = k_pos * (pos[i] - pc[i]) / dt;
+        angular_error(Rt, Rc, dr);
+#pragma unroll
+        for (int i = 0; i < 3; i++) tw[3 + i] = k_ori * dr[i] / dt;
+        T J[6][NJ];
+        jac<T, NJ>(A, q, J);
+        T JJt[6][6], Ad[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+                T s = 0;
+#pragma unroll
+                for (int k = 0; k < NJ; k++) s += J[i][k] * J[j][k];
+                JJt[i][j] = s;
+                Ad[i][j] = s + (i == j ? (T)P.damping : T(0));
+            }
+        chol6_solve(Ad, tw, T(0));
+        T dq[NJ], z[NJ], Jz[6];
+#pragma unroll
+        for (int k = 0; k < NJ; k++) {
+            T s = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) s += J[i][k] * tw[i];
+            dq[k] = s;
+            z[k] = (T)P.k_null[arm][k] * ((T)P.q0[arm][k] - q[k]);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            T s = 0;
+#pragma unroll
+            for (int k = 0; k < NJ; k++) s += J[i][k] * z[k];
+            Jz[i] = s;
+        }
+        chol6_solve(JJt, Jz, T(1e-26));
+#pragma unroll
+        for (int k = 0; k < NJ; k++) {
+            T pj = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) pj += J[i][k] * Jz[i];
+            T d = dq[k] + (z[k] - pj);
+            d = d > vmax ? vmax : (d < -vmax ? -vmax : d);
+            T x = q[k] + d * dt;
+            x = x < (T)A.lo[k] ? (T)A.lo[k] : (x > (T)A.hi[k] ? (T)A.hi[k] : x);
+            q[k] = x;
+        }
+    }
+}
+
+// closed-form rotation angle+axis (replaces mat2quat(eigh)+quat2axisangle inside limit_pose,
+// transform_utils.py:276-278: only the rotation vector of the relative rotation is needed)
+template <typename T>
+__device__ __forceinline__ void rotvec_from_mat(const T* R, T aa[3]) {
+    // quaternion via Shepperd's branch on the largest diagonal term, w >= 0 as mat2quat returns
+    T tr = R[0] + R[4] + R[8], qw, qx, qy, qz;
+    if (tr > 0) {
+        T s = sqrt(tr + 1) * 2;
+        qw = T(0.25) * s; qx = (R[7] - R[5]) / s; qy = (R[2] - R[6]) / s; qz = (R[3] - R[1]) / s;
+    } else if (R[0] > R[4] && R[0] > R[8]) {
+        T s = sqrt(1 + R[0] - R[4] - R[8]) * 2;
+        qw = (R[7] - R[5]) / s; qx = T(0.25) * s; qy = (R[1] + R[3]) / s; qz = (R[2] + R[6]) / s;
+    } else if (R[4] > R[8]) {
+        T s = sqrt(1 + R[4] - R[0] - R[8]) * 2;
+        qw = (R[2] - R[6]) / s; qx = (R[1] + R[3]) / s; qy = T(0.25) * s; qz = (R[5] + R[7]) / s;
+    } else {
+        T s = sqrt(1 + R[8] - R[0] - R[4]) * 2;
+        qw = (R[3] - R[1]) / s; qx = (R[2] + R[6]) / s; qy = (R[5] + R[7]) / s; qz = T(0.25) * s;
+    }
+    T n = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+    qw /= n; qx /= n; qy /= n; qz /= n;
+    if (qw < 0) { qw = -qw; qx = -qx; qy = -qy; qz = -qz; }
+    qw = qw > 1 ? T(1) : qw;
+    T den = sqrt(1 - qw * qw);
+    if (den <= T(1e-8)) { aa[0] = aa[1] = aa[2] = 0; return; }
+    T s = 2 * acos(qw) / den;
+    aa[0] = qx * s; aa[1] = qy * s; aa[2] = qz * s;
+}
+
+// transform_utils.py:263-287
+template <typename T>
+__device__ __forceinline__ void limit_pose(const T cp[3], const T cR[9], const T tp[3], const T tR[9], T maxp, T maxr,
+                                           T op[3], T oR[9]) {
+    T d[3] = {tp[0] - cp[0], tp[1] - cp[1], tp[2] - cp[2]};
+    T n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (n > maxp) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) d[i] = d[i] / n * maxp;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) op[i] = cp[i] + d[i];
+    T ct[9] = {cR[0], cR[3], cR[6], cR[1], cR[4], cR[7], cR[2], cR[5], cR[8]}, rel[9], aa[3];
+    mat3mul(tR, ct, rel);  // inv of a rotation = transpose
+    rotvec_from_mat(rel, aa);
+    T ang = sqrt(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]);
+    if (ang > maxr) {
+        T h = maxr * T(0.5), sc = sin(h) / ang;  // axisangle2quat of aa*(maxr/ang)
+        T q[4] = {aa[0] * sc, aa[1] * sc, aa[2] * sc, cos(h)}, lim[9];
+        quat2mat_xyzw(q, lim);
+        mat3mul(lim, cR, oR);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; i++) oR[i] = tR[i];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T gik_cost(const IkParams& P, const IkArm& A, const T* q, const T* qs, const T* tp, const T* tR) {
+    T Rc[9], pc[3], e[3];
+    fk<T, 6>(A, q, Rc, pc);
+    T d0 = tp[0] - pc[0], d1 = tp[1] - pc[1], d2 = tp[2] - pc[2];
+    T t = (T)P.g_pw * sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    T c = t * t;
+    angular_error(tR, Rc, e);
+    t = (T)P.g_rw * sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    c += t * t;
+    T s = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        T ctr = T(0.5) * ((T)A.lo[i] + (T)A.hi[i]), hr = T(0.5) * ((T)A.hi[i] - (T)A.lo[i]);
+        t = ((T)P.g_jcw[i] / hr) * (q[i] - ctr);
+        s += t * t;
+    }
+    c += s;
+    s = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        t = (T)P.g_jdw[i] * (q[i] - qs[i]);
+        s += t * t;
+    }
+    return c + s;
+}
+
+// grad_ik.py:8-99 (6-DoF manipulators)
+template <typename T>
+__device__ void gradik(const IkParams& P, int arm, const T* qs, const T pos[3], const T tR0[9], int max_it, T* qout) {
+    const IkArm& A = P.arm[arm];
+    const T step = (T)P.g_step;
+    T cR[9], cp[3], tp[3], tR[9];
+    fk<T, 6>(A, qs, cR, cp);
+    limit_pose(cp, cR, pos, tR0, (T)P.g_maxp, (T)P.g_maxr, tp, tR);
+    T init = gik_cost(P, A, qs, qs, tp, tR);
+    T grad[6], work[6], local[6], best[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { work[i] = local[i] = best[i] = qs[i]; grad[i] = 0; }
+    T best_cost = init, prev = 0;
+    for (int it = 0; it < max_it; it++) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            work[i] = local[i] - step;
+            T p1 = gik_cost(P, A, work, qs, tp, tR);
+            work[i] = local[i] + step;
+            T p3 = gik_cost(P, A, work, qs, tp, tR);
+            work[i] = local[i];
+            grad[i] = p3 - p1;
+        }
+        T sum = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) sum += fabs(grad[i]);
+        sum += step;
+        T f = step / sum;
+#pragma unroll
+        for (int i = 0; i < 6; i++) { grad[i] *= f; work[i] = local[i] - grad[i]; }
+        T p1 = gik_cost(P, A, work, qs, tp, tR);
+#pragma unroll
+        for (int i = 0; i < 6; i++) work[i] = local[i] + grad[i];
+        T p3 = gik_cost(P, A, work, qs, tp, tR);
+        T p2 = T(0.5) * (p1 + p3), cd = T(0.5) * (p3 - p1);
+        T jd = (isfinite(cd) && cd != T(0)) ? p2 / cd : T(0);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            T x = local[i] - grad[i] * jd;
+            x = x < (T)A.lo[i] ? (T)A.lo[i] : (x > (T)A.hi[i] ? (T)A.hi[i] : x);
+            local[i] = work[i] = x;
+        }
+        T lc = gik_cost(P, A, local, qs, tp, tR);
+        if (lc < best_cost) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) best[i] = local[i];
+            best_cost = lc;
+        }
+        T Rl[9], pl[3], e[3];
+        fk<T, 6>(A, local, Rl, pl);
+        T d0 = tp[0] - pl[0], d1 = tp[1] - pl[1], d2 = tp[2] - pl[2];
+        angular_error(tR, Rl, e);
+        if (sqrt(d0 * d0 + d1 * d1 + d2 * d2) < (T)P.g_pthr && sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) < (T)P.g_rthr) break;
+        if (fabs(lc - prev) <= (T)P.g_min_delta) break;
+        prev = lc;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) qout[i] = qs[i] + (T)P.g_joint_p * (best[i] - qs[i]);
+}
+
+}  // namespace avs

@@ -1,0 +1,109 @@
+/* include/avsim.h -- C-ABI of libavsim.so: the MI355X-native batched replacement for the hot path
+ * of the AV-ALOHA gym_guided_vision environments.
+ *
+ * Boundary it replaces (reference file:line, all under /root/reference):
+ *   gym_guided_vision/gym_guided_vision/env.py:36-166   GuidedVisionEnv.__init__  -> avsim_create
+ *   env.py:228-249 (+ task overrides :474-501,:513-543,:604-637,:705-735,:792-818) reset -> avsim_reset
+ *   env.py:203-226 step / :255-269 step_action (20 x MuJoCo mj_step, env.py:218)   -> avsim_step
+ *   env.py:168-178 get_obs agent_pos, :425-863 get_reward x5, :224 is_success       -> outputs of avsim_step
+ *   env.py:251-253 set_qpos                                                          -> avsim_set_qpos
+ *   data_collection_scripts/sim_env.py:277-312 step with IK (GradIK/DiffIK)          -> avsim_step_cartesian
+ *   data_collection_scripts/diff_ik.py:89-90 DiffIK.run, grad_ik.py:150-166 GradIK.run -> avsim_ik
+ *
+ * Conventions: every entry point returns 0 on success or a negative AVSIM_E* code; the message is
+ * available from avsim_last_error().  All bulk pointers are HOST pointers unless the handle was
+ * created with AVSIM_IO_DEVICE, in which case they are device pointers on the handle's device and
+ * work is enqueued on the handle's stream without synchronising (call avsim_sync).  The library
+ * never keeps a caller pointer past the call.  One host thread per handle; handles are independent.
+ * There is NO CPU fallback: creation fails if no gfx950 device is usable.
+ */
+#ifndef AVSIM_H
+#define AVSIM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct avsim avsim_t;
+
+enum {
+    AVSIM_OK = 0,
+    AVSIM_EINVAL = -1,  /* bad argument (python facade: AssertionError / ValueError) */
+    AVSIM_ENODEV = -2,  /* no usable HIP device */
+    AVSIM_EHIP = -3,    /* HIP runtime error, text in avsim_last_error */
+    AVSIM_EMODEL = -4,  /* malformed model blob */
+    AVSIM_ENOTIMPL = -5 /* python facade: NotImplementedError (env.py:30) */
+};
+
+enum {
+    AVSIM_IO_DEVICE = 1u << 0, /* bulk I/O pointers are device pointers */
+    AVSIM_F64_PHYSICS = 1u << 1 /* debug: run the physics kernels in double precision */
+};
+
+/* IK controller selection for avsim_step_cartesian / avsim_ik */
+enum {
+    AVSIM_IK_REFERENCE = 0, /* left/right GradIK, middle DiffIK (sim_env.py:89-138) */
+    AVSIM_IK_DLS = 1        /* damped least squares on all three arms (BASELINE.json north_star) */
+};
+
+/* dims[]: 0 nq, 1 nv, 2 nu (actuators, 21), 3 num_joints of the action/agent_pos (14|21), 4 nobj (free objects),
+ * 5 max_reward, 6 num_envs, 7 task id, 8 ncon capacity, 9 nefc capacity */
+#define AVSIM_NDIMS 10
+
+/* Build a batched simulation from a compiled model blob (av_aloha_amd/compiler, replaces env.py:53-56).
+ * num_arms is encoded in the blob (2-arm blobs carry the hidden middle arm of env.py:394-395). */
+int avsim_create(const void* model_blob, size_t nbytes, int num_envs, int device, uint32_t flags, avsim_t** out);
+void avsim_destroy(avsim_t* h);
+const char* avsim_last_error(const avsim_t* h); /* h may be NULL for creation errors */
+int avsim_dims(const avsim_t* h, int32_t dims[AVSIM_NDIMS]);
+
+/* Solver/collision knobs. name: "pgs_iters", "noslip_iters". */
+int avsim_set_option(avsim_t* h, const char* name, double value);
+
+/* env.py:228-249 + task reset: envs with mask[i]!=0 (NULL = all) go to the home pose, zero velocity,
+ * home ctrl; their free objects get obj_qpos[i][nobj][7] = [x y z qw qx qy qz]. Derived quantities are
+ * refreshed (mj_forward).  mask: uint8[N]; obj_qpos: double[N][nobj*7]. */
+int avsim_reset(avsim_t* h, const uint8_t* mask, const double* obj_qpos);
+
+/* env.py:203-226: action float[N][num_joints] -> ctrl, nsub physics substeps, then
+ * agent_pos double[N][num_joints], reward int32[N], success uint8[N]. Any output may be NULL. */
+int avsim_step(avsim_t* h, const float* action, int nsub, double* agent_pos, int32_t* reward, uint8_t* success);
+
+/* sim_env.py:277-312: action double[N][23] Cartesian targets; IK on measured qpos -> ctrl; physics.
+ * Outputs as avsim_step (agent_pos has 21 entries per env here). */
+int avsim_step_cartesian(avsim_t* h, const double* action23, int ik_mode, int nsub, double* agent_pos,
+                         int32_t* reward, uint8_t* success);
+
+/* Stand-alone batched IK (diff_ik.py / grad_ik.py `run`): arm 0 left, 1 right, 2 middle;
+ * q double[n][nj], pos double[n][3], quat_wxyz double[n][4] -> q_out double[n][nj] (nj = 6,6,7).
+ * controller: 0 DiffIK, 1 GradIK; max_iters <= 0 keeps the reference's iteration count (10 / 50). */
+int avsim_ik(avsim_t* h, int arm, int controller, int max_iters, int n, const double* q, const double* pos,
+             const double* quat_wxyz, double* q_out);
+/* kinematics.py:17-24 / :35-50 batched: T double[n][16], J double[n][6][nj] (either may be NULL) */
+int avsim_fk_jac(avsim_t* h, int arm, int n, const double* q, double* T, double* J);
+
+/* env.py:251-253 set_qpos (all envs, double[N][nq]) followed by forward kinematics + collision */
+int avsim_set_qpos(avsim_t* h, const double* qpos);
+/* full state for checkpoint / tests: qpos[N][nq], qvel[N][nv], ctrl[N][nu], warmstart[N][nv]; NULL = skip */
+int avsim_get_state(avsim_t* h, double* qpos, double* qvel, double* ctrl, double* warmstart);
+int avsim_set_state(avsim_t* h, const double* qpos, const double* qvel, const double* ctrl, const double* warmstart);
+/* contacts of the current state, env.py:436-441 view: ncon int32[N], geom pairs int32[N][cap][2], dist double[N][cap] */
+int avsim_get_contacts(avsim_t* h, int32_t* ncon, int32_t* geom_pairs, double* dist);
+/* per-env diagnostics of the last step: int32[N][4] = {ncon, nefc, overflow flag, nan flag} */
+int avsim_get_diag(avsim_t* h, int32_t* diag);
+
+/* stream / timing helpers (HIP events on the stream the kernels are launched on) */
+int avsim_sync(avsim_t* h);
+int avsim_set_stream(avsim_t* h, void* hip_stream);
+int avsim_event_record(avsim_t* h, int slot);                            /* slot in [0,16) */
+int avsim_event_elapsed_ms(avsim_t* h, int slot_a, int slot_b, float* ms); /* synchronises on slot_b */
+/* accumulated device time of the physics kernel since the last call with reset!=0, measured with
+ * HIP events around every launch when enabled via avsim_set_option("kernel_timing", 1) */
+int avsim_kernel_time(avsim_t* h, int reset, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,77 @@
+"""HIP IK kernels (through the C-ABI) vs the golden vectors of the reference's Python and vs the CPU
+oracle.  f64 on the device, so parity is at rounding level."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from avsim_test_util import blob
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+ARMS = {"left": 0, "right": 1, "middle": 2}
+
+
+@pytest.fixture(scope="module")
+def sim():
+    from av_aloha_amd._ffi import Handle
+    h = Handle(blob(), 8)
+    yield h
+    h.close()
+
+
+@pytest.mark.parametrize("arm", ["left", "right", "middle"])
+def test_fk_jac_golden(sim, arm):
+    d = np.load(os.path.join(G, f"fk_jac_{arm}.npz"))
+    q = np.ascontiguousarray(d["q"])
+    n, nj = q.shape
+    T = np.zeros((n, 16))
+    J = np.zeros((n, 6, nj))
+    sim.check(sim.L.avsim_fk_jac(sim.h, ARMS[arm], n, q.ctypes.data, T.ctypes.data, J.ctypes.data))
+    np.testing.assert_allclose(T.reshape(n, 4, 4), d["fk"], atol=1e-12)
+    np.testing.assert_allclose(J, d["jac"], atol=1e-12)
+
+
+@pytest.mark.parametrize("arm", ["left", "right", "middle"])
+def test_diffik_golden_and_oracle(sim, arm):
+    from orc_ffi import dp, lib, load_model
+    d = np.load(os.path.join(G, f"diffik_{arm}.npz"))
+    q = np.ascontiguousarray(d["q"])
+    n, nj = q.shape
+    out = np.zeros((n, nj))
+    pos = np.ascontiguousarray(d["target_pos"])
+    quat = np.ascontiguousarray(d["target_quat_wxyz"])
+    sim.check(sim.L.avsim_ik(sim.h, ARMS[arm], 0, 0, n, q.ctypes.data, pos.ctypes.data, quat.ctypes.data, out.ctypes.data))
+    # vs the reference's own outputs (float32 quat2mat rounding amplified by the 1e-4 damping, see
+    # tests/test_oracle_ik_golden.py)
+    err = np.abs(out - d["q_out"]).max(axis=1)
+    assert np.median(err) < 2e-6 and err.max() < 1e-3, (np.median(err), err.max())
+    # vs the CPU oracle on identical inputs (same float32 quat2mat): Cholesky vs LU / eigen-pinv only
+    L, m = lib(), load_model()
+    ref = np.zeros((n, nj))
+    for i in range(n):
+        o = np.zeros(nj)
+        L.orc_diffik(m, ARMS[arm], dp(q[i].copy()), dp(pos[i].copy()), dp(quat[i].copy()), C.c_double(0.9), C.c_double(0.9),
+                     C.c_double(1e-4), dp(d["k_null"].copy()), dp(d["q0"].copy()), C.c_double(3.14), C.c_double(0.04), 10, dp(o))
+        ref[i] = o
+    err = np.abs(out - ref).max(axis=1)
+    assert np.median(err) < 1e-10 and err.max() < 1e-6, (np.median(err), err.max())
+
+
+@pytest.mark.parametrize("arm", ["left", "right"])
+def test_gradik_truncated(sim, arm):
+    d = np.load(os.path.join(G, f"gradik_{arm}.npz"))
+    q = np.ascontiguousarray(d["q"])
+    n, nj = q.shape
+    pos = np.ascontiguousarray(d["target_pos"])
+    quat = np.ascontiguousarray(d["target_quat_wxyz"])
+    for K, med, mx in ((1, 1e-9, 1e-5), (4, 1e-8, 1e-4), (8, 1e-7, 1e-2)):
+        out = np.zeros((n, nj))
+        sim.check(sim.L.avsim_ik(sim.h, ARMS[arm], 1, K, n, q.ctypes.data, pos.ctypes.data, quat.ctypes.data, out.ctypes.data))
+        err = np.abs(out - d[f"q_out_it{K}"]).max(axis=1)
+        assert np.median(err) < med and err.max() < mx, (K, np.median(err), err.max())
+    out = np.zeros((n, nj))
+    sim.check(sim.L.avsim_ik(sim.h, ARMS[arm], 1, 0, n, q.ctypes.data, pos.ctypes.data, quat.ctypes.data, out.ctypes.data))
+    err = np.abs(out - d["q_out"]).max(axis=1)
+    assert np.median(err) < 1e-3 and err.max() < 0.2, (np.median(err), err.max())
