@@ -1,0 +1,80 @@
+"""Small Python view of the CPU oracle's orc_data (test infrastructure only)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from orc_ffi import ROOT, dp, ip, lib, load_model
+
+MAXCON, MAXEFC = 64, 400
+
+
+class Contact(C.Structure):
+    _fields_ = [("dist", C.c_double), ("pos", C.c_double * 3), ("frame", C.c_double * 9),
+                ("geom1", C.c_int), ("geom2", C.c_int), ("pair", C.c_int), ("dim", C.c_int), ("efc_adr", C.c_int),
+                ("friction", C.c_double * 5), ("solref", C.c_double * 2), ("solimp", C.c_double * 5),
+                ("includemargin", C.c_double)]
+
+
+class Data(C.Structure):
+    _fields_ = ([("m", C.c_void_p)] +
+                [(n, C.POINTER(C.c_double)) for n in ("qpos", "qvel", "ctrl", "qacc_warmstart")] +
+                [("time", C.c_double), ("threaded", C.c_int)] +
+                [(n, C.POINTER(C.c_double)) for n in ("xpos", "xquat", "xmat", "xipos", "ximat", "xanchor", "xaxis", "cdof",
+                                                      "geom_xpos", "geom_xmat", "M", "L", "qfrc_bias", "qfrc_passive",
+                                                      "qfrc_actuator", "qfrc_smooth", "qacc_smooth", "qfrc_constraint", "qacc")] +
+                [("ncon", C.c_int), ("nefc", C.c_int), ("contact", Contact * MAXCON),
+                 ("efc_J", C.POINTER(C.c_double)), ("efc_B", C.POINTER(C.c_double))] +
+                [(n, C.c_double * MAXEFC) for n in ("efc_pos", "efc_margin", "efc_aref", "efc_R", "efc_D", "efc_force",
+                                                    "efc_diag", "efc_floss")] +
+                [("efc_KBIP", C.c_double * (4 * MAXEFC)), ("efc_type", C.c_int * MAXEFC), ("efc_id", C.c_int * MAXEFC),
+                 ("pgs_iters", C.c_int), ("overflow", C.c_int), ("stat_narrow", C.c_long)])
+
+
+class OrcEnv:
+    def __init__(self, task="slot_insertion", num_arms=3):
+        self.L = lib()
+        self.m = load_model(task, num_arms)
+        self.man = json.load(open(os.path.join(ROOT, "models", f"{task}_{num_arms}arms.json")))
+        self.nq, self.nv, self.nu = self.man["nq"], self.man["nv"], self.man["nu"]
+        self.nj = 21 if num_arms == 3 else 14
+        self.L.orc_data_new.restype = C.c_void_p
+        self.dptr = C.c_void_p(self.L.orc_data_new(self.m))
+        self.d = C.cast(self.dptr, C.POINTER(Data)).contents
+
+    def arr(self, name, n):
+        return np.ctypeslib.as_array(getattr(self.d, name), shape=(n,))
+
+    @property
+    def qpos(self):
+        return self.arr("qpos", self.nq)
+
+    @property
+    def qvel(self):
+        return self.arr("qvel", self.nv)
+
+    @property
+    def ctrl(self):
+        return self.arr("ctrl", self.nu)
+
+    def reset(self, obj_qpos):
+        o = np.ascontiguousarray(obj_qpos, dtype=np.float64).reshape(-1)
+        self.L.orc_reset(self.dptr, dp(o))
+
+    def step(self, nsub=20):
+        self.L.orc_step(self.dptr, nsub)
+
+    def env_step(self, action, nsub=20):
+        a = np.ascontiguousarray(action, dtype=np.float64)
+        ap = np.zeros(self.nj)
+        r, s = C.c_int(0), C.c_int(0)
+        self.L.orc_env_step(self.dptr, dp(a), nsub, dp(ap), C.byref(r), C.byref(s))
+        return ap, r.value, bool(s.value)
+
+    def contacts(self):
+        names = self.man["geom_names"]
+        return [(names[c.geom1], names[c.geom2], c.dist, c.efc_adr) for c in list(self.d.contact)[: self.d.ncon]]
+
+    def close(self):
+        self.L.orc_data_free(self.dptr)
