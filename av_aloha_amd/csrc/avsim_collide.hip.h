@@ -1,0 +1,460 @@
+// avsim_collide.hip.h -- narrow-phase geometry, one candidate pair per lane.
+// Replaces the part of MuJoCo's mj_collision [EXT] the reference scenes exercise:
+// sphere-sphere / sphere-box closed forms, box-box by separating axes + reference-face clipping (<=4
+// points), and Minkowski Portal Refinement on support functions for anything involving a convex mesh
+// hull or a cylinder (the libccd scheme MuJoCo 3.2 uses for those pairs; tolerance 1e-6, 50 iterations).
+// Contact convention: normal from geom1 to geom2, pos midway between the surfaces, dist<0 = penetration.
+#pragma once
+#include "avsim_math.hip.h"
+
+namespace avs {
+
+enum { G_SPHERE = 2, G_CYLINDER = 5, G_BOX = 6, G_MESH = 7 };
+
+template <typename T>
+struct Shape {
+    int type;
+    T size[3];
+    T pos[3];      // world position of the geom frame
+    T mat[9];      // geom->world rotation, row-major
+    const T* hull; // hull vertices in the geom frame (global memory)
+    int nh;
+    T center[3];   // an interior point (world)
+};
+
+template <typename T>
+AVS_DEV void support(const Shape<T>& s, const T* d, T* out) {
+    T l[3], p[3] = {0, 0, 0};
+    mulmatT(s.mat, d, l);
+    switch (s.type) {
+        case G_SPHERE: {
+            T n = sqrt(dot3(l, l));
+            if (n > T(0)) { T k = s.size[0] / n; p[0] = k * l[0]; p[1] = k * l[1]; p[2] = k * l[2]; }
+            break;
+        }
+        case G_BOX:
+            p[0] = l[0] >= 0 ? s.size[0] : -s.size[0];
+            p[1] = l[1] >= 0 ? s.size[1] : -s.size[1];
+            p[2] = l[2] >= 0 ? s.size[2] : -s.size[2];
+            break;
+        case G_CYLINDER: {
+            T n = sqrt(l[0] * l[0] + l[1] * l[1]);
+            if (n > T(0)) { T k = s.size[0] / n; p[0] = k * l[0]; p[1] = k * l[1]; }
+            p[2] = l[2] >= 0 ? s.size[1] : -s.size[1];
+            break;
+        }
+        default: {
+            int best = 0;
+            T bd = T(-1e30);
+            for (int i = 0; i < s.nh; i++) {
+                T v = s.hull[3 * i] * l[0] + s.hull[3 * i + 1] * l[1] + s.hull[3 * i + 2] * l[2];
+                if (v > bd) { bd = v; best = i; }
+            }
+            p[0] = s.hull[3 * best]; p[1] = s.hull[3 * best + 1]; p[2] = s.hull[3 * best + 2];
+        }
+    }
+    mulmat(s.mat, p, out);
+    out[0] += s.pos[0]; out[1] += s.pos[1]; out[2] += s.pos[2];
+}
+
+template <typename T>
+struct MPt {
+    T v[3], a[3], b[3];
+};
+
+template <typename T>
+AVS_DEV void msupport(const Shape<T>& A, const Shape<T>& B, const T* d, MPt<T>& o) {
+    T nd[3] = {-d[0], -d[1], -d[2]};
+    support(A, d, o.a);
+    support(B, nd, o.b);
+    sub3(o.a, o.b, o.v);
+}
+
+// closest point to the origin on a triangle (Eberly's region decomposition)
+template <typename T>
+AVS_DEV T point_tri_dist2(const T* p0, const T* p1, const T* p2, T* w) {
+    T e0[3], e1[3];
+    sub3(p1, p0, e0);
+    sub3(p2, p0, e1);
+    T a = dot3(e0, e0), b = dot3(e0, e1), c = dot3(e1, e1), dd = dot3(e0, p0), e = dot3(e1, p0);
+    T det = a * c - b * b, s = b * e - c * dd, t = b * dd - a * e;
+    if (s + t <= det) {
+        if (s < 0) {
+            if (t < 0) {
+                if (dd < 0) { t = 0; s = (-dd >= a ? T(1) : -dd / a); }
+                else { s = 0; t = (e >= 0 ? T(0) : (-e >= c ? T(1) : -e / c)); }
+            } else { s = 0; t = (e >= 0 ? T(0) : (-e >= c ? T(1) : -e / c)); }
+        } else if (t < 0) { t = 0; s = (dd >= 0 ? T(0) : (-dd >= a ? T(1) : -dd / a)); }
+        else { T inv = det > 0 ? T(1) / det : T(0); s *= inv; t *= inv; }
+    } else {
+        if (s < 0) {
+            T t0 = b + dd, t1 = c + e;
+            if (t1 > t0) { T num = t1 - t0, den = a - 2 * b + c; s = (num >= den ? T(1) : num / den); t = 1 - s; }
+            else { s = 0; t = (t1 <= 0 ? T(1) : (e >= 0 ? T(0) : -e / c)); }
+        } else if (t < 0) {
+            T t0 = b + e, t1 = a + dd;
+            if (t1 > t0) { T num = t1 - t0, den = a - 2 * b + c; t = (num >= den ? T(1) : num / den); s = 1 - t; }
+            else { t = 0; s = (t1 <= 0 ? T(1) : (dd >= 0 ? T(0) : -dd / a)); }
+        } else {
+            T num = (c + e) - (b + dd), den = a - 2 * b + c;
+            s = num <= 0 ? T(0) : (num >= den ? T(1) : num / den);
+            t = 1 - s;
+        }
+    }
+    for (int i = 0; i < 3; i++) w[i] = p0[i] + s * e0[i] + t * e1[i];
+    return dot3(w, w);
+}
+
+template <typename T> struct MprTol;
+template <> struct MprTol<double> { static constexpr double tol = 1e-6, tiny2 = 1e-24, eps = 1e-14; };
+template <> struct MprTol<float> { static constexpr float tol = 1e-6f, tiny2 = 1e-16f, eps = 1e-9f; };
+
+// MPR on A - B: returns 1 with depth>0, dir (unit, A -> B) and pos when the shapes overlap
+template <typename T>
+__device__ int mpr_penetration(const Shape<T>& A, const Shape<T>& B, T* depth, T* dir, T* pos) {
+    const T tol = MprTol<T>::tol;
+    const int maxit = 50;
+    MPt<T> v0, v1, v2, v3, v4;
+    T d[3], t[3], t2[3];
+    sub3(A.center, B.center, v0.v);
+    for (int i = 0; i < 3; i++) { v0.a[i] = A.center[i]; v0.b[i] = B.center[i]; }
+    if (dot3(v0.v, v0.v) < T(1e-20)) { v0.v[0] = T(1e-5); v0.a[0] += T(1e-5); }
+    d[0] = -v0.v[0]; d[1] = -v0.v[1]; d[2] = -v0.v[2];
+    normalize3(d);
+    msupport(A, B, d, v1);
+    if (dot3(v1.v, d) <= 0) return 0;
+    cross3(v0.v, v1.v, d);
+    if (dot3(d, d) < MprTol<T>::tiny2) {
+        T n = sqrt(dot3(v1.v, v1.v));
+        *depth = n;
+        for (int i = 0; i < 3; i++) { dir[i] = v1.v[i] / n; pos[i] = T(0.5) * (v1.a[i] + v1.b[i]); }
+        return 1;
+    }
+    normalize3(d);
+    msupport(A, B, d, v2);
+    if (dot3(v2.v, d) <= 0) return 0;
+    sub3(v1.v, v0.v, t);
+    sub3(v2.v, v0.v, t2);
+    cross3(t, t2, d);
+    normalize3(d);
+    if (dot3(d, v0.v) > 0) { MPt<T> s = v1; v1 = v2; v2 = s; d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }
+    for (int it = 0;; it++) {
+        if (it > maxit) return 0;
+        msupport(A, B, d, v3);
+        if (dot3(v3.v, d) <= 0) return 0;
+        cross3(v1.v, v3.v, t);
+        if (dot3(t, v0.v) < -MprTol<T>::eps) {
+            v2 = v3;
+            sub3(v1.v, v0.v, t); sub3(v3.v, v0.v, t2); cross3(t, t2, d); normalize3(d);
+            continue;
+        }
+        cross3(v3.v, v2.v, t);
+        if (dot3(t, v0.v) < -MprTol<T>::eps) {
+            v1 = v3;
+            sub3(v3.v, v0.v, t); sub3(v2.v, v0.v, t2); cross3(t, t2, d); normalize3(d);
+            continue;
+        }
+        break;
+    }
+    for (int it = 0;; it++) {
+        sub3(v2.v, v1.v, t);
+        sub3(v3.v, v1.v, t2);
+        cross3(t, t2, d);
+        if (normalize3(d) == T(0)) return 0;
+        msupport(A, B, d, v4);
+        T dv1 = dot3(v1.v, d), dv2 = dot3(v2.v, d), dv3 = dot3(v3.v, d), dv4 = dot3(v4.v, d);
+        T m = dv4 - dv1;
+        if (dv4 - dv2 < m) m = dv4 - dv2;
+        if (dv4 - dv3 < m) m = dv4 - dv3;
+        if (dv4 <= 0) return 0;
+        if (m <= tol || it >= maxit) {
+            if (dv1 < 0) return 0;
+            T w[3];
+            T d2 = point_tri_dist2(v1.v, v2.v, v3.v, w);
+            *depth = sqrt(d2);
+            if (*depth > T(1e-12)) { for (int i = 0; i < 3; i++) dir[i] = w[i] / *depth; }
+            else { dir[0] = d[0]; dir[1] = d[1]; dir[2] = d[2]; }
+            T b0, b1, b2, b3, c[3];
+            cross3(v1.v, v2.v, c); b0 = dot3(c, v3.v);
+            cross3(v3.v, v2.v, c); b1 = dot3(c, v0.v);
+            cross3(v0.v, v1.v, c); b2 = dot3(c, v3.v);
+            cross3(v2.v, v1.v, c); b3 = dot3(c, v0.v);
+            T sum = b0 + b1 + b2 + b3;
+            if (sum <= 0) {
+                b0 = 0;
+                cross3(v2.v, v3.v, c); b1 = dot3(c, d);
+                cross3(v3.v, v1.v, c); b2 = dot3(c, d);
+                cross3(v1.v, v2.v, c); b3 = dot3(c, d);
+                sum = b1 + b2 + b3;
+            }
+            T inv = T(1) / sum;
+            for (int i = 0; i < 3; i++) {
+                T p1 = (b0 * v0.a[i] + b1 * v1.a[i] + b2 * v2.a[i] + b3 * v3.a[i]) * inv;
+                T p2 = (b0 * v0.b[i] + b1 * v1.b[i] + b2 * v2.b[i] + b3 * v3.b[i]) * inv;
+                pos[i] = T(0.5) * (p1 + p2);
+            }
+            return 1;
+        }
+        T v4v0[3];
+        cross3(v4.v, v0.v, v4v0);
+        if (dot3(v1.v, v4v0) > 0) {
+            if (dot3(v2.v, v4v0) > 0) v1 = v4; else v3 = v4;
+        } else {
+            if (dot3(v3.v, v4v0) > 0) v2 = v4; else v1 = v4;
+        }
+    }
+}
+
+template <typename T>
+AVS_DEV int sphere_sphere(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T* nrm) {
+    T d[3];
+    sub3(b.pos, a.pos, d);
+    T n = sqrt(dot3(d, d)), r = a.size[0] + b.size[0];
+    if (n - r >= 0) return 0;
+    if (n < T(1e-12)) { d[0] = 0; d[1] = 0; d[2] = 1; } else { d[0] /= n; d[1] /= n; d[2] /= n; }
+    *dist = n - r;
+    for (int i = 0; i < 3; i++) { nrm[i] = d[i]; pos[i] = a.pos[i] + d[i] * (a.size[0] + T(0.5) * (*dist)); }
+    return 1;
+}
+
+// sphere a vs box b; normal from the sphere towards the box
+template <typename T>
+AVS_DEV int sphere_box(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T* nrm) {
+    T rel[3], c[3], cl[3];
+    sub3(a.pos, b.pos, rel);
+    mulmatT(b.mat, rel, c);
+    bool inside = true;
+    for (int i = 0; i < 3; i++) {
+        cl[i] = c[i];
+        if (cl[i] > b.size[i]) { cl[i] = b.size[i]; inside = false; }
+        if (cl[i] < -b.size[i]) { cl[i] = -b.size[i]; inside = false; }
+    }
+    T r = a.size[0], nl[3];
+    if (!inside) {
+        T d[3] = {cl[0] - c[0], cl[1] - c[1], cl[2] - c[2]};
+        T dl = sqrt(dot3(d, d));
+        if (dl - r >= 0) return 0;
+        for (int i = 0; i < 3; i++) nl[i] = d[i] / dl;
+        *dist = dl - r;
+    } else {
+        int k = 0;
+        T best = T(1e30);
+        for (int i = 0; i < 3; i++) {
+            T m = b.size[i] - fabs(c[i]);
+            if (m < best) { best = m; k = i; }
+        }
+        nl[0] = nl[1] = nl[2] = 0;
+        T sg = c[k] >= 0 ? T(-1) : T(1);
+        if (k == 0) nl[0] = sg; else if (k == 1) nl[1] = sg; else nl[2] = sg;
+        *dist = -best - r;
+    }
+    mulmat(b.mat, nl, nrm);
+    for (int i = 0; i < 3; i++) pos[i] = a.pos[i] + nrm[i] * (r + T(0.5) * (*dist));
+    return 1;
+}
+
+// box-box: 15-axis SAT then reference-face clipping (face contact, <=4 points) or closest edge points
+template <typename T>
+__device__ int box_box(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T* nrm) {
+    const T *Ra = a.mat, *Rb = b.mat;
+    T p[3], pa[3], pb[3];
+    sub3(b.pos, a.pos, p);
+    mulmatT(Ra, p, pa);
+    mulmatT(Rb, p, pb);
+    T R[3][3], Q[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            R[i][j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j];
+            Q[i][j] = fabs(R[i][j]) + T(1e-12);
+        }
+    T best = T(-1e30);
+    int code = -1;
+    T bn[3] = {0, 0, 0};
+    bool flip = false;
+    for (int i = 0; i < 3; i++) {
+        T s = fabs(pa[i]) - (a.size[i] + b.size[0] * Q[i][0] + b.size[1] * Q[i][1] + b.size[2] * Q[i][2]);
+        if (s > 0) return 0;
+        if (s > best) { best = s; code = i; flip = pa[i] < 0; }
+    }
+    for (int j = 0; j < 3; j++) {
+        T s = fabs(pb[j]) - (b.size[j] + a.size[0] * Q[0][j] + a.size[1] * Q[1][j] + a.size[2] * Q[2][j]);
+        if (s > 0) return 0;
+        if (s > best) { best = s; code = 3 + j; flip = pb[j] < 0; }
+    }
+    const T fudge = T(1.05);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            T c[3] = {R[0][j], R[1][j], R[2][j]}, e[3] = {0, 0, 0}, ax[3];
+            e[i] = 1;
+            cross3(e, c, ax);
+            T l = sqrt(dot3(ax, ax));
+            if (l < T(1e-8)) continue;
+            T sep = fabs(dot3(pa, ax)) - (a.size[i1] * Q[i2][j] + a.size[i2] * Q[i1][j] + b.size[j1] * Q[i][j2] + b.size[j2] * Q[i][j1]);
+            sep /= l;
+            if (sep > 0) return 0;
+            if (sep * fudge > best) {
+                best = sep;
+                code = 6 + 3 * i + j;
+                T axn[3] = {ax[0] / l, ax[1] / l, ax[2] / l};
+                flip = dot3(pa, axn) < 0;
+                mulmat(Ra, axn, bn);
+            }
+        }
+    T depth = -best;
+    T n[3];
+    if (code < 3) { n[0] = Ra[code]; n[1] = Ra[3 + code]; n[2] = Ra[6 + code]; }
+    else if (code < 6) { n[0] = Rb[code - 3]; n[1] = Rb[3 + code - 3]; n[2] = Rb[6 + code - 3]; }
+    else { n[0] = bn[0]; n[1] = bn[1]; n[2] = bn[2]; }
+    if (flip) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+
+    if (code >= 6) {
+        int i = (code - 6) / 3, j = (code - 6) % 3;
+        T pA[3], pB[3], la[3], lb[3];
+        mulmatT(Ra, n, la);
+        mulmatT(Rb, n, lb);
+        for (int k = 0; k < 3; k++) {
+            la[k] = (k == i) ? T(0) : (la[k] > 0 ? a.size[k] : -a.size[k]);
+            lb[k] = (k == j) ? T(0) : (lb[k] > 0 ? -b.size[k] : b.size[k]);
+        }
+        mulmat(Ra, la, pA);
+        mulmat(Rb, lb, pB);
+        for (int k = 0; k < 3; k++) { pA[k] += a.pos[k]; pB[k] += b.pos[k]; }
+        T ua[3] = {Ra[i], Ra[3 + i], Ra[6 + i]}, ub[3] = {Rb[j], Rb[3 + j], Rb[6 + j]}, w[3];
+        sub3(pB, pA, w);
+        T uaub = dot3(ua, ub), q1 = dot3(ua, w), q2 = -dot3(ub, w), den = 1 - uaub * uaub;
+        T alpha = 0, beta = 0;
+        if (den > T(1e-10)) { alpha = (q1 + uaub * q2) / den; beta = (uaub * q1 + q2) / den; }
+        for (int k = 0; k < 3; k++) {
+            pA[k] += ua[k] * alpha;
+            pB[k] += ub[k] * beta;
+            pos[k] = T(0.5) * (pA[k] + pB[k]);
+            nrm[k] = n[k];
+        }
+        dist[0] = -depth;
+        return 1;
+    }
+
+    const Shape<T>& ref = code < 3 ? a : b;
+    const Shape<T>& inc = code < 3 ? b : a;
+    T nr[3] = {n[0], n[1], n[2]};
+    if (code >= 3) { nr[0] = -n[0]; nr[1] = -n[1]; nr[2] = -n[2]; }
+    int ax = code % 3;
+    T li[3];
+    mulmatT(inc.mat, nr, li);
+    int k = 0;
+    if (fabs(li[1]) > fabs(li[k])) k = 1;
+    if (fabs(li[2]) > fabs(li[k])) k = 2;
+    T sgn = li[k] > 0 ? T(-1) : T(1);
+    int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+    T poly[16][3], tmp[16][3];
+    int np = 4;
+    for (int q = 0; q < 4; q++) {
+        T cs0 = (q == 0 || q == 3) ? T(1) : T(-1), cs1 = (q < 2) ? T(1) : T(-1);
+        T l[3];
+        l[k] = sgn * inc.size[k];
+        l[k1] = cs0 * inc.size[k1];
+        l[k2] = cs1 * inc.size[k2];
+        T wv[3], rel[3];
+        mulmat(inc.mat, l, wv);
+        for (int c = 0; c < 3; c++) rel[c] = wv[c] + inc.pos[c] - ref.pos[c];
+        mulmatT(ref.mat, rel, poly[q]);
+    }
+    int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+    for (int side = 0; side < 4; side++) {
+        int axis = side < 2 ? a1 : a2;
+        T s = (side & 1) ? T(-1) : T(1), lim = ref.size[axis];
+        int m = 0;
+        for (int q = 0; q < np; q++) {
+            T* P = poly[q];
+            T* Qp = poly[(q + 1) % np];
+            T dp = s * P[axis] - lim, dq = s * Qp[axis] - lim;
+            if (dp <= 0) { tmp[m][0] = P[0]; tmp[m][1] = P[1]; tmp[m][2] = P[2]; m++; }
+            if ((dp < 0 && dq > 0) || (dp > 0 && dq < 0)) {
+                T t = dp / (dp - dq);
+                for (int c = 0; c < 3; c++) tmp[m][c] = P[c] + t * (Qp[c] - P[c]);
+                m++;
+            }
+            if (m >= 15) break;
+        }
+        np = m;
+        for (int q = 0; q < np; q++) { poly[q][0] = tmp[q][0]; poly[q][1] = tmp[q][1]; poly[q][2] = tmp[q][2]; }
+        if (np == 0) return 0;
+    }
+    T refax[3] = {ref.mat[ax], ref.mat[3 + ax], ref.mat[6 + ax]};
+    T face = dot3(nr, refax) > 0 ? T(1) : T(-1);
+    T dep[16];
+    int m = 0;
+    for (int q = 0; q < np; q++) {
+        T dq = ref.size[ax] - face * poly[q][ax];
+        if (dq >= 0) { tmp[m][0] = poly[q][0]; tmp[m][1] = poly[q][1]; tmp[m][2] = poly[q][2]; dep[m] = dq; m++; }
+    }
+    if (m == 0) return 0;
+    int keep[4], nk = 0;
+    if (m <= 4) { for (int q = 0; q < m; q++) keep[nk++] = q; }
+    else {
+        int i0 = 0;
+        for (int q = 1; q < m; q++) if (dep[q] > dep[i0]) i0 = q;
+        int i1 = i0;
+        T bd = -1;
+        for (int q = 0; q < m; q++) {
+            T dx = tmp[q][a1] - tmp[i0][a1], dy = tmp[q][a2] - tmp[i0][a2], dd = dx * dx + dy * dy;
+            if (dd > bd) { bd = dd; i1 = q; }
+        }
+        T ex = tmp[i1][a1] - tmp[i0][a1], ey = tmp[i1][a2] - tmp[i0][a2];
+        int i2 = -1, i3 = -1;
+        T mx = T(1e-18), mn = T(-1e-18);
+        for (int q = 0; q < m; q++) {
+            T cr = ex * (tmp[q][a2] - tmp[i0][a2]) - ey * (tmp[q][a1] - tmp[i0][a1]);
+            if (cr > mx) { mx = cr; i2 = q; }
+            if (cr < mn) { mn = cr; i3 = q; }
+        }
+        keep[nk++] = i0; keep[nk++] = i1;
+        if (i2 >= 0) keep[nk++] = i2;
+        if (i3 >= 0) keep[nk++] = i3;
+    }
+    for (int x = 0; x < nk; x++)
+        for (int y = x + 1; y < nk; y++)
+            if (keep[y] < keep[x]) { int t = keep[x]; keep[x] = keep[y]; keep[y] = t; }
+    for (int x = 0; x < nk; x++) {
+        int q = keep[x];
+        T l[3] = {tmp[q][0], tmp[q][1], tmp[q][2]};
+        l[ax] += T(0.5) * dep[q] * face;
+        T wv[3];
+        mulmat(ref.mat, l, wv);
+        for (int c = 0; c < 3; c++) { pos[3 * x + c] = wv[c] + ref.pos[c]; nrm[3 * x + c] = n[c]; }
+        dist[x] = -dep[q];
+    }
+    return nk;
+}
+
+// dispatch; outputs up to 4 contacts
+template <typename T>
+__device__ int narrow(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T* nrm) {
+    int ta = a.type, tb = b.type;
+    if (ta == G_SPHERE && tb == G_SPHERE) return sphere_sphere(a, b, dist, pos, nrm);
+    if (ta == G_SPHERE && tb == G_BOX) return sphere_box(a, b, dist, pos, nrm);
+    if (ta == G_BOX && tb == G_SPHERE) {
+        int n = sphere_box(b, a, dist, pos, nrm);
+        for (int i = 0; i < 3 * n; i++) nrm[i] = -nrm[i];
+        return n;
+    }
+    if (ta == G_BOX && tb == G_BOX) return box_box(a, b, dist, pos, nrm);
+    T depth;
+    if (!mpr_penetration(a, b, &depth, nrm, pos)) return 0;
+    dist[0] = -depth;
+    return 1;
+}
+
+// mju_makeFrame [EXT]: tangents from the normal
+template <typename T>
+AVS_DEV void make_frame(const T* n, T* t1, T* t2) {
+    t1[0] = t1[1] = t1[2] = 0;
+    if (n[1] < T(0.5) && n[1] > T(-0.5)) t1[1] = 1; else t1[2] = 1;
+    T d = dot3(n, t1);
+    t1[0] -= d * n[0]; t1[1] -= d * n[1]; t1[2] -= d * n[2];
+    normalize3(t1);
+    cross3(n, t1, t2);
+}
+
+}  // namespace avs

@@ -1,0 +1,88 @@
+"""BatchedSim: numpy-facing wrapper of a libavsim handle (host-pointer I/O mode).
+
+This is the batched engine under the gym-style environments in env.py; every method is a direct call
+into the C-ABI (include/avsim.h).  There is no CPU fallback."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from . import _ffi
+from .constants import MODEL_DIR, SIM_PHYSICS_ENV_STEP_RATIO
+
+TASK_KEYS = ("insert_peg", "slot_insertion", "sew_needle", "tube_transfer", "hook_package")
+
+
+def load_blob(task, num_arms):
+    base = os.path.join(MODEL_DIR, f"{task}_{num_arms}arms")
+    with open(base + ".avm", "rb") as f:
+        blob = f.read()
+    with open(base + ".json") as f:
+        manifest = json.load(f)
+    return blob, manifest
+
+
+class BatchedSim:
+    def __init__(self, task, num_arms=3, num_envs=1, device=0, f64=False, options=None):
+        assert task in TASK_KEYS, task
+        blob, self.manifest = load_blob(task, num_arms)
+        self.h = _ffi.Handle(blob, num_envs, device, _ffi.AVSIM_F64_PHYSICS if f64 else 0)
+        self.N = num_envs
+        for k in ("nq", "nv", "nu", "nj", "nobj", "max_reward", "maxcon", "maxefc"):
+            setattr(self, k, getattr(self.h, k))
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, name, value):
+        self.h.check(self.h.L.avsim_set_option(self.h.h, name.encode(), float(value)))
+
+    def reset(self, obj_qpos, mask=None):
+        obj = np.ascontiguousarray(obj_qpos, dtype=np.float64).reshape(self.N, self.nobj * 7)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self.h.check(self.h.L.avsim_reset(self.h.h, _ffi.ptr(m), obj.ctypes.data))
+
+    def step(self, action, nsub=SIM_PHYSICS_ENV_STEP_RATIO, want_reward=True):
+        a = np.ascontiguousarray(action, dtype=np.float32).reshape(self.N, self.nj)
+        ap = np.empty((self.N, self.nj))
+        rw = np.empty(self.N, dtype=np.int32) if want_reward else None
+        su = np.empty(self.N, dtype=np.uint8) if want_reward else None
+        self.h.check(self.h.L.avsim_step(self.h.h, a.ctypes.data, nsub, ap.ctypes.data, _ffi.ptr(rw), _ffi.ptr(su)))
+        return ap, rw, (su.astype(bool) if su is not None else None)
+
+    def step_cartesian(self, action23, ik_mode=_ffi.IK_REFERENCE, nsub=SIM_PHYSICS_ENV_STEP_RATIO):
+        a = np.ascontiguousarray(action23, dtype=np.float64).reshape(self.N, 23)
+        ap = np.empty((self.N, 21))
+        rw = np.empty(self.N, dtype=np.int32)
+        su = np.empty(self.N, dtype=np.uint8)
+        self.h.check(self.h.L.avsim_step_cartesian(self.h.h, a.ctypes.data, ik_mode, nsub, ap.ctypes.data, rw.ctypes.data, su.ctypes.data))
+        return ap, rw, su.astype(bool)
+
+    def get_state(self):
+        qpos, qvel = np.empty((self.N, self.nq)), np.empty((self.N, self.nv))
+        ctrl, warm = np.empty((self.N, self.nu)), np.empty((self.N, self.nv))
+        self.h.check(self.h.L.avsim_get_state(self.h.h, qpos.ctypes.data, qvel.ctypes.data, ctrl.ctypes.data, warm.ctypes.data))
+        return qpos, qvel, ctrl, warm
+
+    def set_state(self, qpos=None, qvel=None, ctrl=None, warm=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (qpos, qvel, ctrl, warm)]
+        self.h.check(self.h.L.avsim_set_state(self.h.h, *[_ffi.ptr(a) for a in arrs]))
+
+    def set_qpos(self, qpos):
+        q = np.ascontiguousarray(qpos, dtype=np.float64).reshape(self.N, self.nq)
+        self.h.check(self.h.L.avsim_set_qpos(self.h.h, q.ctypes.data))
+
+    def contacts(self):
+        ncon = np.empty(self.N, dtype=np.int32)
+        pairs = np.empty((self.N, self.maxcon, 2), dtype=np.int32)
+        dist = np.empty((self.N, self.maxcon))
+        self.h.check(self.h.L.avsim_get_contacts(self.h.h, ncon.ctypes.data, pairs.ctypes.data, dist.ctypes.data))
+        return ncon, pairs, dist
+
+    def diag(self):
+        d = np.empty((self.N, 4), dtype=np.int32)
+        self.h.check(self.h.L.avsim_get_diag(self.h.h, d.ctypes.data))
+        return d
+
+    def close(self):
+        self.h.close()
