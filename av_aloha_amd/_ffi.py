@@ -40,6 +40,7 @@ def lib():
         L.avsim_step_cartesian.argtypes = [vp, vp, i32, i32, vp, vp, vp]
         L.avsim_ik.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp]
         L.avsim_fk_jac.argtypes = [vp, i32, i32, vp, vp, vp]
+        L.avsim_observe.argtypes = [vp, vp, vp, vp]
         L.avsim_set_qpos.argtypes = [vp, vp]
         L.avsim_get_state.argtypes = [vp, vp, vp, vp, vp]
         L.avsim_set_state.argtypes = [vp, vp, vp, vp, vp]

@@ -51,10 +51,11 @@ struct avsim {
     void* d_io[8] = {};
     size_t d_io_sz[8] = {};
     // kernel timing
+    // kernel timing: pairs of HIP events recorded around every physics launch on the launch stream, read
+    // back (and only then synchronised) by avsim_kernel_time
     bool ktiming = false;
-    double k_ms = 0;
-    int64_t k_launches = 0;
-    hipEvent_t kev[2] = {};
+    std::vector<hipEvent_t> kev;
+    size_t kev_used = 0;
 
     void set_error(const char* fmt, ...) {
         char buf[1024];
@@ -311,8 +312,6 @@ int avsim_create(const void* blob, size_t nbytes, int num_envs, int device, uint
     if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); return AVSIM_EHIP; }
     h->own_stream = true;
     for (auto& ev : h->ev) (void)hipEventCreate(&ev);
-    (void)hipEventCreate(&h->kev[0]);
-    (void)hipEventCreate(&h->kev[1]);
     size_t N = num_envs, r = h->rsz();
     if (hipMalloc(&h->d_qpos, N * h->nq * r) != hipSuccess || hipMalloc(&h->d_qvel, N * h->nv * r) != hipSuccess ||
         hipMalloc(&h->d_ctrl, N * h->nu * r) != hipSuccess || hipMalloc(&h->d_warm, N * h->nv * r) != hipSuccess ||
@@ -351,8 +350,7 @@ void avsim_destroy(avsim_t* h) {
         if (p) (void)hipFree(p);
     for (auto& ev : h->ev)
         if (ev) (void)hipEventDestroy(ev);
-    for (auto& ev : h->kev)
-        if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : h->kev) (void)hipEventDestroy(ev);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -405,10 +403,38 @@ int avsim_event_elapsed_ms(avsim_t* h, int a, int b, float* ms) {
 
 int avsim_kernel_time(avsim_t* h, int reset, double* total_ms, int64_t* launches) {
     if (!h) return AVSIM_EINVAL;
-    if (total_ms) *total_ms = h->k_ms;
-    if (launches) *launches = h->k_launches;
-    if (reset) { h->k_ms = 0; h->k_launches = 0; }
+    HIPCHK(h, hipSetDevice(h->device));
+    double tot = 0;
+    for (size_t i = 0; i + 1 < h->kev_used; i += 2) {
+        float ms = 0;
+        HIPCHK(h, hipEventSynchronize(h->kev[i + 1]));
+        HIPCHK(h, hipEventElapsedTime(&ms, h->kev[i], h->kev[i + 1]));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int64_t)(h->kev_used / 2);
+    if (reset) h->kev_used = 0;
     return AVSIM_OK;
+}
+
+int avsim_observe(avsim_t* h, double* agent_pos, int32_t* reward, uint8_t* success) {
+    if (!h) return AVSIM_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    void *dap = nullptr, *drw = nullptr, *dsu = nullptr;
+    size_t N = h->N;
+    if (agent_pos && (rc = h->out_begin(4, agent_pos, sizeof(double) * N * h->nj, &dap))) return rc;
+    if (reward && (rc = h->out_begin(5, reward, sizeof(int32_t) * N, &drw))) return rc;
+    if (success && (rc = h->out_begin(6, success, N, &dsu))) return rc;
+    h->phys.force_reward = 1;
+    rc = h->phys.launch(h->stream, h->N, 0, nullptr, h->nj, h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, h->d_latch, (double*)dap, (int32_t*)drw,
+                        (uint8_t*)dsu, h->err);
+    h->phys.force_reward = 0;
+    if (rc) return rc;
+    if ((rc = h->out_end(4, agent_pos, sizeof(double) * N * h->nj))) return rc;
+    if ((rc = h->out_end(5, reward, sizeof(int32_t) * N))) return rc;
+    if ((rc = h->out_end(6, success, N))) return rc;
+    return h->finish();
 }
 
 int avsim_fk_jac(avsim_t* h, int arm, int n, const double* q, double* T, double* J) {
@@ -491,17 +517,16 @@ static int step_common(avsim_t* h, const float* d_action, int nsub, double* agen
     if (agent_pos && (rc = h->out_begin(4, agent_pos, sizeof(double) * N * h->nj, &dap))) return rc;
     if (reward && (rc = h->out_begin(5, reward, sizeof(int32_t) * N, &drw))) return rc;
     if (success && (rc = h->out_begin(6, success, N, &dsu))) return rc;
-    if (h->ktiming) HIPCHK(h, hipEventRecord(h->kev[0], h->stream));
+    if (h->ktiming) {
+        while (h->kev.size() < h->kev_used + 2) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->kev.push_back(e); }
+        HIPCHK(h, hipEventRecord(h->kev[h->kev_used], h->stream));
+    }
     if ((rc = h->phys.launch(h->stream, h->N, nsub, d_action, h->nj, h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, h->d_latch, (double*)dap,
                              (int32_t*)drw, (uint8_t*)dsu, h->err)))
         return rc;
     if (h->ktiming) {
-        HIPCHK(h, hipEventRecord(h->kev[1], h->stream));
-        HIPCHK(h, hipEventSynchronize(h->kev[1]));
-        float ms = 0;
-        HIPCHK(h, hipEventElapsedTime(&ms, h->kev[0], h->kev[1]));
-        h->k_ms += ms;
-        h->k_launches++;
+        HIPCHK(h, hipEventRecord(h->kev[h->kev_used + 1], h->stream));
+        h->kev_used += 2;
     }
     if ((rc = h->out_end(4, agent_pos, sizeof(double) * N * h->nj))) return rc;
     if ((rc = h->out_end(5, reward, sizeof(int32_t) * N))) return rc;

@@ -997,7 +997,7 @@ __global__ void __launch_bounds__(64) k_phys(DevModel<real> m, Layout lay, int N
 // host side: device model image, LDS layout, launch
 // ------------------------------------------------------------------------------------------------
 struct PhysHost {
-    int maxcon = 48, maxefc = 144, pgs_iters = 20, group = 64, export_contacts = 1;
+    int maxcon = 48, maxefc = 144, pgs_iters = 20, group = 64, export_contacts = 1, force_reward = 0;
     bool f64 = false;
     int N = 0, max_reward = 0;
     std::vector<void*> allocs;
@@ -1265,7 +1265,7 @@ struct PhysHost {
         }
         if (shmem > 160 * 1024) { err = "per-block LDS exceeds 160 KiB; lower maxefc/maxcon or raise the group size"; return -1; }
         dim3 grid((N + epb - 1) / epb);
-        hipLaunchKernelGGL(kern, grid, dim3(64), shmem, st, m, lay, N, nsub, pgs_iters, action, (reward || success) && nsub > 0 ? 1 : 0,
+        hipLaunchKernelGGL(kern, grid, dim3(64), shmem, st, m, lay, N, nsub, pgs_iters, action, (reward || success) && (nsub > 0 || force_reward) ? 1 : 0,
                            (real*)qpos, (real*)qvel, (real*)ctrl, (real*)warm, latch, agent, (int*)reward, (unsigned char*)success, d_ncon,
                            d_cpairs, d_cdist, d_diag, max_reward, export_contacts);
         hipError_t e = hipGetLastError();

@@ -84,6 +84,10 @@ int avsim_ik(avsim_t* h, int arm, int controller, int max_iters, int n, const do
 /* kinematics.py:17-24 / :35-50 batched: T double[n][16], J double[n][6][nj] (either may be NULL) */
 int avsim_fk_jac(avsim_t* h, int arm, int n, const double* q, double* T, double* J);
 
+/* env.py:168-178 get_obs (agent_pos) and env.py get_reward / :224 is_success of the CURRENT state, no time
+ * stepping; any output may be NULL.  Evaluating the reward advances SewNeedle's latch as env.py:686-689 does. */
+int avsim_observe(avsim_t* h, double* agent_pos, int32_t* reward, uint8_t* success);
+
 /* env.py:251-253 set_qpos (all envs, double[N][nq]) followed by forward kinematics + collision */
 int avsim_set_qpos(avsim_t* h, const double* qpos);
 /* full state for checkpoint / tests: qpos[N][nq], qvel[N][nv], ctrl[N][nu], warmstart[N][nv]; NULL = skip */
@@ -100,7 +104,8 @@ int avsim_set_stream(avsim_t* h, void* hip_stream);
 int avsim_event_record(avsim_t* h, int slot);                            /* slot in [0,16) */
 int avsim_event_elapsed_ms(avsim_t* h, int slot_a, int slot_b, float* ms); /* synchronises on slot_b */
 /* accumulated device time of the physics kernel since the last call with reset!=0, measured with
- * HIP events around every launch when enabled via avsim_set_option("kernel_timing", 1) */
+ * HIP events around every launch (on the launch stream, no per-launch synchronisation) when enabled via
+ * avsim_set_option("kernel_timing", 1); this call synchronises on the recorded events */
 int avsim_kernel_time(avsim_t* h, int reset, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus
