@@ -46,6 +46,7 @@ def lib():
         L.avsim_set_state.argtypes = [vp, vp, vp, vp, vp]
         L.avsim_get_contacts.argtypes = [vp, vp, vp, vp]
         L.avsim_get_diag.argtypes = [vp, vp]
+        L.avsim_get_phase_cycles.argtypes = [vp, vp]
         L.avsim_sync.argtypes = [vp]
         L.avsim_set_stream.argtypes = [vp, vp]
         L.avsim_event_record.argtypes = [vp, i32]

@@ -60,15 +60,70 @@ struct DevModel {
     const real *obs_offset, *obs_scale;
 };
 
+struct MOff {
+    int nreal, nint;
+    int body_parent;
+    int body_jntadr;
+    int body_jntnum;
+    int body_dofadr;
+    int body_dofnum;
+    int body_tree;
+    int body_dofmask;
+    int tree_bodyadr;
+    int tree_bodylist;
+    int tree_dofadr;
+    int tree_dofnum;
+    int tree_madr;
+    int jnt_type;
+    int jnt_qposadr;
+    int jnt_dofadr;
+    int jnt_actfrclimited;
+    int limited_jnt;
+    int dof_body;
+    int dof_parent;
+    int dof_tree;
+    int dof_jnt;
+    int floss_dof;
+    int ment_i;
+    int ment_j;
+    int act_dof;
+    int act_qposadr;
+    int act_ctrllimited;
+    int geom_type;
+    int geom_body;
+    int geom_static;
+    int body_pos;
+    int body_quat;
+    int body_mass;
+    int body_ipos;
+    int body_inertia;
+    int body_invweight0;
+    int jnt_pos;
+    int jnt_axis;
+    int jnt_range;
+    int jnt_actfrcrange;
+    int jnt_margin;
+    int dof_armature;
+    int dof_damping;
+    int dof_frictionloss;
+    int dof_invweight0;
+    int act_kp;
+    int act_kv;
+    int act_gear;
+    int act_ctrlrange;
+    int geom_cpos;
+    int geom_rbound;
+};
+
 // per-env LDS layout (offsets in reals / ints)
 struct Layout {
     int qpos, qvel, ctrl, warm, xpos, xmat, xipos, cdof, gcen, M, L, bias, fsm, asm_, qacc, fcon, U, nreal;
     // scratch union U, phase A
     int cinert, cvel, cacc, cfrc;
     // phase B
-    int cdist, cpos, cnrm, rJ, rB, raref, rR, rden, rf, rmu;
+    int cdist, cpos, cnrm, rJ, rB, rowS;
     // ints
-    int cand, cpair, cefc, cgeom, rmeta, raux, misc, nint;
+    int cand, cpair, cefc, rmeta, rowI, misc, nint;
     int maxcon, maxefc;
     int bytes_per_env;
 };
@@ -93,6 +148,110 @@ AVS_DEV double row16_sum(double x) {
     x += __shfl_xor(x, 2, 16);
     x += __shfl_xor(x, 1, 16);
     return x;
+}
+
+// sum over the 64 lanes of the wave, result broadcast (through an SGPR) to every lane
+AVS_DEV float wave_sum(float x) {
+    x = row16_sum(x);
+    int xi = __builtin_bit_cast(int, x);
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1,3
+    xi = __builtin_bit_cast(int, x);
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2,3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+AVS_DEV double wave_sum(double x) {
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+#define LDS_PTR(T) __attribute__((address_space(3))) T*
+
+// ------------------------------------------------------------------------------------------------
+// P8 inner loop, one env per wave (G == 64): projected Gauss-Seidel with the acceleration vector held in
+// registers, one dof per lane.  Per row: every lane fetches its J/B entry from the row's two tree windows
+// (chain-independent LDS reads), the row residual is a wave-wide DPP sum, the update is a register FMA.
+// Separate noinline function so that the sweep loop gets its own register allocation (no spills).
+// rowS: 8 reals per row (struct RowS); rowI: {dof windows adrA|nA<<8|adrB<<16|nB<<24, flags RF_* | dim<<8} per row.
+// ------------------------------------------------------------------------------------------------
+template <typename real>
+struct RowS {
+    real aref, R, inv, invn, lo, hi, f, muinv;
+};
+enum { RF_NOSLIP = 1, RF_NORMAL = 2, RF_FRICTION = 4, RF_LASTFRIC = 8 };
+
+template <typename real>
+struct RowRegs {
+    real J, B, aref, R, inv, invn, lo, hi, f, muinv;
+    int flags;
+};
+
+template <typename real>
+AVS_DEV void pgs_load(RowRegs<real>& o, int i, int k, LDS_PTR(const RowS<real>) rowS, LDS_PTR(const int) rowI, LDS_PTR(const real) rJ,
+                      LDS_PTR(const real) rB) {
+    const int radr = rowI[2 * i];
+    o.flags = rowI[2 * i + 1];
+    const int ka = k - (radr & 255), kb = k - ((radr >> 16) & 255);
+    const bool inA = (unsigned)ka < (unsigned)((radr >> 8) & 255), inB = (unsigned)kb < (unsigned)((radr >> 24) & 255);
+    const int idx = ROW_W * i + (inA ? ka : (inB ? TREE_W + kb : 0));
+    const real j = rJ[idx], b = rB[idx];   // unconditional (always in range): keeps the loads off the exec-mask path
+    o.J = (inA || inB) ? j : real(0);
+    o.B = (inA || inB) ? b : real(0);
+    LDS_PTR(const real) S = (LDS_PTR(const real))(rowS + i);
+    o.aref = S[0]; o.R = S[1]; o.inv = S[2]; o.invn = S[3]; o.lo = S[4]; o.hi = S[5]; o.f = S[6]; o.muinv = S[7];
+}
+
+template <typename real>
+__device__ __attribute__((noinline)) void pgs_wave(LDS_PTR(RowS<real>) rowS, LDS_PTR(const int) rowI, LDS_PTR(const real) rJ, LDS_PTR(const real) rB,
+                                                   LDS_PTR(real) qacc_lds, int nv, int nefc, int iters, int noslip_iters) {
+    const int k = threadIdx.x & 63;
+    real q = k < nv ? qacc_lds[k] : real(0);
+    if (nefc <= 0) return;
+    for (int it = 0; it < iters + noslip_iters; it++) {
+        const bool noslip = it >= iters;
+        RowRegs<real> c, n;
+        pgs_load(c, 0, k, rowS, rowI, rJ, rB);
+        real fn = 0, s2 = 0;   // running normal force and friction-ellipse norm of the current contact
+        for (int i = 0; i < nefc; i++) {
+            // software pipeline: fetch row i+1 while row i's dependency chain runs (forces of later rows are
+            // not touched by row i, so the early read of n.f is safe; the cone projection below re-reads)
+            const int inext = i + 1 < nefc ? i + 1 : i;
+            pgs_load(n, inext, k, rowS, rowI, rJ, rB);
+            const bool skip = noslip && !(c.flags & RF_NOSLIP);
+            if (!skip) {
+                const real R = noslip ? real(0) : c.R, inv = noslip ? c.invn : c.inv;
+                const real res = wave_sum(c.J * q) - c.aref + R * c.f;
+                real f = c.f - res * inv;
+                f = tmin(tmax(f, c.lo), c.hi);
+                q += c.B * (f - c.f);
+                if (k == 0) rowS[i].f = f;
+                c.f = f;
+            }
+            if (c.flags & RF_NORMAL) { fn = c.f; s2 = 0; }
+            if (c.flags & RF_FRICTION) { const real t = c.f * c.muinv; s2 += t * t; }
+            if ((c.flags & RF_LASTFRIC) && s2 > fn * fn) {
+                // sliding: scale the friction block back onto the elliptic cone
+                const int dim = c.flags >> 8, first = i - (dim - 1);
+                const real sc = fn / sqrt(s2);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                for (int s = 1; s < dim; s++) {
+                    const int rr = first + s, ra2 = rowI[2 * rr];
+                    const int ka2 = k - (ra2 & 255), kb2 = k - ((ra2 >> 16) & 255);
+                    const bool inA2 = (unsigned)ka2 < (unsigned)((ra2 >> 8) & 255), inB2 = (unsigned)kb2 < (unsigned)((ra2 >> 24) & 255);
+                    const real B2 = (inA2 || inB2) ? rB[ROW_W * rr + (inA2 ? ka2 : TREE_W + kb2)] : real(0);
+                    const real fo = rowS[rr].f, fnw = fo * sc;
+                    q += B2 * (fnw - fo);
+                    __builtin_amdgcn_wave_barrier();
+                    if (k == 0) rowS[rr].f = fnw;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (inext == i) { /* nothing prefetched */ }
+            }
+            c = n;
+        }
+    }
+    if (k < nv) qacc_lds[k] = q;
 }
 
 template <int G>
@@ -539,10 +698,10 @@ struct Env {
     // ---- P4 ------------------------------------------------------------------------------------
     __device__ void make_constraints() {
         real *qpos = r + lay.qpos, *qvel = r + lay.qvel;
-        int *misc = ii + lay.misc, *rmeta = ii + lay.rmeta, *raux = ii + lay.raux, *cpair = ii + lay.cpair, *cefc = ii + lay.cefc;
+        int *misc = ii + lay.misc, *rmeta = ii + lay.rmeta, *cpair = ii + lay.cpair, *cefc = ii + lay.cefc;
         real *cdist = r + lay.cdist, *cpos = r + lay.cpos, *cnrm = r + lay.cnrm;
         int ncon = misc[0];
-        // --- row table: meta = type | id<<2 | sub<<12 ; raux = first row of the contact (contacts) ---
+        // --- row table: meta = type | id<<2 | sub<<12 | dim<<20 (tree ids replace dim once the row is filled) ---
         int nefc = m.neq + m.nfloss;
         for (int i = lane; i < m.neq; i += G) rmeta[i] = R_EQ | (i << 2);
         for (int i = lane; i < m.nfloss; i += G) rmeta[m.neq + i] = R_FLOSS | (i << 2);
@@ -581,7 +740,7 @@ struct Env {
                 if (dim > 0 && first + dim <= lay.maxefc) {
                     cefc[c] = first;
                     myend = first + dim;
-                    for (int s = 0; s < dim; s++) { rmeta[first + s] = R_CONTACT | (c << 2) | (s << 12); raux[first + s] = first; }
+                    for (int s = 0; s < dim; s++) rmeta[first + s] = R_CONTACT | (c << 2) | (s << 12) | (dim << 20);
                 } else {
                     cefc[c] = -1;
                     if (dim > 0) ovf = 1;
@@ -595,10 +754,11 @@ struct Env {
         if (lane == 0) { misc[1] = nefc; if (ovf) misc[2] |= 2; }
         GSYNC();
         // --- fill rows (one row per lane) ---
-        real *rJ = r + lay.rJ, *rB = r + lay.rB, *raref = r + lay.raref, *rR = r + lay.rR, *rden = r + lay.rden, *rmu = r + lay.rmu;
+        real *rJ = r + lay.rJ, *rB = r + lay.rB, *rowS = r + lay.rowS, *warm = r + lay.warm;
+        int* rowI = ii + lay.rowI;
         real* Lm = r + lay.L;
         for (int i = lane; i < nefc; i += G) {
-            int meta = rmeta[i], type = meta & 3, id = (meta >> 2) & 1023, sub = meta >> 12;
+            int meta = rmeta[i], type = meta & 3, id = (meta >> 2) & 1023, sub = (meta >> 12) & 255, dim = meta >> 20;
             real J[ROW_W];
             for (int k = 0; k < ROW_W; k++) J[k] = 0;
             int tA = -1, tB = -1;
@@ -675,11 +835,10 @@ struct Env {
                 R = sub == 1 ? R1 : R1 * mu0 * mu0 / tmax(real(1e-15), mur * mur);
                 imp = imp0;
                 K = 0;
-                rmu[i] = mur;
+                floss = mur;
             } else {
                 imp = impedance(solimp, pos, margin);
                 R = tmax(real(1e-15), (1 - imp) * diag0 / imp);
-                rmu[i] = floss;
             }
             // velocity along the row, reference acceleration
             real vel = 0;
@@ -688,8 +847,7 @@ struct Env {
                 for (int k = 0; k < m.tree_dofnum[tA]; k++) vel += J[k] * qvel[a0 + k];
                 if (tB >= 0) { int b0 = m.tree_dofadr[tB]; for (int k = 0; k < m.tree_dofnum[tB]; k++) vel += J[TREE_W + k] * qvel[b0 + k]; }
             }
-            raref[i] = -Bd * vel - K * imp * (pos - margin);
-            rR[i] = R;
+            const real aref = -Bd * vel - K * imp * (pos - margin);
             // B = rows of J M^-1 per tree, diag = J B^T
             real B[ROW_W];
             for (int k = 0; k < ROW_W; k++) B[k] = J[k];
@@ -698,55 +856,46 @@ struct Env {
             else for (int k = 0; k < TREE_W; k++) B[TREE_W + k] = 0;
             real dg = 0;
             for (int k = 0; k < ROW_W; k++) dg += J[k] * B[k];
-            rden[i] = dg;
             for (int k = 0; k < ROW_W; k++) { rJ[ROW_W * i + k] = J[k]; rB[ROW_W * i + k] = B[k]; }
-            rmeta[i] = meta | ((tA + 1) << 20) | ((tB + 1) << 24);
+            // warm start: force implied by last step's acceleration, f = -D (J qacc_ws - aref), made feasible per row
+            const int a0 = m.tree_dofadr[tA], nA = m.tree_dofnum[tA], b0 = tB >= 0 ? m.tree_dofadr[tB] : 0, nB = tB >= 0 ? m.tree_dofnum[tB] : 0;
+            real jw = 0;
+            for (int k = 0; k < nA; k++) jw += J[k] * warm[a0 + k];
+            for (int k = 0; k < nB; k++) jw += J[TREE_W + k] * warm[b0 + k];
+            const real big = real(1e30);
+            real lo = -big, hi = big, muinv = 0;
+            int fl = 0;
+            if (type == R_FLOSS) { lo = -floss; hi = floss; fl = RF_NOSLIP; }
+            else if (type == R_LIMIT) lo = 0;
+            else if (type == R_CONTACT) {
+                if (sub == 0) { lo = 0; fl = RF_NORMAL; }
+                else { fl = RF_NOSLIP | RF_FRICTION | (sub == dim - 1 ? RF_LASTFRIC : 0); muinv = real(1) / tmax(real(1e-15), floss); }
+                fl |= dim << 8;
+            }
+            real f = -(jw - aref) / R;
+            f = tmin(tmax(f, lo), hi);
+            real* S = rowS + 8 * i;
+            S[0] = aref; S[1] = R; S[2] = real(1) / (dg + R); S[3] = real(1) / tmax(dg, real(1e-15)); S[4] = lo; S[5] = hi; S[6] = f; S[7] = muinv;
+            rowI[2 * i] = a0 | (nA << 8) | (b0 << 16) | (nB << 24);
+            rowI[2 * i + 1] = fl;
+            rmeta[i] = (meta & 0xfffff) | ((tA + 1) << 20) | ((tB + 1) << 24);
         }
         GSYNC();
-    }
-
-    // residual J_i.qacc of row i, computed by the 16 lanes of a DPP row (lane16 = lane % 16)
-    AVS_DEV real row_dot(int i, int tA, int tB, const real* vec, int l16) const {
-        const real* J = r + lay.rJ + ROW_W * i;
-        int t = l16 < TREE_W ? tA : tB, k = l16 & (TREE_W - 1);
-        real x = 0;
-        if (t >= 0 && k < m.tree_dofnum[t]) x = J[l16] * vec[m.tree_dofadr[t] + k];
-        return row16_sum(x);
-    }
-    AVS_DEV void row_apply(int i, int tA, int tB, real* vec, int l16, real delta) const {
-        const real* B = r + lay.rB + ROW_W * i;
-        int t = l16 < TREE_W ? tA : tB, k = l16 & (TREE_W - 1);
-        if (t >= 0 && k < m.tree_dofnum[t]) vec[m.tree_dofadr[t] + k] += B[l16] * delta;
     }
 
     // ---- P8 ------------------------------------------------------------------------------------
     __device__ void solve(int pgs_iters) {
-        int *misc = ii + lay.misc, *rmeta = ii + lay.rmeta, *raux = ii + lay.raux, *cefc = ii + lay.cefc, *cpair = ii + lay.cpair;
-        real *qacc = r + lay.qacc, *as = r + lay.asm_, *warm = r + lay.warm, *rf = r + lay.rf, *raref = r + lay.raref, *rR = r + lay.rR;
-        real *rden = r + lay.rden, *rmu = r + lay.rmu, *rJ = r + lay.rJ, *rB = r + lay.rB, *fcon = r + lay.fcon;
+        int *misc = ii + lay.misc, *rmeta = ii + lay.rmeta, *cefc = ii + lay.cefc, *rowI = ii + lay.rowI;
+        real *qacc = r + lay.qacc, *as = r + lay.asm_, *rowS = r + lay.rowS, *rJ = r + lay.rJ, *rB = r + lay.rB, *fcon = r + lay.fcon;
         int nefc = misc[1], ncon = misc[0];
-        // warm start forces, one row per lane
-        for (int i = lane; i < nefc; i += G) {
-            int meta = rmeta[i], type = meta & 3, sub = (meta >> 12) & 255, tA = ((meta >> 20) & 15) - 1, tB = ((meta >> 24) & 15) - 1;
-            const real* J = rJ + ROW_W * i;
-            real s = 0;
-            int a0 = m.tree_dofadr[tA];
-            for (int k = 0; k < m.tree_dofnum[tA]; k++) s += J[k] * warm[a0 + k];
-            if (tB >= 0) { int b0 = m.tree_dofadr[tB]; for (int k = 0; k < m.tree_dofnum[tB]; k++) s += J[TREE_W + k] * warm[b0 + k]; }
-            real f = -(s - raref[i]) / rR[i];
-            if (type == R_FLOSS) f = tclamp(f, -rmu[i], rmu[i]);
-            else if (type == R_LIMIT) f = tmax(f, real(0));
-            else if (type == R_CONTACT && sub == 0) f = tmax(f, real(0));
-            rf[i] = f;
-        }
-        GSYNC();
+        // warm-start forces of friction blocks back onto their cones (one contact per lane)
         for (int c = lane; c < ncon; c += G) {
             int first = cefc[c];
             if (first < 0) continue;
-            int dim = m.pair_condim[cpair[c]];
-            real fn = rf[first], s2 = 0;
-            for (int s = 1; s < dim; s++) { real t = rf[first + s] / tmax(real(1e-15), rmu[first + s]); s2 += t * t; }
-            if (s2 > fn * fn) { real sc = fn / sqrt(s2); for (int s = 1; s < dim; s++) rf[first + s] *= sc; }
+            int dim = rowI[2 * first + 1] >> 8;
+            real fn = rowS[8 * first + 6], s2 = 0;
+            for (int s = 1; s < dim; s++) { real t = rowS[8 * (first + s) + 6] * rowS[8 * (first + s) + 7]; s2 += t * t; }
+            if (s2 > fn * fn) { real sc = fn / sqrt(s2); for (int s = 1; s < dim; s++) rowS[8 * (first + s) + 6] *= sc; }
         }
         GSYNC();
         // qacc = qacc_smooth + sum_i B_i f_i : one dof per lane
@@ -755,62 +904,25 @@ struct Env {
             real s = as[k];
             for (int i = 0; i < nefc; i++) {
                 int meta = rmeta[i], tA = ((meta >> 20) & 15) - 1, tB = ((meta >> 24) & 15) - 1;
-                if (tA == t) s += rB[ROW_W * i + kk] * rf[i];
-                else if (tB == t) s += rB[ROW_W * i + TREE_W + kk] * rf[i];
+                if (tA == t) s += rB[ROW_W * i + kk] * rowS[8 * i + 6];
+                else if (tB == t) s += rB[ROW_W * i + TREE_W + kk] * rowS[8 * i + 6];
             }
             qacc[k] = s;
         }
         GSYNC();
-        // Gauss-Seidel sweeps: rows in order, each row handled by the first 16 lanes of the group
-        int l16 = lane & 15;
-        bool act16 = lane < 16;
-        for (int it = 0; it < pgs_iters + m.noslip_iters; it++) {
-            bool noslip = it >= pgs_iters;
-            for (int i = 0; i < nefc; i++) {
-                int meta = rmeta[i], type = meta & 3, sub = (meta >> 12) & 255, tA = ((meta >> 20) & 15) - 1, tB = ((meta >> 24) & 15) - 1;
-                if (noslip && !(type == R_FLOSS || (type == R_CONTACT && sub > 0))) continue;
-                if (act16) {
-                    real res = row_dot(i, tA, tB, qacc, l16) - raref[i];
-                    real f0 = rf[i], den = rden[i];
-                    if (!noslip) { res += rR[i] * f0; den += rR[i]; }
-                    else den = tmax(den, real(1e-15));
-                    real f = f0 - res / den;
-                    if (type == R_FLOSS) f = tclamp(f, -rmu[i], rmu[i]);
-                    else if (type == R_LIMIT) f = tmax(f, real(0));
-                    else if (type == R_CONTACT && sub == 0) f = tmax(f, real(0));
-                    row_apply(i, tA, tB, qacc, l16, f - f0);
-                    if (l16 == 0) rf[i] = f;
-                }
-                GSYNC();
-                if (type == R_CONTACT && sub > 0) {
-                    int first = raux[i], dim = m.pair_condim[cpair[(meta >> 2) & 1023]];
-                    if (sub == dim - 1 && act16) {
-                        // project the friction block back onto the elliptic cone
-                        real fn = rf[first], s2 = 0;
-                        for (int s = 1; s < dim; s++) { real t = rf[first + s] / tmax(real(1e-15), rmu[first + s]); s2 += t * t; }
-                        if (s2 > fn * fn) {
-                            real sc = fn / sqrt(s2);
-                            for (int s = 1; s < dim; s++) {
-                                int rr = first + s, mt = rmeta[rr], a2 = ((mt >> 20) & 15) - 1, b2 = ((mt >> 24) & 15) - 1;
-                                real fo = rf[rr], fnw = fo * sc;
-                                row_apply(rr, a2, b2, qacc, l16, fnw - fo);
-                                GSYNC();
-                                if (l16 == 0) rf[rr] = fnw;
-                            }
-                        }
-                    }
-                    GSYNC();
-                }
-            }
-        }
+        // Gauss-Seidel sweeps (+ noslip sweeps) in the register-resident wave kernel
+        static_assert(G == 64, "the solver maps one env to one wavefront");
+        pgs_wave<real>((LDS_PTR(RowS<real>))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const real))rJ, (LDS_PTR(const real))rB, (LDS_PTR(real))qacc, m.nv, nefc,
+                       pgs_iters, m.noslip_iters);
+        GSYNC();
         // qfrc_constraint = J^T f
         for (int k = lane; k < m.nv; k += G) {
             int t = m.dof_tree[k], kk = k - m.tree_dofadr[t];
             real s = 0;
             for (int i = 0; i < nefc; i++) {
                 int meta = rmeta[i], tA = ((meta >> 20) & 15) - 1, tB = ((meta >> 24) & 15) - 1;
-                if (tA == t) s += rJ[ROW_W * i + kk] * rf[i];
-                else if (tB == t) s += rJ[ROW_W * i + TREE_W + kk] * rf[i];
+                if (tA == t) s += rJ[ROW_W * i + kk] * rowS[8 * i + 6];
+                else if (tB == t) s += rJ[ROW_W * i + TREE_W + kk] * rowS[8 * i + 6];
             }
             fcon[k] = s;
         }
@@ -911,14 +1023,72 @@ struct Env {
 
 // one wave per block, 64/G envs per wave
 template <typename real, int G>
-__global__ void __launch_bounds__(64) k_phys(DevModel<real> m, Layout lay, int N, int nsub, int pgs_iters, const float* __restrict__ action,
+__global__ void __launch_bounds__(64) k_phys(DevModel<real> mg, Layout lay, MOff mo, const real* __restrict__ img_real, const int* __restrict__ img_int, int N, int nsub, int pgs_iters, const float* __restrict__ action,
                                              int want_reward, real* __restrict__ g_qpos, real* __restrict__ g_qvel, real* __restrict__ g_ctrl,
                                              real* __restrict__ g_warm, int* __restrict__ g_latch, double* __restrict__ o_agent,
                                              int* __restrict__ o_reward, unsigned char* __restrict__ o_success, int* __restrict__ o_ncon,
-                                             int* __restrict__ o_cpairs, double* __restrict__ o_cdist, int* __restrict__ o_diag, int max_reward, int export_contacts) {
+                                             int* __restrict__ o_cpairs, double* __restrict__ o_cdist, int* __restrict__ o_diag, int max_reward, int export_contacts, long long* __restrict__ o_prof) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int grp = threadIdx.x / G, lane = threadIdx.x % G;
     const int env = blockIdx.x * (64 / G) + grp;
+    // hot model tables -> LDS, once per block (the block is a single wave: a fence orders the copy)
+    real* lr = reinterpret_cast<real*>(smem + (size_t)(64 / G) * lay.bytes_per_env);
+    int* li = reinterpret_cast<int*>(lr + mo.nreal);
+    for (int i = threadIdx.x; i < mo.nreal; i += 64) lr[i] = img_real[i];
+    for (int i = threadIdx.x; i < mo.nint; i += 64) li[i] = img_int[i];
+    GSYNC();
+    DevModel<real> m = mg;
+    m.body_parent = li + mo.body_parent;
+    m.body_jntadr = li + mo.body_jntadr;
+    m.body_jntnum = li + mo.body_jntnum;
+    m.body_dofadr = li + mo.body_dofadr;
+    m.body_dofnum = li + mo.body_dofnum;
+    m.body_tree = li + mo.body_tree;
+    m.body_dofmask = li + mo.body_dofmask;
+    m.tree_bodyadr = li + mo.tree_bodyadr;
+    m.tree_bodylist = li + mo.tree_bodylist;
+    m.tree_dofadr = li + mo.tree_dofadr;
+    m.tree_dofnum = li + mo.tree_dofnum;
+    m.tree_madr = li + mo.tree_madr;
+    m.jnt_type = li + mo.jnt_type;
+    m.jnt_qposadr = li + mo.jnt_qposadr;
+    m.jnt_dofadr = li + mo.jnt_dofadr;
+    m.jnt_actfrclimited = li + mo.jnt_actfrclimited;
+    m.limited_jnt = li + mo.limited_jnt;
+    m.dof_body = li + mo.dof_body;
+    m.dof_parent = li + mo.dof_parent;
+    m.dof_tree = li + mo.dof_tree;
+    m.dof_jnt = li + mo.dof_jnt;
+    m.floss_dof = li + mo.floss_dof;
+    m.ment_i = li + mo.ment_i;
+    m.ment_j = li + mo.ment_j;
+    m.act_dof = li + mo.act_dof;
+    m.act_qposadr = li + mo.act_qposadr;
+    m.act_ctrllimited = li + mo.act_ctrllimited;
+    m.geom_type = li + mo.geom_type;
+    m.geom_body = li + mo.geom_body;
+    m.geom_static = li + mo.geom_static;
+    m.body_pos = lr + mo.body_pos;
+    m.body_quat = lr + mo.body_quat;
+    m.body_mass = lr + mo.body_mass;
+    m.body_ipos = lr + mo.body_ipos;
+    m.body_inertia = lr + mo.body_inertia;
+    m.body_invweight0 = lr + mo.body_invweight0;
+    m.jnt_pos = lr + mo.jnt_pos;
+    m.jnt_axis = lr + mo.jnt_axis;
+    m.jnt_range = lr + mo.jnt_range;
+    m.jnt_actfrcrange = lr + mo.jnt_actfrcrange;
+    m.jnt_margin = lr + mo.jnt_margin;
+    m.dof_armature = lr + mo.dof_armature;
+    m.dof_damping = lr + mo.dof_damping;
+    m.dof_frictionloss = lr + mo.dof_frictionloss;
+    m.dof_invweight0 = lr + mo.dof_invweight0;
+    m.act_kp = lr + mo.act_kp;
+    m.act_kv = lr + mo.act_kv;
+    m.act_gear = lr + mo.act_gear;
+    m.act_ctrlrange = lr + mo.act_ctrlrange;
+    m.geom_cpos = lr + mo.geom_cpos;
+    m.geom_rbound = lr + mo.geom_rbound;
     if (env >= N) return;  // whole groups drop out together; no block barrier is used below
     real* r = reinterpret_cast<real*>(smem + (size_t)grp * lay.bytes_per_env);
     int* ii = reinterpret_cast<int*>(r + lay.nreal);
@@ -945,16 +1115,19 @@ __global__ void __launch_bounds__(64) k_phys(DevModel<real> m, Layout lay, int N
         }
         GSYNC();
     }
+    long long tp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF(k, stmt) do { if (o_prof) { long long t0_ = __builtin_readcyclecounter(); stmt; tp[k] += __builtin_readcyclecounter() - t0_; } else { stmt; } } while (0)
     for (int s = 0; s < nsub; s++) {
-        E.kinematics();
-        E.crb();
-        E.rne_bias();
-        E.smooth();
-        E.collide();
-        E.make_constraints();
-        E.solve(pgs_iters);
-        E.euler();
+        PROF(0, E.kinematics());
+        PROF(1, E.crb());
+        PROF(2, E.rne_bias());
+        PROF(3, E.smooth());
+        PROF(4, E.collide());
+        PROF(5, E.make_constraints());
+        PROF(6, E.solve(pgs_iters));
+        PROF(7, E.euler());
     }
+    if (o_prof && lane == 0) for (int k = 0; k < 8; k++) o_prof[(size_t)env * 8 + k] = tp[k];
     // trailing refresh of the position-dependent quantities of the final state
     int nefc_last = ii[lay.misc + 1];
     E.kinematics();
@@ -1007,8 +1180,14 @@ struct PhysHost {
     double *d_qpos_home = nullptr, *d_ctrl_home = nullptr;
     int* d_obj_qadr = nullptr;
     int *d_ncon = nullptr, *d_cpairs = nullptr, *d_diag = nullptr;
+    long long* d_prof = nullptr;   // optional per-env phase cycle counters (option "profile_phases")
     double* d_cdist = nullptr;
 
+    std::vector<int> img_int;
+    std::vector<double> img_real;
+    MOff moff;
+    void* d_img_real = nullptr;
+    int* d_img_int = nullptr;
     template <typename T>
     T* up(const std::vector<T>& v) {
         void* p = nullptr;
@@ -1093,23 +1272,23 @@ struct PhysHost {
         for (int j = 0; j < m.njnt; j++) if (jl[j]) lj.push_back(j);
         m.nfloss = (int)fl.size();
         m.nlimited = (int)lj.size();
-        m.body_parent = up(body_parent); m.body_jntadr = up(I("body_jntadr")); m.body_jntnum = up(I("body_jntnum"));
-        m.body_dofadr = up(body_dofadr); m.body_dofnum = up(body_dofnum); m.body_tree = up(body_tree); m.body_dofmask = up(mask);
-        m.body_pos = upr<real>(bpos); m.body_quat = upr<real>(bquat); m.body_mass = upr<real>(F("body_mass")); m.body_ipos = upr<real>(F("body_ipos"));
-        m.body_inertia = upr<real>(F("body_inertia")); m.body_invweight0 = upr<real>(F("body_invweight0"));
+        m.body_parent = up(body_parent); moff.body_parent = (int)img_int.size(); { auto v_ = body_parent; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.body_jntadr = up(I("body_jntadr")); moff.body_jntadr = (int)img_int.size(); { auto v_ = I("body_jntadr"); img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.body_jntnum = up(I("body_jntnum")); moff.body_jntnum = (int)img_int.size(); { auto v_ = I("body_jntnum"); img_int.insert(img_int.end(), v_.begin(), v_.end()); }
+        m.body_dofadr = up(body_dofadr); moff.body_dofadr = (int)img_int.size(); { auto v_ = body_dofadr; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.body_dofnum = up(body_dofnum); moff.body_dofnum = (int)img_int.size(); { auto v_ = body_dofnum; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.body_tree = up(body_tree); moff.body_tree = (int)img_int.size(); { auto v_ = body_tree; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.body_dofmask = up(mask); moff.body_dofmask = (int)img_int.size(); { auto v_ = mask; img_int.insert(img_int.end(), v_.begin(), v_.end()); }
+        m.body_pos = upr<real>(bpos); moff.body_pos = (int)img_real.size(); { auto v_ = bpos; img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.body_quat = upr<real>(bquat); moff.body_quat = (int)img_real.size(); { auto v_ = bquat; img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.body_mass = upr<real>(F("body_mass")); moff.body_mass = (int)img_real.size(); { auto v_ = F("body_mass"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.body_ipos = upr<real>(F("body_ipos")); moff.body_ipos = (int)img_real.size(); { auto v_ = F("body_ipos"); img_real.insert(img_real.end(), v_.begin(), v_.end()); }
+        m.body_inertia = upr<real>(F("body_inertia")); moff.body_inertia = (int)img_real.size(); { auto v_ = F("body_inertia"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.body_invweight0 = upr<real>(F("body_invweight0")); moff.body_invweight0 = (int)img_real.size(); { auto v_ = F("body_invweight0"); img_real.insert(img_real.end(), v_.begin(), v_.end()); }
         m.static_xpos = upr<real>(sx); m.static_xmat = upr<real>(sm);
-        m.tree_bodyadr = up(tba); m.tree_bodylist = up(tbl); m.tree_dofadr = up(tree_dofadr); m.tree_dofnum = up(tree_dofnum); m.tree_madr = up(madr);
-        m.jnt_type = up(I("jnt_type")); m.jnt_qposadr = up(I("jnt_qposadr")); m.jnt_dofadr = up(I("jnt_dofadr"));
-        m.jnt_actfrclimited = up(I("jnt_actfrclimited")); m.limited_jnt = up(lj);
-        m.jnt_pos = upr<real>(F("jnt_pos")); m.jnt_axis = upr<real>(F("jnt_axis")); m.jnt_range = upr<real>(F("jnt_range"));
-        m.jnt_actfrcrange = upr<real>(F("jnt_actfrcrange")); m.jnt_solref = upr<real>(F("jnt_solref")); m.jnt_solimp = upr<real>(F("jnt_solimp"));
-        m.jnt_margin = upr<real>(F("jnt_margin"));
-        m.dof_body = up(dof_body); m.dof_parent = up(dof_parent); m.dof_tree = up(dof_tree); m.dof_jnt = up(I("dof_jnt"));
-        m.floss_dof = up(fl); m.ment_i = up(mi); m.ment_j = up(mj);
-        m.dof_armature = upr<real>(F("dof_armature")); m.dof_damping = upr<real>(F("dof_damping")); m.dof_frictionloss = upr<real>(floss);
-        m.dof_invweight0 = upr<real>(F("dof_invweight0")); m.dof_solref = upr<real>(F("dof_solref")); m.dof_solimp = upr<real>(F("dof_solimp"));
-        m.act_dof = up(I("act_dof")); m.act_qposadr = up(I("act_qposadr")); m.act_ctrllimited = up(I("act_ctrllimited"));
-        m.act_kp = upr<real>(F("act_kp")); m.act_kv = upr<real>(F("act_kv")); m.act_gear = upr<real>(F("act_gear")); m.act_ctrlrange = upr<real>(F("act_ctrlrange"));
+        m.tree_bodyadr = up(tba); moff.tree_bodyadr = (int)img_int.size(); { auto v_ = tba; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.tree_bodylist = up(tbl); moff.tree_bodylist = (int)img_int.size(); { auto v_ = tbl; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.tree_dofadr = up(tree_dofadr); moff.tree_dofadr = (int)img_int.size(); { auto v_ = tree_dofadr; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.tree_dofnum = up(tree_dofnum); moff.tree_dofnum = (int)img_int.size(); { auto v_ = tree_dofnum; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.tree_madr = up(madr); moff.tree_madr = (int)img_int.size(); { auto v_ = madr; img_int.insert(img_int.end(), v_.begin(), v_.end()); }
+        m.jnt_type = up(I("jnt_type")); moff.jnt_type = (int)img_int.size(); { auto v_ = I("jnt_type"); img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.jnt_qposadr = up(I("jnt_qposadr")); moff.jnt_qposadr = (int)img_int.size(); { auto v_ = I("jnt_qposadr"); img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.jnt_dofadr = up(I("jnt_dofadr")); moff.jnt_dofadr = (int)img_int.size(); { auto v_ = I("jnt_dofadr"); img_int.insert(img_int.end(), v_.begin(), v_.end()); }
+        m.jnt_actfrclimited = up(I("jnt_actfrclimited")); moff.jnt_actfrclimited = (int)img_int.size(); { auto v_ = I("jnt_actfrclimited"); img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.limited_jnt = up(lj); moff.limited_jnt = (int)img_int.size(); { auto v_ = lj; img_int.insert(img_int.end(), v_.begin(), v_.end()); }
+        m.jnt_pos = upr<real>(F("jnt_pos")); moff.jnt_pos = (int)img_real.size(); { auto v_ = F("jnt_pos"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.jnt_axis = upr<real>(F("jnt_axis")); moff.jnt_axis = (int)img_real.size(); { auto v_ = F("jnt_axis"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.jnt_range = upr<real>(F("jnt_range")); moff.jnt_range = (int)img_real.size(); { auto v_ = F("jnt_range"); img_real.insert(img_real.end(), v_.begin(), v_.end()); }
+        m.jnt_actfrcrange = upr<real>(F("jnt_actfrcrange")); moff.jnt_actfrcrange = (int)img_real.size(); { auto v_ = F("jnt_actfrcrange"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.jnt_solref = upr<real>(F("jnt_solref")); m.jnt_solimp = upr<real>(F("jnt_solimp"));
+        m.jnt_margin = upr<real>(F("jnt_margin")); moff.jnt_margin = (int)img_real.size(); { auto v_ = F("jnt_margin"); img_real.insert(img_real.end(), v_.begin(), v_.end()); }
+        m.dof_body = up(dof_body); moff.dof_body = (int)img_int.size(); { auto v_ = dof_body; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.dof_parent = up(dof_parent); moff.dof_parent = (int)img_int.size(); { auto v_ = dof_parent; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.dof_tree = up(dof_tree); moff.dof_tree = (int)img_int.size(); { auto v_ = dof_tree; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.dof_jnt = up(I("dof_jnt")); moff.dof_jnt = (int)img_int.size(); { auto v_ = I("dof_jnt"); img_int.insert(img_int.end(), v_.begin(), v_.end()); }
+        m.floss_dof = up(fl); moff.floss_dof = (int)img_int.size(); { auto v_ = fl; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.ment_i = up(mi); moff.ment_i = (int)img_int.size(); { auto v_ = mi; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.ment_j = up(mj); moff.ment_j = (int)img_int.size(); { auto v_ = mj; img_int.insert(img_int.end(), v_.begin(), v_.end()); }
+        m.dof_armature = upr<real>(F("dof_armature")); moff.dof_armature = (int)img_real.size(); { auto v_ = F("dof_armature"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.dof_damping = upr<real>(F("dof_damping")); moff.dof_damping = (int)img_real.size(); { auto v_ = F("dof_damping"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.dof_frictionloss = upr<real>(floss); moff.dof_frictionloss = (int)img_real.size(); { auto v_ = floss; img_real.insert(img_real.end(), v_.begin(), v_.end()); }
+        m.dof_invweight0 = upr<real>(F("dof_invweight0")); moff.dof_invweight0 = (int)img_real.size(); { auto v_ = F("dof_invweight0"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.dof_solref = upr<real>(F("dof_solref")); m.dof_solimp = upr<real>(F("dof_solimp"));
+        m.act_dof = up(I("act_dof")); moff.act_dof = (int)img_int.size(); { auto v_ = I("act_dof"); img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.act_qposadr = up(I("act_qposadr")); moff.act_qposadr = (int)img_int.size(); { auto v_ = I("act_qposadr"); img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.act_ctrllimited = up(I("act_ctrllimited")); moff.act_ctrllimited = (int)img_int.size(); { auto v_ = I("act_ctrllimited"); img_int.insert(img_int.end(), v_.begin(), v_.end()); }
+        m.act_kp = upr<real>(F("act_kp")); moff.act_kp = (int)img_real.size(); { auto v_ = F("act_kp"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.act_kv = upr<real>(F("act_kv")); moff.act_kv = (int)img_real.size(); { auto v_ = F("act_kv"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.act_gear = upr<real>(F("act_gear")); moff.act_gear = (int)img_real.size(); { auto v_ = F("act_gear"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.act_ctrlrange = upr<real>(F("act_ctrlrange")); moff.act_ctrlrange = (int)img_real.size(); { auto v_ = F("act_ctrlrange"); img_real.insert(img_real.end(), v_.begin(), v_.end()); }
         m.eq_dof1 = up(I("eq_dof1")); m.eq_dof2 = up(I("eq_dof2")); m.eq_qpos1 = up(I("eq_qpos1")); m.eq_qpos2 = up(I("eq_qpos2"));
         m.eq_polycoef = upr<real>(F("eq_polycoef")); m.eq_solref = upr<real>(F("eq_solref")); m.eq_solimp = upr<real>(F("eq_solimp"));
         m.qpos0 = upr<real>(F("qpos0"));
@@ -1153,14 +1332,21 @@ struct PhysHost {
                     }
             }
         }
-        m.geom_type = up(I("geom_type")); m.geom_body = up(gbody); m.geom_hull = up(I("geom_hull")); m.geom_class = up(I("geom_class")); m.geom_static = up(gstat);
-        m.geom_pos = upr<real>(gpos); m.geom_mat = upr<real>(gmat); m.geom_size = upr<real>(F("geom_size")); m.geom_cpos = upr<real>(gcp);
-        m.geom_rbound = upr<real>(F("geom_rbound")); m.geom_xpos0 = upr<real>(gx0); m.geom_xmat0 = upr<real>(gm0); m.geom_cen0 = upr<real>(gc0); m.geom_aabb0 = upr<real>(gaabb);
+        m.geom_type = up(I("geom_type")); moff.geom_type = (int)img_int.size(); { auto v_ = I("geom_type"); img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.geom_body = up(gbody); moff.geom_body = (int)img_int.size(); { auto v_ = gbody; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.geom_hull = up(I("geom_hull")); m.geom_class = up(I("geom_class")); m.geom_static = up(gstat); moff.geom_static = (int)img_int.size(); { auto v_ = gstat; img_int.insert(img_int.end(), v_.begin(), v_.end()); }
+        m.geom_pos = upr<real>(gpos); m.geom_mat = upr<real>(gmat); m.geom_size = upr<real>(F("geom_size")); m.geom_cpos = upr<real>(gcp); moff.geom_cpos = (int)img_real.size(); { auto v_ = gcp; img_real.insert(img_real.end(), v_.begin(), v_.end()); }
+        m.geom_rbound = upr<real>(F("geom_rbound")); moff.geom_rbound = (int)img_real.size(); { auto v_ = F("geom_rbound"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.geom_xpos0 = upr<real>(gx0); m.geom_xmat0 = upr<real>(gm0); m.geom_cen0 = upr<real>(gc0); m.geom_aabb0 = upr<real>(gaabb);
         m.hull_vert = upr<real>(F("hull_vert"));
         m.pair_geom = up(I("pair_geom")); m.pair_condim = up(I("pair_condim"));
         m.pair_friction = upr<real>(F("pair_friction")); m.pair_solref = upr<real>(F("pair_solref")); m.pair_solimp = upr<real>(F("pair_solimp"));
         m.pair_margin = upr<real>(F("pair_margin")); m.pair_gap = upr<real>(F("pair_gap"));
         m.obs_qposadr = up(I("obs_qposadr")); m.obs_offset = upr<real>(F("obs_offset")); m.obs_scale = upr<real>(F("obs_scale"));
+        // packed image of the hot tables: copied into LDS by every block (global latency is paid once per launch)
+        while (img_real.size() % 4) img_real.push_back(0.0);
+        while (img_int.size() % 4) img_int.push_back(0);
+        moff.nreal = (int)img_real.size();
+        moff.nint = (int)img_int.size();
+        d_img_real = (void*)upr<real>(img_real);
+        d_img_int = up(img_int);
     }
 
     void make_layout(int nq, int nv, int nu, int nb, int ng, int msize) {
@@ -1177,12 +1363,12 @@ struct PhysHost {
         int bq = o;
         L.cdist = bq; bq += maxcon; L.cpos = bq; bq += 3 * maxcon; L.cnrm = bq; bq += 3 * maxcon;
         L.rJ = bq; bq += ROW_W * maxefc; L.rB = bq; bq += ROW_W * maxefc;
-        L.raref = bq; bq += maxefc; L.rR = bq; bq += maxefc; L.rden = bq; bq += maxefc; L.rf = bq; bq += maxefc; L.rmu = bq; bq += maxefc;
+        bq = (bq + 3) & ~3; L.rowS = bq; bq += 8 * maxefc;
         o = a > bq ? a : bq;
         L.nreal = (o + 3) & ~3;
         int io = 0;
         auto Iq = [&](int n) { int x = io; io += n; return x; };
-        L.cand = Iq(CAND_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.cgeom = Iq(0); L.rmeta = Iq(maxefc); L.raux = Iq(maxefc); L.misc = Iq(4);
+        L.cand = Iq(CAND_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); io = (io + 3) & ~3; L.rowI = Iq(2 * maxefc); L.misc = Iq(4);
         L.nint = (io + 3) & ~3;
         L.maxcon = maxcon;
         L.maxefc = maxefc;
@@ -1238,6 +1424,11 @@ struct PhysHost {
         std::string n(name);
         if (n == "pgs_iters") { pgs_iters = (int)v; return true; }
         if (n == "export_contacts") { export_contacts = v != 0; return true; }
+        if (n == "profile_phases") {
+            if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * 8, 0));
+            if (v == 0) d_prof = nullptr;
+            return true;
+        }
         if (n == "maxefc" || n == "maxcon") {
             int x = (int)v;
             if (x < 16 || x > 1000) return false;
@@ -1247,7 +1438,6 @@ struct PhysHost {
             try { alloc_contacts(); } catch (...) { return false; }
             return true;
         }
-        if (n == "group") { int g = (int)v; if (g == 16 || g == 32 || g == 64) { group = g; return true; } return false; }
         return false;
     }
 
@@ -1255,7 +1445,7 @@ struct PhysHost {
     int launch_t(hipStream_t st, const DevModel<real>& m, int nsub, const float* action, void* qpos, void* qvel, void* ctrl, void* warm,
                  int* latch, double* agent, int32_t* reward, uint8_t* success, std::string& err) {
         int epb = 64 / G;
-        size_t shmem = (size_t)lay.bytes_per_env * epb;
+        size_t shmem = (size_t)lay.bytes_per_env * epb + (size_t)moff.nreal * sizeof(real) + (size_t)moff.nint * 4;
         auto kern = k_phys<real, G>;
         static bool attr_set = false;
         if (!attr_set) {
@@ -1265,9 +1455,9 @@ struct PhysHost {
         }
         if (shmem > 160 * 1024) { err = "per-block LDS exceeds 160 KiB; lower maxefc/maxcon or raise the group size"; return -1; }
         dim3 grid((N + epb - 1) / epb);
-        hipLaunchKernelGGL(kern, grid, dim3(64), shmem, st, m, lay, N, nsub, pgs_iters, action, (reward || success) && (nsub > 0 || force_reward) ? 1 : 0,
+        hipLaunchKernelGGL(kern, grid, dim3(64), shmem, st, m, lay, moff, (const real*)d_img_real, (const int*)d_img_int, N, nsub, pgs_iters, action, (reward || success) && (nsub > 0 || force_reward) ? 1 : 0,
                            (real*)qpos, (real*)qvel, (real*)ctrl, (real*)warm, latch, agent, (int*)reward, (unsigned char*)success, d_ncon,
-                           d_cpairs, d_cdist, d_diag, max_reward, export_contacts);
+                           d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("physics kernel launch: ") + hipGetErrorString(e); return -3; }
         return 0;
@@ -1280,11 +1470,7 @@ struct PhysHost {
             // double precision doubles the LDS record; one env per wave only
             return launch_t<double, 64>(st, md, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
         }
-        switch (group) {
-            case 16: return launch_t<float, 16>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
-            case 32: return launch_t<float, 32>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
-            default: return launch_t<float, 64>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
-        }
+        return launch_t<float, 64>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
     }
 };
 

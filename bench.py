@@ -139,7 +139,6 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--group", type=int, default=0, help="lanes per env (16/32/64); 0 = library default")
     ap.add_argument("--pgs-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -171,8 +170,6 @@ def main():
     h.check(L.avsim_set_stream(h.h, stream.cuda_stream))
     for name, v in (("pgs_iters", args.pgs_iters), ("export_contacts", 0), ("kernel_timing", 1)):
         h.check(L.avsim_set_option(h.h, name.encode(), float(v)))
-    if args.group:
-        h.check(L.avsim_set_option(h.h, b"group", float(args.group)))
 
     dev = torch.device("cuda", local)
     total = args.warmup + args.steps
@@ -247,7 +244,7 @@ def main():
             "config": {"workload": "gym_guided_vision/SlotInsertion-3Arms-v0 (BASELINE configs[1] at the metric's 4096 envs): "
                                    "23-D Cartesian action -> DLS IK on 3 arms -> 20 substeps (dt 0.002) + agent_pos + reward/success, no render",
                        "envs_per_gpu": N, "envs_total": n_total, "substeps_per_step": 20, "pgs_iters": args.pgs_iters,
-                       "noslip_iters": 3, "lanes_per_env": args.group or 64, "episode_len": EPISODE_LEN,
+                       "noslip_iters": 3, "lanes_per_env": 64, "episode_len": EPISODE_LEN,
                        "physics_substeps_per_s": value * 20,
                        "overflow_envs": int((diag[:, 2] != 0).sum()), "nan_envs": int((diag[:, 3] & 1).sum()),
                        "mean_ncon": float(diag[:, 0].mean()), "mean_nefc": float(diag[:, 1].mean())},

@@ -98,6 +98,10 @@ int avsim_get_contacts(avsim_t* h, int32_t* ncon, int32_t* geom_pairs, double* d
 /* per-env diagnostics of the last step: int32[N][4] = {ncon, nefc, overflow flag, nan flag} */
 int avsim_get_diag(avsim_t* h, int32_t* diag);
 
+/* debug: shader-clock cycles each env's wave spent in the 8 phases (kinematics, CRB, RNE, smooth, collide, rows,
+ * solve, integrate) during the last launch; needs avsim_set_option("profile_phases", 1); int64[N][8] */
+int avsim_get_phase_cycles(avsim_t* h, int64_t* out);
+
 /* stream / timing helpers (HIP events on the stream the kernels are launched on) */
 int avsim_sync(avsim_t* h);
 int avsim_set_stream(avsim_t* h, void* hip_stream);
