@@ -122,7 +122,7 @@ def cpu_baseline(n_total):
     from av_aloha_amd.build import build_oracle
     build_oracle()
     cores = max(1, min(os.cpu_count() or 1, 64))
-    per, steps = 2, 40                      # ~10-20 s: 2 envs x 40 env-steps per core at ~10 env-steps/s/core
+    per, steps = 4, 150                     # ~10-25 s per core: 4 envs x 150 env-steps at ~40-60 env-steps/s/core
     jobs = [(list(range(c * per, (c + 1) * per)), n_total, steps) for c in range(cores)]
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(cores) as pool:
@@ -162,7 +162,8 @@ def main():
     build_hip()
     N = args.envs_per_gpu
     n_total = N * world
-    ids = np.arange(rank * N, (rank + 1) * N)           # contiguous shard, global env ids
+    from av_aloha_amd.dist import gather_episode_stats, shard_ids
+    ids = shard_ids(rank, world, N)                     # contiguous shard, global env ids
     blob, _ = load_blob("slot_insertion", 3)
     h = _ffi.Handle(blob, N, local, _ffi.AVSIM_IO_DEVICE)
     L = h.L
@@ -205,11 +206,9 @@ def main():
     t0 = time.perf_counter()
     for t in range(args.warmup, total):
         do_step(t)
+    # end-of-rollout exchange: one all-gather (RCCL) of (return f32, success i32) per env
+    all_ret, all_succ = gather_episode_stats(ret, succ_any, dist)
     if dist is not None:
-        # end-of-rollout exchange: one all-gather of (return f32, success i32) per env
-        pack = torch.stack([ret, succ_any.to(torch.float32)], dim=1).contiguous()
-        gathered = [torch.empty_like(pack) for _ in range(world)]
-        dist.all_gather(gathered, pack)
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -247,7 +246,9 @@ def main():
                        "noslip_iters": 3, "lanes_per_env": 64, "episode_len": EPISODE_LEN,
                        "physics_substeps_per_s": value * 20,
                        "overflow_envs": int((diag[:, 2] != 0).sum()), "nan_envs": int((diag[:, 3] & 1).sum()),
-                       "mean_ncon": float(diag[:, 0].mean()), "mean_nefc": float(diag[:, 1].mean())},
+                       "mean_ncon": float(diag[:, 0].mean()), "mean_nefc": float(diag[:, 1].mean()),
+                       "gathered_envs": int(all_ret.numel()), "mean_return": float(all_ret.mean().item()),
+                       "success_rate": float(all_succ.to(torch.float32).mean().item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_phys<float>", "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": int(k_n.value),

@@ -234,6 +234,55 @@ def main():
         rw[f"{t}_pairs"] = np.array(seqs).reshape(S, L, C, 2)
         rw[f"{t}_reward"] = np.array(rewards, dtype=np.int32).reshape(S, L)
     np.savez_compressed(os.path.join(HERE, "reward_tables.npz"), **rw)
+
+    # ---- reset sampling (task `reset` overrides, env.py:474-501, 513-543, 604-637, 705-735, 792-818) ----
+    # run the reference's own reset() against a recording stand-in for dm_control's Physics: every
+    # `physics.bind(elem).qpos = value` is captured, so the draw order (incl. the discarded draws) is pinned
+    class Rec:
+        def __init__(self, log, elem):
+            object.__setattr__(self, "_log", log)
+            object.__setattr__(self, "_elem", elem)
+
+        def __setattr__(self, k, v):
+            self._log.append((self._elem, k, np.array(v, dtype=np.float64).copy()))
+
+    class RecPhysics:
+        def __init__(self):
+            self.log = []
+
+        def bind(self, elem):
+            return Rec(self.log, elem if isinstance(elem, str) else tuple(elem))
+
+        def reset(self):
+            pass
+
+        def forward(self):
+            pass
+
+    rs = {}
+    joints = {"insert_peg": ("_peg_joint", "_hole_joint"), "slot_insertion": ("_slot_joint", "_stick_joint"),
+              "sew_needle": ("_needle_joint", "_wall_joint"), "tube_transfer": ("_ball_joint", "_tube1_joint", "_tube2_joint"),
+              "hook_package": ("_hook_joint", "_package_joint")}
+    for t, cls in tasks.items():
+        env = object.__new__(cls)
+        env._physics = RecPhysics()
+        env.get_obs = lambda: None
+        for nm in ("_left_joints", "_right_joints", "_middle_joints", "_left_actuators", "_right_actuators", "_middle_actuators",
+                   "_left_gripper_joints", "_right_gripper_joints"):
+            setattr(env, nm, [nm + str(i) for i in range(7)])
+        env.left_gripper_unnorm_fn = env.right_gripper_unnorm_fn = lambda x: x * 0.035 + 0.002
+        for jn in joints[t]:
+            setattr(env, jn, jn)
+        out = []
+        for seed in range(16):
+            env._physics.log.clear()
+            np.random.seed(seed)
+            env.reset(seed=seed)
+            got = {e: v for e, k, v in env._physics.log if k == "qpos" and isinstance(e, str) and e in joints[t]}
+            out.append(np.stack([got[jn] for jn in joints[t]]))
+        rs[t] = np.stack(out)                      # [seed][object in the order of `joints[t]`][7]
+        rs[t + "_order"] = np.array(joints[t])
+    np.savez_compressed(os.path.join(HERE, "reset_samples.npz"), **rs)
     print("golden vectors written to", HERE)
 
 
