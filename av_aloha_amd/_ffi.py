@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libavsim.so")
 AVSIM_IO_DEVICE = 1
 AVSIM_F64_PHYSICS = 2
 IK_REFERENCE, IK_DLS = 0, 1
-NDIMS = 10
+NDIMS = 12
 
 _lib = None
 
@@ -85,7 +85,7 @@ class Handle:
         d = np.zeros(NDIMS, dtype=np.int32)
         self.check(L.avsim_dims(h, d.ctypes.data))
         (self.nq, self.nv, self.nu, self.nj, self.nobj, self.max_reward, self.num_envs, self.task_id,
-         self.maxcon, self.maxefc) = [int(x) for x in d]
+         self.maxcon, self.maxefc, self.lds_bytes, self.blocks_per_cu) = [int(x) for x in d]
         self.flags = flags
 
     def check(self, rc):

@@ -359,6 +359,8 @@ int avsim_dims(const avsim_t* h, int32_t d[AVSIM_NDIMS]) {
     if (!h || !d) return AVSIM_EINVAL;
     d[0] = h->nq; d[1] = h->nv; d[2] = h->nu; d[3] = h->nj; d[4] = h->nobj; d[5] = h->max_reward; d[6] = h->N;
     d[7] = h->task_id; d[8] = h->phys.maxcon; d[9] = h->phys.maxefc;
+    d[10] = (int32_t)h->phys.lds_bytes();
+    d[11] = (int32_t)(160 * 1024 / (h->phys.lds_bytes() ? h->phys.lds_bytes() : 1));
     return AVSIM_OK;
 }
 

@@ -121,9 +121,10 @@ struct Layout {
     // scratch union U, phase A
     int cinert, cvel, cacc, cfrc;
     // phase B
-    int cdist, cpos, cnrm, rJ, rB, rowS;
+    int cdist, cpos, cnrm, rJ, rB, rowS, gA;
     // ints
-    int cand, cpair, cefc, rmeta, rowI, misc, nint;
+    int cand, cpair, cefc, rmeta, rowI, gI, misc, nint;
+    int maxgrp;
     int maxcon, maxefc;
     int bytes_per_env;
 };
@@ -171,87 +172,119 @@ AVS_DEV double wave_sum(double x) {
 // registers, one dof per lane.  Per row: every lane fetches its J/B entry from the row's two tree windows
 // (chain-independent LDS reads), the row residual is a wave-wide DPP sum, the update is a register FMA.
 // Separate noinline function so that the sweep loop gets its own register allocation (no spills).
-// rowS: 8 reals per row (struct RowS); rowI: {dof windows adrA|nA<<8|adrB<<16|nB<<24, flags RF_* | dim<<8} per row.
 // ------------------------------------------------------------------------------------------------
+// Per-row solver record in LDS (8 reals): reference acceleration, regulariser, 1/(diag+R), 1/diag for the noslip
+// sweeps (0 = the row does not take part in them), clamp bounds, current force, 1/mu (friction rows of contacts).
 template <typename real>
 struct RowS {
     real aref, R, inv, invn, lo, hi, f, muinv;
 };
-enum { RF_NOSLIP = 1, RF_NORMAL = 2, RF_FRICTION = 4, RF_LASTFRIC = 8 };
 
-template <typename real>
-struct RowRegs {
-    real J, B, aref, R, inv, invn, lo, hi, f, muinv;
-    int flags;
-};
-
-template <typename real>
-AVS_DEV void pgs_load(RowRegs<real>& o, int i, int k, LDS_PTR(const RowS<real>) rowS, LDS_PTR(const int) rowI, LDS_PTR(const real) rJ,
-                      LDS_PTR(const real) rB) {
-    const int radr = rowI[2 * i];
-    o.flags = rowI[2 * i + 1];
-    const int ka = k - (radr & 255), kb = k - ((radr >> 16) & 255);
-    const bool inA = (unsigned)ka < (unsigned)((radr >> 8) & 255), inB = (unsigned)kb < (unsigned)((radr >> 24) & 255);
-    const int idx = ROW_W * i + (inA ? ka : (inB ? TREE_W + kb : 0));
-    const real j = rJ[idx], b = rB[idx];   // unconditional (always in range): keeps the loads off the exec-mask path
-    o.J = (inA || inB) ? j : real(0);
-    o.B = (inA || inB) ? b : real(0);
-    LDS_PTR(const real) S = (LDS_PTR(const real))(rowS + i);
-    o.aref = S[0]; o.R = S[1]; o.inv = S[2]; o.invn = S[3]; o.lo = S[4]; o.hi = S[5]; o.f = S[6]; o.muinv = S[7];
+AVS_DEV float oct_sum(float x) {   // sum over each aligned group of 8 lanes
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    return x;
 }
+AVS_DEV double oct_sum(double x) {
+    x += __shfl_xor(x, 1, 8);
+    x += __shfl_xor(x, 2, 8);
+    x += __shfl_xor(x, 4, 8);
+    return x;
+}
+AVS_DEV float lane_get(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
+AVS_DEV double lane_get(double x, int l) { return __shfl(x, l, 64); }
 
+constexpr int GRP_MAX = 6;   // rows per Gauss-Seidel group (a condim-6 contact is one group)
+
+// ------------------------------------------------------------------------------------------------
+// P8 inner loop, one env per wavefront: projected Gauss-Seidel over GROUPS of up to 6 consecutive rows.
+// A group's rows are relaxed in the reference order, but their mutual coupling A_rs = J_r M^-1 J_s^T is
+// precomputed (gA, lower triangle), so the sweep is mathematically identical to row-by-row GS while
+//   - the <=6 row residuals J_r.qacc are formed together: each 16-lane DPP row handles one matrix row
+//     (its two 8-dof tree windows), 4 rows per pass;
+//   - the sequential part runs on lanes 0..5 (lane r owns row r: force, bounds, couplings) with one
+//     v_readlane + one FMA per step;
+//   - the acceleration update is a returnless LDS atomic add per (row, dof), again 4 rows per pass.
+// A contact is exactly one group, so the elliptic-cone projection of its friction block is local to the group.
+// Separate noinline function: the sweep loop gets its own register allocation.
+// rowI[i] = dof windows of row i: adrA | nA << 8 | adrB << 16 | nB << 24.
+// ------------------------------------------------------------------------------------------------
 template <typename real>
-__device__ __attribute__((noinline)) void pgs_wave(LDS_PTR(RowS<real>) rowS, LDS_PTR(const int) rowI, LDS_PTR(const real) rJ, LDS_PTR(const real) rB,
-                                                   LDS_PTR(real) qacc_lds, int nv, int nefc, int iters, int noslip_iters) {
-    const int k = threadIdx.x & 63;
-    real q = k < nv ? qacc_lds[k] : real(0);
-    if (nefc <= 0) return;
-    for (int it = 0; it < iters + noslip_iters; it++) {
+__device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const real) rJ, LDS_PTR(const real) rB,
+                                                     LDS_PTR(real) q, LDS_PTR(const int) gI, LDS_PTR(const real) gA, int ngrp, int iters,
+                                                     int noslip_iters) {
+    const int lane = threadIdx.x & 63, d = lane >> 4, l16 = lane & 15, sh = l16 < TREE_W ? 0 : 16, k8 = l16 & (TREE_W - 1);
+    const int lr = lane < GRP_MAX ? lane : 0;          // row slot owned in the sequential phase
+    const int tri = lr * (lr - 1) / 2;                 // offset of that row in the packed lower triangle
+    if (ngrp <= 0) return;
+    // software pipeline: group headers two groups ahead, row windows one group ahead
+    int gi = __builtin_amdgcn_readfirstlane(gI[0]);
+    int gin = __builtin_amdgcn_readfirstlane(gI[ngrp > 1 ? 1 : 0]);
+    int ra0 = rowI[(gi & 0xffff) + d], ra1 = rowI[(gi & 0xffff) + 4 + d];
+    const int total = (iters + noslip_iters) * ngrp;
+    int g = 0, it = 0;
+    for (int step = 0; step < total; step++) {
         const bool noslip = it >= iters;
-        RowRegs<real> c, n;
-        pgs_load(c, 0, k, rowS, rowI, rJ, rB);
-        real fn = 0, s2 = 0;   // running normal force and friction-ellipse norm of the current contact
-        for (int i = 0; i < nefc; i++) {
-            // software pipeline: fetch row i+1 while row i's dependency chain runs (forces of later rows are
-            // not touched by row i, so the early read of n.f is safe; the cone projection below re-reads)
-            const int inext = i + 1 < nefc ? i + 1 : i;
-            pgs_load(n, inext, k, rowS, rowI, rJ, rB);
-            const bool skip = noslip && !(c.flags & RF_NOSLIP);
-            if (!skip) {
-                const real R = noslip ? real(0) : c.R, inv = noslip ? c.invn : c.inv;
-                const real res = wave_sum(c.J * q) - c.aref + R * c.f;
-                real f = c.f - res * inv;
-                f = tmin(tmax(f, c.lo), c.hi);
-                q += c.B * (f - c.f);
-                if (k == 0) rowS[i].f = f;
-                c.f = f;
-            }
-            if (c.flags & RF_NORMAL) { fn = c.f; s2 = 0; }
-            if (c.flags & RF_FRICTION) { const real t = c.f * c.muinv; s2 += t * t; }
-            if ((c.flags & RF_LASTFRIC) && s2 > fn * fn) {
-                // sliding: scale the friction block back onto the elliptic cone
-                const int dim = c.flags >> 8, first = i - (dim - 1);
-                const real sc = fn / sqrt(s2);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                for (int s = 1; s < dim; s++) {
-                    const int rr = first + s, ra2 = rowI[2 * rr];
-                    const int ka2 = k - (ra2 & 255), kb2 = k - ((ra2 >> 16) & 255);
-                    const bool inA2 = (unsigned)ka2 < (unsigned)((ra2 >> 8) & 255), inB2 = (unsigned)kb2 < (unsigned)((ra2 >> 24) & 255);
-                    const real B2 = (inA2 || inB2) ? rB[ROW_W * rr + (inA2 ? ka2 : TREE_W + kb2)] : real(0);
-                    const real fo = rowS[rr].f, fnw = fo * sc;
-                    q += B2 * (fnw - fo);
-                    __builtin_amdgcn_wave_barrier();
-                    if (k == 0) rowS[rr].f = fnw;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                if (inext == i) { /* nothing prefetched */ }
-            }
-            c = n;
+        const int start = gi & 0xffff, cnt = (gi >> 16) & 15;
+        const bool contact = (gi >> 24) & 1;
+        const int g1 = g + 1 < ngrp ? g + 1 : 0, g2 = g1 + 1 < ngrp ? g1 + 1 : 0;
+        // ---- issue every LDS read of this group (and the look-ahead ones) in one batch ----
+        const int ginn_v = gI[g2];
+        const int ra0n = rowI[(gin & 0xffff) + d], ra1n = rowI[(gin & 0xffff) + 4 + d];
+        const int row0 = start + d, row1 = start + 4 + d;
+        const int adr0 = ((ra0 >> sh) & 255) + k8, adr1 = ((ra1 >> sh) & 255) + k8;
+        const bool in0 = d < cnt && k8 < ((ra0 >> (sh + 8)) & 255), in1 = 4 + d < cnt && k8 < ((ra1 >> (sh + 8)) & 255);
+        const real J0 = rJ[ROW_W * row0 + l16], B0 = rB[ROW_W * row0 + l16], q0 = q[in0 ? adr0 : 0];
+        const real J1 = rJ[ROW_W * row1 + l16], B1 = rB[ROW_W * row1 + l16], q1 = q[in1 ? adr1 : 0];
+        const bool mine = lane < cnt;
+        LDS_PTR(real) S = rowS + 8 * (start + (mine ? lane : 0));
+        const real aref = S[0], R = S[1], inv2 = S[2], inv3 = S[3], lo = S[4], hi = S[5], f0 = S[6], muinv = S[7];
+        real a[GRP_MAX - 1];
+#pragma unroll
+        for (int s = 0; s < GRP_MAX - 1; s++) a[s] = gA[16 * g + tri + s];
+#pragma unroll
+        for (int s = 0; s < GRP_MAX - 1; s++) a[s] = (mine && s < lane) ? a[s] : real(0);
+        // ---- row residual dot products: one matrix row per 16-lane DPP row, two passes ----
+        real x0 = row16_sum(in0 ? J0 * q0 : real(0)), x1 = row16_sum(in1 ? J1 * q1 : real(0));
+        const real y0 = __shfl(x0, 16 * (lane & 3), 64), y1 = __shfl(x1, 16 * (lane & 3), 64);
+        const real dot = lane < 4 ? y0 : y1;
+        // ---- sequential relaxation on lanes 0..cnt-1 (lane r = row start + r) ----
+        const real inv = noslip ? inv3 : inv2;
+        real res = dot - aref + (noslip ? real(0) : R * f0);
+        real f = f0;
+#pragma unroll
+        for (int s = 0; s < GRP_MAX; s++) {
+            const real fs = tmin(tmax(f0 - res * inv, lo), hi);
+            const real ds = s < cnt ? lane_get(fs - f0, s) : real(0);
+            if (lane == s && s < cnt) f = fs;
+            if (s < GRP_MAX - 1) res += a[s < GRP_MAX - 1 ? s : 0] * ds;
         }
+        // ---- elliptic cone: scale the friction block back when sliding ----
+        if (contact && cnt > 1) {
+            const real fn = lane_get(f, 0);
+            const real t = (mine && lane >= 1) ? f * muinv : real(0);
+            const real s2 = lane_get(oct_sum(t * t), 0);
+            if (s2 > fn * fn) {
+                const real sc = fn / sqrt(s2);
+                if (mine && lane >= 1) f *= sc;
+            }
+        }
+        if (mine) S[6] = f;
+        const real delta = mine ? f - f0 : real(0);
+        // ---- qacc += B_r^T delta_r, 4 rows per pass ----
+        const real dd0 = __shfl(delta, d, 64), dd1 = __shfl(delta, 4 + d, 64);
+        if (in0) __hip_atomic_fetch_add(q + adr0, B0 * dd0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (in1) __hip_atomic_fetch_add(q + adr1, B1 * dd1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        gi = gin;
+        gin = __builtin_amdgcn_readfirstlane(ginn_v);
+        ra0 = ra0n;
+        ra1 = ra1n;
+        g = g1;
+        if (g1 == 0) it++;
     }
-    if (k < nv) qacc_lds[k] = q;
 }
 
 template <int G>
@@ -721,6 +754,7 @@ struct Env {
         }
         int ovf = 0;
         if (nefc > lay.maxefc) { nefc = lay.maxefc; ovf = 1; }
+        if (lane == 0) misc[4] = nefc;   // rows before the contacts
         int cend = nefc;   // end of the last contact block that fits under the row cap (row offsets are monotonic)
         for (int base = 0; base < ncon; base += G) {
             int c = base + lane, dim = 0;
@@ -864,21 +898,64 @@ struct Env {
             for (int k = 0; k < nB; k++) jw += J[TREE_W + k] * warm[b0 + k];
             const real big = real(1e30);
             real lo = -big, hi = big, muinv = 0;
-            int fl = 0;
-            if (type == R_FLOSS) { lo = -floss; hi = floss; fl = RF_NOSLIP; }
+            bool ns = false;   // takes part in the noslip sweeps (dry friction and contact friction rows)
+            if (type == R_FLOSS) { lo = -floss; hi = floss; ns = true; }
             else if (type == R_LIMIT) lo = 0;
             else if (type == R_CONTACT) {
-                if (sub == 0) { lo = 0; fl = RF_NORMAL; }
-                else { fl = RF_NOSLIP | RF_FRICTION | (sub == dim - 1 ? RF_LASTFRIC : 0); muinv = real(1) / tmax(real(1e-15), floss); }
-                fl |= dim << 8;
+                if (sub == 0) lo = 0;
+                else { ns = true; muinv = real(1) / tmax(real(1e-15), floss); }
             }
             real f = -(jw - aref) / R;
             f = tmin(tmax(f, lo), hi);
             real* S = rowS + 8 * i;
-            S[0] = aref; S[1] = R; S[2] = real(1) / (dg + R); S[3] = real(1) / tmax(dg, real(1e-15)); S[4] = lo; S[5] = hi; S[6] = f; S[7] = muinv;
-            rowI[2 * i] = a0 | (nA << 8) | (b0 << 16) | (nB << 24);
-            rowI[2 * i + 1] = fl;
+            S[0] = aref; S[1] = R; S[2] = real(1) / (dg + R); S[3] = ns ? real(1) / tmax(dg, real(1e-15)) : real(0);
+            S[4] = lo; S[5] = hi; S[6] = f; S[7] = muinv;
+            rowI[i] = a0 | (nA << 8) | (b0 << 16) | (nB << 24);
             rmeta[i] = (meta & 0xfffff) | ((tA + 1) << 20) | ((tB + 1) << 24);
+        }
+        GSYNC();
+        // --- Gauss-Seidel groups: the leading non-contact rows in packs of GRP_MAX, then one group per contact ---
+        int* gI = ii + lay.gI;
+        real* gA = r + lay.gA;
+        const int nlead = misc[4];   // number of equality / dry-friction / limit rows (they precede the contacts)
+        int ngrp = 0;
+        for (int base = 0; base < nefc; base += G) {
+            int i = base + lane;
+            bool head = false;
+            int cnt = 0, isc = 0;
+            if (i < nefc) {
+                if (i < nlead) { head = (i % GRP_MAX) == 0; cnt = nlead - i < GRP_MAX ? nlead - i : GRP_MAX; }
+                else { int meta = rmeta[i]; head = ((meta >> 12) & 255) == 0; cnt = m.pair_condim[cpair[(meta >> 2) & 1023]]; isc = 1; }
+            }
+            int tot, rk = group_rank<G>(head, grp, lane, &tot);
+            if (head && ngrp + rk < lay.maxgrp) gI[ngrp + rk] = i | (cnt << 16) | (isc << 24);
+            ngrp += tot;
+        }
+        if (ngrp > lay.maxgrp) ngrp = lay.maxgrp;
+        if (lane == 0) misc[5] = ngrp;
+        GSYNC();
+        // couplings A_rs = J_r . B_s (r > s) inside each group, one pair per lane
+        for (int w = lane; w < ngrp * 15; w += G) {
+            int g = w / 15, e = w - 15 * g;
+            int rr = 1;
+            while ((rr + 1) * rr / 2 <= e) rr++;          // e = rr*(rr-1)/2 + ss
+            int ss = e - rr * (rr - 1) / 2;
+            int gi = gI[g], start = gi & 0xffff, cnt = (gi >> 16) & 15;
+            real v = 0;
+            if (rr < cnt) {
+                int ir = start + rr, is = start + ss, ra = rowI[ir], rs = rowI[is];
+                // windows of row r against windows of row s (match by dof address)
+                for (int wr = 0; wr < 2; wr++) {
+                    int ar = (ra >> (16 * wr)) & 255, nr = (ra >> (16 * wr + 8)) & 255;
+                    if (nr == 0) continue;
+                    for (int ws = 0; ws < 2; ws++) {
+                        int as_ = (rs >> (16 * ws)) & 255, ns_ = (rs >> (16 * ws + 8)) & 255;
+                        if (ns_ == 0 || as_ != ar) continue;
+                        for (int k = 0; k < nr; k++) v += rJ[ROW_W * ir + TREE_W * wr + k] * rB[ROW_W * is + TREE_W * ws + k];
+                    }
+                }
+            }
+            gA[16 * g + e] = v;
         }
         GSYNC();
     }
@@ -892,7 +969,7 @@ struct Env {
         for (int c = lane; c < ncon; c += G) {
             int first = cefc[c];
             if (first < 0) continue;
-            int dim = rowI[2 * first + 1] >> 8;
+            int dim = m.pair_condim[(ii + lay.cpair)[c]];
             real fn = rowS[8 * first + 6], s2 = 0;
             for (int s = 1; s < dim; s++) { real t = rowS[8 * (first + s) + 6] * rowS[8 * (first + s) + 7]; s2 += t * t; }
             if (s2 > fn * fn) { real sc = fn / sqrt(s2); for (int s = 1; s < dim; s++) rowS[8 * (first + s) + 6] *= sc; }
@@ -912,8 +989,8 @@ struct Env {
         GSYNC();
         // Gauss-Seidel sweeps (+ noslip sweeps) in the register-resident wave kernel
         static_assert(G == 64, "the solver maps one env to one wavefront");
-        pgs_wave<real>((LDS_PTR(RowS<real>))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const real))rJ, (LDS_PTR(const real))rB, (LDS_PTR(real))qacc, m.nv, nefc,
-                       pgs_iters, m.noslip_iters);
+        pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const real))rJ, (LDS_PTR(const real))rB, (LDS_PTR(real))qacc,
+                         (LDS_PTR(const int))(ii + lay.gI), (LDS_PTR(const real))(r + lay.gA), misc[5], pgs_iters, m.noslip_iters);
         GSYNC();
         // qfrc_constraint = J^T f
         for (int k = lane; k < m.nv; k += G) {
@@ -1364,11 +1441,12 @@ struct PhysHost {
         L.cdist = bq; bq += maxcon; L.cpos = bq; bq += 3 * maxcon; L.cnrm = bq; bq += 3 * maxcon;
         L.rJ = bq; bq += ROW_W * maxefc; L.rB = bq; bq += ROW_W * maxefc;
         bq = (bq + 3) & ~3; L.rowS = bq; bq += 8 * maxefc;
+        L.maxgrp = maxefc / 3 + 8; L.gA = bq; bq += 16 * L.maxgrp;
         o = a > bq ? a : bq;
         L.nreal = (o + 3) & ~3;
         int io = 0;
         auto Iq = [&](int n) { int x = io; io += n; return x; };
-        L.cand = Iq(CAND_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); io = (io + 3) & ~3; L.rowI = Iq(2 * maxefc); L.misc = Iq(4);
+        L.cand = Iq(CAND_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.misc = Iq(8);
         L.nint = (io + 3) & ~3;
         L.maxcon = maxcon;
         L.maxefc = maxefc;
@@ -1377,6 +1455,7 @@ struct PhysHost {
     }
 
     int dims[6] = {0, 0, 0, 0, 0, 0};
+    size_t lds_bytes() const { return (size_t)lay.bytes_per_env + (size_t)moff.nreal * (f64 ? 8 : 4) + (size_t)moff.nint * 4; }
     void alloc_contacts() {
         if (d_cpairs) (void)hipFree(d_cpairs);
         if (d_cdist) (void)hipFree(d_cdist);

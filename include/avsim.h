@@ -49,8 +49,9 @@ enum {
 };
 
 /* dims[]: 0 nq, 1 nv, 2 nu (actuators, 21), 3 num_joints of the action/agent_pos (14|21), 4 nobj (free objects),
- * 5 max_reward, 6 num_envs, 7 task id, 8 ncon capacity, 9 nefc capacity */
-#define AVSIM_NDIMS 10
+ * 5 max_reward, 6 num_envs, 7 task id, 8 ncon capacity, 9 nefc capacity, 10 LDS bytes per block (one env per
+ * wavefront + the hot model tables), 11 blocks that fit one CU's 160 KiB */
+#define AVSIM_NDIMS 12
 
 /* Build a batched simulation from a compiled model blob (av_aloha_amd/compiler, replaces env.py:53-56).
  * num_arms is encoded in the blob (2-arm blobs carry the hidden middle arm of env.py:394-395). */
