@@ -117,11 +117,11 @@ struct MOff {
 
 // per-env LDS layout (offsets in reals / ints)
 struct Layout {
-    int qpos, qvel, ctrl, warm, xpos, xmat, xipos, cdof, gcen, M, L, bias, fsm, asm_, qacc, fcon, U, nreal;
+    int qpos, qvel, ctrl, warm, xpos, xmat, xipos, cdof, gcen, M, L, Minv, bias, fsm, asm_, qacc, fcon, U, nreal;
     // scratch union U, phase A
     int cinert, cvel, cacc, cfrc;
     // phase B
-    int cdist, cpos, cnrm, rJ, rB, rowS, gA;
+    int cdist, cpos, cnrm, rJ, rowS, gA;
     // ints
     int cand, cpair, cefc, rmeta, rowI, gI, misc, nint;
     int maxgrp;
@@ -208,13 +208,14 @@ constexpr int GRP_MAX = 6;   // rows per Gauss-Seidel group (a condim-6 contact 
 //   - the acceleration update is a returnless LDS atomic add per (row, dof), again 4 rows per pass.
 // A contact is exactly one group, so the elliptic-cone projection of its friction block is local to the group.
 // Separate noinline function: the sweep loop gets its own register allocation.
-// rowI[i] = dof windows of row i: adrA | nA << 8 | adrB << 16 | nB << 24.
+// rowI[i] = two 13-bit dof windows of row i: first dof (6) | count (4) | kinematic tree (3).
+// B = J M^-1 is not stored: each lane rebuilds its entry from the tree's dense 8x8 inverse (Minv) and the row's J window.
 // ------------------------------------------------------------------------------------------------
 template <typename real>
-__device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const real) rJ, LDS_PTR(const real) rB,
+__device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const real) rJ, LDS_PTR(const real) Minv,
                                                      LDS_PTR(real) q, LDS_PTR(const int) gI, LDS_PTR(const real) gA, int ngrp, int iters,
                                                      int noslip_iters) {
-    const int lane = threadIdx.x & 63, d = lane >> 4, l16 = lane & 15, sh = l16 < TREE_W ? 0 : 16, k8 = l16 & (TREE_W - 1);
+    const int lane = threadIdx.x & 63, d = lane >> 4, l16 = lane & 15, sh = l16 < TREE_W ? 0 : 13, k8 = l16 & (TREE_W - 1), w8 = l16 & TREE_W;
     const int lr = lane < GRP_MAX ? lane : 0;          // row slot owned in the sequential phase
     const int tri = lr * (lr - 1) / 2;                 // offset of that row in the packed lower triangle
     if (ngrp <= 0) return;
@@ -233,10 +234,19 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         const int ginn_v = gI[g2];
         const int ra0n = rowI[(gin & 0xffff) + d], ra1n = rowI[(gin & 0xffff) + 4 + d];
         const int row0 = start + d, row1 = start + 4 + d;
-        const int adr0 = ((ra0 >> sh) & 255) + k8, adr1 = ((ra1 >> sh) & 255) + k8;
-        const bool in0 = d < cnt && k8 < ((ra0 >> (sh + 8)) & 255), in1 = 4 + d < cnt && k8 < ((ra1 >> (sh + 8)) & 255);
-        const real J0 = rJ[ROW_W * row0 + l16], B0 = rB[ROW_W * row0 + l16], q0 = q[in0 ? adr0 : 0];
-        const real J1 = rJ[ROW_W * row1 + l16], B1 = rB[ROW_W * row1 + l16], q1 = q[in1 ? adr1 : 0];
+        const int adr0 = ((ra0 >> sh) & 63) + k8, adr1 = ((ra1 >> sh) & 63) + k8;
+        const bool in0 = d < cnt && k8 < ((ra0 >> (sh + 6)) & 15), in1 = 4 + d < cnt && k8 < ((ra1 >> (sh + 6)) & 15);
+        const real J0 = rJ[ROW_W * row0 + l16], q0 = q[in0 ? adr0 : 0];
+        const real J1 = rJ[ROW_W * row1 + l16], q1 = q[in1 ? adr1 : 0];
+        real B0 = 0, B1 = 0;
+        {
+            LDS_PTR(const real) Mi0 = Minv + 64 * ((ra0 >> (sh + 10)) & 7) + 8 * k8;
+            LDS_PTR(const real) Mi1 = Minv + 64 * ((ra1 >> (sh + 10)) & 7) + 8 * k8;
+            LDS_PTR(const real) Jw0 = rJ + ROW_W * row0 + w8;
+            LDS_PTR(const real) Jw1 = rJ + ROW_W * row1 + w8;
+#pragma unroll
+            for (int j = 0; j < TREE_W; j++) { B0 += Mi0[j] * Jw0[j]; B1 += Mi1[j] * Jw1[j]; }
+        }
         const bool mine = lane < cnt;
         LDS_PTR(real) S = rowS + 8 * (start + (mine ? lane : 0));
         const real aref = S[0], R = S[1], inv2 = S[2], inv3 = S[3], lo = S[4], hi = S[5], f0 = S[6], muinv = S[7];
@@ -538,6 +548,16 @@ struct Env {
         GSYNC();
         for (int t = lane; t < m.ntree; t += G) chol_block(M + m.tree_madr[t], L + m.tree_madr[t], m.tree_dofnum[t]);
         GSYNC();
+        // dense per-tree inverse (8x8, zero padded): B = J M^-1 is formed on the fly from it, so rows store only J
+        real* Minv = r + lay.Minv;
+        for (int w = lane; w < m.ntree * TREE_W; w += G) {
+            int t = w >> 3, j = w & 7, n = m.tree_dofnum[t];
+            real x[TREE_W];
+            for (int k = 0; k < TREE_W; k++) x[k] = (k == j && j < n) ? real(1) : real(0);
+            if (j < n) chol_solve_block(L + m.tree_madr[t], x, n);
+            for (int k = 0; k < TREE_W; k++) Minv[64 * t + 8 * k + j] = (k < n && j < n) ? x[k] : real(0);
+        }
+        GSYNC();
     }
 
     // ---- P5 bias -------------------------------------------------------------------------------
@@ -788,7 +808,7 @@ struct Env {
         if (lane == 0) { misc[1] = nefc; if (ovf) misc[2] |= 2; }
         GSYNC();
         // --- fill rows (one row per lane) ---
-        real *rJ = r + lay.rJ, *rB = r + lay.rB, *rowS = r + lay.rowS, *warm = r + lay.warm;
+        real *rJ = r + lay.rJ, *rowS = r + lay.rowS, *warm = r + lay.warm, *Minv = r + lay.Minv;
         int* rowI = ii + lay.rowI;
         real* Lm = r + lay.L;
         for (int i = lane; i < nefc; i += G) {
@@ -882,15 +902,18 @@ struct Env {
                 if (tB >= 0) { int b0 = m.tree_dofadr[tB]; for (int k = 0; k < m.tree_dofnum[tB]; k++) vel += J[TREE_W + k] * qvel[b0 + k]; }
             }
             const real aref = -Bd * vel - K * imp * (pos - margin);
-            // B = rows of J M^-1 per tree, diag = J B^T
+            // B = J M^-1 per tree (dense 8x8 inverse), diag = J B^T
             real B[ROW_W];
-            for (int k = 0; k < ROW_W; k++) B[k] = J[k];
-            chol_solve_block(Lm + m.tree_madr[tA], B, m.tree_dofnum[tA]);
-            if (tB >= 0) chol_solve_block(Lm + m.tree_madr[tB], B + TREE_W, m.tree_dofnum[tB]);
-            else for (int k = 0; k < TREE_W; k++) B[TREE_W + k] = 0;
+            for (int k = 0; k < TREE_W; k++) {
+                real sa = 0, sb = 0;
+                for (int j = 0; j < TREE_W; j++) sa += Minv[64 * tA + 8 * k + j] * J[j];
+                if (tB >= 0) for (int j = 0; j < TREE_W; j++) sb += Minv[64 * tB + 8 * k + j] * J[TREE_W + j];
+                B[k] = sa;
+                B[TREE_W + k] = sb;
+            }
             real dg = 0;
             for (int k = 0; k < ROW_W; k++) dg += J[k] * B[k];
-            for (int k = 0; k < ROW_W; k++) { rJ[ROW_W * i + k] = J[k]; rB[ROW_W * i + k] = B[k]; }
+            for (int k = 0; k < ROW_W; k++) rJ[ROW_W * i + k] = J[k];
             // warm start: force implied by last step's acceleration, f = -D (J qacc_ws - aref), made feasible per row
             const int a0 = m.tree_dofadr[tA], nA = m.tree_dofnum[tA], b0 = tB >= 0 ? m.tree_dofadr[tB] : 0, nB = tB >= 0 ? m.tree_dofnum[tB] : 0;
             real jw = 0;
@@ -910,7 +933,7 @@ struct Env {
             real* S = rowS + 8 * i;
             S[0] = aref; S[1] = R; S[2] = real(1) / (dg + R); S[3] = ns ? real(1) / tmax(dg, real(1e-15)) : real(0);
             S[4] = lo; S[5] = hi; S[6] = f; S[7] = muinv;
-            rowI[i] = a0 | (nA << 8) | (b0 << 16) | (nB << 24);
+            rowI[i] = a0 | (nA << 6) | (tA << 10) | ((b0 | (nB << 6) | ((tB >= 0 ? tB : 0) << 10)) << 13);
             rmeta[i] = (meta & 0xfffff) | ((tA + 1) << 20) | ((tB + 1) << 24);
         }
         GSYNC();
@@ -944,14 +967,17 @@ struct Env {
             real v = 0;
             if (rr < cnt) {
                 int ir = start + rr, is = start + ss, ra = rowI[ir], rs = rowI[is];
-                // windows of row r against windows of row s (match by dof address)
+                // J_r M^-1 J_s^T over the kinematic trees both rows touch
                 for (int wr = 0; wr < 2; wr++) {
-                    int ar = (ra >> (16 * wr)) & 255, nr = (ra >> (16 * wr + 8)) & 255;
-                    if (nr == 0) continue;
+                    if (((ra >> (13 * wr + 6)) & 15) == 0) continue;
+                    int tr = (ra >> (13 * wr + 10)) & 7;
                     for (int ws = 0; ws < 2; ws++) {
-                        int as_ = (rs >> (16 * ws)) & 255, ns_ = (rs >> (16 * ws + 8)) & 255;
-                        if (ns_ == 0 || as_ != ar) continue;
-                        for (int k = 0; k < nr; k++) v += rJ[ROW_W * ir + TREE_W * wr + k] * rB[ROW_W * is + TREE_W * ws + k];
+                        if (((rs >> (13 * ws + 6)) & 15) == 0 || ((rs >> (13 * ws + 10)) & 7) != tr) continue;
+                        for (int k = 0; k < TREE_W; k++) {
+                            real t = 0;
+                            for (int j = 0; j < TREE_W; j++) t += Minv[64 * tr + 8 * k + j] * rJ[ROW_W * is + TREE_W * ws + j];
+                            v += rJ[ROW_W * ir + TREE_W * wr + k] * t;
+                        }
                     }
                 }
             }
@@ -963,7 +989,7 @@ struct Env {
     // ---- P8 ------------------------------------------------------------------------------------
     __device__ void solve(int pgs_iters) {
         int *misc = ii + lay.misc, *rmeta = ii + lay.rmeta, *cefc = ii + lay.cefc, *rowI = ii + lay.rowI;
-        real *qacc = r + lay.qacc, *as = r + lay.asm_, *rowS = r + lay.rowS, *rJ = r + lay.rJ, *rB = r + lay.rB, *fcon = r + lay.fcon;
+        real *qacc = r + lay.qacc, *as = r + lay.asm_, *rowS = r + lay.rowS, *rJ = r + lay.rJ, *fcon = r + lay.fcon;
         int nefc = misc[1], ncon = misc[0];
         // warm-start forces of friction blocks back onto their cones (one contact per lane)
         for (int c = lane; c < ncon; c += G) {
@@ -975,21 +1001,29 @@ struct Env {
             if (s2 > fn * fn) { real sc = fn / sqrt(s2); for (int s = 1; s < dim; s++) rowS[8 * (first + s) + 6] *= sc; }
         }
         GSYNC();
-        // qacc = qacc_smooth + sum_i B_i f_i : one dof per lane
+        // qacc = qacc_smooth + M^-1 J^T f : generalized force per dof first, then the per-tree inverse
+        real* Minv = r + lay.Minv;
         for (int k = lane; k < m.nv; k += G) {
             int t = m.dof_tree[k], kk = k - m.tree_dofadr[t];
-            real s = as[k];
+            real s = 0;
             for (int i = 0; i < nefc; i++) {
                 int meta = rmeta[i], tA = ((meta >> 20) & 15) - 1, tB = ((meta >> 24) & 15) - 1;
-                if (tA == t) s += rB[ROW_W * i + kk] * rowS[8 * i + 6];
-                else if (tB == t) s += rB[ROW_W * i + TREE_W + kk] * rowS[8 * i + 6];
+                if (tA == t) s += rJ[ROW_W * i + kk] * rowS[8 * i + 6];
+                else if (tB == t) s += rJ[ROW_W * i + TREE_W + kk] * rowS[8 * i + 6];
             }
+            fcon[k] = s;
+        }
+        GSYNC();
+        for (int k = lane; k < m.nv; k += G) {
+            int t = m.dof_tree[k], a0 = m.tree_dofadr[t], kk = k - a0, n = m.tree_dofnum[t];
+            real s = as[k];
+            for (int j = 0; j < n; j++) s += Minv[64 * t + 8 * kk + j] * fcon[a0 + j];
             qacc[k] = s;
         }
         GSYNC();
         // Gauss-Seidel sweeps (+ noslip sweeps) in the register-resident wave kernel
         static_assert(G == 64, "the solver maps one env to one wavefront");
-        pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const real))rJ, (LDS_PTR(const real))rB, (LDS_PTR(real))qacc,
+        pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const real))rJ, (LDS_PTR(const real))Minv, (LDS_PTR(real))qacc,
                          (LDS_PTR(const int))(ii + lay.gI), (LDS_PTR(const real))(r + lay.gA), misc[5], pgs_iters, m.noslip_iters);
         GSYNC();
         // qfrc_constraint = J^T f
@@ -1098,22 +1132,23 @@ struct Env {
     }
 };
 
-// one wave per block, 64/G envs per wave
-template <typename real, int G>
-__global__ void __launch_bounds__(64) k_phys(DevModel<real> mg, Layout lay, MOff mo, const real* __restrict__ img_real, const int* __restrict__ img_int, int N, int nsub, int pgs_iters, const float* __restrict__ action,
+// WPB wavefronts per block, one env per wavefront; the block shares one LDS copy of the hot model tables
+template <typename real, int G, int WPB>
+__global__ void __launch_bounds__(64 * WPB) k_phys(DevModel<real> mg, Layout lay, MOff mo, const real* __restrict__ img_real, const int* __restrict__ img_int, int N, int nsub, int pgs_iters, const float* __restrict__ action,
                                              int want_reward, real* __restrict__ g_qpos, real* __restrict__ g_qvel, real* __restrict__ g_ctrl,
                                              real* __restrict__ g_warm, int* __restrict__ g_latch, double* __restrict__ o_agent,
                                              int* __restrict__ o_reward, unsigned char* __restrict__ o_success, int* __restrict__ o_ncon,
                                              int* __restrict__ o_cpairs, double* __restrict__ o_cdist, int* __restrict__ o_diag, int max_reward, int export_contacts, long long* __restrict__ o_prof) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int grp = threadIdx.x / G, lane = threadIdx.x % G;
-    const int env = blockIdx.x * (64 / G) + grp;
-    // hot model tables -> LDS, once per block (the block is a single wave: a fence orders the copy)
-    real* lr = reinterpret_cast<real*>(smem + (size_t)(64 / G) * lay.bytes_per_env);
+    static_assert(G == 64, "one env per wavefront");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = 0;
+    const int env = blockIdx.x * WPB + wave;
+    // hot model tables -> LDS, once per block
+    real* lr = reinterpret_cast<real*>(smem + (size_t)WPB * lay.bytes_per_env);
     int* li = reinterpret_cast<int*>(lr + mo.nreal);
-    for (int i = threadIdx.x; i < mo.nreal; i += 64) lr[i] = img_real[i];
-    for (int i = threadIdx.x; i < mo.nint; i += 64) li[i] = img_int[i];
-    GSYNC();
+    for (int i = threadIdx.x; i < mo.nreal; i += 64 * WPB) lr[i] = img_real[i];
+    for (int i = threadIdx.x; i < mo.nint; i += 64 * WPB) li[i] = img_int[i];
+    if (WPB > 1) __syncthreads(); else GSYNC();
     DevModel<real> m = mg;
     m.body_parent = li + mo.body_parent;
     m.body_jntadr = li + mo.body_jntadr;
@@ -1167,7 +1202,7 @@ __global__ void __launch_bounds__(64) k_phys(DevModel<real> mg, Layout lay, MOff
     m.geom_cpos = lr + mo.geom_cpos;
     m.geom_rbound = lr + mo.geom_rbound;
     if (env >= N) return;  // whole groups drop out together; no block barrier is used below
-    real* r = reinterpret_cast<real*>(smem + (size_t)grp * lay.bytes_per_env);
+    real* r = reinterpret_cast<real*>(smem + (size_t)wave * lay.bytes_per_env);
     int* ii = reinterpret_cast<int*>(r + lay.nreal);
     Env<real, G> E(m, lay, r, ii, lane, grp);
 
@@ -1247,7 +1282,7 @@ __global__ void __launch_bounds__(64) k_phys(DevModel<real> mg, Layout lay, MOff
 // host side: device model image, LDS layout, launch
 // ------------------------------------------------------------------------------------------------
 struct PhysHost {
-    int maxcon = 48, maxefc = 144, pgs_iters = 20, group = 64, export_contacts = 1, force_reward = 0;
+    int maxcon = 48, maxefc = 144, pgs_iters = 20, group = 64, export_contacts = 1, force_reward = 0, wpb_override = 0;
     bool f64 = false;
     int N = 0, max_reward = 0;
     std::vector<void*> allocs;
@@ -1432,14 +1467,14 @@ struct PhysHost {
         auto R = [&](int n) { int a = o; o += n; return a; };
         L.qpos = R(nq); L.qvel = R(nv); L.ctrl = R(nu); L.warm = R(nv);
         L.xpos = R(3 * nb); L.xmat = R(9 * nb); L.xipos = R(3 * nb); L.cdof = R(6 * nv); L.gcen = R(3 * ng);
-        L.M = R(msize); L.L = R(msize);
+        L.M = R(msize); L.L = R(msize); o = (o + 3) & ~3; L.Minv = R(64 * 8);
         L.bias = R(nv); L.fsm = R(nv); L.asm_ = R(nv); L.qacc = R(nv); L.fcon = R(nv);
         L.U = o;
         int a = o;
         L.cinert = a; a += 10 * nb; L.cvel = a; a += 6 * nb; L.cacc = a; a += 6 * nb; L.cfrc = a; a += 6 * nb;
         int bq = o;
         L.cdist = bq; bq += maxcon; L.cpos = bq; bq += 3 * maxcon; L.cnrm = bq; bq += 3 * maxcon;
-        L.rJ = bq; bq += ROW_W * maxefc; L.rB = bq; bq += ROW_W * maxefc;
+        bq = (bq + 3) & ~3; L.rJ = bq; bq += ROW_W * maxefc;
         bq = (bq + 3) & ~3; L.rowS = bq; bq += 8 * maxefc;
         L.maxgrp = maxefc / 3 + 8; L.gA = bq; bq += 16 * L.maxgrp;
         o = a > bq ? a : bq;
@@ -1455,7 +1490,7 @@ struct PhysHost {
     }
 
     int dims[6] = {0, 0, 0, 0, 0, 0};
-    size_t lds_bytes() const { return (size_t)lay.bytes_per_env + (size_t)moff.nreal * (f64 ? 8 : 4) + (size_t)moff.nint * 4; }
+    size_t lds_bytes() const { return (size_t)lay.bytes_per_env + (size_t)moff.nreal * (f64 ? 8 : 4) + (size_t)moff.nint * 4; }   // WPB = 1 figure
     void alloc_contacts() {
         if (d_cpairs) (void)hipFree(d_cpairs);
         if (d_cdist) (void)hipFree(d_cdist);
@@ -1503,6 +1538,7 @@ struct PhysHost {
         std::string n(name);
         if (n == "pgs_iters") { pgs_iters = (int)v; return true; }
         if (n == "export_contacts") { export_contacts = v != 0; return true; }
+        if (n == "waves_per_block") { int x = (int)v; if (x == 0 || x == 1 || x == 2 || x == 4) { wpb_override = x; return true; } return false; }
         if (n == "profile_phases") {
             if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * 8, 0));
             if (v == 0) d_prof = nullptr;
@@ -1520,12 +1556,12 @@ struct PhysHost {
         return false;
     }
 
-    template <typename real, int G>
+    template <typename real, int G, int WPB>
     int launch_t(hipStream_t st, const DevModel<real>& m, int nsub, const float* action, void* qpos, void* qvel, void* ctrl, void* warm,
                  int* latch, double* agent, int32_t* reward, uint8_t* success, std::string& err) {
-        int epb = 64 / G;
+        int epb = WPB;
         size_t shmem = (size_t)lay.bytes_per_env * epb + (size_t)moff.nreal * sizeof(real) + (size_t)moff.nint * 4;
-        auto kern = k_phys<real, G>;
+        auto kern = k_phys<real, G, WPB>;
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1534,7 +1570,7 @@ struct PhysHost {
         }
         if (shmem > 160 * 1024) { err = "per-block LDS exceeds 160 KiB; lower maxefc/maxcon or raise the group size"; return -1; }
         dim3 grid((N + epb - 1) / epb);
-        hipLaunchKernelGGL(kern, grid, dim3(64), shmem, st, m, lay, moff, (const real*)d_img_real, (const int*)d_img_int, N, nsub, pgs_iters, action, (reward || success) && (nsub > 0 || force_reward) ? 1 : 0,
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WPB), shmem, st, m, lay, moff, (const real*)d_img_real, (const int*)d_img_int, N, nsub, pgs_iters, action, (reward || success) && (nsub > 0 || force_reward) ? 1 : 0,
                            (real*)qpos, (real*)qvel, (real*)ctrl, (real*)warm, latch, agent, (int*)reward, (unsigned char*)success, d_ncon,
                            d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof);
         hipError_t e = hipGetLastError();
@@ -1547,9 +1583,15 @@ struct PhysHost {
         (void)N_; (void)nj;
         if (f64) {
             // double precision doubles the LDS record; one env per wave only
-            return launch_t<double, 64>(st, md, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
+            return launch_t<double, 64, 1>(st, md, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
         }
-        return launch_t<float, 64>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
+        // as many envs (wavefronts) per block as fit next to one copy of the tables in 160 KiB, at most 4 (one per SIMD)
+        size_t tables = (size_t)moff.nreal * 4 + (size_t)moff.nint * 4;
+        int wpb = (int)((160 * 1024 - tables) / (size_t)lay.bytes_per_env);
+        if (wpb_override > 0) wpb = wpb_override;
+        if (wpb >= 4) return launch_t<float, 64, 4>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
+        if (wpb >= 2) return launch_t<float, 64, 2>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
+        return launch_t<float, 64, 1>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
     }
 };
 
