@@ -640,12 +640,12 @@ int avsim_get_contacts(avsim_t* h, int32_t* ncon, int32_t* pairs, double* dist) 
     return AVSIM_OK;
 }
 
-/* debug: per-env cycle counters of the 8 physics phases of the last launch (option "profile_phases"); int64[N][8] */
+/* debug: per-env cycle counters of the 8 physics phases of the last launch (option "profile_phases"); int64[N][10] */
 int avsim_get_phase_cycles(avsim_t* h, int64_t* out) {
     if (!h || !out || !h->phys.d_prof) return AVSIM_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out, h->phys.d_prof, (size_t)h->N * 64, h->io_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out, h->phys.d_prof, (size_t)h->N * 80, h->io_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return AVSIM_OK;
 }
 

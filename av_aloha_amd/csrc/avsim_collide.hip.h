@@ -20,6 +20,7 @@ struct Shape {
     const T* hull; // hull vertices in the geom frame (global memory)
     int nh;
     T center[3];   // an interior point (world)
+    T lc[3], lh[3]; // local bounding box: centre and half extents in the geom frame
 };
 
 template <typename T>
@@ -253,16 +254,26 @@ AVS_DEV int sphere_box(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T*
     return 1;
 }
 
-// box-box: 15-axis SAT then reference-face clipping (face contact, <=4 points) or closest edge points
+#define AVS_LDS(T) __attribute__((address_space(3))) T*
+
+// select component k of a 3-vector / column k of a row-major 3x3 without dynamic indexing (keeps data in registers)
+template <typename T> AVS_DEV T sel3(const T* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
+template <typename T> AVS_DEV void col3(const T* M, int k, T* o) { o[0] = sel3(M, k); o[1] = sel3(M + 3, k); o[2] = sel3(M + 6, k); }
+
+// box-box: 15-axis SAT then reference-face clipping (face contact, <=4 points) or closest edge points.
+// `scr` = 56 words of per-lane LDS scratch: clipped polygon while working (dynamic indexing would otherwise spill it
+// to scratch memory), results on return: dist [0,4), pos [4,16), common normal [16,19).
 template <typename T>
-__device__ int box_box(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T* nrm) {
+__device__ int box_box(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr) {
     const T *Ra = a.mat, *Rb = b.mat;
     T p[3], pa[3], pb[3];
     sub3(b.pos, a.pos, p);
     mulmatT(Ra, p, pa);
     mulmatT(Rb, p, pb);
     T R[3][3], Q[3][3];
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) {
             R[i][j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j];
             Q[i][j] = fabs(R[i][j]) + T(1e-12);
@@ -271,18 +282,22 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T*
     int code = -1;
     T bn[3] = {0, 0, 0};
     bool flip = false;
+#pragma unroll
     for (int i = 0; i < 3; i++) {
         T s = fabs(pa[i]) - (a.size[i] + b.size[0] * Q[i][0] + b.size[1] * Q[i][1] + b.size[2] * Q[i][2]);
         if (s > 0) return 0;
         if (s > best) { best = s; code = i; flip = pa[i] < 0; }
     }
+#pragma unroll
     for (int j = 0; j < 3; j++) {
         T s = fabs(pb[j]) - (b.size[j] + a.size[0] * Q[0][j] + a.size[1] * Q[1][j] + a.size[2] * Q[2][j]);
         if (s > 0) return 0;
         if (s > best) { best = s; code = 3 + j; flip = pb[j] < 0; }
     }
     const T fudge = T(1.05);
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) {
             int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
             T c[3] = {R[0][j], R[1][j], R[2][j]}, e[3] = {0, 0, 0}, ax[3];
@@ -303,8 +318,8 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T*
         }
     T depth = -best;
     T n[3];
-    if (code < 3) { n[0] = Ra[code]; n[1] = Ra[3 + code]; n[2] = Ra[6 + code]; }
-    else if (code < 6) { n[0] = Rb[code - 3]; n[1] = Rb[3 + code - 3]; n[2] = Rb[6 + code - 3]; }
+    if (code < 3) col3(Ra, code, n);
+    else if (code < 6) col3(Rb, code - 3, n);
     else { n[0] = bn[0]; n[1] = bn[1]; n[2] = bn[2]; }
     if (flip) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
 
@@ -313,6 +328,7 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T*
         T pA[3], pB[3], la[3], lb[3];
         mulmatT(Ra, n, la);
         mulmatT(Rb, n, lb);
+#pragma unroll
         for (int k = 0; k < 3; k++) {
             la[k] = (k == i) ? T(0) : (la[k] > 0 ? a.size[k] : -a.size[k]);
             lb[k] = (k == j) ? T(0) : (lb[k] > 0 ? -b.size[k] : b.size[k]);
@@ -320,7 +336,9 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T*
         mulmat(Ra, la, pA);
         mulmat(Rb, lb, pB);
         for (int k = 0; k < 3; k++) { pA[k] += a.pos[k]; pB[k] += b.pos[k]; }
-        T ua[3] = {Ra[i], Ra[3 + i], Ra[6 + i]}, ub[3] = {Rb[j], Rb[3 + j], Rb[6 + j]}, w[3];
+        T ua[3], ub[3], w[3];
+        col3(Ra, i, ua);
+        col3(Rb, j, ub);
         sub3(pB, pA, w);
         T uaub = dot3(ua, ub), q1 = dot3(ua, w), q2 = -dot3(ub, w), den = 1 - uaub * uaub;
         T alpha = 0, beta = 0;
@@ -328,66 +346,72 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T*
         for (int k = 0; k < 3; k++) {
             pA[k] += ua[k] * alpha;
             pB[k] += ub[k] * beta;
-            pos[k] = T(0.5) * (pA[k] + pB[k]);
-            nrm[k] = n[k];
+            scr[4 + k] = T(0.5) * (pA[k] + pB[k]);
+            scr[16 + k] = n[k];
         }
-        dist[0] = -depth;
+        scr[0] = -depth;
         return 1;
     }
 
-    const Shape<T>& ref = code < 3 ? a : b;
-    const Shape<T>& inc = code < 3 ? b : a;
+    // reference / incident box chosen by component-wise selects (a dynamic reference would force both shapes to memory)
+    const bool ra = code < 3;
+    T rpos[3], rmat[9], rsize[3], ipos[3], imat[9], isize[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { rpos[q] = ra ? a.pos[q] : b.pos[q]; ipos[q] = ra ? b.pos[q] : a.pos[q]; rsize[q] = ra ? a.size[q] : b.size[q]; isize[q] = ra ? b.size[q] : a.size[q]; }
+#pragma unroll
+    for (int q = 0; q < 9; q++) { rmat[q] = ra ? a.mat[q] : b.mat[q]; imat[q] = ra ? b.mat[q] : a.mat[q]; }
     T nr[3] = {n[0], n[1], n[2]};
     if (code >= 3) { nr[0] = -n[0]; nr[1] = -n[1]; nr[2] = -n[2]; }
     int ax = code % 3;
     T li[3];
-    mulmatT(inc.mat, nr, li);
+    mulmatT(imat, nr, li);
     int k = 0;
-    if (fabs(li[1]) > fabs(li[k])) k = 1;
-    if (fabs(li[2]) > fabs(li[k])) k = 2;
-    T sgn = li[k] > 0 ? T(-1) : T(1);
+    if (fabs(li[1]) > fabs(li[0])) k = 1;
+    if (fabs(li[2]) > fabs(sel3(li, k))) k = 2;
+    T sgn = sel3(li, k) > 0 ? T(-1) : T(1);
     int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
-    T poly[16][3], tmp[16][3];
+    AVS_LDS(T) poly = scr;          // [8][3]
+    AVS_LDS(T) tmp = scr + 24;      // [8][3]
+    AVS_LDS(T) dep = scr + 48;      // [8]
     int np = 4;
+#pragma unroll
     for (int q = 0; q < 4; q++) {
         T cs0 = (q == 0 || q == 3) ? T(1) : T(-1), cs1 = (q < 2) ? T(1) : T(-1);
         T l[3];
-        l[k] = sgn * inc.size[k];
-        l[k1] = cs0 * inc.size[k1];
-        l[k2] = cs1 * inc.size[k2];
+#pragma unroll
+        for (int j = 0; j < 3; j++) l[j] = (j == k ? sgn : (j == k1 ? cs0 : cs1)) * isize[j];
         T wv[3], rel[3];
-        mulmat(inc.mat, l, wv);
-        for (int c = 0; c < 3; c++) rel[c] = wv[c] + inc.pos[c] - ref.pos[c];
-        mulmatT(ref.mat, rel, poly[q]);
+        mulmat(imat, l, wv);
+        for (int cc = 0; cc < 3; cc++) rel[cc] = wv[cc] + ipos[cc] - rpos[cc];
+        { T pv[3]; mulmatT(rmat, rel, pv); poly[3 * q] = pv[0]; poly[3 * q + 1] = pv[1]; poly[3 * q + 2] = pv[2]; }
     }
     int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
     for (int side = 0; side < 4; side++) {
         int axis = side < 2 ? a1 : a2;
-        T s = (side & 1) ? T(-1) : T(1), lim = ref.size[axis];
+        T s = (side & 1) ? T(-1) : T(1), lim = sel3(rsize, axis);
         int m = 0;
         for (int q = 0; q < np; q++) {
-            T* P = poly[q];
-            T* Qp = poly[(q + 1) % np];
-            T dp = s * P[axis] - lim, dq = s * Qp[axis] - lim;
-            if (dp <= 0) { tmp[m][0] = P[0]; tmp[m][1] = P[1]; tmp[m][2] = P[2]; m++; }
-            if ((dp < 0 && dq > 0) || (dp > 0 && dq < 0)) {
+            int qn = (q + 1) % np;
+            T P[3] = {poly[3 * q], poly[3 * q + 1], poly[3 * q + 2]}, Qp[3] = {poly[3 * qn], poly[3 * qn + 1], poly[3 * qn + 2]};
+            T dp = s * sel3(P, axis) - lim, dq = s * sel3(Qp, axis) - lim;
+            if (dp <= 0 && m < 8) { tmp[3 * m] = P[0]; tmp[3 * m + 1] = P[1]; tmp[3 * m + 2] = P[2]; m++; }
+            if (((dp < 0 && dq > 0) || (dp > 0 && dq < 0)) && m < 8) {
                 T t = dp / (dp - dq);
-                for (int c = 0; c < 3; c++) tmp[m][c] = P[c] + t * (Qp[c] - P[c]);
+                for (int c = 0; c < 3; c++) tmp[3 * m + c] = P[c] + t * (Qp[c] - P[c]);
                 m++;
             }
-            if (m >= 15) break;
         }
         np = m;
-        for (int q = 0; q < np; q++) { poly[q][0] = tmp[q][0]; poly[q][1] = tmp[q][1]; poly[q][2] = tmp[q][2]; }
+        for (int q = 0; q < 3 * np; q++) poly[q] = tmp[q];
         if (np == 0) return 0;
     }
-    T refax[3] = {ref.mat[ax], ref.mat[3 + ax], ref.mat[6 + ax]};
+    T refax[3];
+    col3(rmat, ax, refax);
     T face = dot3(nr, refax) > 0 ? T(1) : T(-1);
-    T dep[16];
     int m = 0;
     for (int q = 0; q < np; q++) {
-        T dq = ref.size[ax] - face * poly[q][ax];
-        if (dq >= 0) { tmp[m][0] = poly[q][0]; tmp[m][1] = poly[q][1]; tmp[m][2] = poly[q][2]; dep[m] = dq; m++; }
+        T dq = sel3(rsize, ax) - face * poly[3 * q + ax];
+        if (dq >= 0) { tmp[3 * m] = poly[3 * q]; tmp[3 * m + 1] = poly[3 * q + 1]; tmp[3 * m + 2] = poly[3 * q + 2]; dep[m] = dq; m++; }
     }
     if (m == 0) return 0;
     int keep[4], nk = 0;
@@ -398,14 +422,14 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T*
         int i1 = i0;
         T bd = -1;
         for (int q = 0; q < m; q++) {
-            T dx = tmp[q][a1] - tmp[i0][a1], dy = tmp[q][a2] - tmp[i0][a2], dd = dx * dx + dy * dy;
+            T dx = tmp[3 * q + a1] - tmp[3 * i0 + a1], dy = tmp[3 * q + a2] - tmp[3 * i0 + a2], dd = dx * dx + dy * dy;
             if (dd > bd) { bd = dd; i1 = q; }
         }
-        T ex = tmp[i1][a1] - tmp[i0][a1], ey = tmp[i1][a2] - tmp[i0][a2];
+        T ex = tmp[3 * i1 + a1] - tmp[3 * i0 + a1], ey = tmp[3 * i1 + a2] - tmp[3 * i0 + a2];
         int i2 = -1, i3 = -1;
         T mx = T(1e-18), mn = T(-1e-18);
         for (int q = 0; q < m; q++) {
-            T cr = ex * (tmp[q][a2] - tmp[i0][a2]) - ey * (tmp[q][a1] - tmp[i0][a1]);
+            T cr = ex * (tmp[3 * q + a2] - tmp[3 * i0 + a2]) - ey * (tmp[3 * q + a1] - tmp[3 * i0 + a1]);
             if (cr > mx) { mx = cr; i2 = q; }
             if (cr < mn) { mn = cr; i3 = q; }
         }
@@ -418,32 +442,63 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T*
             if (keep[y] < keep[x]) { int t = keep[x]; keep[x] = keep[y]; keep[y] = t; }
     for (int x = 0; x < nk; x++) {
         int q = keep[x];
-        T l[3] = {tmp[q][0], tmp[q][1], tmp[q][2]};
-        l[ax] += T(0.5) * dep[q] * face;
+        T l[3] = {tmp[3 * q], tmp[3 * q + 1], tmp[3 * q + 2]};
+#pragma unroll
+        for (int j = 0; j < 3; j++) l[j] += (j == ax) ? T(0.5) * dep[q] * face : T(0);
         T wv[3];
-        mulmat(ref.mat, l, wv);
-        for (int c = 0; c < 3; c++) { pos[3 * x + c] = wv[c] + ref.pos[c]; nrm[3 * x + c] = n[c]; }
-        dist[x] = -dep[q];
+        mulmat(rmat, l, wv);
+        T dq_ = dep[q];
+        for (int c = 0; c < 3; c++) scr[4 + 3 * x + c] = wv[c] + rpos[c];
+        scr[x] = -dq_;
     }
+    for (int c = 0; c < 3; c++) scr[16 + c] = n[c];
     return nk;
 }
 
-// dispatch; outputs up to 4 contacts
+// conservative cull: separating-axis test of the two local bounding boxes on their 6 face axes
 template <typename T>
-__device__ int narrow(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T* nrm) {
-    int ta = a.type, tb = b.type;
-    if (ta == G_SPHERE && tb == G_SPHERE) return sphere_sphere(a, b, dist, pos, nrm);
-    if (ta == G_SPHERE && tb == G_BOX) return sphere_box(a, b, dist, pos, nrm);
-    if (ta == G_BOX && tb == G_SPHERE) {
-        int n = sphere_box(b, a, dist, pos, nrm);
-        for (int i = 0; i < 3 * n; i++) nrm[i] = -nrm[i];
-        return n;
+AVS_DEV bool boxes_separated(const Shape<T>& a, const Shape<T>& b) {
+    T ca[3], cb[3], t[3];
+    mulmat(a.mat, a.lc, ca);
+    mulmat(b.mat, b.lc, cb);
+    for (int k = 0; k < 3; k++) t[k] = (b.pos[k] + cb[k]) - (a.pos[k] + ca[k]);
+    T R[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R[i][j] = fabs(a.mat[i] * b.mat[j] + a.mat[3 + i] * b.mat[3 + j] + a.mat[6 + i] * b.mat[6 + j]) + T(1e-6);
+    for (int i = 0; i < 3; i++) {
+        T ta = fabs(t[0] * a.mat[i] + t[1] * a.mat[3 + i] + t[2] * a.mat[6 + i]);
+        if (ta > a.lh[i] + b.lh[0] * R[i][0] + b.lh[1] * R[i][1] + b.lh[2] * R[i][2]) return true;
     }
-    if (ta == G_BOX && tb == G_BOX) return box_box(a, b, dist, pos, nrm);
-    T depth;
-    if (!mpr_penetration(a, b, &depth, nrm, pos)) return 0;
-    dist[0] = -depth;
-    return 1;
+    for (int j = 0; j < 3; j++) {
+        T tb = fabs(t[0] * b.mat[j] + t[1] * b.mat[3 + j] + t[2] * b.mat[6 + j]);
+        if (tb > b.lh[j] + a.lh[0] * R[0][j] + a.lh[1] * R[1][j] + a.lh[2] * R[2][j]) return true;
+    }
+    return false;
+}
+
+// dispatch; up to 4 contacts written to the lane's LDS scratch: dist [0,4), pos [4,16), common normal [16,19)
+template <typename T>
+__device__ int narrow(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr) {
+    int ta = a.type, tb = b.type;
+    if (boxes_separated(a, b)) return 0;
+    if (ta == G_BOX && tb == G_BOX) return box_box(a, b, scr);
+    T dist[1], pos[3], nrm[3];
+    int n;
+    if (ta == G_SPHERE && tb == G_SPHERE) n = sphere_sphere(a, b, dist, pos, nrm);
+    else if (ta == G_SPHERE && tb == G_BOX) n = sphere_box(a, b, dist, pos, nrm);
+    else if (ta == G_BOX && tb == G_SPHERE) {
+        n = sphere_box(b, a, dist, pos, nrm);
+        nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2];
+    } else {
+        T depth;
+        n = mpr_penetration(a, b, &depth, nrm, pos);
+        dist[0] = -depth;
+    }
+    if (n) {
+        scr[0] = dist[0];
+        for (int k = 0; k < 3; k++) { scr[4 + k] = pos[k]; scr[16 + k] = nrm[k]; }
+    }
+    return n;
 }
 
 // mju_makeFrame [EXT]: tangents from the normal

@@ -28,7 +28,8 @@ enum { J_FREE = 0, J_BALL = 1, J_SLIDE = 2, J_HINGE = 3 };
 enum { R_EQ = 0, R_FLOSS = 1, R_LIMIT = 2, R_CONTACT = 3 };
 constexpr int TREE_W = 8;     // max dofs of one kinematic tree (8, 8, 7, 6, 6 here)
 constexpr int ROW_W = 2 * TREE_W;
-constexpr int CAND_MAX = 256; // broad-phase survivors kept per env and substep
+constexpr int CAND_MAX = 64;   // exact broad-phase survivors per substep (narrow-phase work list)
+constexpr int NEAR_MAX = 192;  // Verlet neighbour list: pairs within reach + skin, rebuilt when a geom moved > skin/2
 
 template <typename real>
 struct DevModel {
@@ -51,7 +52,7 @@ struct DevModel {
     const real *eq_polycoef, *eq_solref, *eq_solimp, *qpos0;
     // geoms
     const int *geom_type, *geom_body, *geom_hull, *geom_class, *geom_static;
-    const real *geom_pos, *geom_mat, *geom_size, *geom_cpos, *geom_rbound, *geom_xpos0, *geom_xmat0, *geom_cen0, *geom_aabb0, *hull_vert;
+    const real *geom_pos, *geom_mat, *geom_size, *geom_cpos, *geom_rbound, *geom_xpos0, *geom_xmat0, *geom_cen0, *geom_aabb0, *geom_lbox, *hull_vert;
     // pairs
     const int *pair_geom, *pair_condim;
     const real *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
@@ -117,13 +118,13 @@ struct MOff {
 
 // per-env LDS layout (offsets in reals / ints)
 struct Layout {
-    int qpos, qvel, ctrl, warm, xpos, xmat, xipos, cdof, gcen, M, L, Minv, bias, fsm, asm_, qacc, fcon, U, nreal;
+    int qpos, qvel, ctrl, warm, xpos, xmat, xipos, cdof, gcen, gref, M, L, Minv, bias, fsm, asm_, qacc, fcon, U, nreal;
     // scratch union U, phase A
     int cinert, cvel, cacc, cfrc;
     // phase B
     int cdist, cpos, cnrm, rJ, rowS, gA;
     // ints
-    int cand, cpair, cefc, rmeta, rowI, gI, misc, nint;
+    int cand, nearl, cpair, cefc, rmeta, rowI, gI, misc, nint;
     int maxgrp;
     int maxcon, maxefc;
     int bytes_per_env;
@@ -426,6 +427,7 @@ struct Env {
     real* r;  // real region of this env
     int* ii;  // int region of this env
     int lane, grp;
+    long long t_broad = 0, t_narrow = 0;
     __device__ Env(const DevModel<real>& m_, const Layout& l_, real* r_, int* i_, int lane_, int grp_)
         : m(m_), lay(l_), r(r_), ii(i_), lane(lane_), grp(grp_) {}
 
@@ -646,6 +648,7 @@ struct Env {
         for (int k = 0; k < 3; k++) s.size[k] = m.geom_size[3 * g + k];
         s.hull = m.hull_vert + 3 * m.geom_hull[2 * g];
         s.nh = m.geom_hull[2 * g + 1];
+        for (int k = 0; k < 3; k++) { s.lc[k] = m.geom_lbox[6 * g + k]; s.lh[k] = m.geom_lbox[6 * g + 3 + k]; }
         if (m.geom_static[g]) {
             for (int k = 0; k < 3; k++) { s.pos[k] = m.geom_xpos0[3 * g + k]; s.center[k] = m.geom_cen0[3 * g + k]; }
             for (int k = 0; k < 9; k++) s.mat[k] = m.geom_xmat0[9 * g + k];
@@ -666,56 +669,97 @@ struct Env {
         real* gcen = r + lay.gcen;
         int *cand = ii + lay.cand, *misc = ii + lay.misc;
         int ncand = 0;
-        for (int base = 0; base < m.npair; base += G) {
-            int p = base + lane;
-            bool hit = false;
-            if (p < m.npair) {
-                int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
-                bool s1 = m.geom_static[g1], s2 = m.geom_static[g2];
-                real rr = m.geom_rbound[g1] + m.geom_rbound[g2] + m.pair_margin[p];
-                if (s1 || s2) {
-                    // dynamic bounding sphere against the world AABB of the static geom
-                    int gs = s1 ? g1 : g2, gd = s1 ? g2 : g1;
-                    real rd = m.geom_rbound[gd] + m.pair_margin[p], d2 = 0;
-                    for (int k = 0; k < 3; k++) {
-                        real c = gcen[3 * gd + k], lo = m.geom_aabb0[6 * gs + k], hi = m.geom_aabb0[6 * gs + 3 + k];
-                        real e = c < lo ? lo - c : (c > hi ? c - hi : real(0));
-                        d2 += e * e;
-                    }
-                    hit = !(d2 > rd * rd);
-                } else {
-                    real d[3];
-                    sub3(gcen + 3 * g2, gcen + 3 * g1, d);
-                    hit = !(dot3(d, d) > rr * rr);
+        long long tb0 = __builtin_readcyclecounter();
+        const real skin = real(0.05);
+        real* gref = r + lay.gref;
+        int* nearl = ii + lay.nearl;
+        // pair test with extra reach `pad` (0 = exact broad phase)
+        auto pair_hit = [&](int p, real pad) -> bool {
+            int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
+            bool s1 = m.geom_static[g1], s2 = m.geom_static[g2];
+            real mg = m.pair_margin[p] + pad;
+            if (s1 || s2) {
+                // dynamic bounding sphere against the world AABB of the static geom
+                int gs = s1 ? g1 : g2, gd = s1 ? g2 : g1;
+                real rd = m.geom_rbound[gd] + mg, d2 = 0;
+                for (int k = 0; k < 3; k++) {
+                    real c = gcen[3 * gd + k], lo = m.geom_aabb0[6 * gs + k], hi = m.geom_aabb0[6 * gs + 3 + k];
+                    real e = c < lo ? lo - c : (c > hi ? c - hi : real(0));
+                    d2 += e * e;
                 }
+                return !(d2 > rd * rd);
             }
-            int tot, rk = group_rank<G>(hit, grp, lane, &tot);
-            if (hit && ncand + rk < CAND_MAX) cand[ncand + rk] = p;
-            if (ncand + tot > CAND_MAX && lane == 0) misc[2] |= 4;
-            ncand = ncand + tot < CAND_MAX ? ncand + tot : CAND_MAX;
+            real d[3], rr = m.geom_rbound[g1] + m.geom_rbound[g2] + mg;
+            sub3(gcen + 3 * g2, gcen + 3 * g1, d);
+            return !(dot3(d, d) > rr * rr);
+        };
+        // Verlet neighbour list: valid while no dynamic geom centre moved more than skin/2 since it was built
+        bool moved = false;
+        if (misc[7]) {
+            for (int g = lane; g < m.ngeom; g += G)
+                if (!m.geom_static[g]) {
+                    real d[3];
+                    sub3(gcen + 3 * g, gref + 3 * g, d);
+                    moved |= dot3(d, d) > real(0.25) * skin * skin;
+                }
+        }
+        bool rebuild = !misc[7] || __any(moved);
+        int nnear = misc[6];
+        if (rebuild) {
+            nnear = 0;
+            for (int base = 0; base < m.npair; base += G) {
+                int p = base + lane;
+                bool hit = p < m.npair && pair_hit(p, skin);
+                int tot, rk = group_rank<G>(hit, grp, lane, &tot);
+                if (hit && nnear + rk < NEAR_MAX) nearl[nnear + rk] = p;
+                nnear += tot;
+            }
+            for (int i = lane; i < 3 * m.ngeom; i += G) gref[i] = gcen[i];
+            if (lane == 0) { misc[6] = nnear < NEAR_MAX ? nnear : NEAR_MAX; misc[7] = nnear <= NEAR_MAX; if (nnear > NEAR_MAX) misc[2] |= 8; }
+            GSYNC();
+        }
+        if (nnear <= NEAR_MAX) {
+            for (int base = 0; base < nnear; base += G) {
+                int i = base + lane, p = i < nnear ? nearl[i] : 0;
+                bool hit = i < nnear && pair_hit(p, real(0));
+                int tot, rk = group_rank<G>(hit, grp, lane, &tot);
+                if (hit && ncand + rk < CAND_MAX) cand[ncand + rk] = p;
+                if (ncand + tot > CAND_MAX && lane == 0) misc[2] |= 4;
+                ncand = ncand + tot < CAND_MAX ? ncand + tot : CAND_MAX;
+            }
+        } else {
+            // neighbour list overflow: exact test over the whole compiled pair list
+            for (int base = 0; base < m.npair; base += G) {
+                int p = base + lane;
+                bool hit = p < m.npair && pair_hit(p, real(0));
+                int tot, rk = group_rank<G>(hit, grp, lane, &tot);
+                if (hit && ncand + rk < CAND_MAX) cand[ncand + rk] = p;
+                if (ncand + tot > CAND_MAX && lane == 0) misc[2] |= 4;
+                ncand = ncand + tot < CAND_MAX ? ncand + tot : CAND_MAX;
+            }
         }
         if (lane == 0) misc[3] = ncand;
         GSYNC();
+        long long tb1 = __builtin_readcyclecounter();
+        t_broad += tb1 - tb0;
         real *cdist = r + lay.cdist, *cpos = r + lay.cpos, *cnrm = r + lay.cnrm;
         int* cpair = ii + lay.cpair;
         int ncon = 0, ovf = 0;
         for (int base = 0; base < ncand; base += G) {
             int ci = base + lane, n = 0, p = 0;
-            real dist[4], pos[12], nrm[12];
+            // per-lane LDS scratch (polygon work space + results): the row storage is not live during collision
+            LDS_PTR(real) scr = (LDS_PTR(real))(r + lay.rJ + 56 * lane);
+            int keepmask = 0;
             if (ci < ncand) {
                 p = cand[ci];
                 Shape<real> a, b;
                 load_shape(m.pair_geom[2 * p], a);
                 load_shape(m.pair_geom[2 * p + 1], b);
-                n = narrow(a, b, dist, pos, nrm);
+                int nn = narrow(a, b, scr);
                 // drop separated points (margin = 0 here) while keeping order
-                int w = 0;
-                for (int k = 0; k < n; k++)
-                    if (dist[k] < m.pair_margin[p]) {
-                        if (w != k) { dist[w] = dist[k]; for (int q = 0; q < 3; q++) { pos[3 * w + q] = pos[3 * k + q]; nrm[3 * w + q] = nrm[3 * k + q]; } }
-                        w++;
-                    }
-                n = w;
+                real mg = m.pair_margin[p];
+                for (int k = 0; k < nn; k++)
+                    if (scr[k] < mg) { keepmask |= 1 << k; n++; }
             }
             int off = 0, tot = 0;
             for (int j = 1; j <= 4; j++) {
@@ -723,19 +767,23 @@ struct Env {
                 off += rj;
                 tot += tj;
             }
-            for (int k = 0; k < n; k++) {
-                int c = ncon + off + k;
-                if (c < lay.maxcon) {
-                    cdist[c] = dist[k];
-                    cpair[c] = p;
-                    for (int q = 0; q < 3; q++) { cpos[3 * c + q] = pos[3 * k + q]; cnrm[3 * c + q] = nrm[3 * k + q]; }
+            int w = 0;
+            for (int k = 0; k < 4; k++)
+                if ((keepmask >> k) & 1) {
+                    int c = ncon + off + w;
+                    w++;
+                    if (c < lay.maxcon) {
+                        cdist[c] = scr[k];
+                        cpair[c] = p;
+                        for (int q = 0; q < 3; q++) { cpos[3 * c + q] = scr[4 + 3 * k + q]; cnrm[3 * c + q] = scr[16 + q]; }
+                    }
                 }
-            }
             if (ncon + tot > lay.maxcon) ovf = 1;
             ncon = ncon + tot < lay.maxcon ? ncon + tot : lay.maxcon;
         }
         if (lane == 0) { misc[0] = ncon; misc[2] |= ovf; }
         GSYNC();
+        t_narrow += __builtin_readcyclecounter() - tb1;
     }
 
     // Jacobian entry of body b's point p for tree-local dof slot k of tree t (translational row along ax, or rotational)
@@ -1215,7 +1263,7 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(DevModel<real> mg, Layout lay
         for (int k = 0; k < 9; k++) r[lay.xmat + 9 * b + k] = m.static_xmat[9 * b + k];
         for (int k = 0; k < 3; k++) r[lay.xipos + 3 * b + k] = 0;
     }
-    if (lane == 0) { ii[lay.misc + 0] = 0; ii[lay.misc + 1] = 0; ii[lay.misc + 2] = 0; }
+    if (lane == 0) for (int k = 0; k < 8; k++) ii[lay.misc + k] = 0;
     GSYNC();
     if (action) {
         // env.py:203-215: action -> ctrl, grippers un-normalised (env.py:156-161)
@@ -1239,7 +1287,7 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(DevModel<real> mg, Layout lay
         PROF(6, E.solve(pgs_iters));
         PROF(7, E.euler());
     }
-    if (o_prof && lane == 0) for (int k = 0; k < 8; k++) o_prof[(size_t)env * 8 + k] = tp[k];
+    if (o_prof && lane == 0) { for (int k = 0; k < 8; k++) o_prof[(size_t)env * 10 + k] = tp[k]; o_prof[(size_t)env * 10 + 8] = E.t_broad; o_prof[(size_t)env * 10 + 9] = E.t_narrow; }
     // trailing refresh of the position-dependent quantities of the final state
     int nefc_last = ii[lay.misc + 1];
     E.kinematics();
@@ -1410,12 +1458,25 @@ struct PhysHost {
         int ng = m.ngeom;
         std::vector<double> gmat(9 * ng), gcp(3 * ng), gx0(3 * ng, 0.0), gm0(9 * ng, 0.0), gc0(3 * ng, 0.0);
         std::vector<int> gstat(ng);
-        std::vector<double> gaabb(6 * ng, 0.0);
+        std::vector<double> gaabb(6 * ng, 0.0), glbox(6 * ng, 0.0);   // world AABB of static geoms; local box (centre, half extents) of every geom
         auto ghull = I("geom_hull"); auto gtype = I("geom_type"); auto gsize = F("geom_size"); auto hv = F("hull_vert");
         for (int g = 0; g < ng; g++) {
             q2m(&gquat[4 * g], &gmat[9 * g]);
             for (int i = 0; i < 3; i++)
                 gcp[3 * g + i] = gpos[3 * g + i] + gmat[9 * g + 3 * i] * gbc[3 * g] + gmat[9 * g + 3 * i + 1] * gbc[3 * g + 1] + gmat[9 * g + 3 * i + 2] * gbc[3 * g + 2];
+            {
+                double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
+                if (gtype[g] == G_MESH) {
+                    for (int v = 0; v < ghull[2 * g + 1]; v++)
+                        for (int k = 0; k < 3; k++) { double x = hv[3 * (ghull[2 * g] + v) + k]; if (x < lo[k]) lo[k] = x; if (x > hi[k]) hi[k] = x; }
+                } else {
+                    double ex[3] = {gsize[3 * g], gsize[3 * g + 1], gsize[3 * g + 2]};
+                    if (gtype[g] == G_SPHERE) ex[1] = ex[2] = ex[0];
+                    if (gtype[g] == G_CYLINDER) { ex[2] = ex[1]; ex[1] = ex[0]; }
+                    for (int k = 0; k < 3; k++) { lo[k] = -ex[k]; hi[k] = ex[k]; }
+                }
+                for (int k = 0; k < 3; k++) { glbox[6 * g + k] = 0.5 * (lo[k] + hi[k]); glbox[6 * g + 3 + k] = 0.5 * (hi[k] - lo[k]); }
+            }
             int bb = gbody[g];
             gstat[g] = body_tree[bb] < 0;
             if (gstat[g]) {
@@ -1446,7 +1507,7 @@ struct PhysHost {
         }
         m.geom_type = up(I("geom_type")); moff.geom_type = (int)img_int.size(); { auto v_ = I("geom_type"); img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.geom_body = up(gbody); moff.geom_body = (int)img_int.size(); { auto v_ = gbody; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.geom_hull = up(I("geom_hull")); m.geom_class = up(I("geom_class")); m.geom_static = up(gstat); moff.geom_static = (int)img_int.size(); { auto v_ = gstat; img_int.insert(img_int.end(), v_.begin(), v_.end()); }
         m.geom_pos = upr<real>(gpos); m.geom_mat = upr<real>(gmat); m.geom_size = upr<real>(F("geom_size")); m.geom_cpos = upr<real>(gcp); moff.geom_cpos = (int)img_real.size(); { auto v_ = gcp; img_real.insert(img_real.end(), v_.begin(), v_.end()); }
-        m.geom_rbound = upr<real>(F("geom_rbound")); moff.geom_rbound = (int)img_real.size(); { auto v_ = F("geom_rbound"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.geom_xpos0 = upr<real>(gx0); m.geom_xmat0 = upr<real>(gm0); m.geom_cen0 = upr<real>(gc0); m.geom_aabb0 = upr<real>(gaabb);
+        m.geom_rbound = upr<real>(F("geom_rbound")); moff.geom_rbound = (int)img_real.size(); { auto v_ = F("geom_rbound"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.geom_xpos0 = upr<real>(gx0); m.geom_xmat0 = upr<real>(gm0); m.geom_cen0 = upr<real>(gc0); m.geom_aabb0 = upr<real>(gaabb); m.geom_lbox = upr<real>(glbox);
         m.hull_vert = upr<real>(F("hull_vert"));
         m.pair_geom = up(I("pair_geom")); m.pair_condim = up(I("pair_condim"));
         m.pair_friction = upr<real>(F("pair_friction")); m.pair_solref = upr<real>(F("pair_solref")); m.pair_solimp = upr<real>(F("pair_solimp"));
@@ -1466,7 +1527,7 @@ struct PhysHost {
         int o = 0;
         auto R = [&](int n) { int a = o; o += n; return a; };
         L.qpos = R(nq); L.qvel = R(nv); L.ctrl = R(nu); L.warm = R(nv);
-        L.xpos = R(3 * nb); L.xmat = R(9 * nb); L.xipos = R(3 * nb); L.cdof = R(6 * nv); L.gcen = R(3 * ng);
+        L.xpos = R(3 * nb); L.xmat = R(9 * nb); L.xipos = R(3 * nb); L.cdof = R(6 * nv); L.gcen = R(3 * ng); L.gref = R(3 * ng);
         L.M = R(msize); L.L = R(msize); o = (o + 3) & ~3; L.Minv = R(64 * 8);
         L.bias = R(nv); L.fsm = R(nv); L.asm_ = R(nv); L.qacc = R(nv); L.fcon = R(nv);
         L.U = o;
@@ -1481,7 +1542,7 @@ struct PhysHost {
         L.nreal = (o + 3) & ~3;
         int io = 0;
         auto Iq = [&](int n) { int x = io; io += n; return x; };
-        L.cand = Iq(CAND_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.misc = Iq(8);
+        L.cand = Iq(CAND_MAX); L.nearl = Iq(NEAR_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.misc = Iq(8);
         L.nint = (io + 3) & ~3;
         L.maxcon = maxcon;
         L.maxefc = maxefc;
@@ -1540,7 +1601,7 @@ struct PhysHost {
         if (n == "export_contacts") { export_contacts = v != 0; return true; }
         if (n == "waves_per_block") { int x = (int)v; if (x == 0 || x == 1 || x == 2 || x == 4) { wpb_override = x; return true; } return false; }
         if (n == "profile_phases") {
-            if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * 8, 0));
+            if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * 10, 0));
             if (v == 0) d_prof = nullptr;
             return true;
         }

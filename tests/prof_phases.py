@@ -14,10 +14,11 @@ md = model_dict()
 a = np.repeat(home_action(md)[None], N, 0)
 for _ in range(3):
     sim.step(a)
-out = np.zeros((N, 8), dtype=np.int64)
+out = np.zeros((N, 10), dtype=np.int64)
 sim.h.check(sim.h.L.avsim_get_phase_cycles(sim.h.h, out.ctypes.data))
 names = ["kinematics", "crb", "rne", "smooth", "collide", "rows", "solve", "euler"]
-m = out.mean(0) / 20
+print("broad/narrow per collide call:", out[:, 8].mean() / 21, out[:, 9].mean() / 21)
+m = out[:, :8].mean(0) / 20
 print("cycles per substep per wave (mean over envs):")
 for n, v in zip(names, m):
     print(f"  {n:10s} {v:10.0f}  {100 * v / m.sum():5.1f}%")
