@@ -551,6 +551,7 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
         float(m.option.get("impratio", 1)),      # aloha_sim.xml:4
         float(m.option.get("noslip_iterations", 0)),
         1.0 if m.option.get("cone", "pyramidal") == "elliptic" else 0.0,
+        float(np.trace(M) / nv),                 # stat.meaninertia at qpos0 [EXT], scales the solver tolerance
     ])
     md["task_id"] = task_id
     md["num_arms"] = num_arms

@@ -427,9 +427,65 @@ struct Env {
     real* r;  // real region of this env
     int* ii;  // int region of this env
     int lane, grp;
+    const MOff& mo;   // offsets of the hot tables inside the block's LDS image
+    const real* lr;
+    const int* li;
     long long t_broad = 0, t_narrow = 0;
-    __device__ Env(const DevModel<real>& m_, const Layout& l_, real* r_, int* i_, int lane_, int grp_)
-        : m(m_), lay(l_), r(r_), ii(i_), lane(lane_), grp(grp_) {}
+    __device__ Env(const DevModel<real>& m_, const Layout& l_, real* r_, int* i_, int lane_, int grp_, const MOff& mo_, const real* lr_, const int* li_)
+        : m(m_), lay(l_), r(r_), ii(i_), lane(lane_), grp(grp_), mo(mo_), lr(lr_), li(li_) {}
+    // hot model tables live in LDS (copied once per block); the accessors rebuild the pointer from the kernarg offset
+    AVS_DEV const int* body_parent_() const { return li + mo.body_parent; }
+    AVS_DEV const int* body_jntadr_() const { return li + mo.body_jntadr; }
+    AVS_DEV const int* body_jntnum_() const { return li + mo.body_jntnum; }
+    AVS_DEV const int* body_dofadr_() const { return li + mo.body_dofadr; }
+    AVS_DEV const int* body_dofnum_() const { return li + mo.body_dofnum; }
+    AVS_DEV const int* body_tree_() const { return li + mo.body_tree; }
+    AVS_DEV const int* body_dofmask_() const { return li + mo.body_dofmask; }
+    AVS_DEV const int* tree_bodyadr_() const { return li + mo.tree_bodyadr; }
+    AVS_DEV const int* tree_bodylist_() const { return li + mo.tree_bodylist; }
+    AVS_DEV const int* tree_dofadr_() const { return li + mo.tree_dofadr; }
+    AVS_DEV const int* tree_dofnum_() const { return li + mo.tree_dofnum; }
+    AVS_DEV const int* tree_madr_() const { return li + mo.tree_madr; }
+    AVS_DEV const int* jnt_type_() const { return li + mo.jnt_type; }
+    AVS_DEV const int* jnt_qposadr_() const { return li + mo.jnt_qposadr; }
+    AVS_DEV const int* jnt_dofadr_() const { return li + mo.jnt_dofadr; }
+    AVS_DEV const int* jnt_actfrclimited_() const { return li + mo.jnt_actfrclimited; }
+    AVS_DEV const int* limited_jnt_() const { return li + mo.limited_jnt; }
+    AVS_DEV const int* dof_body_() const { return li + mo.dof_body; }
+    AVS_DEV const int* dof_parent_() const { return li + mo.dof_parent; }
+    AVS_DEV const int* dof_tree_() const { return li + mo.dof_tree; }
+    AVS_DEV const int* dof_jnt_() const { return li + mo.dof_jnt; }
+    AVS_DEV const int* floss_dof_() const { return li + mo.floss_dof; }
+    AVS_DEV const int* ment_i_() const { return li + mo.ment_i; }
+    AVS_DEV const int* ment_j_() const { return li + mo.ment_j; }
+    AVS_DEV const int* act_dof_() const { return li + mo.act_dof; }
+    AVS_DEV const int* act_qposadr_() const { return li + mo.act_qposadr; }
+    AVS_DEV const int* act_ctrllimited_() const { return li + mo.act_ctrllimited; }
+    AVS_DEV const int* geom_type_() const { return li + mo.geom_type; }
+    AVS_DEV const int* geom_body_() const { return li + mo.geom_body; }
+    AVS_DEV const int* geom_static_() const { return li + mo.geom_static; }
+    AVS_DEV const real* body_pos_() const { return lr + mo.body_pos; }
+    AVS_DEV const real* body_quat_() const { return lr + mo.body_quat; }
+    AVS_DEV const real* body_mass_() const { return lr + mo.body_mass; }
+    AVS_DEV const real* body_ipos_() const { return lr + mo.body_ipos; }
+    AVS_DEV const real* body_inertia_() const { return lr + mo.body_inertia; }
+    AVS_DEV const real* body_invweight0_() const { return lr + mo.body_invweight0; }
+    AVS_DEV const real* jnt_pos_() const { return lr + mo.jnt_pos; }
+    AVS_DEV const real* jnt_axis_() const { return lr + mo.jnt_axis; }
+    AVS_DEV const real* jnt_range_() const { return lr + mo.jnt_range; }
+    AVS_DEV const real* jnt_actfrcrange_() const { return lr + mo.jnt_actfrcrange; }
+    AVS_DEV const real* jnt_margin_() const { return lr + mo.jnt_margin; }
+    AVS_DEV const real* dof_armature_() const { return lr + mo.dof_armature; }
+    AVS_DEV const real* dof_damping_() const { return lr + mo.dof_damping; }
+    AVS_DEV const real* dof_frictionloss_() const { return lr + mo.dof_frictionloss; }
+    AVS_DEV const real* dof_invweight0_() const { return lr + mo.dof_invweight0; }
+    AVS_DEV const real* act_kp_() const { return lr + mo.act_kp; }
+    AVS_DEV const real* act_kv_() const { return lr + mo.act_kv; }
+    AVS_DEV const real* act_gear_() const { return lr + mo.act_gear; }
+    AVS_DEV const real* act_ctrlrange_() const { return lr + mo.act_ctrlrange; }
+    AVS_DEV const real* geom_cpos_() const { return lr + mo.geom_cpos; }
+    AVS_DEV const real* geom_rbound_() const { return lr + mo.geom_rbound; }
+
 
     // ---- P1 ------------------------------------------------------------------------------------
     __device__ void kinematics() {
@@ -437,11 +493,11 @@ struct Env {
         for (int i = lane; i < 6 * m.nv; i += G) cdof[i] = 0;
         GSYNC();
         for (int t = lane; t < m.ntree; t += G) {
-            for (int bi = m.tree_bodyadr[t]; bi < m.tree_bodyadr[t + 1]; bi++) {
-                int b = m.tree_bodylist[bi], p = m.body_parent[b], ja = m.body_jntadr[b], jn = m.body_jntnum[b];
+            for (int bi = tree_bodyadr_()[t]; bi < tree_bodyadr_()[t + 1]; bi++) {
+                int b = tree_bodylist_()[bi], p = body_parent_()[b], ja = body_jntadr_()[b], jn = body_jntnum_()[b];
                 real pos[3], quat[4], R[9];
-                if (jn == 1 && m.jnt_type[ja] == J_FREE) {
-                    int qa = m.jnt_qposadr[ja], da = m.jnt_dofadr[ja];
+                if (jn == 1 && jnt_type_()[ja] == J_FREE) {
+                    int qa = jnt_qposadr_()[ja], da = jnt_dofadr_()[ja];
                     for (int k = 0; k < 3; k++) pos[k] = qpos[qa + k];
                     for (int k = 0; k < 4; k++) quat[k] = qpos[qa + 3 + k];
                     quatnorm(quat);
@@ -453,28 +509,28 @@ struct Env {
                         for (int q = 0; q < 3; q++) { cdof[6 * (da + 3 + k) + q] = w[q]; cdof[6 * (da + 3 + k) + 3 + q] = c[q]; }
                     }
                 } else {
-                    real t3[3], pq[4], bp[3] = {m.body_pos[3 * b], m.body_pos[3 * b + 1], m.body_pos[3 * b + 2]};
+                    real t3[3], pq[4], bp[3] = {body_pos_()[3 * b], body_pos_()[3 * b + 1], body_pos_()[3 * b + 2]};
                     // parent pose: LDS for dynamic parents, constants for static ones (copied to LDS at launch)
                     mulmat(xmat + 9 * p, bp, t3);
                     for (int k = 0; k < 3; k++) pos[k] = xpos[3 * p + k] + t3[k];
                     // parent quaternion is not stored: carry orientation as a matrix product instead
                     real Rb[9], Rl[9];
-                    real bq[4] = {m.body_quat[4 * b], m.body_quat[4 * b + 1], m.body_quat[4 * b + 2], m.body_quat[4 * b + 3]};
+                    real bq[4] = {body_quat_()[4 * b], body_quat_()[4 * b + 1], body_quat_()[4 * b + 2], body_quat_()[4 * b + 3]};
                     quat2mat(bq, Rl);
                     const real* Rp = xmat + 9 * p;
                     for (int i = 0; i < 3; i++)
                         for (int j = 0; j < 3; j++) Rb[3 * i + j] = Rp[3 * i] * Rl[j] + Rp[3 * i + 1] * Rl[3 + j] + Rp[3 * i + 2] * Rl[6 + j];
                     (void)pq;
                     for (int j = ja; j < ja + jn; j++) {
-                        real ax[3] = {m.jnt_axis[3 * j], m.jnt_axis[3 * j + 1], m.jnt_axis[3 * j + 2]};
-                        real jp[3] = {m.jnt_pos[3 * j], m.jnt_pos[3 * j + 1], m.jnt_pos[3 * j + 2]};
+                        real ax[3] = {jnt_axis_()[3 * j], jnt_axis_()[3 * j + 1], jnt_axis_()[3 * j + 2]};
+                        real jp[3] = {jnt_pos_()[3 * j], jnt_pos_()[3 * j + 1], jnt_pos_()[3 * j + 2]};
                         real axis[3], anchor[3];
                         mulmat(Rb, ax, axis);
                         mulmat(Rb, jp, anchor);
                         for (int k = 0; k < 3; k++) anchor[k] += pos[k];
-                        real q = qpos[m.jnt_qposadr[j]];
-                        int dof = m.jnt_dofadr[j];
-                        if (m.jnt_type[j] == J_HINGE) {
+                        real q = qpos[jnt_qposadr_()[j]];
+                        int dof = jnt_dofadr_()[j];
+                        if (jnt_type_()[j] == J_HINGE) {
                             real c[3];
                             cross3(anchor, axis, c);
                             for (int k = 0; k < 3; k++) { cdof[6 * dof + k] = axis[k]; cdof[6 * dof + 3 + k] = c[k]; }
@@ -498,7 +554,7 @@ struct Env {
                 }
                 for (int k = 0; k < 3; k++) xpos[3 * b + k] = pos[k];
                 for (int k = 0; k < 9; k++) xmat[9 * b + k] = R[k];
-                real ip[3] = {m.body_ipos[3 * b], m.body_ipos[3 * b + 1], m.body_ipos[3 * b + 2]}, t3[3];
+                real ip[3] = {body_ipos_()[3 * b], body_ipos_()[3 * b + 1], body_ipos_()[3 * b + 2]}, t3[3];
                 mulmat(R, ip, t3);
                 for (int k = 0; k < 3; k++) xipos[3 * b + k] = pos[k] + t3[k];
             }
@@ -506,9 +562,9 @@ struct Env {
         GSYNC();
         real* gcen = r + lay.gcen;
         for (int g = lane; g < m.ngeom; g += G) {
-            if (m.geom_static[g]) continue;
-            int b = m.geom_body[g];
-            real c[3] = {m.geom_cpos[3 * g], m.geom_cpos[3 * g + 1], m.geom_cpos[3 * g + 2]}, t3[3];
+            if (geom_static_()[g]) continue;
+            int b = geom_body_()[g];
+            real c[3] = {geom_cpos_()[3 * g], geom_cpos_()[3 * g + 1], geom_cpos_()[3 * g + 2]}, t3[3];
             mulmat(xmat + 9 * b, c, t3);
             for (int k = 0; k < 3; k++) gcen[3 * g + k] = xpos[3 * b + k] + t3[k];
         }
@@ -520,7 +576,7 @@ struct Env {
         real *xmat = r + lay.xmat, *xipos = r + lay.xipos, *cdof = r + lay.cdof, *ci = r + lay.cinert, *M = r + lay.M, *L = r + lay.L;
         for (int b = lane; b < m.nbody; b += G) {
             SInert<real> s;
-            if (m.body_tree[b] >= 0) body_inertia(m, xmat, xipos, b, s);
+            if (body_tree_()[b] >= 0) body_inertia(m, xmat, xipos, b, s);
             else { s.m = 0; for (int k = 0; k < 3; k++) s.h[k] = 0; for (int k = 0; k < 6; k++) s.I[k] = 0; }
             real* o = ci + 10 * b;
             o[0] = s.m;
@@ -530,33 +586,52 @@ struct Env {
         for (int i = lane; i < m.msize; i += G) M[i] = 0;
         GSYNC();
         for (int t = lane; t < m.ntree; t += G)
-            for (int bi = m.tree_bodyadr[t + 1] - 1; bi > m.tree_bodyadr[t]; bi--) {
-                int b = m.tree_bodylist[bi], p = m.body_parent[b];
-                if (m.body_tree[p] != t) continue;
+            for (int bi = tree_bodyadr_()[t + 1] - 1; bi > tree_bodyadr_()[t]; bi--) {
+                int b = tree_bodylist_()[bi], p = body_parent_()[b];
+                if (body_tree_()[p] != t) continue;
                 for (int k = 0; k < 10; k++) ci[10 * p + k] += ci[10 * b + k];
             }
         GSYNC();
         for (int e = lane; e < m.nment; e += G) {
-            int i = m.ment_i[e], j = m.ment_j[e], t = m.dof_tree[i], n = m.tree_dofnum[t], a = m.tree_dofadr[t];
+            int i = ment_i_()[e], j = ment_j_()[e], t = dof_tree_()[i], n = tree_dofnum_()[t], a = tree_dofadr_()[t];
             real f[6];
-            inert_mul(ci + 10 * m.dof_body[i], cdof + 6 * i, f);
+            inert_mul(ci + 10 * dof_body_()[i], cdof + 6 * i, f);
             real v = 0;
             for (int k = 0; k < 6; k++) v += cdof[6 * j + k] * f[k];
-            if (i == j) v += m.dof_armature[i];
-            real* Mb = M + m.tree_madr[t];
+            if (i == j) v += dof_armature_()[i];
+            real* Mb = M + tree_madr_()[t];
             Mb[(i - a) * n + (j - a)] = v;
             Mb[(j - a) * n + (i - a)] = v;
         }
         GSYNC();
-        for (int t = lane; t < m.ntree; t += G) chol_block(M + m.tree_madr[t], L + m.tree_madr[t], m.tree_dofnum[t]);
+        for (int t = lane; t < m.ntree; t += G) chol_block(M + tree_madr_()[t], L + tree_madr_()[t], tree_dofnum_()[t]);
         GSYNC();
         // dense per-tree inverse (8x8, zero padded): B = J M^-1 is formed on the fly from it, so rows store only J
         real* Minv = r + lay.Minv;
         for (int w = lane; w < m.ntree * TREE_W; w += G) {
-            int t = w >> 3, j = w & 7, n = m.tree_dofnum[t];
+            int t = w >> 3, j = w & 7, n = tree_dofnum_()[t];
             real x[TREE_W];
+            const real* Lt = L + tree_madr_()[t];
+#pragma unroll
             for (int k = 0; k < TREE_W; k++) x[k] = (k == j && j < n) ? real(1) : real(0);
-            if (j < n) chol_solve_block(L + m.tree_madr[t], x, n);
+            // triangular solves unrolled to 8 with predicates: x stays in registers
+#pragma unroll
+            for (int i = 0; i < TREE_W; i++)
+                if (i < n) {
+                    real sacc = x[i];
+#pragma unroll
+                    for (int k = 0; k < i; k++) sacc -= Lt[i * n + k] * x[k];
+                    x[i] = sacc / Lt[i * n + i];
+                }
+#pragma unroll
+            for (int i = TREE_W - 1; i >= 0; i--)
+                if (i < n) {
+                    real sacc = x[i];
+#pragma unroll
+                    for (int k = i + 1; k < TREE_W; k++) if (k < n) sacc -= Lt[k * n + i] * x[k];
+                    x[i] = sacc / Lt[i * n + i];
+                }
+#pragma unroll
             for (int k = 0; k < TREE_W; k++) Minv[64 * t + 8 * k + j] = (k < n && j < n) ? x[k] : real(0);
         }
         GSYNC();
@@ -567,16 +642,16 @@ struct Env {
         real *xmat = r + lay.xmat, *xipos = r + lay.xipos, *cdof = r + lay.cdof, *qvel = r + lay.qvel;
         real *cvel = r + lay.cvel, *cacc = r + lay.cacc, *cfrc = r + lay.cfrc, *bias = r + lay.bias;
         for (int t = lane; t < m.ntree; t += G) {
-            int b0 = m.tree_bodyadr[t], b1 = m.tree_bodyadr[t + 1];
+            int b0 = tree_bodyadr_()[t], b1 = tree_bodyadr_()[t + 1];
             for (int bi = b0; bi < b1; bi++) {
-                int b = m.tree_bodylist[bi], p = m.body_parent[b];
+                int b = tree_bodylist_()[bi], p = body_parent_()[b];
                 real v[6], a[6];
-                if (m.body_tree[p] == t) { for (int k = 0; k < 6; k++) { v[k] = cvel[6 * p + k]; a[k] = cacc[6 * p + k]; } }
+                if (body_tree_()[p] == t) { for (int k = 0; k < 6; k++) { v[k] = cvel[6 * p + k]; a[k] = cacc[6 * p + k]; } }
                 else { for (int k = 0; k < 6; k++) { v[k] = 0; a[k] = 0; } a[3] = -m.gravity[0]; a[4] = -m.gravity[1]; a[5] = -m.gravity[2]; }
-                int da = m.body_dofadr[b], dn = m.body_dofnum[b], j = 0;
+                int da = body_dofadr_()[b], dn = body_dofnum_()[b], j = 0;
                 while (j < dn) {
                     int dof = da + j;
-                    if (m.jnt_type[m.dof_jnt[dof]] == J_FREE) {
+                    if (jnt_type_()[dof_jnt_()[dof]] == J_FREE) {
                         for (int k = 0; k < 3; k++)
                             for (int q = 0; q < 6; q++) v[q] += cdof[6 * (dof + k) + q] * qvel[dof + k];
                         real dot[3][6];
@@ -601,14 +676,14 @@ struct Env {
                 for (int k = 0; k < 6; k++) { cvel[6 * b + k] = v[k]; cacc[6 * b + k] = a[k]; cfrc[6 * b + k] = Ia[k] + vIv[k]; }
             }
             for (int bi = b1 - 1; bi > b0; bi--) {
-                int b = m.tree_bodylist[bi], p = m.body_parent[b];
-                if (m.body_tree[p] != t) continue;
+                int b = tree_bodylist_()[bi], p = body_parent_()[b];
+                if (body_tree_()[p] != t) continue;
                 for (int k = 0; k < 6; k++) cfrc[6 * p + k] += cfrc[6 * b + k];
             }
-            int a0 = m.tree_dofadr[t];
-            for (int i = a0; i < a0 + m.tree_dofnum[t]; i++) {
+            int a0 = tree_dofadr_()[t];
+            for (int i = a0; i < a0 + tree_dofnum_()[t]; i++) {
                 real s = 0;
-                for (int k = 0; k < 6; k++) s += cdof[6 * i + k] * cfrc[6 * m.dof_body[i] + k];
+                for (int k = 0; k < 6; k++) s += cdof[6 * i + k] * cfrc[6 * dof_body_()[i] + k];
                 bias[i] = s;
             }
         }
@@ -623,37 +698,37 @@ struct Env {
         GSYNC();
         for (int u = lane; u < m.nu; u += G) {
             real c = ctrl[u];
-            if (m.act_ctrllimited[u]) c = tclamp(c, m.act_ctrlrange[2 * u], m.act_ctrlrange[2 * u + 1]);
-            int dof = m.act_dof[u];
-            real f = m.act_kp[u] * c - m.act_kp[u] * qpos[m.act_qposadr[u]] - m.act_kv[u] * qvel[dof];
-            act[dof] += m.act_gear[u] * f;   // one actuator per dof in these models
+            if (act_ctrllimited_()[u]) c = tclamp(c, act_ctrlrange_()[2 * u], act_ctrlrange_()[2 * u + 1]);
+            int dof = act_dof_()[u];
+            real f = act_kp_()[u] * c - act_kp_()[u] * qpos[act_qposadr_()[u]] - act_kv_()[u] * qvel[dof];
+            act[dof] += act_gear_()[u] * f;   // one actuator per dof in these models
         }
         GSYNC();
         for (int i = lane; i < m.nv; i += G) {
-            int j = m.dof_jnt[i];
+            int j = dof_jnt_()[i];
             real a = act[i];
-            if (m.jnt_actfrclimited[j] && m.jnt_type[j] != J_FREE) a = tclamp(a, m.jnt_actfrcrange[2 * j], m.jnt_actfrcrange[2 * j + 1]);
-            real f = -m.dof_damping[i] * qvel[i] - bias[i] + a;
+            if (jnt_actfrclimited_()[j] && jnt_type_()[j] != J_FREE) a = tclamp(a, jnt_actfrcrange_()[2 * j], jnt_actfrcrange_()[2 * j + 1]);
+            real f = -dof_damping_()[i] * qvel[i] - bias[i] + a;
             fsm[i] = f;
             as[i] = f;
         }
         GSYNC();
-        for (int t = lane; t < m.ntree; t += G) chol_solve_block(r + lay.L + m.tree_madr[t], as + m.tree_dofadr[t], m.tree_dofnum[t]);
+        for (int t = lane; t < m.ntree; t += G) chol_solve_block(r + lay.L + tree_madr_()[t], as + tree_dofadr_()[t], tree_dofnum_()[t]);
         GSYNC();
     }
 
     __device__ void load_shape(int g, Shape<real>& s) {
         real *xpos = r + lay.xpos, *xmat = r + lay.xmat, *gcen = r + lay.gcen;
-        s.type = m.geom_type[g];
+        s.type = geom_type_()[g];
         for (int k = 0; k < 3; k++) s.size[k] = m.geom_size[3 * g + k];
         s.hull = m.hull_vert + 3 * m.geom_hull[2 * g];
         s.nh = m.geom_hull[2 * g + 1];
         for (int k = 0; k < 3; k++) { s.lc[k] = m.geom_lbox[6 * g + k]; s.lh[k] = m.geom_lbox[6 * g + 3 + k]; }
-        if (m.geom_static[g]) {
+        if (geom_static_()[g]) {
             for (int k = 0; k < 3; k++) { s.pos[k] = m.geom_xpos0[3 * g + k]; s.center[k] = m.geom_cen0[3 * g + k]; }
             for (int k = 0; k < 9; k++) s.mat[k] = m.geom_xmat0[9 * g + k];
         } else {
-            int b = m.geom_body[g];
+            int b = geom_body_()[g];
             real gp[3] = {m.geom_pos[3 * g], m.geom_pos[3 * g + 1], m.geom_pos[3 * g + 2]}, t3[3];
             mulmat(xmat + 9 * b, gp, t3);
             for (int k = 0; k < 3; k++) { s.pos[k] = xpos[3 * b + k] + t3[k]; s.center[k] = gcen[3 * g + k]; }
@@ -676,12 +751,12 @@ struct Env {
         // pair test with extra reach `pad` (0 = exact broad phase)
         auto pair_hit = [&](int p, real pad) -> bool {
             int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
-            bool s1 = m.geom_static[g1], s2 = m.geom_static[g2];
+            bool s1 = geom_static_()[g1], s2 = geom_static_()[g2];
             real mg = m.pair_margin[p] + pad;
             if (s1 || s2) {
                 // dynamic bounding sphere against the world AABB of the static geom
                 int gs = s1 ? g1 : g2, gd = s1 ? g2 : g1;
-                real rd = m.geom_rbound[gd] + mg, d2 = 0;
+                real rd = geom_rbound_()[gd] + mg, d2 = 0;
                 for (int k = 0; k < 3; k++) {
                     real c = gcen[3 * gd + k], lo = m.geom_aabb0[6 * gs + k], hi = m.geom_aabb0[6 * gs + 3 + k];
                     real e = c < lo ? lo - c : (c > hi ? c - hi : real(0));
@@ -689,7 +764,7 @@ struct Env {
                 }
                 return !(d2 > rd * rd);
             }
-            real d[3], rr = m.geom_rbound[g1] + m.geom_rbound[g2] + mg;
+            real d[3], rr = geom_rbound_()[g1] + geom_rbound_()[g2] + mg;
             sub3(gcen + 3 * g2, gcen + 3 * g1, d);
             return !(dot3(d, d) > rr * rr);
         };
@@ -697,7 +772,7 @@ struct Env {
         bool moved = false;
         if (misc[7]) {
             for (int g = lane; g < m.ngeom; g += G)
-                if (!m.geom_static[g]) {
+                if (!geom_static_()[g]) {
                     real d[3];
                     sub3(gcen + 3 * g, gref + 3 * g, d);
                     moved |= dot3(d, d) > real(0.25) * skin * skin;
@@ -788,8 +863,8 @@ struct Env {
 
     // Jacobian entry of body b's point p for tree-local dof slot k of tree t (translational row along ax, or rotational)
     AVS_DEV real jac_entry(int b, int t, int k, const real* p, const real* ax, bool rot) const {
-        if (m.body_tree[b] != t || !((m.body_dofmask[b] >> k) & 1)) return real(0);
-        const real* cd = r + lay.cdof + 6 * (m.tree_dofadr[t] + k);
+        if (body_tree_()[b] != t || !((body_dofmask_()[b] >> k) & 1)) return real(0);
+        const real* cd = r + lay.cdof + 6 * (tree_dofadr_()[t] + k);
         if (rot) return ax[0] * cd[0] + ax[1] * cd[1] + ax[2] * cd[2];
         real c[3];
         cross3(cd, p, c);
@@ -809,10 +884,10 @@ struct Env {
         for (int base = 0; base < m.nlimited; base += G) {
             int li = base + lane, lo = 0, hi = 0, j = 0;
             if (li < m.nlimited) {
-                j = m.limited_jnt[li];
-                real q = qpos[m.jnt_qposadr[j]];
-                lo = (q - m.jnt_range[2 * j]) < m.jnt_margin[j];
-                hi = (m.jnt_range[2 * j + 1] - q) < m.jnt_margin[j];
+                j = limited_jnt_()[li];
+                real q = qpos[jnt_qposadr_()[j]];
+                lo = (q - jnt_range_()[2 * j]) < jnt_margin_()[j];
+                hi = (jnt_range_()[2 * j + 1] - q) < jnt_margin_()[j];
             }
             int t1, t2, r1 = group_rank<G>(lo, grp, lane, &t1), r2 = group_rank<G>(hi, grp, lane, &t2);
             int pos = nefc + r1 + r2;   // rows of lower lanes come first; a joint's lower side before its upper side
@@ -861,9 +936,12 @@ struct Env {
         real* Lm = r + lay.L;
         for (int i = lane; i < nefc; i += G) {
             int meta = rmeta[i], type = meta & 3, id = (meta >> 2) & 1023, sub = (meta >> 12) & 255, dim = meta >> 20;
-            real J[ROW_W];
+            real J[ROW_W];   // kept in registers: every index below is a compile-time constant after unrolling
+#pragma unroll
             for (int k = 0; k < ROW_W; k++) J[k] = 0;
             int tA = -1, tB = -1;
+            int j1 = -1, j2 = -1;      // slots of the (at most two) non-zero entries of non-contact rows
+            real v1 = 0, v2 = 0;
             real pos = 0, margin = 0, diag0 = 0, floss = 0;
             real solref[2], solimp[5];
             bool valid = true;
@@ -873,56 +951,62 @@ struct Env {
                 real poly = c[0] + q2 * (c[1] + q2 * (c[2] + q2 * (c[3] + q2 * c[4])));
                 real dpoly = c[1] + q2 * (2 * c[2] + q2 * (3 * c[3] + q2 * 4 * c[4]));
                 int d1 = m.eq_dof1[id], d2 = m.eq_dof2[id];
-                tA = m.dof_tree[d1];
+                tA = dof_tree_()[d1];
                 pos = q1 - poly;
-                diag0 = m.dof_invweight0[d1] + m.dof_invweight0[d2];
-                J[d1 - m.tree_dofadr[tA]] = 1;
-                J[d2 - m.tree_dofadr[tA]] = -dpoly;   // both joints of a gripper live in the same tree
+                diag0 = dof_invweight0_()[d1] + dof_invweight0_()[d2];
+                j1 = d1 - tree_dofadr_()[tA]; v1 = 1;
+                j2 = d2 - tree_dofadr_()[tA]; v2 = -dpoly;   // both joints of a gripper live in the same tree
                 for (int k = 0; k < 2; k++) solref[k] = m.eq_solref[2 * id + k];
                 for (int k = 0; k < 5; k++) solimp[k] = m.eq_solimp[5 * id + k];
             } else if (type == R_FLOSS) {
-                int d = m.floss_dof[id];
-                tA = m.dof_tree[d];
-                diag0 = m.dof_invweight0[d];
-                floss = m.dof_frictionloss[d];
-                J[d - m.tree_dofadr[tA]] = 1;
+                int d = floss_dof_()[id];
+                tA = dof_tree_()[d];
+                diag0 = dof_invweight0_()[d];
+                floss = dof_frictionloss_()[d];
+                j1 = d - tree_dofadr_()[tA]; v1 = 1;
                 for (int k = 0; k < 2; k++) solref[k] = m.dof_solref[2 * d + k];
                 for (int k = 0; k < 5; k++) solimp[k] = m.dof_solimp[5 * d + k];
             } else if (type == R_LIMIT) {
-                int j = id, d = m.jnt_dofadr[j];
-                real q = qpos[m.jnt_qposadr[j]];
-                tA = m.dof_tree[d];
-                pos = sub == 0 ? q - m.jnt_range[2 * j] : m.jnt_range[2 * j + 1] - q;
-                margin = m.jnt_margin[j];
-                diag0 = m.dof_invweight0[d];
-                J[d - m.tree_dofadr[tA]] = sub == 0 ? real(1) : real(-1);
+                int j = id, d = jnt_dofadr_()[j];
+                real q = qpos[jnt_qposadr_()[j]];
+                tA = dof_tree_()[d];
+                pos = sub == 0 ? q - jnt_range_()[2 * j] : jnt_range_()[2 * j + 1] - q;
+                margin = jnt_margin_()[j];
+                diag0 = dof_invweight0_()[d];
+                j1 = d - tree_dofadr_()[tA]; v1 = sub == 0 ? real(1) : real(-1);
                 for (int k = 0; k < 2; k++) solref[k] = m.jnt_solref[2 * j + k];
                 for (int k = 0; k < 5; k++) solimp[k] = m.jnt_solimp[5 * j + k];
             } else {
                 int c = id, p = cpair[c];
-                int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1], b1 = m.geom_body[g1], b2 = m.geom_body[g2];
-                int t1 = m.body_tree[b1], t2 = m.body_tree[b2];
+                int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1], b1 = geom_body_()[g1], b2 = geom_body_()[g2];
+                int t1 = body_tree_()[b1], t2 = body_tree_()[b2];
                 tA = t1 >= 0 ? t1 : t2;
                 tB = (t1 >= 0 && t2 >= 0 && t2 != t1) ? t2 : -1;
                 real n[3] = {cnrm[3 * c], cnrm[3 * c + 1], cnrm[3 * c + 2]}, t1v[3], t2v[3], cp[3] = {cpos[3 * c], cpos[3 * c + 1], cpos[3 * c + 2]};
                 make_frame(n, t1v, t2v);
-                const real* ax = (sub % 3 == 0) ? n : ((sub % 3 == 1) ? t1v : t2v);
+                const int sm = sub % 3;
+                real ax[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++) ax[q] = sm == 0 ? n[q] : (sm == 1 ? t1v[q] : t2v[q]);
                 bool rot = sub >= 3;
+#pragma unroll
                 for (int k = 0; k < TREE_W; k++) {
                     real a = 0;
-                    if (k < m.tree_dofnum[tA]) a = jac_entry(b2, tA, k, cp, ax, rot) - jac_entry(b1, tA, k, cp, ax, rot);
+                    if (k < tree_dofnum_()[tA]) a = jac_entry(b2, tA, k, cp, ax, rot) - jac_entry(b1, tA, k, cp, ax, rot);
                     J[k] = a;
                     real b = 0;
-                    if (tB >= 0 && k < m.tree_dofnum[tB]) b = jac_entry(b2, tB, k, cp, ax, rot) - jac_entry(b1, tB, k, cp, ax, rot);
+                    if (tB >= 0 && k < tree_dofnum_()[tB]) b = jac_entry(b2, tB, k, cp, ax, rot) - jac_entry(b1, tB, k, cp, ax, rot);
                     J[TREE_W + k] = b;
                 }
                 pos = sub == 0 ? cdist[c] : real(0);
                 margin = m.pair_margin[p] - m.pair_gap[p];
-                diag0 = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
+                diag0 = body_invweight0_()[2 * b1] + body_invweight0_()[2 * b2];
                 for (int k = 0; k < 2; k++) solref[k] = m.pair_solref[2 * p + k];
                 for (int k = 0; k < 5; k++) solimp[k] = m.pair_solimp[5 * p + k];
             }
             (void)valid;
+#pragma unroll
+            for (int k = 0; k < TREE_W; k++) J[k] += (k == j1 ? v1 : real(0)) + (k == j2 ? v2 : real(0));
             // K, B, impedance, R [EXT: mj_makeImpedance]
             real dmax = tclamp(solimp[1], real(0.0001), real(0.9999));
             real tc = tmax(solref[0], 2 * m.timestep), dr = solref[1];
@@ -945,28 +1029,37 @@ struct Env {
             // velocity along the row, reference acceleration
             real vel = 0;
             {
-                int a0 = m.tree_dofadr[tA];
-                for (int k = 0; k < m.tree_dofnum[tA]; k++) vel += J[k] * qvel[a0 + k];
-                if (tB >= 0) { int b0 = m.tree_dofadr[tB]; for (int k = 0; k < m.tree_dofnum[tB]; k++) vel += J[TREE_W + k] * qvel[b0 + k]; }
+                int a0 = tree_dofadr_()[tA], na = tree_dofnum_()[tA], b0 = tB >= 0 ? tree_dofadr_()[tB] : 0, nb = tB >= 0 ? tree_dofnum_()[tB] : 0;
+#pragma unroll
+                for (int k = 0; k < TREE_W; k++) {
+                    if (k < na) vel += J[k] * qvel[a0 + k];
+                    if (k < nb) vel += J[TREE_W + k] * qvel[b0 + k];
+                }
             }
             const real aref = -Bd * vel - K * imp * (pos - margin);
             // B = J M^-1 per tree (dense 8x8 inverse), diag = J B^T
-            real B[ROW_W];
+            real dg = 0;
+#pragma unroll
             for (int k = 0; k < TREE_W; k++) {
                 real sa = 0, sb = 0;
+#pragma unroll
                 for (int j = 0; j < TREE_W; j++) sa += Minv[64 * tA + 8 * k + j] * J[j];
-                if (tB >= 0) for (int j = 0; j < TREE_W; j++) sb += Minv[64 * tB + 8 * k + j] * J[TREE_W + j];
-                B[k] = sa;
-                B[TREE_W + k] = sb;
+                if (tB >= 0) {
+#pragma unroll
+                    for (int j = 0; j < TREE_W; j++) sb += Minv[64 * tB + 8 * k + j] * J[TREE_W + j];
+                }
+                dg += J[k] * sa + J[TREE_W + k] * sb;
             }
-            real dg = 0;
-            for (int k = 0; k < ROW_W; k++) dg += J[k] * B[k];
+#pragma unroll
             for (int k = 0; k < ROW_W; k++) rJ[ROW_W * i + k] = J[k];
             // warm start: force implied by last step's acceleration, f = -D (J qacc_ws - aref), made feasible per row
-            const int a0 = m.tree_dofadr[tA], nA = m.tree_dofnum[tA], b0 = tB >= 0 ? m.tree_dofadr[tB] : 0, nB = tB >= 0 ? m.tree_dofnum[tB] : 0;
+            const int a0 = tree_dofadr_()[tA], nA = tree_dofnum_()[tA], b0 = tB >= 0 ? tree_dofadr_()[tB] : 0, nB = tB >= 0 ? tree_dofnum_()[tB] : 0;
             real jw = 0;
-            for (int k = 0; k < nA; k++) jw += J[k] * warm[a0 + k];
-            for (int k = 0; k < nB; k++) jw += J[TREE_W + k] * warm[b0 + k];
+#pragma unroll
+            for (int k = 0; k < TREE_W; k++) {
+                if (k < nA) jw += J[k] * warm[a0 + k];
+                if (k < nB) jw += J[TREE_W + k] * warm[b0 + k];
+            }
             const real big = real(1e30);
             real lo = -big, hi = big, muinv = 0;
             bool ns = false;   // takes part in the noslip sweeps (dry friction and contact friction rows)
@@ -1052,7 +1145,7 @@ struct Env {
         // qacc = qacc_smooth + M^-1 J^T f : generalized force per dof first, then the per-tree inverse
         real* Minv = r + lay.Minv;
         for (int k = lane; k < m.nv; k += G) {
-            int t = m.dof_tree[k], kk = k - m.tree_dofadr[t];
+            int t = dof_tree_()[k], kk = k - tree_dofadr_()[t];
             real s = 0;
             for (int i = 0; i < nefc; i++) {
                 int meta = rmeta[i], tA = ((meta >> 20) & 15) - 1, tB = ((meta >> 24) & 15) - 1;
@@ -1063,7 +1156,7 @@ struct Env {
         }
         GSYNC();
         for (int k = lane; k < m.nv; k += G) {
-            int t = m.dof_tree[k], a0 = m.tree_dofadr[t], kk = k - a0, n = m.tree_dofnum[t];
+            int t = dof_tree_()[k], a0 = tree_dofadr_()[t], kk = k - a0, n = tree_dofnum_()[t];
             real s = as[k];
             for (int j = 0; j < n; j++) s += Minv[64 * t + 8 * kk + j] * fcon[a0 + j];
             qacc[k] = s;
@@ -1076,7 +1169,7 @@ struct Env {
         GSYNC();
         // qfrc_constraint = J^T f
         for (int k = lane; k < m.nv; k += G) {
-            int t = m.dof_tree[k], kk = k - m.tree_dofadr[t];
+            int t = dof_tree_()[k], kk = k - tree_dofadr_()[t];
             real s = 0;
             for (int i = 0; i < nefc; i++) {
                 int meta = rmeta[i], tA = ((meta >> 20) & 15) - 1, tB = ((meta >> 24) & 15) - 1;
@@ -1096,17 +1189,17 @@ struct Env {
         for (int i = lane; i < m.nv; i += G) { tmp[i] = fsm[i] + fcon[i]; warm[i] = qacc[i]; }
         GSYNC();
         for (int t = lane; t < m.ntree; t += G) {
-            int n = m.tree_dofnum[t], a0 = m.tree_dofadr[t];
-            real* Mb = M + m.tree_madr[t];
-            for (int i = 0; i < n; i++) Mb[i * n + i] += h * m.dof_damping[a0 + i];   // M is rebuilt next substep
-            chol_block(Mb, L + m.tree_madr[t], n);
-            chol_solve_block(L + m.tree_madr[t], tmp + a0, n);
+            int n = tree_dofnum_()[t], a0 = tree_dofadr_()[t];
+            real* Mb = M + tree_madr_()[t];
+            for (int i = 0; i < n; i++) Mb[i * n + i] += h * dof_damping_()[a0 + i];   // M is rebuilt next substep
+            chol_block(Mb, L + tree_madr_()[t], n);
+            chol_solve_block(L + tree_madr_()[t], tmp + a0, n);
             for (int i = 0; i < n; i++) qvel[a0 + i] += h * tmp[a0 + i];
         }
         GSYNC();
         for (int j = lane; j < m.njnt; j += G) {
-            int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
-            if (m.jnt_type[j] == J_FREE) {
+            int qa = jnt_qposadr_()[j], da = jnt_dofadr_()[j];
+            if (jnt_type_()[j] == J_FREE) {
                 for (int k = 0; k < 3; k++) qpos[qa + k] += h * qvel[da + k];
                 real q[4] = {qpos[qa + 3], qpos[qa + 4], qpos[qa + 5], qpos[qa + 6]}, w[3] = {qvel[da + 3], qvel[da + 4], qvel[da + 5]};
                 real wn = sqrt(dot3(w, w)), ang = h * wn;
@@ -1197,62 +1290,11 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(DevModel<real> mg, Layout lay
     for (int i = threadIdx.x; i < mo.nreal; i += 64 * WPB) lr[i] = img_real[i];
     for (int i = threadIdx.x; i < mo.nint; i += 64 * WPB) li[i] = img_int[i];
     if (WPB > 1) __syncthreads(); else GSYNC();
-    DevModel<real> m = mg;
-    m.body_parent = li + mo.body_parent;
-    m.body_jntadr = li + mo.body_jntadr;
-    m.body_jntnum = li + mo.body_jntnum;
-    m.body_dofadr = li + mo.body_dofadr;
-    m.body_dofnum = li + mo.body_dofnum;
-    m.body_tree = li + mo.body_tree;
-    m.body_dofmask = li + mo.body_dofmask;
-    m.tree_bodyadr = li + mo.tree_bodyadr;
-    m.tree_bodylist = li + mo.tree_bodylist;
-    m.tree_dofadr = li + mo.tree_dofadr;
-    m.tree_dofnum = li + mo.tree_dofnum;
-    m.tree_madr = li + mo.tree_madr;
-    m.jnt_type = li + mo.jnt_type;
-    m.jnt_qposadr = li + mo.jnt_qposadr;
-    m.jnt_dofadr = li + mo.jnt_dofadr;
-    m.jnt_actfrclimited = li + mo.jnt_actfrclimited;
-    m.limited_jnt = li + mo.limited_jnt;
-    m.dof_body = li + mo.dof_body;
-    m.dof_parent = li + mo.dof_parent;
-    m.dof_tree = li + mo.dof_tree;
-    m.dof_jnt = li + mo.dof_jnt;
-    m.floss_dof = li + mo.floss_dof;
-    m.ment_i = li + mo.ment_i;
-    m.ment_j = li + mo.ment_j;
-    m.act_dof = li + mo.act_dof;
-    m.act_qposadr = li + mo.act_qposadr;
-    m.act_ctrllimited = li + mo.act_ctrllimited;
-    m.geom_type = li + mo.geom_type;
-    m.geom_body = li + mo.geom_body;
-    m.geom_static = li + mo.geom_static;
-    m.body_pos = lr + mo.body_pos;
-    m.body_quat = lr + mo.body_quat;
-    m.body_mass = lr + mo.body_mass;
-    m.body_ipos = lr + mo.body_ipos;
-    m.body_inertia = lr + mo.body_inertia;
-    m.body_invweight0 = lr + mo.body_invweight0;
-    m.jnt_pos = lr + mo.jnt_pos;
-    m.jnt_axis = lr + mo.jnt_axis;
-    m.jnt_range = lr + mo.jnt_range;
-    m.jnt_actfrcrange = lr + mo.jnt_actfrcrange;
-    m.jnt_margin = lr + mo.jnt_margin;
-    m.dof_armature = lr + mo.dof_armature;
-    m.dof_damping = lr + mo.dof_damping;
-    m.dof_frictionloss = lr + mo.dof_frictionloss;
-    m.dof_invweight0 = lr + mo.dof_invweight0;
-    m.act_kp = lr + mo.act_kp;
-    m.act_kv = lr + mo.act_kv;
-    m.act_gear = lr + mo.act_gear;
-    m.act_ctrlrange = lr + mo.act_ctrlrange;
-    m.geom_cpos = lr + mo.geom_cpos;
-    m.geom_rbound = lr + mo.geom_rbound;
+    const DevModel<real>& m = mg;
     if (env >= N) return;  // whole groups drop out together; no block barrier is used below
     real* r = reinterpret_cast<real*>(smem + (size_t)wave * lay.bytes_per_env);
     int* ii = reinterpret_cast<int*>(r + lay.nreal);
-    Env<real, G> E(m, lay, r, ii, lane, grp);
+    Env<real, G> E(m, lay, r, ii, lane, grp, mo, lr, li);
 
     // ---- load state (coalesced: consecutive lanes read consecutive words of this env's record) ----
     for (int i = lane; i < m.nq; i += G) r[lay.qpos + i] = g_qpos[(size_t)env * m.nq + i];

@@ -34,7 +34,7 @@ enum { ORC_EQ = 0, ORC_FLOSS = 1, ORC_LIMIT = 2, ORC_CONTACT = 3 };
 typedef struct {
     /* sizes */
     int nq, nv, nu, nbody, njnt, ngeom, npair, ntree, neq, task_id, num_arms, nhullvert;
-    double timestep, gravity[3], impratio;
+    double timestep, gravity[3], impratio, meaninertia;
     int noslip_iterations, cone_elliptic;
     /* bodies */
     const int *body_parent, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_weldid, *body_tree;
@@ -90,6 +90,8 @@ typedef struct {
         efc_D[ORC_MAXEFC], efc_force[ORC_MAXEFC], efc_diag[ORC_MAXEFC], efc_floss[ORC_MAXEFC], efc_KBIP[ORC_MAXEFC * 4];
     int efc_type[ORC_MAXEFC], efc_id[ORC_MAXEFC];
     int pgs_iters;
+    double pgs_tol, pgs_scale; /* early-termination tolerance (0 = fixed sweep count) and 1/(meaninertia*nv) */
+    int stat_sweeps;
     int overflow; /* set when ORC_MAXCON / ORC_MAXEFC was hit */
     long stat_narrow; /* narrow-phase calls, for the flop/pair accounting */
 } orc_data;

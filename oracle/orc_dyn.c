@@ -64,6 +64,8 @@ orc_data* orc_data_new(const orc_model* m) {
     d->qacc_smooth = zalloc(nv); d->qfrc_constraint = zalloc(nv); d->qacc = zalloc(nv);
     d->efc_J = zalloc((size_t)ORC_MAXEFC * nv); d->efc_B = zalloc((size_t)ORC_MAXEFC * nv);
     d->pgs_iters = 50;
+    d->pgs_tol = 0;
+    d->pgs_scale = 1.0 / (m->meaninertia * (m->nv > 1 ? m->nv : 1));
     memcpy(d->qpos, m->qpos0, sizeof(double) * m->nq);
     return d;
 }
@@ -561,8 +563,14 @@ void orc_solve(orc_data* d) {
     }
     for (int i = 0; i < ne; i++) apply_delta(d, i, d->efc_force[i]);
 
+    d->stat_sweeps = 0;
     for (int it = 0; it < d->pgs_iters; it++) {
+        /* early termination as MuJoCo's PGS [EXT]: stop when the scaled decrease of the dual cost over one sweep,
+         * sum_i 1/2 (A_ii + R_i) delta_i^2 / (meaninertia * nv), drops below the tolerance (0 disables the test) */
+        double improvement = 0;
+        d->stat_sweeps++;
         for (int i = 0; i < ne; i++) {
+            double fprev = d->efc_force[i];
             double f = d->efc_force[i] - row_res(d, i, 1) / (d->efc_diag[i] + d->efc_R[i]);
             int t = d->efc_type[i];
             if (t == ORC_FLOSS) { if (f > d->efc_floss[i]) f = d->efc_floss[i]; if (f < -d->efc_floss[i]) f = -d->efc_floss[i]; }
@@ -572,12 +580,15 @@ void orc_solve(orc_data* d) {
                 if (i == c->efc_adr && f < 0) f = 0;
                 apply_delta(d, i, f - d->efc_force[i]);
                 d->efc_force[i] = f;
+                improvement += 0.5 * (d->efc_diag[i] + d->efc_R[i]) * (f - fprev) * (f - fprev);
                 if (i == c->efc_adr + c->dim - 1 && c->dim > 1) cone_project(d, c, c->efc_adr);
                 continue;
             }
             apply_delta(d, i, f - d->efc_force[i]);
             d->efc_force[i] = f;
+            improvement += 0.5 * (d->efc_diag[i] + d->efc_R[i]) * (f - fprev) * (f - fprev);
         }
+        if (d->pgs_tol > 0 && improvement * d->pgs_scale < d->pgs_tol) break;
     }
     /* noslip post-pass (aloha_sim.xml:4 noslip_iterations=3): PGS sweeps over dry-friction and contact
      * friction rows with the regulariser R removed; normal forces are held fixed [EXT: mj_solNoSlip] */

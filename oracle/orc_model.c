@@ -36,7 +36,7 @@ orc_model* orc_model_load(const void* blob_in, size_t nbytes) {
     m->task_id = S(b, "task_id"); m->num_arms = S(b, "num_arms");
     const double* opt = F(b, "opt");
     m->timestep = opt[0]; m->gravity[0] = opt[1]; m->gravity[1] = opt[2]; m->gravity[2] = opt[3];
-    m->impratio = opt[4]; m->noslip_iterations = (int)opt[5]; m->cone_elliptic = (int)opt[6];
+    m->impratio = opt[4]; m->noslip_iterations = (int)opt[5]; m->cone_elliptic = (int)opt[6]; m->meaninertia = opt[7];
 #define LF(x) m->x = F(b, #x)
 #define LI(x) m->x = I(b, #x)
     LI(body_parent); LI(body_jntadr); LI(body_jntnum); LI(body_dofadr); LI(body_dofnum); LI(body_weldid); LI(body_tree);

@@ -29,7 +29,8 @@ class Data(C.Structure):
                 [(n, C.c_double * MAXEFC) for n in ("efc_pos", "efc_margin", "efc_aref", "efc_R", "efc_D", "efc_force",
                                                     "efc_diag", "efc_floss")] +
                 [("efc_KBIP", C.c_double * (4 * MAXEFC)), ("efc_type", C.c_int * MAXEFC), ("efc_id", C.c_int * MAXEFC),
-                 ("pgs_iters", C.c_int), ("overflow", C.c_int), ("stat_narrow", C.c_long)])
+                 ("pgs_iters", C.c_int), ("pgs_tol", C.c_double), ("pgs_scale", C.c_double), ("stat_sweeps", C.c_int),
+                 ("overflow", C.c_int), ("stat_narrow", C.c_long)])
 
 
 class OrcEnv:
