@@ -36,6 +36,8 @@ struct DevModel {
     int nq, nv, nu, nbody, njnt, ngeom, npair, ntree, neq, nfloss, nlimited, nment, task_id, nj, msize;
     real timestep, gravity[3], impratio, grip_lo, grip_hi;
     int noslip_iters;
+    int solver, newton_iters;     // 0 = PGS (dual), 1 = Newton (primal, the reference's default solver)
+    real newton_tol, nscale;      // MuJoCo tolerance and 1/(meaninertia*nv) scaling of the termination tests
     // bodies
     const int *body_parent, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_tree, *body_dofmask;
     const real *body_pos, *body_quat, *body_mass, *body_ipos, *body_inertia, *body_invweight0, *static_xpos, *static_xmat;
@@ -118,13 +120,13 @@ struct MOff {
 
 // per-env LDS layout (offsets in reals / ints)
 struct Layout {
-    int qpos, qvel, ctrl, warm, xpos, xmat, xipos, cdof, gcen, gref, M, L, Minv, bias, fsm, asm_, qacc, fcon, U, nreal;
+    int qpos, qvel, ctrl, warm, xpos, xmat, xipos, cdof, gcen, gref, M, L, Minv, bias, fsm, asm_, qacc, fcon, nH, ng, ndl, nx, U, nreal;
     // scratch union U, phase A
     int cinert, cvel, cacc, cfrc;
     // phase B
     int cdist, cpos, cnrm, rJ, rowS, gA;
     // ints
-    int cand, nearl, cpair, cefc, rmeta, rowI, gI, misc, nint;
+    int cand, nearl, cpair, cefc, rmeta, rowI, gI, czone, misc, nint;
     int maxgrp;
     int maxcon, maxefc;
     int bytes_per_env;
@@ -298,6 +300,10 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
     }
 }
 
+}  // namespace avs
+#include "avsim_newton.hip.h"
+namespace avs {
+
 template <int G>
 AVS_DEV unsigned long long group_mask(int grp) {
     if (G == 64) return ~0ull;
@@ -423,6 +429,7 @@ AVS_DEV int has_pair(int c1, int c2, int a, int b) { return ((c1 & a) && (c2 & b
 template <typename real, int G>
 struct Env {
     const DevModel<real>& m;
+    int nit_sum = 0, nit_max = 0;   // Newton iterations over the launch's substeps (diagnostics)
     const Layout& lay;
     real* r;  // real region of this env
     int* ii;  // int region of this env
@@ -491,6 +498,11 @@ struct Env {
     __device__ void kinematics() {
         real *xpos = r + lay.xpos, *xmat = r + lay.xmat, *xipos = r + lay.xipos, *cdof = r + lay.cdof, *qpos = r + lay.qpos;
         for (int i = lane; i < 6 * m.nv; i += G) cdof[i] = 0;
+        // bodies welded to the world: constant poses (the Newton scratch overlays this region during the solve)
+        for (int b = lane; b < m.nbody; b += G) {
+            for (int k = 0; k < 3; k++) { xpos[3 * b + k] = m.static_xpos[3 * b + k]; xipos[3 * b + k] = 0; }
+            for (int k = 0; k < 9; k++) xmat[9 * b + k] = m.static_xmat[9 * b + k];
+        }
         GSYNC();
         for (int t = lane; t < m.ntree; t += G) {
             for (int bi = tree_bodyadr_()[t]; bi < tree_bodyadr_()[t + 1]; bi++) {
@@ -918,6 +930,7 @@ struct Env {
                     cefc[c] = first;
                     myend = first + dim;
                     for (int s = 0; s < dim; s++) rmeta[first + s] = R_CONTACT | (c << 2) | (s << 12) | (dim << 20);
+                    (ii + lay.czone)[first] = dim << 8;
                 } else {
                     cefc[c] = -1;
                     if (dim > 0) ovf = 1;
@@ -1128,10 +1141,31 @@ struct Env {
     }
 
     // ---- P8 ------------------------------------------------------------------------------------
-    __device__ void solve(int pgs_iters) {
+    __device__ void solve(int pgs_iters, int solver, int newton_iters, real newton_tol, real scale) {
         int *misc = ii + lay.misc, *rmeta = ii + lay.rmeta, *cefc = ii + lay.cefc, *rowI = ii + lay.rowI;
         real *qacc = r + lay.qacc, *as = r + lay.asm_, *rowS = r + lay.rowS, *rJ = r + lay.rJ, *fcon = r + lay.fcon;
         int nefc = misc[1], ncon = misc[0];
+        real* Minv = r + lay.Minv;
+        if (solver == 1) {
+            // ---- primal Newton (the reference's MuJoCo default), then the noslip sweeps on the dual ----
+            real* warm = r + lay.warm;
+            for (int k = lane; k < m.nv; k += G) qacc[k] = warm[k];
+            GSYNC();
+            NewtonArgs<real> A;
+            A.rowS = (LDS_PTR(real))rowS; A.rowI = (LDS_PTR(const int))rowI; A.rmeta = (LDS_PTR(const int))rmeta; A.rJ = (LDS_PTR(const real))rJ;
+            A.M = (LDS_PTR(const real))(r + lay.M); A.a = (LDS_PTR(real))qacc; A.as = (LDS_PTR(const real))as;
+            A.H = (LDS_PTR(real))(r + lay.nH); A.g = (LDS_PTR(real))(r + lay.ng); A.dl = (LDS_PTR(real))(r + lay.ndl); A.x = (LDS_PTR(real))(r + lay.nx);
+            A.czone = (LDS_PTR(int))(ii + lay.czone);
+            A.tree_dofadr = (LDS_PTR(const int))tree_dofadr_(); A.tree_dofnum = (LDS_PTR(const int))tree_dofnum_();
+            A.tree_madr = (LDS_PTR(const int))tree_madr_(); A.dof_tree = (LDS_PTR(const int))dof_tree_();
+            A.nv = m.nv; A.nefc = nefc; A.ntree = m.ntree; A.iters = newton_iters;
+            A.tol = newton_tol; A.scale = scale; A.ls_tol = sizeof(real) == 8 ? real(1e-10) : real(1e-4);
+            int used = newton_solve<real>(A);
+            nit_sum += used; nit_max = used > nit_max ? used : nit_max;
+            GSYNC();
+            pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const real))rJ, (LDS_PTR(const real))Minv, (LDS_PTR(real))qacc,
+                             (LDS_PTR(const int))(ii + lay.gI), (LDS_PTR(const real))(r + lay.gA), misc[5], 0, m.noslip_iters);
+        } else {
         // warm-start forces of friction blocks back onto their cones (one contact per lane)
         for (int c = lane; c < ncon; c += G) {
             int first = cefc[c];
@@ -1143,7 +1177,6 @@ struct Env {
         }
         GSYNC();
         // qacc = qacc_smooth + M^-1 J^T f : generalized force per dof first, then the per-tree inverse
-        real* Minv = r + lay.Minv;
         for (int k = lane; k < m.nv; k += G) {
             int t = dof_tree_()[k], kk = k - tree_dofadr_()[t];
             real s = 0;
@@ -1166,6 +1199,7 @@ struct Env {
         static_assert(G == 64, "the solver maps one env to one wavefront");
         pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const real))rJ, (LDS_PTR(const real))Minv, (LDS_PTR(real))qacc,
                          (LDS_PTR(const int))(ii + lay.gI), (LDS_PTR(const real))(r + lay.gA), misc[5], pgs_iters, m.noslip_iters);
+        }
         GSYNC();
         // qfrc_constraint = J^T f
         for (int k = lane; k < m.nv; k += G) {
@@ -1300,11 +1334,6 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(DevModel<real> mg, Layout lay
     for (int i = lane; i < m.nq; i += G) r[lay.qpos + i] = g_qpos[(size_t)env * m.nq + i];
     for (int i = lane; i < m.nv; i += G) { r[lay.qvel + i] = g_qvel[(size_t)env * m.nv + i]; r[lay.warm + i] = g_warm[(size_t)env * m.nv + i]; }
     for (int i = lane; i < m.nu; i += G) r[lay.ctrl + i] = g_ctrl[(size_t)env * m.nu + i];
-    for (int b = lane; b < m.nbody; b += G) {
-        for (int k = 0; k < 3; k++) r[lay.xpos + 3 * b + k] = m.static_xpos[3 * b + k];
-        for (int k = 0; k < 9; k++) r[lay.xmat + 9 * b + k] = m.static_xmat[9 * b + k];
-        for (int k = 0; k < 3; k++) r[lay.xipos + 3 * b + k] = 0;
-    }
     if (lane == 0) for (int k = 0; k < 8; k++) ii[lay.misc + k] = 0;
     GSYNC();
     if (action) {
@@ -1326,7 +1355,7 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(DevModel<real> mg, Layout lay
         PROF(3, E.smooth());
         PROF(4, E.collide());
         PROF(5, E.make_constraints());
-        PROF(6, E.solve(pgs_iters));
+        PROF(6, E.solve(pgs_iters, m.solver, m.newton_iters, m.newton_tol, m.nscale));
         PROF(7, E.euler());
     }
     if (o_prof && lane == 0) { for (int k = 0; k < 8; k++) o_prof[(size_t)env * 10 + k] = tp[k]; o_prof[(size_t)env * 10 + 8] = E.t_broad; o_prof[(size_t)env * 10 + 9] = E.t_narrow; }
@@ -1364,7 +1393,7 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(DevModel<real> mg, Layout lay
         o_ncon[env] = ncon;
         bool bad = false;
         for (int i = 0; i < m.nq; i++) bad |= !(fabs(r[lay.qpos + i]) < real(1e6));
-        o_diag[4 * env] = ncon; o_diag[4 * env + 1] = nefc_last; o_diag[4 * env + 2] = ii[lay.misc + 2]; o_diag[4 * env + 3] = (bad ? 1 : 0) | (ii[lay.misc + 3] << 8);
+        o_diag[4 * env] = ncon; o_diag[4 * env + 1] = nefc_last; o_diag[4 * env + 2] = ii[lay.misc + 2]; o_diag[4 * env + 3] = (bad ? 1 : 0) | ((ii[lay.misc + 3] & 0xff) << 8) | ((E.nit_sum & 0xfff) << 16) | ((E.nit_max & 0xf) << 28);
     }
 }
 
@@ -1416,6 +1445,8 @@ struct PhysHost {
         auto opt = F("opt");
         m.timestep = (real)opt[0]; m.gravity[0] = (real)opt[1]; m.gravity[1] = (real)opt[2]; m.gravity[2] = (real)opt[3];
         m.impratio = (real)opt[4]; m.noslip_iters = (int)opt[5];
+        m.solver = 1; m.newton_iters = 8; m.newton_tol = sizeof(real) == 8 ? (real)1e-8 : (real)1e-6;
+        m.nscale = (real)(1.0 / ((opt.size() > 7 && opt[7] > 0 ? opt[7] : 1.0) * std::max(1, m.nv)));
         auto gr = F("grip_range");
         m.grip_lo = (real)gr[0]; m.grip_hi = (real)gr[1];
         auto body_parent = I("body_parent"), body_dofadr = I("body_dofadr"), body_dofnum = I("body_dofnum"), body_tree = I("body_tree");
@@ -1572,6 +1603,13 @@ struct PhysHost {
         L.xpos = R(3 * nb); L.xmat = R(9 * nb); L.xipos = R(3 * nb); L.cdof = R(6 * nv); L.gcen = R(3 * ng); L.gref = R(3 * ng);
         L.M = R(msize); L.L = R(msize); o = (o + 3) & ~3; L.Minv = R(64 * 8);
         L.bias = R(nv); L.fsm = R(nv); L.asm_ = R(nv); L.qacc = R(nv); L.fcon = R(nv);
+        // Newton scratch (packed Hessian, gradient, direction, trial point) lives over xpos..gcen: every
+        // position-derived quantity is dead between make_constraints and the next substep's kinematics
+        {
+            int need = nv * (nv + 1) / 2 + 3 * nv, avail = 15 * nb + 6 * nv + 3 * ng;
+            int base = need <= avail ? L.xpos : R(need);
+            L.nH = base; L.ng = base + nv * (nv + 1) / 2; L.ndl = L.ng + nv; L.nx = L.ndl + nv;
+        }
         L.U = o;
         int a = o;
         L.cinert = a; a += 10 * nb; L.cvel = a; a += 6 * nb; L.cacc = a; a += 6 * nb; L.cfrc = a; a += 6 * nb;
@@ -1584,7 +1622,7 @@ struct PhysHost {
         L.nreal = (o + 3) & ~3;
         int io = 0;
         auto Iq = [&](int n) { int x = io; io += n; return x; };
-        L.cand = Iq(CAND_MAX); L.nearl = Iq(NEAR_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.misc = Iq(8);
+        L.cand = Iq(CAND_MAX); L.nearl = Iq(NEAR_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.czone = Iq(maxefc); L.misc = Iq(8);
         L.nint = (io + 3) & ~3;
         L.maxcon = maxcon;
         L.maxefc = maxefc;
@@ -1640,6 +1678,9 @@ struct PhysHost {
     bool set_option(const char* name, double v) {
         std::string n(name);
         if (n == "pgs_iters") { pgs_iters = (int)v; return true; }
+        if (n == "solver") { if (v != 0 && v != 1) return false; mf.solver = md.solver = (int)v; return true; }
+        if (n == "newton_iters") { if (v < 1 || v > 100) return false; mf.newton_iters = md.newton_iters = (int)v; return true; }
+        if (n == "newton_tol") { if (v < 0) return false; mf.newton_tol = (float)v; md.newton_tol = v; return true; }
         if (n == "export_contacts") { export_contacts = v != 0; return true; }
         if (n == "waves_per_block") { int x = (int)v; if (x == 0 || x == 1 || x == 2 || x == 4) { wpb_override = x; return true; } return false; }
         if (n == "profile_phases") {

@@ -95,7 +95,7 @@ def scripted_actions(global_ids, n_total, t):
 
 
 def cpu_baseline_worker(args):
-    ids, n_total, steps = args
+    ids, n_total, steps, solver = args
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from orc_env import OrcEnv
     from orc_ffi import dp
@@ -104,6 +104,7 @@ def cpu_baseline_worker(args):
     for k in range(len(ids)):
         e = OrcEnv("slot_insertion", 3)
         e.d.pgs_iters = 20
+        e.d.solver = solver
         e.reset(poses[k])
         envs.append(e)
     a21 = np.zeros(21)
@@ -116,21 +117,21 @@ def cpu_baseline_worker(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(n_total):
+def cpu_baseline(n_total, solver=1):
     """Oracle (kind 'port') on the host cores: every core steps its own envs of the same workload."""
     import multiprocessing as mp
     from av_aloha_amd.build import build_oracle
     build_oracle()
     cores = max(1, min(os.cpu_count() or 1, 64))
     per, steps = 4, 150                     # ~10-25 s per core: 4 envs x 150 env-steps at ~40-60 env-steps/s/core
-    jobs = [(list(range(c * per, (c + 1) * per)), n_total, steps) for c in range(cores)]
+    jobs = [(list(range(c * per, (c + 1) * per)), n_total, steps, solver) for c in range(cores)]
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(cores) as pool:
         pool.map(cpu_baseline_worker, jobs)
     wall = time.perf_counter() - t0
     return {"value": cores * per * steps / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{cores * per} envs x {steps} env-steps of the same workload (oracle/liborc.so, scalar f64 C, "
-                      f"one process per core, pgs_iters=20), wall {wall:.1f} s incl. process start"}
+                      f"one process per core, solver={'newton' if solver else 'pgs-20'}), wall {wall:.1f} s incl. process start"}
 
 
 def main():
@@ -140,6 +141,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--pgs-iters", type=int, default=20)
+    ap.add_argument("--solver", choices=["pgs", "newton"], default="newton")
+    ap.add_argument("--newton-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -169,7 +172,8 @@ def main():
     L = h.L
     stream = torch.cuda.current_stream()
     h.check(L.avsim_set_stream(h.h, stream.cuda_stream))
-    for name, v in (("pgs_iters", args.pgs_iters), ("export_contacts", 0), ("kernel_timing", 1)):
+    for name, v in (("pgs_iters", args.pgs_iters), ("solver", 1 if args.solver == "newton" else 0), ("newton_iters", args.newton_iters),
+                    ("export_contacts", 0), ("kernel_timing", 1)):
         h.check(L.avsim_set_option(h.h, name.encode(), float(v)))
 
     dev = torch.device("cuda", local)
@@ -242,10 +246,11 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "gym_guided_vision/SlotInsertion-3Arms-v0 (BASELINE configs[1] at the metric's 4096 envs): "
                                    "23-D Cartesian action -> DLS IK on 3 arms -> 20 substeps (dt 0.002) + agent_pos + reward/success, no render",
-                       "envs_per_gpu": N, "envs_total": n_total, "substeps_per_step": 20, "pgs_iters": args.pgs_iters,
+                       "envs_per_gpu": N, "envs_total": n_total, "substeps_per_step": 20, "solver": args.solver, "pgs_iters": args.pgs_iters, "newton_iters": args.newton_iters,
                        "noslip_iters": 3, "lanes_per_env": 64, "episode_len": EPISODE_LEN,
                        "physics_substeps_per_s": value * 20,
                        "overflow_envs": int((diag[:, 2] != 0).sum()), "nan_envs": int((diag[:, 3] & 1).sum()),
+                       "newton_iters_per_substep": float(((diag[:, 3] >> 16) & 0xfff).mean()) / 20.0, "newton_iters_max": int(((diag[:, 3] >> 28) & 0xf).max()),
                        "mean_ncon": float(diag[:, 0].mean()), "mean_nefc": float(diag[:, 1].mean()),
                        "gathered_envs": int(all_ret.numel()), "mean_return": float(all_ret.mean().item()),
                        "success_rate": float(all_succ.to(torch.float32).mean().item())},
@@ -259,7 +264,7 @@ def main():
                                  "VALU/LDS-latency bound (SURVEY 8d), the HBM fraction is reported because the contract asks for it"},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n_total)
+            out["cpu_baseline"] = cpu_baseline(n_total, 1 if args.solver == "newton" else 0)
         elif world > 1:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

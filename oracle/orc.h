@@ -92,6 +92,8 @@ typedef struct {
     int pgs_iters;
     double pgs_tol, pgs_scale; /* early-termination tolerance (0 = fixed sweep count) and 1/(meaninertia*nv) */
     int stat_sweeps;
+    int solver;       /* 0 = PGS (north_star), 1 = Newton (the reference's MuJoCo default) */
+    int newton_iters; double newton_tol;
     int overflow; /* set when ORC_MAXCON / ORC_MAXEFC was hit */
     long stat_narrow; /* narrow-phase calls, for the flop/pair accounting */
 } orc_data;
@@ -120,6 +122,8 @@ void orc_rne_bias(orc_data* d);
 void orc_collide(orc_data* d);
 void orc_make_constraints(orc_data* d);
 void orc_solve(orc_data* d);
+void orc_solve_newton(orc_data* d);
+void orc_noslip(orc_data* d);
 
 /* narrow phase entry for tests: geometry types as ORC_*; returns number of contacts (<=8) */
 int orc_narrow(int t1, const double* size1, const double* pos1, const double* mat1, const double* hull1, int nh1,

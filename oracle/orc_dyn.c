@@ -65,6 +65,9 @@ orc_data* orc_data_new(const orc_model* m) {
     d->efc_J = zalloc((size_t)ORC_MAXEFC * nv); d->efc_B = zalloc((size_t)ORC_MAXEFC * nv);
     d->pgs_iters = 50;
     d->pgs_tol = 0;
+    d->solver = 0;
+    d->newton_iters = 30;
+    d->newton_tol = 1e-8;
     d->pgs_scale = 1.0 / (m->meaninertia * (m->nv > 1 ? m->nv : 1));
     memcpy(d->qpos, m->qpos0, sizeof(double) * m->nq);
     return d;
@@ -590,6 +593,12 @@ void orc_solve(orc_data* d) {
         }
         if (d->pgs_tol > 0 && improvement * d->pgs_scale < d->pgs_tol) break;
     }
+    orc_noslip(d);
+}
+
+void orc_noslip(orc_data* d) {
+    const orc_model* m = d->m;
+    int nv = m->nv, ne = d->nefc;
     /* noslip post-pass (aloha_sim.xml:4 noslip_iterations=3): PGS sweeps over dry-friction and contact
      * friction rows with the regulariser R removed; normal forces are held fixed [EXT: mj_solNoSlip] */
     for (int it = 0; it < m->noslip_iterations; it++) {
@@ -626,7 +635,12 @@ void orc_forward(orc_data* d) {
     orc_rne_bias(d);
     smooth_forces(d);
     orc_make_constraints(d);
-    orc_solve(d);
+    if (d->solver == 1) {
+        orc_solve_newton(d);
+        orc_noslip(d);   /* noslip runs on the dual after the main solve [EXT]; qacc and forces stay consistent */
+    } else {
+        orc_solve(d);
+    }
 }
 
 /* P9: mj_Euler with implicit joint damping [EXT]: (M + h diag(b)) qacc_d = qfrc_smooth + qfrc_constraint */

@@ -17,9 +17,10 @@ def make(task="slot_insertion", na=3, N=1, f64=False, **opt):
     return BatchedSim(task, na, N, f64=f64, options=opt)
 
 
-def oracle_rollout(task, na, obj, actions, pgs):
+def oracle_rollout(task, na, obj, actions, pgs, solver=0):
     e = OrcEnv(task, na)
     e.d.pgs_iters = pgs
+    e.d.solver = solver
     e.reset(obj)
     out = []
     for a in actions:
@@ -50,7 +51,7 @@ def test_f64_step_parity_with_contacts():
     md = model_dict()
     acts = actions_wiggle(md, 12)
     ref = oracle_rollout("slot_insertion", 3, OBJ, acts, 20)
-    sim = make(f64=True, pgs_iters=20)
+    sim = make(f64=True, pgs_iters=20, solver=0)
     sim.reset(OBJ[None])
     for t, a in enumerate(acts):
         ap, rw, su = sim.step(a[None])
@@ -70,7 +71,7 @@ def test_f64_parity_other_tasks(task):
     obj = md["qpos_home"][md["objects_qposadr"][0]:].reshape(-1, 7).copy()
     acts = actions_wiggle(md, 6)
     ref = oracle_rollout(task, 3, obj, acts, 20)
-    sim = make(task, f64=True, pgs_iters=20)
+    sim = make(task, f64=True, pgs_iters=20, solver=0)
     sim.reset(obj[None])
     for t, a in enumerate(acts):
         ap, rw, su = sim.step(a[None])
@@ -88,7 +89,7 @@ def test_f32_short_horizon_parity_and_batch_consistency():
     acts = actions_wiggle(md, 10)
     ref = oracle_rollout("slot_insertion", 3, OBJ, acts, 20)
     N = 70
-    sim = make(N=N, pgs_iters=20)
+    sim = make(N=N, pgs_iters=20, solver=0)
     sim.reset(np.repeat(OBJ[None], N, 0))
     for t, a in enumerate(acts):
         ap, rw, su = sim.step(np.repeat(a[None], N, 0))
@@ -105,7 +106,7 @@ def test_two_arm_variant_and_state_roundtrip():
     md = model_dict("slot_insertion", 2)
     acts = actions_wiggle(md, 5, nj=14)
     ref = oracle_rollout("slot_insertion", 2, OBJ, acts, 20)
-    sim = make("slot_insertion", 2, 3, f64=True, pgs_iters=20)
+    sim = make("slot_insertion", 2, 3, f64=True, pgs_iters=20, solver=0)
     assert sim.nj == 14
     sim.reset(np.repeat(OBJ[None], 3, 0))
     for t, a in enumerate(acts):
@@ -116,4 +117,43 @@ def test_two_arm_variant_and_state_roundtrip():
     sim.set_state(q, v, c, w)
     q2, v2, c2, w2 = sim.get_state()
     assert np.array_equal(q, q2) and np.array_equal(v, v2) and np.array_equal(w, w2)
+    sim.close()
+
+
+def test_newton_f64_parity_and_f32_tolerance():
+    """The reference leaves MuJoCo's solver at its default (Newton, aloha_sim.xml:4 sets only noslip/cone/impratio):
+    the device Newton in f64 follows the oracle's Newton at rounding level, and the f32 product path stays
+    within 2e-5 rad / m of the f64 oracle over 30 env steps (600 substeps) with contacts switching."""
+    md = model_dict()
+    acts = actions_wiggle(md, 30)
+    ref = oracle_rollout("slot_insertion", 3, OBJ, acts, 20, solver=1)
+    for f64, tol_q, tol_v in ((True, 1e-10, 1e-8), (False, 2e-5, 2e-4)):
+        sim = make(f64=f64, solver=1)
+        sim.reset(OBJ[None])
+        for t, a in enumerate(acts):
+            ap, rw, su = sim.step(a[None])
+            qpos, qvel, _, _ = sim.get_state()
+            assert int(sim.contacts()[0][0]) == ref[t][5], (f64, t)
+            np.testing.assert_allclose(qpos[0], ref[t][0], atol=tol_q, err_msg=f"f64={f64} qpos step {t}")
+            np.testing.assert_allclose(qvel[0], ref[t][1], atol=tol_v, err_msg=f"f64={f64} qvel step {t}")
+            assert rw[0] == ref[t][3] and bool(su[0]) == ref[t][4]
+        d = sim.diag()[0]
+        assert d[2] == 0 and (d[3] & 1) == 0
+        assert 1 <= ((d[3] >> 28) & 0xf) <= 8          # Newton needed at most the 8-iteration cap
+        sim.close()
+
+
+@pytest.mark.parametrize("task", ["insert_peg", "sew_needle", "hook_package", "tube_transfer"])
+def test_newton_f64_parity_other_tasks(task):
+    md = model_dict(task)
+    obj = md["qpos_home"][md["objects_qposadr"][0]:].reshape(-1, 7).copy()
+    acts = actions_wiggle(md, 6)
+    ref = oracle_rollout(task, 3, obj, acts, 20, solver=1)
+    sim = make(task, f64=True, solver=1)
+    sim.reset(obj[None])
+    for t, a in enumerate(acts):
+        ap, rw, su = sim.step(a[None])
+        qpos, qvel, _, _ = sim.get_state()
+        np.testing.assert_allclose(qpos[0], ref[t][0], atol=1e-8, err_msg=f"{task} qpos step {t}")
+        assert rw[0] == ref[t][3]
     sim.close()
