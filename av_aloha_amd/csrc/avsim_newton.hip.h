@@ -8,11 +8,20 @@
 // with MuJoCo's per-row costs [EXT]: quadratic equalities, Huber-type dry friction, one-sided limits, three-zone
 // elliptic-cone contacts.  oracle/orc_newton.c is the f64 restatement it is tested against.
 //
-// Mapping: constraint rows are spread over lanes (row i -> lane i % 64); a contact is evaluated by the lane of its first
-// row.  H = M + J^T D J (+ cone blocks) is assembled into a packed lower triangle in LDS with returnless LDS atomics,
-// factorised in place (one lane per matrix row), the Newton direction comes from two register-resident triangular
-// solves (v_readlane broadcasts), and the exact line search is a safeguarded 1-D Newton iteration whose phi', phi''
-// are wave-wide DPP sums.
+// Mapping on the wavefront
+//   rows      row i -> lane i % 64 (residuals J_i a - aref_i, J_i dl; gradient scatter with returnless LDS atomics)
+//   contacts  contact c -> lane c % 64: zone, cone forces and the line-search derivatives of its <= 6 rows in registers
+//   Hessian   H = M + sum_blocks J_b^T C_b J_b in a packed lower triangle in LDS.  The wave walks the blocks (a scalar
+//             row or a contact) one at a time; the cone block is never formed: in the middle zone
+//                 C = S (Dm n n^T + kappa (I_t - u u^T)) S      n = (1, -mu u),  u = U_t / |U_t|
+//             so J^T C J = sum_p w_p J_p^T J_p + Dm y1 y1^T - kappa y2 y2^T with two 16-vectors y1, y2; every lane owns
+//             <= 4 entries of the block's 16 x 16 dof window and adds them with returnless LDS atomics.
+//   Cholesky  lane i holds row i of H in registers; the column loop is rolled, the register row is rotated by one
+//             entry per column so that the pivot column is always element 0 (static register indices, no scratch);
+//             multipliers travel by v_readlane.  Lane nv carries -g as an extra row, so the forward substitution
+//             comes out of the factorisation; the backward substitution reads L's columns back from LDS.
+//   search    exact line search: safeguarded 1-D Newton on phi'(alpha); J a and J dl are fixed per iteration, so an
+//             evaluation is a handful of FMAs per lane and two wave-wide DPP sums.
 #pragma once
 #include "avsim_math.hip.h"
 
@@ -21,7 +30,7 @@ namespace avs {
 template <typename real>
 struct NewtonArgs {
     // LDS views of one env
-    LDS_PTR(real) rowS;          // 8 reals per row: aref, R, 1/(diag+R), 1/diag|0, lo, hi, force, 1/friction
+    LDS_PTR(real) rowS;          // 8 reals per row: aref, R, [Newton: J a - aref], 1/diag|0, lo, hi, force, 1/friction
     LDS_PTR(const int) rowI;     // dof windows of the row: (adr 6 | n 4 | tree 3) x 2
     LDS_PTR(const int) rmeta;    // type 2 | id 10 | sub 8 | tree ids
     LDS_PTR(const real) rJ;      // 16 reals per row
@@ -29,19 +38,23 @@ struct NewtonArgs {
     LDS_PTR(real) a;             // qacc (in: start point, out: solution)
     LDS_PTR(const real) as;      // qacc_smooth
     LDS_PTR(real) H;             // packed lower triangle nv(nv+1)/2
-    LDS_PTR(real) g;             // gradient / scratch vector nv
+    LDS_PTR(real) g;             // gradient nv; MUST be H + nv(nv+1)/2 (the factorisation reads it as row nv)
     LDS_PTR(real) dl;            // search direction nv
-    LDS_PTR(real) x;             // trial point nv
-    LDS_PTR(int) czone;          // per contact-head row: zone of the contact (indexed by row)
+    LDS_PTR(real) jv;            // per row: J dl (line search) / curvature of the scalar rows (Hessian phase)
+    LDS_PTR(const int) cefc;     // first row of contact c, or -1
+    LDS_PTR(const int) czone;    // per contact-head row: dim << 8
     LDS_PTR(const int) tree_dofadr;
     LDS_PTR(const int) tree_dofnum;
     LDS_PTR(const int) tree_madr;
     LDS_PTR(const int) dof_tree;
-    int nv, nefc, ntree, iters;
+    LDS_PTR(int) prof;           // optional cycle counters (8 ints) or null
+    int nv, nefc, ncon, nlead, ntree, iters;
     real tol, scale, ls_tol;
 };
 
 enum { NR_EQ = 0, NR_FLOSS = 1, NR_LIMIT = 2, NR_CONTACT = 3 };
+constexpr int NCH = 2;       // contact chunks of 64 (one contact per lane and chunk)
+constexpr int NVMAX = 48;    // register row of the factorisation
 
 // J_i . v for row i (v in LDS, dof indexed)
 template <typename real>
@@ -52,8 +65,8 @@ AVS_DEV real nrow_dot(const NewtonArgs<real>& A, int i, LDS_PTR(const real) v) {
     real s = 0;
 #pragma unroll
     for (int k = 0; k < TREE_W; k++) {
-        if (k < nA) s += J[k] * v[a0 + k];
-        if (k < nB) s += J[TREE_W + k] * v[b0 + k];
+        const real ja = J[k], va = v[k < nA ? a0 + k : 0], jb = J[TREE_W + k], vb = v[k < nB ? b0 + k : 0];
+        s += (k < nA ? ja * va : real(0)) + (k < nB ? jb * vb : real(0));
     }
     return s;
 }
@@ -84,64 +97,83 @@ AVS_DEV real nrow_scalar_cost(int type, real z, real R, real eta) {
     return z < 0 ? real(0.5) * D * z * z : real(0);
 }
 
-// elliptic contact with rows i..i+dim-1 at residuals jar[]: zone, forces, and (middle zone) the dim x dim curvature block
+// the alpha-independent part of one contact (held by its lane for the whole solve)
 template <typename real>
-AVS_DEV int ncontact(const NewtonArgs<real>& A, int i, int dim, const real* jar, real* f, real* C, bool want_C, real* cost = nullptr) {
-    const real R0 = A.rowS[8 * i + 1];
-    if (cost) *cost = 0;
-    if (dim == 1) {
-        real h;
-        nrow_scalar<real>(NR_LIMIT, jar[0], R0, real(0), f, &h);
-        if (cost) *cost = nrow_scalar_cost<real>(NR_LIMIT, jar[0], R0, real(0));
-        return jar[0] < 0 ? 1 : 0;
-    }
-    const real R1 = A.rowS[8 * (i + 1) + 1];
-    real fr[6];   // friction coefficient of row j (j >= 1)
-    fr[0] = 0;
+struct NCon {
+    int head, dim;        // first row (-1: none), rows
+    real S[6];            // S[0] = mu (cone scaling of the normal), S[j] = friction of row j
+    real D[6];            // 1 / R_j
+    real mu, Dm;          // middle-zone curvature scale
+};
+
+// zone (0 top / 1 bottom / 2 middle), forces, cost, and the Hessian coefficients of the block:
+//   J^T C J = sum_p w_p J_p^T J_p + s1 y1 y1^T - s2 y2 y2^T,  y1 = sum_p c1_p J_p,  y2 = sum_p c2_p J_p
+template <typename real>
+AVS_DEV int ncone(const NCon<real>& c, const real* jar, real* f, real* cost, real* w, real* c1, real* c2, real* s1, real* s2) {
 #pragma unroll
-    for (int j = 1; j < 6; j++) fr[j] = j < dim ? real(1) / A.rowS[8 * (i + j) + 7] : real(0);
-    const real mu = fr[1] * sqrt(R1 / R0);
-    real U[6], t2 = 0;
-    U[0] = jar[0] * mu;
-#pragma unroll
-    for (int j = 1; j < 6; j++) { U[j] = j < dim ? jar[j] * fr[j] : real(0); t2 += U[j] * U[j]; }
-    const real N = U[0], T = sqrt(t2);
-    if (N >= mu * T || (T <= 0 && N >= 0)) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) f[j] = 0;
-        return 0;
-    }
-    if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const real Dj = real(1) / A.rowS[8 * (i + (j < dim ? j : 0)) + 1];
-            f[j] = j < dim ? -jar[j] * Dj : real(0);
-            if (cost && j < dim) *cost += real(0.5) * Dj * jar[j] * jar[j];
-        }
+    for (int j = 0; j < 6; j++) { f[j] = 0; w[j] = 0; c1[j] = 0; c2[j] = 0; }
+    *cost = 0; *s1 = 0; *s2 = 0;
+    if (c.dim == 1) {
+        if (!(jar[0] < 0)) return 0;
+        f[0] = -c.D[0] * jar[0]; w[0] = c.D[0];
+        *cost = real(0.5) * c.D[0] * jar[0] * jar[0];
         return 1;
     }
-    const real Dm = (real(1) / R0) / tmax(real(1e-15), mu * mu * (1 + mu * mu)), NT = N - mu * T;
-    f[0] = -Dm * NT * mu;
-    if (cost) *cost = real(0.5) * Dm * NT * NT;
+    real U[6], t2 = 0;
+    U[0] = jar[0] * c.mu;
 #pragma unroll
-    for (int j = 1; j < 6; j++) f[j] = j < dim ? -f[0] / T * U[j] * fr[j] : real(0);
-    if (want_C) {
-        real S[6];
-        S[0] = mu;
+    for (int j = 1; j < 6; j++) { U[j] = j < c.dim ? jar[j] * c.S[j] : real(0); t2 += U[j] * U[j]; }
+    const real N = U[0], T = sqrt(t2), mu = c.mu;
+    if (N >= mu * T || (T <= 0 && N >= 0)) return 0;
+    if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
 #pragma unroll
-        for (int j = 1; j < 6; j++) S[j] = fr[j];
-#pragma unroll
-        for (int p = 0; p < 6; p++)
-#pragma unroll
-            for (int q = 0; q < 6; q++) {
-                real h;
-                if (p == 0 && q == 0) h = Dm;
-                else if (p == 0 || q == 0) { const real u = p == 0 ? U[q] : U[p]; h = -Dm * mu * u / T; }
-                else h = Dm * mu * mu * U[p] * U[q] / (T * T) - Dm * NT * mu * ((p == q ? real(1) / T : real(0)) - U[p] * U[q] / (T * T * T));
-                C[6 * p + q] = (p < dim && q < dim) ? h * S[p] * S[q] : real(0);
-            }
+        for (int j = 0; j < 6; j++)
+            if (j < c.dim) { f[j] = -jar[j] * c.D[j]; w[j] = c.D[j]; *cost += real(0.5) * c.D[j] * jar[j] * jar[j]; }
+        return 1;
     }
+    const real NT = N - mu * T, Ti = real(1) / T, kap = -c.Dm * NT * mu * Ti;
+    f[0] = -c.Dm * NT * mu;
+    *cost = real(0.5) * c.Dm * NT * NT;
+    c1[0] = mu; *s1 = c.Dm; *s2 = kap;
+#pragma unroll
+    for (int j = 1; j < 6; j++)
+        if (j < c.dim) {
+            const real us = U[j] * Ti * c.S[j];     // u_j S_j
+            f[j] = -f[0] * us;
+            w[j] = kap * c.S[j] * c.S[j];
+            c1[j] = -mu * us;
+            c2[j] = us;
+        }
     return 2;
+}
+
+// phi'(alpha), phi''(alpha) of one contact at residuals jar (= jar0 + alpha jv)
+template <typename real>
+AVS_DEV void ncone_ls(const NCon<real>& c, const real* jar, const real* jv, real* d1, real* d2) {
+    *d1 = 0; *d2 = 0;
+    if (c.dim == 1) {
+        if (jar[0] < 0) { *d1 = c.D[0] * jar[0] * jv[0]; *d2 = c.D[0] * jv[0] * jv[0]; }
+        return;
+    }
+    real U[6], V[6], t2 = 0, uv = 0, v2 = 0;
+    U[0] = jar[0] * c.mu; V[0] = jv[0] * c.mu;
+#pragma unroll
+    for (int j = 1; j < 6; j++) {
+        U[j] = j < c.dim ? jar[j] * c.S[j] : real(0);
+        V[j] = j < c.dim ? jv[j] * c.S[j] : real(0);
+        t2 += U[j] * U[j]; uv += U[j] * V[j]; v2 += V[j] * V[j];
+    }
+    const real N = U[0], T = sqrt(t2), mu = c.mu;
+    if (N >= mu * T || (T <= 0 && N >= 0)) return;
+    if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+            if (j < c.dim) { *d1 += c.D[j] * jar[j] * jv[j]; *d2 += c.D[j] * jv[j] * jv[j]; }
+        return;
+    }
+    const real Ti = real(1) / T, T1 = uv * Ti, T2 = (v2 - T1 * T1) * Ti, NT = N - mu * T, N1 = V[0] - mu * T1;
+    *d1 = c.Dm * NT * N1;
+    *d2 = c.Dm * N1 * N1 - c.Dm * NT * mu * T2;
 }
 
 // global dof of window slot s (0..15) of a row, or -1
@@ -150,23 +182,36 @@ AVS_DEV int nslot_dof(int ra, int s) {
     return k < ((ra >> (sh + 6)) & 15) ? ((ra >> sh) & 63) + k : -1;
 }
 
-// H[p,q] += w * (Jp_row slot outer Jq_row slot) over the two rows' windows (rp, rq may be the same row)
+// H += J_b^T C_b J_b for the block of rows r0 .. r0+dim-1 (every argument wave-uniform).  Lane l owns column
+// t = l & 15 of the block's 16 x 16 dof window and rows (l >> 4) + 4u; lower-triangle entries only.
 template <typename real>
-AVS_DEV void nouter(const NewtonArgs<real>& A, int rp, int rq, real w, bool sym_same) {
-    const int rap = A.rowI[rp], raq = A.rowI[rq];
-    LDS_PTR(const real) Jp = A.rJ + ROW_W * rp;
-    LDS_PTR(const real) Jq = A.rJ + ROW_W * rq;
-    for (int s = 0; s < ROW_W; s++) {
-        const int gp = nslot_dof(rap, s);
-        if (gp < 0) continue;
-        const real jp = Jp[s] * w;
-        for (int t = 0; t < ROW_W; t++) {
-            const int gq = nslot_dof(raq, t);
-            if (gq < 0 || gq > gp) continue;                    // lower triangle only
-            real v = jp * Jq[t];
-            if (!sym_same && gq == gp) { /* diagonal entry of an off-diagonal block pair is added once per ordered pair */ }
-            __hip_atomic_fetch_add(A.H + gp * (gp + 1) / 2 + gq, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+AVS_DEV void nblock(const NewtonArgs<real>& A, int lane, int r0, int dim, bool full, const real* w, const real* c1, const real* c2, real s1, real s2) {
+    const int ra = A.rowI[r0], t = lane & 15, gq = nslot_dof(ra, t);
+    const int nu = ((ra >> 19) & 15) > 0 ? 4 : 2;
+    LDS_PTR(const real) J = A.rJ + ROW_W * r0;
+    real Jt[6], y1t = 0, y2t = 0;
+#pragma unroll
+    for (int p = 0; p < 6; p++) Jt[p] = p < dim ? J[ROW_W * p + t] : real(0);
+    if (full) {
+#pragma unroll
+        for (int p = 0; p < 6; p++) { y1t += c1[p] * Jt[p]; y2t += c2[p] * Jt[p]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (u >= nu) continue;
+        const int s = (lane >> 4) + 4 * u, gp = nslot_dof(ra, s);
+        real Js[6], acc = 0;
+#pragma unroll
+        for (int p = 0; p < 6; p++) Js[p] = p < dim ? J[ROW_W * p + s] : real(0);
+#pragma unroll
+        for (int p = 0; p < 6; p++) acc += w[p] * Js[p] * Jt[p];
+        if (full) {
+            real y1s = 0, y2s = 0;
+#pragma unroll
+            for (int p = 0; p < 6; p++) { y1s += c1[p] * Js[p]; y2s += c2[p] * Js[p]; }
+            acc += s1 * y1s * y1t - s2 * y2s * y2t;
         }
+        if (gp >= 0 && gq >= 0 && gq <= gp) __hip_atomic_fetch_add(A.H + gp * (gp + 1) / 2 + gq, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
@@ -175,79 +220,134 @@ AVS_DEV void nouter(const NewtonArgs<real>& A, int rp, int rq, real w, bool sym_
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); \
         __builtin_amdgcn_wave_barrier();                     \
     } while (0)
+#define NPROF(k)                                                                           \
+    do {                                                                                   \
+        if (A.prof) { const long long t_ = __builtin_readcyclecounter(); if (lane == 0) A.prof[k] += (int)(t_ - tp0); tp0 = t_; } \
+    } while (0)
+
+// cost of the point v (LDS, dof indexed): rows + contacts + 1/2 (v - a_s)^T M (v - a_s)
+template <typename real>
+AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, LDS_PTR(const real) v) {
+    real cs = 0;
+    for (int i = lane; i < A.nefc; i += 64) A.rowS[8 * i + 2] = nrow_dot(A, i, v) - A.rowS[8 * i];
+    NSYNC();
+    for (int i = lane; i < A.nlead; i += 64) cs += nrow_scalar_cost<real>(A.rmeta[i] & 3, A.rowS[8 * i + 2], A.rowS[8 * i + 1], A.rowS[8 * i + 5]);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        if (ch * 64 >= A.ncon) break;
+        const NCon<real>& c = con[ch];
+        if (c.head >= 0) {
+            real jar[6], f[6], w[6], c1[6], c2[6], cc, s1, s2;
+#pragma unroll
+            for (int j = 0; j < 6; j++) jar[j] = j < c.dim ? A.rowS[8 * (c.head + j) + 2] : real(0);
+            ncone(c, jar, f, &cc, w, c1, c2, &s1, &s2);
+            cs += cc;
+        }
+    }
+    for (int k = lane; k < A.nv; k += 64) {
+        const int t = A.dof_tree[k], a0 = A.tree_dofadr[t], n = A.tree_dofnum[t], kk = k - a0;
+        real sacc = 0;
+        for (int j = 0; j < n; j++) sacc += A.M[A.tree_madr[t] + kk * n + j] * (v[a0 + j] - A.as[a0 + j]);
+        cs += real(0.5) * sacc * (v[k] - A.as[k]);
+    }
+    return wave_sum(cs);
+}
 
 template <typename real>
 __device__ __attribute__((noinline)) int newton_solve(NewtonArgs<real> A) {
     const int lane = threadIdx.x & 63;
+    // arguments of a non-kernel function arrive in VGPRs: make the wave-uniform ones scalar again
+    A.nv = __builtin_amdgcn_readfirstlane(A.nv); A.nefc = __builtin_amdgcn_readfirstlane(A.nefc);
+    A.ncon = __builtin_amdgcn_readfirstlane(A.ncon); A.nlead = __builtin_amdgcn_readfirstlane(A.nlead);
+    A.iters = __builtin_amdgcn_readfirstlane(A.iters);
     const int nv = A.nv, ne = A.nefc;
     int used = 0;
-    // ---- start from the warm start (already in a) or from the smooth acceleration, whichever costs less ----
-    {
-        real c[2];
-        for (int trial = 0; trial < 2; trial++) {
-            LDS_PTR(const real) v = trial == 0 ? (LDS_PTR(const real))A.a : A.as;
-            real cs = 0;
-            for (int i = lane; i < ne; i += 64) {
-                const int meta = A.rmeta[i], type = meta & 3, sub = (meta >> 12) & 255;
-                if (type != NR_CONTACT) cs += nrow_scalar_cost<real>(type, nrow_dot(A, i, v) - A.rowS[8 * i], A.rowS[8 * i + 1], A.rowS[8 * i + 5]);
-                else if (sub == 0) {
-                    const int dim = A.czone[i] >> 8;
-                    real jar[6], f[6], C[1], cc;
+    long long tp0 = A.prof ? __builtin_readcyclecounter() : 0;
+    // ---- per-contact constants ----
+    NCon<real> con[NCH];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) jar[j] = j < dim ? nrow_dot(A, i + j, v) - A.rowS[8 * (i + j)] : real(0);
-                    ncontact(A, i, dim, jar, f, C, false, &cc);
-                    cs += cc;
-                }
+    for (int ch = 0; ch < NCH; ch++) {
+        NCon<real>& c = con[ch];
+        const int ci = ch * 64 + lane;
+        c.head = ci < A.ncon ? A.cefc[ci] : -1;
+        c.dim = c.head >= 0 ? (A.czone[c.head] >> 8) : 0;
+        c.mu = 0; c.Dm = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) { c.S[j] = 0; c.D[j] = 0; }
+        if (c.head >= 0) {
+#pragma unroll
+            for (int j = 0; j < 6; j++)
+                if (j < c.dim) { c.D[j] = real(1) / A.rowS[8 * (c.head + j) + 1]; if (j > 0) c.S[j] = real(1) / A.rowS[8 * (c.head + j) + 7]; }
+            if (c.dim > 1) {
+                const real R0 = A.rowS[8 * c.head + 1], R1 = A.rowS[8 * (c.head + 1) + 1];
+                c.mu = c.S[1] * sqrt(R1 / R0);
+                c.S[0] = c.mu;
+                c.Dm = (real(1) / R0) / tmax(real(1e-15), c.mu * c.mu * (1 + c.mu * c.mu));
             }
-            for (int k = lane; k < nv; k += 64) {
-                const int t = A.dof_tree[k], a0 = A.tree_dofadr[t], n = A.tree_dofnum[t], kk = k - a0;
-                real sacc = 0;
-                for (int j = 0; j < n; j++) sacc += A.M[A.tree_madr[t] + kk * n + j] * (v[a0 + j] - A.as[a0 + j]);
-                cs += real(0.5) * sacc * (v[k] - A.as[k]);
-            }
-            c[trial] = wave_sum(cs);
-        }
-        if (!(c[0] < c[1])) {
-            for (int k = lane; k < nv; k += 64) A.a[k] = A.as[k];
-            NSYNC();
         }
     }
-    for (int it = 0; it < A.iters; it++) {
-        used++;
-        // ---- gradient g = M (a - a_s) - J^T f(a), forces written to rowS.f ----
-        for (int i = lane; i < ne; i += 64) {
-            const int meta = A.rmeta[i], type = meta & 3, sub = (meta >> 12) & 255;
-            if (type != NR_CONTACT) {
-                real f, h;
-                nrow_scalar<real>(type, nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[8 * i], A.rowS[8 * i + 1], A.rowS[8 * i + 5], &f, &h);
-                A.rowS[8 * i + 6] = f;
-            } else if (sub == 0) {
-                const int dim = A.czone[i] >> 8;
-                real jar[6], f[6], C[1];
-#pragma unroll
-                for (int j = 0; j < 6; j++) jar[j] = j < dim ? nrow_dot(A, i + j, (LDS_PTR(const real))A.a) - A.rowS[8 * (i + j)] : real(0);
-                const int zn = ncontact(A, i, dim, jar, f, C, false);
-                A.czone[i] = (dim << 8) | zn;
-#pragma unroll
-                for (int j = 0; j < 6; j++) if (j < dim) A.rowS[8 * (i + j) + 6] = f[j];
-            }
+    // ---- start from the warm start (already in a) or from the smooth acceleration, whichever costs less ----
+    {
+        const real c0 = ncost(A, lane, con, (LDS_PTR(const real))A.a);
+        NSYNC();
+        const real c1 = ncost(A, lane, con, A.as);
+        if (!(c0 < c1)) {
+            for (int k = lane; k < nv; k += 64) A.a[k] = A.as[k];
         }
         NSYNC();
-        real gn2 = 0;
+    }
+    NPROF(0);
+    int zone[NCH];
+    real cw[NCH][6], cc1[NCH][6], cc2[NCH][6], cs1[NCH], cs2[NCH];
+    for (int it = 0; it < A.iters; it++) {
+        used++;
+        // ---- residuals, forces (-> rowS.f), curvature of the scalar rows (-> jv) ----
+        for (int i = lane; i < ne; i += 64) A.rowS[8 * i + 2] = nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[8 * i];
+        NSYNC();
+        for (int i = lane; i < A.nlead; i += 64) {
+            real f, h;
+            nrow_scalar<real>(A.rmeta[i] & 3, A.rowS[8 * i + 2], A.rowS[8 * i + 1], A.rowS[8 * i + 5], &f, &h);
+            A.rowS[8 * i + 6] = f;
+            A.jv[i] = h;
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            zone[ch] = 0;
+            if (ch * 64 >= A.ncon) break;
+            const NCon<real>& c = con[ch];
+            if (c.head >= 0) {
+                real jar[6], f[6], cc;
+#pragma unroll
+                for (int j = 0; j < 6; j++) jar[j] = j < c.dim ? A.rowS[8 * (c.head + j) + 2] : real(0);
+                zone[ch] = ncone(c, jar, f, &cc, cw[ch], cc1[ch], cc2[ch], &cs1[ch], &cs2[ch]);
+#pragma unroll
+                for (int j = 0; j < 6; j++) if (j < c.dim) A.rowS[8 * (c.head + j) + 6] = f[j];
+            }
+        }
+        // ---- gradient g = M (a - a_s) - J^T f ----
         for (int k = lane; k < nv; k += 64) {
             const int t = A.dof_tree[k], a0 = A.tree_dofadr[t], n = A.tree_dofnum[t], kk = k - a0;
             real s = 0;
             for (int j = 0; j < n; j++) s += A.M[A.tree_madr[t] + kk * n + j] * (A.a[a0 + j] - A.as[a0 + j]);
-            for (int i = 0; i < ne; i++) {
-                const int ra = A.rowI[i];
-                const int da = k - (ra & 63), db = k - ((ra >> 13) & 63);
-                if ((unsigned)da < (unsigned)((ra >> 6) & 15)) s -= A.rJ[ROW_W * i + da] * A.rowS[8 * i + 6];
-                else if ((unsigned)db < (unsigned)((ra >> 19) & 15)) s -= A.rJ[ROW_W * i + TREE_W + db] * A.rowS[8 * i + 6];
-            }
             A.g[k] = s;
-            gn2 += s * s;
         }
+        NSYNC();
+        for (int i = lane; i < ne; i += 64) {
+            const real f = A.rowS[8 * i + 6];
+            if (f == 0) continue;
+            const int ra = A.rowI[i];
+            LDS_PTR(const real) J = A.rJ + ROW_W * i;
+#pragma unroll
+            for (int s = 0; s < ROW_W; s++) {
+                const int dof = nslot_dof(ra, s);
+                if (dof >= 0) __hip_atomic_fetch_add(A.g + dof, -J[s] * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        NSYNC();
+        real gn2 = 0;
+        for (int k = lane; k < nv; k += 64) { const real s = A.g[k]; gn2 += s * s; }
         gn2 = wave_sum(gn2);
+        NPROF(1);
         if (sqrt(gn2) * A.scale < A.tol) break;
         // ---- Hessian: packed lower triangle ----
         for (int e = lane; e < nv * (nv + 1) / 2; e += 64) A.H[e] = 0;
@@ -257,60 +357,81 @@ __device__ __attribute__((noinline)) int newton_solve(NewtonArgs<real> A) {
             if (j8 < n && j8 <= kk) A.H[k * (k + 1) / 2 + a0 + j8] = A.M[A.tree_madr[t] + kk * n + j8];
         }
         NSYNC();
-        for (int i = lane; i < ne; i += 64) {
-            const int meta = A.rmeta[i], type = meta & 3, sub = (meta >> 12) & 255;
-            if (type != NR_CONTACT) {
-                real f, h;
-                nrow_scalar<real>(type, nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[8 * i], A.rowS[8 * i + 1], A.rowS[8 * i + 5], &f, &h);
-                if (h != 0) nouter(A, i, i, h, true);
-            } else {
-                const int head = i - sub, zn = A.czone[head] & 255, dim = A.czone[head] >> 8;
-                if (zn == 1) nouter(A, i, i, real(1) / A.rowS[8 * i + 1], true);
-                else if (zn == 2 && sub == 0) {
-                    real jar[6], f[6], C[36];
+        {
+            real w1[6] = {0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < A.nlead; i++) {
+                w1[0] = lane_get(A.jv[i], 0);
+                if (w1[0] != 0) nblock<real>(A, lane, i, 1, false, w1, w1, w1, real(0), real(0));
+            }
+        }
 #pragma unroll
-                    for (int j = 0; j < 6; j++) jar[j] = j < dim ? nrow_dot(A, i + j, (LDS_PTR(const real))A.a) - A.rowS[8 * (i + j)] : real(0);
-                    ncontact(A, i, dim, jar, f, C, true);
-                    // J_c^T C J_c, lower triangle: ordered pairs (p,q) contribute their lower part; symmetric C
-                    for (int p = 0; p < dim; p++)
-                        for (int q = 0; q < dim; q++) {
-                            real w = 0;
+        for (int ch = 0; ch < NCH; ch++) {
+            if (ch * 64 >= A.ncon) break;
+            const int nc = A.ncon - ch * 64 < 64 ? A.ncon - ch * 64 : 64;
+            for (int c = 0; c < nc; c++) {
+                const int zn = __builtin_amdgcn_readlane(zone[ch], c);
+                if (zn == 0) continue;
+                const int head = __builtin_amdgcn_readlane(con[ch].head, c), dim = __builtin_amdgcn_readlane(con[ch].dim, c);
+                real w[6], c1[6], c2[6];
 #pragma unroll
-                            for (int u = 0; u < 36; u++) w = (u == 6 * p + q) ? C[u] : w;
-                            nouter(A, i + p, i + q, w, false);
+                for (int p = 0; p < 6; p++) { w[p] = lane_get(cw[ch][p], c); c1[p] = lane_get(cc1[ch][p], c); c2[p] = lane_get(cc2[ch][p], c); }
+                nblock<real>(A, lane, head, dim, zn == 2, w, c1, c2, lane_get(cs1[ch], c), lane_get(cs2[ch], c));
+            }
+        }
+        NSYNC();
+        NPROF(2);
+        // ---- Cholesky + forward substitution in registers: lane i = row i, lane nv = -g ----
+        {
+            // g sits right behind the packed triangle (NewtonArgs contract), i.e. it is "row nv" of the same array
+            real row[NVMAX];
+            const int rbase = lane * (lane + 1) / 2;
+            const real sgn = lane == nv ? real(-1) : real(1);
+#pragma unroll
+            for (int k = 0; k < NVMAX; k++) {
+                const bool ok = lane <= nv && k <= lane && k < nv;
+                const real v = A.H[ok ? rbase + k : 0];
+                row[k] = ok ? sgn * v : real(0);
+            }
+            for (int j = 0; j < nv; j++) {
+                // pivot: d = sqrt(H_jj), column j = row[0] / d.  f32 takes the hardware rsq (1 ulp), f64 the exact pair
+                const real piv = tmax(lane_get(row[0], j), real(1e-30));
+                real d, rinv;
+                if (sizeof(real) == 4) { rinv = (real)__builtin_amdgcn_rsqf((float)piv); d = piv * rinv; }
+                else { d = sqrt(piv); rinv = real(1) / d; }
+                const real lij = row[0] * rinv;
+                // L_ij for the rows below, d on the diagonal, y_j = (L^-1 (-g))_j from lane nv ("row nv" is g's storage)
+                if (lane >= j && lane <= nv) A.H[rbase + j] = lane == j ? d : lij;
+#pragma unroll
+                for (int mb = 1; mb < NVMAX; mb += 4) {
+                    if (j + mb <= nv - 1) {          // wave-uniform: the rest of the row is past the matrix
+#pragma unroll
+                        for (int mm = 0; mm < 4; mm++) {
+                            const int m = mb + mm;
+                            if (m < NVMAX) row[m - 1] = row[m] - lij * lane_get(lij, j + m);
                         }
+                    }
                 }
             }
         }
         NSYNC();
-        // ---- Cholesky in place, one lane per matrix row ----
-        for (int j = 0; j < nv; j++) {
-            const real dj = sqrt(tmax(A.H[j * (j + 1) / 2 + j], real(1e-30)));
-            real lij = 0;
-            if (lane > j && lane < nv) lij = A.H[lane * (lane + 1) / 2 + j] / dj;
+        NPROF(3);
+        // ---- backward substitution L^T x = y, lane j holds x_j; column entries prefetched one step ahead ----
+        {
+            real x = lane < nv ? A.g[lane] : real(0);
+            const real dinv = lane < nv ? real(1) / A.H[lane * (lane + 1) / 2 + lane] : real(0);
+            real Lnext = lane < nv - 1 ? A.H[(nv - 1) * nv / 2 + lane] : real(0);
+            for (int i = nv - 1; i >= 0; i--) {
+                const real Lc = Lnext;
+                if (i > 0) Lnext = lane < i - 1 ? A.H[(i - 1) * i / 2 + lane] : real(0);
+                const real xi = lane_get(x * dinv, i);
+                if (lane == i) x = xi;
+                else if (lane < i) x -= Lc * xi;
+            }
             NSYNC();
-            if (lane == j) A.H[j * (j + 1) / 2 + j] = dj;
-            if (lane > j && lane < nv) A.H[lane * (lane + 1) / 2 + j] = lij;
-            NSYNC();
-            if (lane > j && lane < nv)
-                for (int k = j + 1; k <= lane; k++) A.H[lane * (lane + 1) / 2 + k] -= lij * A.H[k * (k + 1) / 2 + j];
-            NSYNC();
+            if (lane < nv) A.dl[lane] = x;
         }
-        // ---- dl = -H^-1 g : register-resident triangular solves (lane i holds component i) ----
-        real xi = lane < nv ? -A.g[lane] : real(0);
-        const real dinv = lane < nv ? real(1) / A.H[lane * (lane + 1) / 2 + lane] : real(0);
-        for (int j = 0; j < nv; j++) {
-            const real yj = lane_get(xi * dinv, j);
-            if (lane == j) xi = yj;
-            if (lane > j && lane < nv) xi -= A.H[lane * (lane + 1) / 2 + j] * yj;
-        }
-        for (int j = nv - 1; j >= 0; j--) {
-            const real yj = lane_get(xi * dinv, j);
-            if (lane == j) xi = yj;
-            if (lane < j) xi -= A.H[j * (j + 1) / 2 + lane] * yj;
-        }
-        if (lane < nv) A.dl[lane] = xi;
         NSYNC();
+        NPROF(7);
         // ---- exact line search along dl ----
         real q1 = 0, q2 = 0;
         for (int k = lane; k < nv; k += 64) {
@@ -322,40 +443,37 @@ __device__ __attribute__((noinline)) int newton_solve(NewtonArgs<real> A) {
         }
         q1 = wave_sum(q1);
         q2 = wave_sum(q2);
+        for (int i = lane; i < ne; i += 64) A.jv[i] = nrow_dot(A, i, (LDS_PTR(const real))A.dl);
+        NSYNC();
+        real cj0[NCH][6], cjv[NCH][6];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const bool on = con[ch].head >= 0 && j < con[ch].dim;
+                cj0[ch][j] = on ? A.rowS[8 * (con[ch].head + j) + 2] : real(0);
+                cjv[ch][j] = on ? A.jv[con[ch].head + j] : real(0);
+            }
         real alpha = 0, lo = 0, hi = -1, dphi0 = 0;
         for (int ls = 0; ls < 40; ls++) {
-            // trial point, then phi'(alpha), phi''(alpha)
-            for (int k = lane; k < nv; k += 64) A.x[k] = A.a[k] + alpha * A.dl[k];
-            NSYNC();
             real gsum = 0, hsum = 0;
-            for (int i = lane; i < ne; i += 64) {
-                const int meta = A.rmeta[i], type = meta & 3, sub = (meta >> 12) & 255;
-                if (type != NR_CONTACT) {
-                    real f, h;
-                    const real jvi = nrow_dot(A, i, (LDS_PTR(const real))A.dl);
-                    nrow_scalar<real>(type, nrow_dot(A, i, (LDS_PTR(const real))A.x) - A.rowS[8 * i], A.rowS[8 * i + 1], A.rowS[8 * i + 5], &f, &h);
-                    gsum -= f * jvi;
-                    hsum += h * jvi * jvi;
-                } else if (sub == 0) {
-                    const int dim = A.czone[i] >> 8;
-                    real jar[6], jv[6], f[6], C[36];
+            for (int i = lane; i < A.nlead; i += 64) {
+                real f, h;
+                const real jvi = A.jv[i];
+                nrow_scalar<real>(A.rmeta[i] & 3, A.rowS[8 * i + 2] + alpha * jvi, A.rowS[8 * i + 1], A.rowS[8 * i + 5], &f, &h);
+                gsum -= f * jvi;
+                hsum += h * jvi * jvi;
+            }
 #pragma unroll
-                    for (int j = 0; j < 6; j++) {
-                        jar[j] = j < dim ? nrow_dot(A, i + j, (LDS_PTR(const real))A.x) - A.rowS[8 * (i + j)] : real(0);
-                        jv[j] = j < dim ? nrow_dot(A, i + j, (LDS_PTR(const real))A.dl) : real(0);
-                    }
-                    const int zn = ncontact(A, i, dim, jar, f, C, true);
+            for (int ch = 0; ch < NCH; ch++) {
+                if (ch * 64 >= A.ncon) break;
+                if (con[ch].head >= 0) {
+                    real jar[6], d1, d2;
 #pragma unroll
-                    for (int j = 0; j < 6; j++) gsum -= f[j] * jv[j];
-                    if (zn == 1) {
-#pragma unroll
-                        for (int j = 0; j < 6; j++) if (j < dim) hsum += jv[j] * jv[j] / A.rowS[8 * (i + j) + 1];
-                    } else if (zn == 2) {
-#pragma unroll
-                        for (int p = 0; p < 6; p++)
-#pragma unroll
-                            for (int q = 0; q < 6; q++) hsum += jv[p] * C[6 * p + q] * jv[q];
-                    }
+                    for (int j = 0; j < 6; j++) jar[j] = cj0[ch][j] + alpha * cjv[ch][j];
+                    ncone_ls(con[ch], jar, cjv[ch], &d1, &d2);
+                    gsum += d1;
+                    hsum += d2;
                 }
             }
             const real dphi = q1 + alpha * q2 + wave_sum(gsum), ddphi = q2 + wave_sum(hsum);
@@ -373,6 +491,7 @@ __device__ __attribute__((noinline)) int newton_solve(NewtonArgs<real> A) {
             if (fabs(nx - alpha) < real(1e-7) * A.ls_tol * (1 + fabs(alpha))) { alpha = nx; break; }
             alpha = nx;
         }
+        NPROF(4);
         if (!(dphi0 < 0)) break;
         real st2 = 0;
         for (int k = lane; k < nv; k += 64) { const real s = alpha * A.dl[k]; A.a[k] += s; st2 += s * s; }
@@ -381,23 +500,28 @@ __device__ __attribute__((noinline)) int newton_solve(NewtonArgs<real> A) {
         if (sqrt(st2) * A.scale < real(1e-2) * A.tol) break;
     }
     // ---- forces at the solution ----
-    for (int i = lane; i < ne; i += 64) {
-        const int meta = A.rmeta[i], type = meta & 3, sub = (meta >> 12) & 255;
-        if (type != NR_CONTACT) {
-            real f, h;
-            nrow_scalar<real>(type, nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[8 * i], A.rowS[8 * i + 1], A.rowS[8 * i + 5], &f, &h);
-            A.rowS[8 * i + 6] = f;
-        } else if (sub == 0) {
-            const int dim = A.czone[i] >> 8;
-            real jar[6], f[6], C[1];
+    for (int i = lane; i < ne; i += 64) A.rowS[8 * i + 2] = nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[8 * i];
+    NSYNC();
+    for (int i = lane; i < A.nlead; i += 64) {
+        real f, h;
+        nrow_scalar<real>(A.rmeta[i] & 3, A.rowS[8 * i + 2], A.rowS[8 * i + 1], A.rowS[8 * i + 5], &f, &h);
+        A.rowS[8 * i + 6] = f;
+    }
 #pragma unroll
-            for (int j = 0; j < 6; j++) jar[j] = j < dim ? nrow_dot(A, i + j, (LDS_PTR(const real))A.a) - A.rowS[8 * (i + j)] : real(0);
-            ncontact(A, i, dim, jar, f, C, false);
+    for (int ch = 0; ch < NCH; ch++) {
+        if (ch * 64 >= A.ncon) break;
+        const NCon<real>& c = con[ch];
+        if (c.head >= 0) {
+            real jar[6], f[6], w[6], c1[6], c2[6], cc, s1, s2;
 #pragma unroll
-            for (int j = 0; j < 6; j++) if (j < dim) A.rowS[8 * (i + j) + 6] = f[j];
+            for (int j = 0; j < 6; j++) jar[j] = j < c.dim ? A.rowS[8 * (c.head + j) + 2] : real(0);
+            ncone(c, jar, f, &cc, w, c1, c2, &s1, &s2);
+#pragma unroll
+            for (int j = 0; j < 6; j++) if (j < c.dim) A.rowS[8 * (c.head + j) + 6] = f[j];
         }
     }
     NSYNC();
+    NPROF(5);
     return used;
 }
 

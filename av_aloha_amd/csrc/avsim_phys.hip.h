@@ -120,13 +120,13 @@ struct MOff {
 
 // per-env LDS layout (offsets in reals / ints)
 struct Layout {
-    int qpos, qvel, ctrl, warm, xpos, xmat, xipos, cdof, gcen, gref, M, L, Minv, bias, fsm, asm_, qacc, fcon, nH, ng, ndl, nx, U, nreal;
+    int qpos, qvel, ctrl, warm, xpos, xmat, xipos, cdof, gcen, gref, M, L, Minv, bias, fsm, asm_, qacc, fcon, nH, ng, ndl, njv, U, nreal;
     // scratch union U, phase A
     int cinert, cvel, cacc, cfrc;
     // phase B
     int cdist, cpos, cnrm, rJ, rowS, gA;
     // ints
-    int cand, nearl, cpair, cefc, rmeta, rowI, gI, czone, misc, nint;
+    int cand, nearl, cpair, cefc, rmeta, rowI, gI, czone, misc, nprof, nint;
     int maxgrp;
     int maxcon, maxefc;
     int bytes_per_env;
@@ -196,7 +196,11 @@ AVS_DEV double oct_sum(double x) {
     return x;
 }
 AVS_DEV float lane_get(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
-AVS_DEV double lane_get(double x, int l) { return __shfl(x, l, 64); }
+AVS_DEV double lane_get(double x, int l) {   // l is wave-uniform at every call site
+    const long long b = __builtin_bit_cast(long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
 
 constexpr int GRP_MAX = 6;   // rows per Gauss-Seidel group (a condim-6 contact is one group)
 
@@ -430,6 +434,7 @@ template <typename real, int G>
 struct Env {
     const DevModel<real>& m;
     int nit_sum = 0, nit_max = 0;   // Newton iterations over the launch's substeps (diagnostics)
+    bool profiling = false;
     const Layout& lay;
     real* r;  // real region of this env
     int* ii;  // int region of this env
@@ -1154,17 +1159,20 @@ struct Env {
             NewtonArgs<real> A;
             A.rowS = (LDS_PTR(real))rowS; A.rowI = (LDS_PTR(const int))rowI; A.rmeta = (LDS_PTR(const int))rmeta; A.rJ = (LDS_PTR(const real))rJ;
             A.M = (LDS_PTR(const real))(r + lay.M); A.a = (LDS_PTR(real))qacc; A.as = (LDS_PTR(const real))as;
-            A.H = (LDS_PTR(real))(r + lay.nH); A.g = (LDS_PTR(real))(r + lay.ng); A.dl = (LDS_PTR(real))(r + lay.ndl); A.x = (LDS_PTR(real))(r + lay.nx);
-            A.czone = (LDS_PTR(int))(ii + lay.czone);
+            A.H = (LDS_PTR(real))(r + lay.nH); A.g = (LDS_PTR(real))(r + lay.ng); A.dl = (LDS_PTR(real))(r + lay.ndl); A.jv = (LDS_PTR(real))(r + lay.njv);
+            A.czone = (LDS_PTR(const int))(ii + lay.czone); A.cefc = (LDS_PTR(const int))cefc;
+            A.prof = profiling ? (LDS_PTR(int))(ii + lay.nprof) : (LDS_PTR(int))nullptr;
             A.tree_dofadr = (LDS_PTR(const int))tree_dofadr_(); A.tree_dofnum = (LDS_PTR(const int))tree_dofnum_();
             A.tree_madr = (LDS_PTR(const int))tree_madr_(); A.dof_tree = (LDS_PTR(const int))dof_tree_();
-            A.nv = m.nv; A.nefc = nefc; A.ntree = m.ntree; A.iters = newton_iters;
+            A.nv = m.nv; A.nefc = nefc; A.ncon = ncon; A.nlead = misc[4]; A.ntree = m.ntree; A.iters = newton_iters;
             A.tol = newton_tol; A.scale = scale; A.ls_tol = sizeof(real) == 8 ? real(1e-10) : real(1e-4);
             int used = newton_solve<real>(A);
             nit_sum += used; nit_max = used > nit_max ? used : nit_max;
             GSYNC();
+            long long tn0 = profiling ? __builtin_readcyclecounter() : 0;
             pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const real))rJ, (LDS_PTR(const real))Minv, (LDS_PTR(real))qacc,
                              (LDS_PTR(const int))(ii + lay.gI), (LDS_PTR(const real))(r + lay.gA), misc[5], 0, m.noslip_iters);
+            if (profiling && lane == 0) (ii + lay.nprof)[6] += (int)(__builtin_readcyclecounter() - tn0);
         } else {
         // warm-start forces of friction blocks back onto their cones (one contact per lane)
         for (int c = lane; c < ncon; c += G) {
@@ -1177,17 +1185,7 @@ struct Env {
         }
         GSYNC();
         // qacc = qacc_smooth + M^-1 J^T f : generalized force per dof first, then the per-tree inverse
-        for (int k = lane; k < m.nv; k += G) {
-            int t = dof_tree_()[k], kk = k - tree_dofadr_()[t];
-            real s = 0;
-            for (int i = 0; i < nefc; i++) {
-                int meta = rmeta[i], tA = ((meta >> 20) & 15) - 1, tB = ((meta >> 24) & 15) - 1;
-                if (tA == t) s += rJ[ROW_W * i + kk] * rowS[8 * i + 6];
-                else if (tB == t) s += rJ[ROW_W * i + TREE_W + kk] * rowS[8 * i + 6];
-            }
-            fcon[k] = s;
-        }
-        GSYNC();
+        jt_force(fcon, nefc);
         for (int k = lane; k < m.nv; k += G) {
             int t = dof_tree_()[k], a0 = tree_dofadr_()[t], kk = k - a0, n = tree_dofnum_()[t];
             real s = as[k];
@@ -1202,15 +1200,24 @@ struct Env {
         }
         GSYNC();
         // qfrc_constraint = J^T f
-        for (int k = lane; k < m.nv; k += G) {
-            int t = dof_tree_()[k], kk = k - tree_dofadr_()[t];
-            real s = 0;
-            for (int i = 0; i < nefc; i++) {
-                int meta = rmeta[i], tA = ((meta >> 20) & 15) - 1, tB = ((meta >> 24) & 15) - 1;
-                if (tA == t) s += rJ[ROW_W * i + kk] * rowS[8 * i + 6];
-                else if (tB == t) s += rJ[ROW_W * i + TREE_W + kk] * rowS[8 * i + 6];
+        jt_force(fcon, nefc);
+    }
+
+    // out = J^T f: one row per lane, scattered over the row's two dof windows with returnless LDS atomics
+    __device__ void jt_force(real* out, int nefc) {
+        int* rowI = ii + lay.rowI;
+        real *rowS = r + lay.rowS, *rJ = r + lay.rJ;
+        for (int k = lane; k < m.nv; k += G) out[k] = 0;
+        GSYNC();
+        for (int i = lane; i < nefc; i += G) {
+            const real f = rowS[8 * i + 6];
+            if (f == 0) continue;
+            const int ra = rowI[i];
+#pragma unroll
+            for (int s = 0; s < ROW_W; s++) {
+                const int dof = nslot_dof(ra, s);
+                if (dof >= 0) __hip_atomic_fetch_add(out + dof, rJ[ROW_W * i + s] * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            fcon[k] = s;
         }
         GSYNC();
     }
@@ -1334,7 +1341,8 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(DevModel<real> mg, Layout lay
     for (int i = lane; i < m.nq; i += G) r[lay.qpos + i] = g_qpos[(size_t)env * m.nq + i];
     for (int i = lane; i < m.nv; i += G) { r[lay.qvel + i] = g_qvel[(size_t)env * m.nv + i]; r[lay.warm + i] = g_warm[(size_t)env * m.nv + i]; }
     for (int i = lane; i < m.nu; i += G) r[lay.ctrl + i] = g_ctrl[(size_t)env * m.nu + i];
-    if (lane == 0) for (int k = 0; k < 8; k++) ii[lay.misc + k] = 0;
+    if (lane == 0) for (int k = 0; k < 8; k++) { ii[lay.misc + k] = 0; ii[lay.nprof + k] = 0; }
+    E.profiling = o_prof != nullptr;
     GSYNC();
     if (action) {
         // env.py:203-215: action -> ctrl, grippers un-normalised (env.py:156-161)
@@ -1358,7 +1366,11 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(DevModel<real> mg, Layout lay
         PROF(6, E.solve(pgs_iters, m.solver, m.newton_iters, m.newton_tol, m.nscale));
         PROF(7, E.euler());
     }
-    if (o_prof && lane == 0) { for (int k = 0; k < 8; k++) o_prof[(size_t)env * 10 + k] = tp[k]; o_prof[(size_t)env * 10 + 8] = E.t_broad; o_prof[(size_t)env * 10 + 9] = E.t_narrow; }
+    if (o_prof && lane == 0) {
+        for (int k = 0; k < 8; k++) o_prof[(size_t)env * 18 + k] = tp[k];
+        o_prof[(size_t)env * 18 + 8] = E.t_broad; o_prof[(size_t)env * 18 + 9] = E.t_narrow;
+        for (int k = 0; k < 8; k++) o_prof[(size_t)env * 18 + 10 + k] = ii[lay.nprof + k];   // Newton: init, grad, hess, chol, search, final, noslip
+    }
     // trailing refresh of the position-dependent quantities of the final state
     int nefc_last = ii[lay.misc + 1];
     E.kinematics();
@@ -1603,12 +1615,13 @@ struct PhysHost {
         L.xpos = R(3 * nb); L.xmat = R(9 * nb); L.xipos = R(3 * nb); L.cdof = R(6 * nv); L.gcen = R(3 * ng); L.gref = R(3 * ng);
         L.M = R(msize); L.L = R(msize); o = (o + 3) & ~3; L.Minv = R(64 * 8);
         L.bias = R(nv); L.fsm = R(nv); L.asm_ = R(nv); L.qacc = R(nv); L.fcon = R(nv);
-        // Newton scratch (packed Hessian, gradient, direction, trial point) lives over xpos..gcen: every
+        // Newton scratch (packed Hessian, gradient, direction, per-row J.dl) lives over xpos..gcen where it fits: every
         // position-derived quantity is dead between make_constraints and the next substep's kinematics
         {
-            int need = nv * (nv + 1) / 2 + 3 * nv, avail = 15 * nb + 6 * nv + 3 * ng;
-            int base = need <= avail ? L.xpos : R(need);
-            L.nH = base; L.ng = base + nv * (nv + 1) / 2; L.ndl = L.ng + nv; L.nx = L.ndl + nv;
+            int nvh = nv * (nv + 1) / 2, need1 = nvh + 2 * nv, need2 = need1 + maxefc, avail = 15 * nb + 6 * nv + 3 * ng;
+            int base = need1 <= avail ? L.xpos : R(need1);
+            L.nH = base; L.ng = base + nvh; L.ndl = L.ng + nv;
+            L.njv = need2 <= avail ? L.ndl + nv : R(maxefc);
         }
         L.U = o;
         int a = o;
@@ -1622,7 +1635,7 @@ struct PhysHost {
         L.nreal = (o + 3) & ~3;
         int io = 0;
         auto Iq = [&](int n) { int x = io; io += n; return x; };
-        L.cand = Iq(CAND_MAX); L.nearl = Iq(NEAR_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.czone = Iq(maxefc); L.misc = Iq(8);
+        L.cand = Iq(CAND_MAX); L.nearl = Iq(NEAR_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.czone = Iq(maxefc); L.misc = Iq(8); L.nprof = Iq(8);
         L.nint = (io + 3) & ~3;
         L.maxcon = maxcon;
         L.maxefc = maxefc;
@@ -1684,7 +1697,7 @@ struct PhysHost {
         if (n == "export_contacts") { export_contacts = v != 0; return true; }
         if (n == "waves_per_block") { int x = (int)v; if (x == 0 || x == 1 || x == 2 || x == 4) { wpb_override = x; return true; } return false; }
         if (n == "profile_phases") {
-            if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * 10, 0));
+            if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * 18, 0));
             if (v == 0) d_prof = nullptr;
             return true;
         }

@@ -102,7 +102,8 @@ int avsim_get_diag(avsim_t* h, int32_t* diag);
 
 /* debug: shader-clock cycles each env's wave spent in the 8 phases (kinematics, CRB, RNE, smooth, collide, rows,
  * solve, integrate, + broad / narrow phase incl. the trailing refresh) during the last launch; needs
- * avsim_set_option("profile_phases", 1); int64[N][10] */
+ * avsim_set_option("profile_phases", 1); int64[N][18]: 8 phases, broad, narrow, then the Newton solver's
+ * init / gradient / Hessian / factorisation / line search / final forces / noslip cycles, one spare */
 int avsim_get_phase_cycles(avsim_t* h, int64_t* out);
 
 /* stream / timing helpers (HIP events on the stream the kernels are launched on) */

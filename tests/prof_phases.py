@@ -14,7 +14,7 @@ md = model_dict()
 a = np.repeat(home_action(md)[None], N, 0)
 for _ in range(3):
     sim.step(a)
-out = np.zeros((N, 10), dtype=np.int64)
+out = np.zeros((N, 18), dtype=np.int64)
 sim.h.check(sim.h.L.avsim_get_phase_cycles(sim.h.h, out.ctypes.data))
 names = ["kinematics", "crb", "rne", "smooth", "collide", "rows", "solve", "euler"]
 print("broad/narrow per collide call:", out[:, 8].mean() / 21, out[:, 9].mean() / 21)
@@ -23,3 +23,6 @@ print("cycles per substep per wave (mean over envs):")
 for n, v in zip(names, m):
     print(f"  {n:10s} {v:10.0f}  {100 * v / m.sum():5.1f}%")
 print(f"  total      {m.sum():10.0f}  -> {m.sum() * 20 / 2.4e6:.2f} ms per env-step per wave at 2.4 GHz;  diag {sim.diag()[0]}")
+nn = ["init", "grad", "hess", "chol", "search", "final", "noslip", "backsub"]
+mn = out[:, 10:18].mean(0) / 20
+print("inside solve (Newton):", "  ".join(f"{n} {v:.0f}" for n, v in zip(nn, mn)), f"  iterations/substep {((sim.diag()[:, 3] >> 16) & 0xfff).mean() / 20:.2f}")
