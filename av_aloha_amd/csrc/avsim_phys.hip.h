@@ -328,10 +328,29 @@ struct SInert {
 };
 
 // spatial inertia of body b about the world origin in world axes
+// everything the kernel needs to know about the model: read through a constant-address-space pointer, so that the ~90 table
+// pointers and ~100 offsets are scalar-loaded where they are used instead of being held (and spilled) for the whole kernel
 template <typename real>
-AVS_DEV void body_inertia(const DevModel<real>& m, const real* xmat, const real* xipos, int b, SInert<real>& s) {
+struct KArgs {
+    DevModel<real> m;
+    Layout lay;
+    MOff mo;
+};
+template <typename real>
+using KPtr = const KArgs<real> __attribute__((address_space(4)))*;
+// start of a phase: forget what was loaded through ka so far (keeps the live ranges of model scalars inside one phase)
+#define PHASE_BEGIN()                                                                                  \
+    do {                                                                                               \
+        const unsigned long long p_ = (unsigned long long)ka;                                          \
+        unsigned lo_ = __builtin_amdgcn_readfirstlane((unsigned)p_), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(p_ >> 32)); \
+        asm volatile("" : "+s"(lo_), "+s"(hi_));                                                       \
+        ka = (decltype(ka))(((unsigned long long)hi_ << 32) | lo_);                                    \
+    } while (0)
+
+template <typename real>
+AVS_DEV void body_inertia(KPtr<real> ka, const real* xmat, const real* xipos, int b, SInert<real>& s) {
     const real* R = xmat + 9 * b;
-    const real* Ib = m.body_inertia + 6 * b;
+    const real* Ib = ka->m.body_inertia + 6 * b;
     real I3[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]}, T[9], Ic[9];
 #pragma unroll
     for (int i = 0; i < 3; i++)
@@ -341,7 +360,7 @@ AVS_DEV void body_inertia(const DevModel<real>& m, const real* xmat, const real*
     for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) Ic[3 * i + j] = T[3 * i] * R[3 * j] + T[3 * i + 1] * R[3 * j + 1] + T[3 * i + 2] * R[3 * j + 2];
-    real ms = m.body_mass[b];
+    real ms = ka->m.body_mass[b];
     real c[3] = {xipos[3 * b], xipos[3 * b + 1], xipos[3 * b + 2]};
     real cc = dot3(c, c);
     s.m = ms;
@@ -432,84 +451,83 @@ AVS_DEV int has_pair(int c1, int c2, int a, int b) { return ((c1 & a) && (c2 & b
 
 template <typename real, int G>
 struct Env {
-    const DevModel<real>& m;
+    KPtr<real> ka;   // model, LDS layout and table offsets: one struct in constant memory, re-read per phase (PHASE_BEGIN)
     int nit_sum = 0, nit_max = 0;   // Newton iterations over the launch's substeps (diagnostics)
     bool profiling = false;
-    const Layout& lay;
     real* r;  // real region of this env
     int* ii;  // int region of this env
     int lane, grp;
-    const MOff& mo;   // offsets of the hot tables inside the block's LDS image
     const real* lr;
     const int* li;
     long long t_broad = 0, t_narrow = 0;
-    __device__ Env(const DevModel<real>& m_, const Layout& l_, real* r_, int* i_, int lane_, int grp_, const MOff& mo_, const real* lr_, const int* li_)
-        : m(m_), lay(l_), r(r_), ii(i_), lane(lane_), grp(grp_), mo(mo_), lr(lr_), li(li_) {}
+    __device__ Env(KPtr<real> ka_, real* r_, int* i_, int lane_, int grp_, const real* lr_, const int* li_)
+        : ka(ka_), r(r_), ii(i_), lane(lane_), grp(grp_), lr(lr_), li(li_) {}
     // hot model tables live in LDS (copied once per block); the accessors rebuild the pointer from the kernarg offset
-    AVS_DEV const int* body_parent_() const { return li + mo.body_parent; }
-    AVS_DEV const int* body_jntadr_() const { return li + mo.body_jntadr; }
-    AVS_DEV const int* body_jntnum_() const { return li + mo.body_jntnum; }
-    AVS_DEV const int* body_dofadr_() const { return li + mo.body_dofadr; }
-    AVS_DEV const int* body_dofnum_() const { return li + mo.body_dofnum; }
-    AVS_DEV const int* body_tree_() const { return li + mo.body_tree; }
-    AVS_DEV const int* body_dofmask_() const { return li + mo.body_dofmask; }
-    AVS_DEV const int* tree_bodyadr_() const { return li + mo.tree_bodyadr; }
-    AVS_DEV const int* tree_bodylist_() const { return li + mo.tree_bodylist; }
-    AVS_DEV const int* tree_dofadr_() const { return li + mo.tree_dofadr; }
-    AVS_DEV const int* tree_dofnum_() const { return li + mo.tree_dofnum; }
-    AVS_DEV const int* tree_madr_() const { return li + mo.tree_madr; }
-    AVS_DEV const int* jnt_type_() const { return li + mo.jnt_type; }
-    AVS_DEV const int* jnt_qposadr_() const { return li + mo.jnt_qposadr; }
-    AVS_DEV const int* jnt_dofadr_() const { return li + mo.jnt_dofadr; }
-    AVS_DEV const int* jnt_actfrclimited_() const { return li + mo.jnt_actfrclimited; }
-    AVS_DEV const int* limited_jnt_() const { return li + mo.limited_jnt; }
-    AVS_DEV const int* dof_body_() const { return li + mo.dof_body; }
-    AVS_DEV const int* dof_parent_() const { return li + mo.dof_parent; }
-    AVS_DEV const int* dof_tree_() const { return li + mo.dof_tree; }
-    AVS_DEV const int* dof_jnt_() const { return li + mo.dof_jnt; }
-    AVS_DEV const int* floss_dof_() const { return li + mo.floss_dof; }
-    AVS_DEV const int* ment_i_() const { return li + mo.ment_i; }
-    AVS_DEV const int* ment_j_() const { return li + mo.ment_j; }
-    AVS_DEV const int* act_dof_() const { return li + mo.act_dof; }
-    AVS_DEV const int* act_qposadr_() const { return li + mo.act_qposadr; }
-    AVS_DEV const int* act_ctrllimited_() const { return li + mo.act_ctrllimited; }
-    AVS_DEV const int* geom_type_() const { return li + mo.geom_type; }
-    AVS_DEV const int* geom_body_() const { return li + mo.geom_body; }
-    AVS_DEV const int* geom_static_() const { return li + mo.geom_static; }
-    AVS_DEV const real* body_pos_() const { return lr + mo.body_pos; }
-    AVS_DEV const real* body_quat_() const { return lr + mo.body_quat; }
-    AVS_DEV const real* body_mass_() const { return lr + mo.body_mass; }
-    AVS_DEV const real* body_ipos_() const { return lr + mo.body_ipos; }
-    AVS_DEV const real* body_inertia_() const { return lr + mo.body_inertia; }
-    AVS_DEV const real* body_invweight0_() const { return lr + mo.body_invweight0; }
-    AVS_DEV const real* jnt_pos_() const { return lr + mo.jnt_pos; }
-    AVS_DEV const real* jnt_axis_() const { return lr + mo.jnt_axis; }
-    AVS_DEV const real* jnt_range_() const { return lr + mo.jnt_range; }
-    AVS_DEV const real* jnt_actfrcrange_() const { return lr + mo.jnt_actfrcrange; }
-    AVS_DEV const real* jnt_margin_() const { return lr + mo.jnt_margin; }
-    AVS_DEV const real* dof_armature_() const { return lr + mo.dof_armature; }
-    AVS_DEV const real* dof_damping_() const { return lr + mo.dof_damping; }
-    AVS_DEV const real* dof_frictionloss_() const { return lr + mo.dof_frictionloss; }
-    AVS_DEV const real* dof_invweight0_() const { return lr + mo.dof_invweight0; }
-    AVS_DEV const real* act_kp_() const { return lr + mo.act_kp; }
-    AVS_DEV const real* act_kv_() const { return lr + mo.act_kv; }
-    AVS_DEV const real* act_gear_() const { return lr + mo.act_gear; }
-    AVS_DEV const real* act_ctrlrange_() const { return lr + mo.act_ctrlrange; }
-    AVS_DEV const real* geom_cpos_() const { return lr + mo.geom_cpos; }
-    AVS_DEV const real* geom_rbound_() const { return lr + mo.geom_rbound; }
+    AVS_DEV const int* body_parent_() const { return li + ka->mo.body_parent; }
+    AVS_DEV const int* body_jntadr_() const { return li + ka->mo.body_jntadr; }
+    AVS_DEV const int* body_jntnum_() const { return li + ka->mo.body_jntnum; }
+    AVS_DEV const int* body_dofadr_() const { return li + ka->mo.body_dofadr; }
+    AVS_DEV const int* body_dofnum_() const { return li + ka->mo.body_dofnum; }
+    AVS_DEV const int* body_tree_() const { return li + ka->mo.body_tree; }
+    AVS_DEV const int* body_dofmask_() const { return li + ka->mo.body_dofmask; }
+    AVS_DEV const int* tree_bodyadr_() const { return li + ka->mo.tree_bodyadr; }
+    AVS_DEV const int* tree_bodylist_() const { return li + ka->mo.tree_bodylist; }
+    AVS_DEV const int* tree_dofadr_() const { return li + ka->mo.tree_dofadr; }
+    AVS_DEV const int* tree_dofnum_() const { return li + ka->mo.tree_dofnum; }
+    AVS_DEV const int* tree_madr_() const { return li + ka->mo.tree_madr; }
+    AVS_DEV const int* jnt_type_() const { return li + ka->mo.jnt_type; }
+    AVS_DEV const int* jnt_qposadr_() const { return li + ka->mo.jnt_qposadr; }
+    AVS_DEV const int* jnt_dofadr_() const { return li + ka->mo.jnt_dofadr; }
+    AVS_DEV const int* jnt_actfrclimited_() const { return li + ka->mo.jnt_actfrclimited; }
+    AVS_DEV const int* limited_jnt_() const { return li + ka->mo.limited_jnt; }
+    AVS_DEV const int* dof_body_() const { return li + ka->mo.dof_body; }
+    AVS_DEV const int* dof_parent_() const { return li + ka->mo.dof_parent; }
+    AVS_DEV const int* dof_tree_() const { return li + ka->mo.dof_tree; }
+    AVS_DEV const int* dof_jnt_() const { return li + ka->mo.dof_jnt; }
+    AVS_DEV const int* floss_dof_() const { return li + ka->mo.floss_dof; }
+    AVS_DEV const int* ment_i_() const { return li + ka->mo.ment_i; }
+    AVS_DEV const int* ment_j_() const { return li + ka->mo.ment_j; }
+    AVS_DEV const int* act_dof_() const { return li + ka->mo.act_dof; }
+    AVS_DEV const int* act_qposadr_() const { return li + ka->mo.act_qposadr; }
+    AVS_DEV const int* act_ctrllimited_() const { return li + ka->mo.act_ctrllimited; }
+    AVS_DEV const int* geom_type_() const { return li + ka->mo.geom_type; }
+    AVS_DEV const int* geom_body_() const { return li + ka->mo.geom_body; }
+    AVS_DEV const int* geom_static_() const { return li + ka->mo.geom_static; }
+    AVS_DEV const real* body_pos_() const { return lr + ka->mo.body_pos; }
+    AVS_DEV const real* body_quat_() const { return lr + ka->mo.body_quat; }
+    AVS_DEV const real* body_mass_() const { return lr + ka->mo.body_mass; }
+    AVS_DEV const real* body_ipos_() const { return lr + ka->mo.body_ipos; }
+    AVS_DEV const real* body_inertia_() const { return lr + ka->mo.body_inertia; }
+    AVS_DEV const real* body_invweight0_() const { return lr + ka->mo.body_invweight0; }
+    AVS_DEV const real* jnt_pos_() const { return lr + ka->mo.jnt_pos; }
+    AVS_DEV const real* jnt_axis_() const { return lr + ka->mo.jnt_axis; }
+    AVS_DEV const real* jnt_range_() const { return lr + ka->mo.jnt_range; }
+    AVS_DEV const real* jnt_actfrcrange_() const { return lr + ka->mo.jnt_actfrcrange; }
+    AVS_DEV const real* jnt_margin_() const { return lr + ka->mo.jnt_margin; }
+    AVS_DEV const real* dof_armature_() const { return lr + ka->mo.dof_armature; }
+    AVS_DEV const real* dof_damping_() const { return lr + ka->mo.dof_damping; }
+    AVS_DEV const real* dof_frictionloss_() const { return lr + ka->mo.dof_frictionloss; }
+    AVS_DEV const real* dof_invweight0_() const { return lr + ka->mo.dof_invweight0; }
+    AVS_DEV const real* act_kp_() const { return lr + ka->mo.act_kp; }
+    AVS_DEV const real* act_kv_() const { return lr + ka->mo.act_kv; }
+    AVS_DEV const real* act_gear_() const { return lr + ka->mo.act_gear; }
+    AVS_DEV const real* act_ctrlrange_() const { return lr + ka->mo.act_ctrlrange; }
+    AVS_DEV const real* geom_cpos_() const { return lr + ka->mo.geom_cpos; }
+    AVS_DEV const real* geom_rbound_() const { return lr + ka->mo.geom_rbound; }
 
 
     // ---- P1 ------------------------------------------------------------------------------------
     __device__ void kinematics() {
-        real *xpos = r + lay.xpos, *xmat = r + lay.xmat, *xipos = r + lay.xipos, *cdof = r + lay.cdof, *qpos = r + lay.qpos;
-        for (int i = lane; i < 6 * m.nv; i += G) cdof[i] = 0;
+        PHASE_BEGIN();
+        real *xpos = r + ka->lay.xpos, *xmat = r + ka->lay.xmat, *xipos = r + ka->lay.xipos, *cdof = r + ka->lay.cdof, *qpos = r + ka->lay.qpos;
+        for (int i = lane; i < 6 * ka->m.nv; i += G) cdof[i] = 0;
         // bodies welded to the world: constant poses (the Newton scratch overlays this region during the solve)
-        for (int b = lane; b < m.nbody; b += G) {
-            for (int k = 0; k < 3; k++) { xpos[3 * b + k] = m.static_xpos[3 * b + k]; xipos[3 * b + k] = 0; }
-            for (int k = 0; k < 9; k++) xmat[9 * b + k] = m.static_xmat[9 * b + k];
+        for (int b = lane; b < ka->m.nbody; b += G) {
+            for (int k = 0; k < 3; k++) { xpos[3 * b + k] = ka->m.static_xpos[3 * b + k]; xipos[3 * b + k] = 0; }
+            for (int k = 0; k < 9; k++) xmat[9 * b + k] = ka->m.static_xmat[9 * b + k];
         }
         GSYNC();
-        for (int t = lane; t < m.ntree; t += G) {
+        for (int t = lane; t < ka->m.ntree; t += G) {
             for (int bi = tree_bodyadr_()[t]; bi < tree_bodyadr_()[t + 1]; bi++) {
                 int b = tree_bodylist_()[bi], p = body_parent_()[b], ja = body_jntadr_()[b], jn = body_jntnum_()[b];
                 real pos[3], quat[4], R[9];
@@ -577,8 +595,8 @@ struct Env {
             }
         }
         GSYNC();
-        real* gcen = r + lay.gcen;
-        for (int g = lane; g < m.ngeom; g += G) {
+        real* gcen = r + ka->lay.gcen;
+        for (int g = lane; g < ka->m.ngeom; g += G) {
             if (geom_static_()[g]) continue;
             int b = geom_body_()[g];
             real c[3] = {geom_cpos_()[3 * g], geom_cpos_()[3 * g + 1], geom_cpos_()[3 * g + 2]}, t3[3];
@@ -590,26 +608,27 @@ struct Env {
 
     // ---- P2 ------------------------------------------------------------------------------------
     __device__ void crb() {
-        real *xmat = r + lay.xmat, *xipos = r + lay.xipos, *cdof = r + lay.cdof, *ci = r + lay.cinert, *M = r + lay.M, *L = r + lay.L;
-        for (int b = lane; b < m.nbody; b += G) {
+        PHASE_BEGIN();
+        real *xmat = r + ka->lay.xmat, *xipos = r + ka->lay.xipos, *cdof = r + ka->lay.cdof, *ci = r + ka->lay.cinert, *M = r + ka->lay.M, *L = r + ka->lay.L;
+        for (int b = lane; b < ka->m.nbody; b += G) {
             SInert<real> s;
-            if (body_tree_()[b] >= 0) body_inertia(m, xmat, xipos, b, s);
+            if (body_tree_()[b] >= 0) body_inertia(ka, xmat, xipos, b, s);
             else { s.m = 0; for (int k = 0; k < 3; k++) s.h[k] = 0; for (int k = 0; k < 6; k++) s.I[k] = 0; }
             real* o = ci + 10 * b;
             o[0] = s.m;
             for (int k = 0; k < 3; k++) o[1 + k] = s.h[k];
             for (int k = 0; k < 6; k++) o[4 + k] = s.I[k];
         }
-        for (int i = lane; i < m.msize; i += G) M[i] = 0;
+        for (int i = lane; i < ka->m.msize; i += G) M[i] = 0;
         GSYNC();
-        for (int t = lane; t < m.ntree; t += G)
+        for (int t = lane; t < ka->m.ntree; t += G)
             for (int bi = tree_bodyadr_()[t + 1] - 1; bi > tree_bodyadr_()[t]; bi--) {
                 int b = tree_bodylist_()[bi], p = body_parent_()[b];
                 if (body_tree_()[p] != t) continue;
                 for (int k = 0; k < 10; k++) ci[10 * p + k] += ci[10 * b + k];
             }
         GSYNC();
-        for (int e = lane; e < m.nment; e += G) {
+        for (int e = lane; e < ka->m.nment; e += G) {
             int i = ment_i_()[e], j = ment_j_()[e], t = dof_tree_()[i], n = tree_dofnum_()[t], a = tree_dofadr_()[t];
             real f[6];
             inert_mul(ci + 10 * dof_body_()[i], cdof + 6 * i, f);
@@ -621,11 +640,11 @@ struct Env {
             Mb[(j - a) * n + (i - a)] = v;
         }
         GSYNC();
-        for (int t = lane; t < m.ntree; t += G) chol_block(M + tree_madr_()[t], L + tree_madr_()[t], tree_dofnum_()[t]);
+        for (int t = lane; t < ka->m.ntree; t += G) chol_block(M + tree_madr_()[t], L + tree_madr_()[t], tree_dofnum_()[t]);
         GSYNC();
         // dense per-tree inverse (8x8, zero padded): B = J M^-1 is formed on the fly from it, so rows store only J
-        real* Minv = r + lay.Minv;
-        for (int w = lane; w < m.ntree * TREE_W; w += G) {
+        real* Minv = r + ka->lay.Minv;
+        for (int w = lane; w < ka->m.ntree * TREE_W; w += G) {
             int t = w >> 3, j = w & 7, n = tree_dofnum_()[t];
             real x[TREE_W];
             const real* Lt = L + tree_madr_()[t];
@@ -656,15 +675,16 @@ struct Env {
 
     // ---- P5 bias -------------------------------------------------------------------------------
     __device__ void rne_bias() {
-        real *xmat = r + lay.xmat, *xipos = r + lay.xipos, *cdof = r + lay.cdof, *qvel = r + lay.qvel;
-        real *cvel = r + lay.cvel, *cacc = r + lay.cacc, *cfrc = r + lay.cfrc, *bias = r + lay.bias;
-        for (int t = lane; t < m.ntree; t += G) {
+        PHASE_BEGIN();
+        real *xmat = r + ka->lay.xmat, *xipos = r + ka->lay.xipos, *cdof = r + ka->lay.cdof, *qvel = r + ka->lay.qvel;
+        real *cvel = r + ka->lay.cvel, *cacc = r + ka->lay.cacc, *cfrc = r + ka->lay.cfrc, *bias = r + ka->lay.bias;
+        for (int t = lane; t < ka->m.ntree; t += G) {
             int b0 = tree_bodyadr_()[t], b1 = tree_bodyadr_()[t + 1];
             for (int bi = b0; bi < b1; bi++) {
                 int b = tree_bodylist_()[bi], p = body_parent_()[b];
                 real v[6], a[6];
                 if (body_tree_()[p] == t) { for (int k = 0; k < 6; k++) { v[k] = cvel[6 * p + k]; a[k] = cacc[6 * p + k]; } }
-                else { for (int k = 0; k < 6; k++) { v[k] = 0; a[k] = 0; } a[3] = -m.gravity[0]; a[4] = -m.gravity[1]; a[5] = -m.gravity[2]; }
+                else { for (int k = 0; k < 6; k++) { v[k] = 0; a[k] = 0; } a[3] = -ka->m.gravity[0]; a[4] = -ka->m.gravity[1]; a[5] = -ka->m.gravity[2]; }
                 int da = body_dofadr_()[b], dn = body_dofnum_()[b], j = 0;
                 while (j < dn) {
                     int dof = da + j;
@@ -684,7 +704,7 @@ struct Env {
                     }
                 }
                 SInert<real> s;
-                body_inertia(m, xmat, xipos, b, s);
+                body_inertia(ka, xmat, xipos, b, s);
                 real sv[10] = {s.m, s.h[0], s.h[1], s.h[2], s.I[0], s.I[1], s.I[2], s.I[3], s.I[4], s.I[5]};
                 real Ia[6], Iv[6], vIv[6];
                 inert_mul(sv, a, Ia);
@@ -709,11 +729,12 @@ struct Env {
 
     // ---- P5 passive + P6 actuation + P7 smooth acceleration ---------------------------------------
     __device__ void smooth() {
-        real *qpos = r + lay.qpos, *qvel = r + lay.qvel, *ctrl = r + lay.ctrl, *bias = r + lay.bias, *fsm = r + lay.fsm, *as = r + lay.asm_;
-        real* act = r + lay.fcon;  // reuse as qfrc_actuator until the solve
-        for (int i = lane; i < m.nv; i += G) act[i] = 0;
+        PHASE_BEGIN();
+        real *qpos = r + ka->lay.qpos, *qvel = r + ka->lay.qvel, *ctrl = r + ka->lay.ctrl, *bias = r + ka->lay.bias, *fsm = r + ka->lay.fsm, *as = r + ka->lay.asm_;
+        real* act = r + ka->lay.fcon;  // reuse as qfrc_actuator until the solve
+        for (int i = lane; i < ka->m.nv; i += G) act[i] = 0;
         GSYNC();
-        for (int u = lane; u < m.nu; u += G) {
+        for (int u = lane; u < ka->m.nu; u += G) {
             real c = ctrl[u];
             if (act_ctrllimited_()[u]) c = tclamp(c, act_ctrlrange_()[2 * u], act_ctrlrange_()[2 * u + 1]);
             int dof = act_dof_()[u];
@@ -721,7 +742,7 @@ struct Env {
             act[dof] += act_gear_()[u] * f;   // one actuator per dof in these models
         }
         GSYNC();
-        for (int i = lane; i < m.nv; i += G) {
+        for (int i = lane; i < ka->m.nv; i += G) {
             int j = dof_jnt_()[i];
             real a = act[i];
             if (jnt_actfrclimited_()[j] && jnt_type_()[j] != J_FREE) a = tclamp(a, jnt_actfrcrange_()[2 * j], jnt_actfrcrange_()[2 * j + 1]);
@@ -730,27 +751,27 @@ struct Env {
             as[i] = f;
         }
         GSYNC();
-        for (int t = lane; t < m.ntree; t += G) chol_solve_block(r + lay.L + tree_madr_()[t], as + tree_dofadr_()[t], tree_dofnum_()[t]);
+        for (int t = lane; t < ka->m.ntree; t += G) chol_solve_block(r + ka->lay.L + tree_madr_()[t], as + tree_dofadr_()[t], tree_dofnum_()[t]);
         GSYNC();
     }
 
     __device__ void load_shape(int g, Shape<real>& s) {
-        real *xpos = r + lay.xpos, *xmat = r + lay.xmat, *gcen = r + lay.gcen;
+        real *xpos = r + ka->lay.xpos, *xmat = r + ka->lay.xmat, *gcen = r + ka->lay.gcen;
         s.type = geom_type_()[g];
-        for (int k = 0; k < 3; k++) s.size[k] = m.geom_size[3 * g + k];
-        s.hull = m.hull_vert + 3 * m.geom_hull[2 * g];
-        s.nh = m.geom_hull[2 * g + 1];
-        for (int k = 0; k < 3; k++) { s.lc[k] = m.geom_lbox[6 * g + k]; s.lh[k] = m.geom_lbox[6 * g + 3 + k]; }
+        for (int k = 0; k < 3; k++) s.size[k] = ka->m.geom_size[3 * g + k];
+        s.hull = ka->m.hull_vert + 3 * ka->m.geom_hull[2 * g];
+        s.nh = ka->m.geom_hull[2 * g + 1];
+        for (int k = 0; k < 3; k++) { s.lc[k] = ka->m.geom_lbox[6 * g + k]; s.lh[k] = ka->m.geom_lbox[6 * g + 3 + k]; }
         if (geom_static_()[g]) {
-            for (int k = 0; k < 3; k++) { s.pos[k] = m.geom_xpos0[3 * g + k]; s.center[k] = m.geom_cen0[3 * g + k]; }
-            for (int k = 0; k < 9; k++) s.mat[k] = m.geom_xmat0[9 * g + k];
+            for (int k = 0; k < 3; k++) { s.pos[k] = ka->m.geom_xpos0[3 * g + k]; s.center[k] = ka->m.geom_cen0[3 * g + k]; }
+            for (int k = 0; k < 9; k++) s.mat[k] = ka->m.geom_xmat0[9 * g + k];
         } else {
             int b = geom_body_()[g];
-            real gp[3] = {m.geom_pos[3 * g], m.geom_pos[3 * g + 1], m.geom_pos[3 * g + 2]}, t3[3];
+            real gp[3] = {ka->m.geom_pos[3 * g], ka->m.geom_pos[3 * g + 1], ka->m.geom_pos[3 * g + 2]}, t3[3];
             mulmat(xmat + 9 * b, gp, t3);
             for (int k = 0; k < 3; k++) { s.pos[k] = xpos[3 * b + k] + t3[k]; s.center[k] = gcen[3 * g + k]; }
             const real* Rb = xmat + 9 * b;
-            const real* Rg = m.geom_mat + 9 * g;
+            const real* Rg = ka->m.geom_mat + 9 * g;
             for (int i = 0; i < 3; i++)
                 for (int j = 0; j < 3; j++) s.mat[3 * i + j] = Rb[3 * i] * Rg[j] + Rb[3 * i + 1] * Rg[3 + j] + Rb[3 * i + 2] * Rg[6 + j];
         }
@@ -758,24 +779,25 @@ struct Env {
 
     // ---- P3 ------------------------------------------------------------------------------------
     __device__ void collide() {
-        real* gcen = r + lay.gcen;
-        int *cand = ii + lay.cand, *misc = ii + lay.misc;
+        PHASE_BEGIN();
+        real* gcen = r + ka->lay.gcen;
+        int *cand = ii + ka->lay.cand, *misc = ii + ka->lay.misc;
         int ncand = 0;
         long long tb0 = __builtin_readcyclecounter();
         const real skin = real(0.05);
-        real* gref = r + lay.gref;
-        int* nearl = ii + lay.nearl;
+        real* gref = r + ka->lay.gref;
+        int* nearl = ii + ka->lay.nearl;
         // pair test with extra reach `pad` (0 = exact broad phase)
         auto pair_hit = [&](int p, real pad) -> bool {
-            int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
+            int g1 = ka->m.pair_geom[2 * p], g2 = ka->m.pair_geom[2 * p + 1];
             bool s1 = geom_static_()[g1], s2 = geom_static_()[g2];
-            real mg = m.pair_margin[p] + pad;
+            real mg = ka->m.pair_margin[p] + pad;
             if (s1 || s2) {
                 // dynamic bounding sphere against the world AABB of the static geom
                 int gs = s1 ? g1 : g2, gd = s1 ? g2 : g1;
                 real rd = geom_rbound_()[gd] + mg, d2 = 0;
                 for (int k = 0; k < 3; k++) {
-                    real c = gcen[3 * gd + k], lo = m.geom_aabb0[6 * gs + k], hi = m.geom_aabb0[6 * gs + 3 + k];
+                    real c = gcen[3 * gd + k], lo = ka->m.geom_aabb0[6 * gs + k], hi = ka->m.geom_aabb0[6 * gs + 3 + k];
                     real e = c < lo ? lo - c : (c > hi ? c - hi : real(0));
                     d2 += e * e;
                 }
@@ -788,7 +810,7 @@ struct Env {
         // Verlet neighbour list: valid while no dynamic geom centre moved more than skin/2 since it was built
         bool moved = false;
         if (misc[7]) {
-            for (int g = lane; g < m.ngeom; g += G)
+            for (int g = lane; g < ka->m.ngeom; g += G)
                 if (!geom_static_()[g]) {
                     real d[3];
                     sub3(gcen + 3 * g, gref + 3 * g, d);
@@ -799,14 +821,14 @@ struct Env {
         int nnear = misc[6];
         if (rebuild) {
             nnear = 0;
-            for (int base = 0; base < m.npair; base += G) {
+            for (int base = 0; base < ka->m.npair; base += G) {
                 int p = base + lane;
-                bool hit = p < m.npair && pair_hit(p, skin);
+                bool hit = p < ka->m.npair && pair_hit(p, skin);
                 int tot, rk = group_rank<G>(hit, grp, lane, &tot);
                 if (hit && nnear + rk < NEAR_MAX) nearl[nnear + rk] = p;
                 nnear += tot;
             }
-            for (int i = lane; i < 3 * m.ngeom; i += G) gref[i] = gcen[i];
+            for (int i = lane; i < 3 * ka->m.ngeom; i += G) gref[i] = gcen[i];
             if (lane == 0) { misc[6] = nnear < NEAR_MAX ? nnear : NEAR_MAX; misc[7] = nnear <= NEAR_MAX; if (nnear > NEAR_MAX) misc[2] |= 8; }
             GSYNC();
         }
@@ -821,9 +843,9 @@ struct Env {
             }
         } else {
             // neighbour list overflow: exact test over the whole compiled pair list
-            for (int base = 0; base < m.npair; base += G) {
+            for (int base = 0; base < ka->m.npair; base += G) {
                 int p = base + lane;
-                bool hit = p < m.npair && pair_hit(p, real(0));
+                bool hit = p < ka->m.npair && pair_hit(p, real(0));
                 int tot, rk = group_rank<G>(hit, grp, lane, &tot);
                 if (hit && ncand + rk < CAND_MAX) cand[ncand + rk] = p;
                 if (ncand + tot > CAND_MAX && lane == 0) misc[2] |= 4;
@@ -834,22 +856,22 @@ struct Env {
         GSYNC();
         long long tb1 = __builtin_readcyclecounter();
         t_broad += tb1 - tb0;
-        real *cdist = r + lay.cdist, *cpos = r + lay.cpos, *cnrm = r + lay.cnrm;
-        int* cpair = ii + lay.cpair;
+        real *cdist = r + ka->lay.cdist, *cpos = r + ka->lay.cpos, *cnrm = r + ka->lay.cnrm;
+        int* cpair = ii + ka->lay.cpair;
         int ncon = 0, ovf = 0;
         for (int base = 0; base < ncand; base += G) {
             int ci = base + lane, n = 0, p = 0;
             // per-lane LDS scratch (polygon work space + results): the row storage is not live during collision
-            LDS_PTR(real) scr = (LDS_PTR(real))(r + lay.rJ + 56 * lane);
+            LDS_PTR(real) scr = (LDS_PTR(real))(r + ka->lay.rJ + 56 * lane);
             int keepmask = 0;
             if (ci < ncand) {
                 p = cand[ci];
                 Shape<real> a, b;
-                load_shape(m.pair_geom[2 * p], a);
-                load_shape(m.pair_geom[2 * p + 1], b);
+                load_shape(ka->m.pair_geom[2 * p], a);
+                load_shape(ka->m.pair_geom[2 * p + 1], b);
                 int nn = narrow(a, b, scr);
                 // drop separated points (margin = 0 here) while keeping order
-                real mg = m.pair_margin[p];
+                real mg = ka->m.pair_margin[p];
                 for (int k = 0; k < nn; k++)
                     if (scr[k] < mg) { keepmask |= 1 << k; n++; }
             }
@@ -864,14 +886,14 @@ struct Env {
                 if ((keepmask >> k) & 1) {
                     int c = ncon + off + w;
                     w++;
-                    if (c < lay.maxcon) {
+                    if (c < ka->lay.maxcon) {
                         cdist[c] = scr[k];
                         cpair[c] = p;
                         for (int q = 0; q < 3; q++) { cpos[3 * c + q] = scr[4 + 3 * k + q]; cnrm[3 * c + q] = scr[16 + q]; }
                     }
                 }
-            if (ncon + tot > lay.maxcon) ovf = 1;
-            ncon = ncon + tot < lay.maxcon ? ncon + tot : lay.maxcon;
+            if (ncon + tot > ka->lay.maxcon) ovf = 1;
+            ncon = ncon + tot < ka->lay.maxcon ? ncon + tot : ka->lay.maxcon;
         }
         if (lane == 0) { misc[0] = ncon; misc[2] |= ovf; }
         GSYNC();
@@ -881,7 +903,7 @@ struct Env {
     // Jacobian entry of body b's point p for tree-local dof slot k of tree t (translational row along ax, or rotational)
     AVS_DEV real jac_entry(int b, int t, int k, const real* p, const real* ax, bool rot) const {
         if (body_tree_()[b] != t || !((body_dofmask_()[b] >> k) & 1)) return real(0);
-        const real* cd = r + lay.cdof + 6 * (tree_dofadr_()[t] + k);
+        const real* cd = r + ka->lay.cdof + 6 * (tree_dofadr_()[t] + k);
         if (rot) return ax[0] * cd[0] + ax[1] * cd[1] + ax[2] * cd[2];
         real c[3];
         cross3(cd, p, c);
@@ -890,17 +912,18 @@ struct Env {
 
     // ---- P4 ------------------------------------------------------------------------------------
     __device__ void make_constraints() {
-        real *qpos = r + lay.qpos, *qvel = r + lay.qvel;
-        int *misc = ii + lay.misc, *rmeta = ii + lay.rmeta, *cpair = ii + lay.cpair, *cefc = ii + lay.cefc;
-        real *cdist = r + lay.cdist, *cpos = r + lay.cpos, *cnrm = r + lay.cnrm;
+        PHASE_BEGIN();
+        real *qpos = r + ka->lay.qpos, *qvel = r + ka->lay.qvel;
+        int *misc = ii + ka->lay.misc, *rmeta = ii + ka->lay.rmeta, *cpair = ii + ka->lay.cpair, *cefc = ii + ka->lay.cefc;
+        real *cdist = r + ka->lay.cdist, *cpos = r + ka->lay.cpos, *cnrm = r + ka->lay.cnrm;
         int ncon = misc[0];
         // --- row table: meta = type | id<<2 | sub<<12 | dim<<20 (tree ids replace dim once the row is filled) ---
-        int nefc = m.neq + m.nfloss;
-        for (int i = lane; i < m.neq; i += G) rmeta[i] = R_EQ | (i << 2);
-        for (int i = lane; i < m.nfloss; i += G) rmeta[m.neq + i] = R_FLOSS | (i << 2);
-        for (int base = 0; base < m.nlimited; base += G) {
+        int nefc = ka->m.neq + ka->m.nfloss;
+        for (int i = lane; i < ka->m.neq; i += G) rmeta[i] = R_EQ | (i << 2);
+        for (int i = lane; i < ka->m.nfloss; i += G) rmeta[ka->m.neq + i] = R_FLOSS | (i << 2);
+        for (int base = 0; base < ka->m.nlimited; base += G) {
             int li = base + lane, lo = 0, hi = 0, j = 0;
-            if (li < m.nlimited) {
+            if (li < ka->m.nlimited) {
                 j = limited_jnt_()[li];
                 real q = qpos[jnt_qposadr_()[j]];
                 lo = (q - jnt_range_()[2 * j]) < jnt_margin_()[j];
@@ -908,19 +931,19 @@ struct Env {
             }
             int t1, t2, r1 = group_rank<G>(lo, grp, lane, &t1), r2 = group_rank<G>(hi, grp, lane, &t2);
             int pos = nefc + r1 + r2;   // rows of lower lanes come first; a joint's lower side before its upper side
-            if (lo && pos < lay.maxefc) rmeta[pos] = R_LIMIT | (j << 2) | (0 << 12);
-            if (hi && pos + lo < lay.maxefc) rmeta[pos + lo] = R_LIMIT | (j << 2) | (1 << 12);
+            if (lo && pos < ka->lay.maxefc) rmeta[pos] = R_LIMIT | (j << 2) | (0 << 12);
+            if (hi && pos + lo < ka->lay.maxefc) rmeta[pos + lo] = R_LIMIT | (j << 2) | (1 << 12);
             nefc += t1 + t2;
         }
         int ovf = 0;
-        if (nefc > lay.maxefc) { nefc = lay.maxefc; ovf = 1; }
+        if (nefc > ka->lay.maxefc) { nefc = ka->lay.maxefc; ovf = 1; }
         if (lane == 0) misc[4] = nefc;   // rows before the contacts
         int cend = nefc;   // end of the last contact block that fits under the row cap (row offsets are monotonic)
         for (int base = 0; base < ncon; base += G) {
             int c = base + lane, dim = 0;
             if (c < ncon) {
                 int p = cpair[c];
-                if (cdist[c] < m.pair_margin[p] - m.pair_gap[p]) dim = m.pair_condim[p];
+                if (cdist[c] < ka->m.pair_margin[p] - ka->m.pair_gap[p]) dim = ka->m.pair_condim[p];
             }
             int off = 0, tot = 0;
             for (int j = 1; j <= 6; j++) {
@@ -931,11 +954,11 @@ struct Env {
             int myend = 0;
             if (c < ncon) {
                 int first = nefc + off;
-                if (dim > 0 && first + dim <= lay.maxefc) {
+                if (dim > 0 && first + dim <= ka->lay.maxefc) {
                     cefc[c] = first;
                     myend = first + dim;
                     for (int s = 0; s < dim; s++) rmeta[first + s] = R_CONTACT | (c << 2) | (s << 12) | (dim << 20);
-                    (ii + lay.czone)[first] = dim << 8;
+                    (ii + ka->lay.czone)[first] = dim << 8;
                 } else {
                     cefc[c] = -1;
                     if (dim > 0) ovf = 1;
@@ -949,9 +972,9 @@ struct Env {
         if (lane == 0) { misc[1] = nefc; if (ovf) misc[2] |= 2; }
         GSYNC();
         // --- fill rows (one row per lane) ---
-        real *rJ = r + lay.rJ, *rowS = r + lay.rowS, *warm = r + lay.warm, *Minv = r + lay.Minv;
-        int* rowI = ii + lay.rowI;
-        real* Lm = r + lay.L;
+        real *rJ = r + ka->lay.rJ, *rowS = r + ka->lay.rowS, *warm = r + ka->lay.warm, *Minv = r + ka->lay.Minv;
+        int* rowI = ii + ka->lay.rowI;
+        real* Lm = r + ka->lay.L;
         for (int i = lane; i < nefc; i += G) {
             int meta = rmeta[i], type = meta & 3, id = (meta >> 2) & 1023, sub = (meta >> 12) & 255, dim = meta >> 20;
             real J[ROW_W];   // kept in registers: every index below is a compile-time constant after unrolling
@@ -964,26 +987,26 @@ struct Env {
             real solref[2], solimp[5];
             bool valid = true;
             if (type == R_EQ) {
-                const real* c = m.eq_polycoef + 5 * id;
-                real q1 = qpos[m.eq_qpos1[id]] - m.qpos0[m.eq_qpos1[id]], q2 = qpos[m.eq_qpos2[id]] - m.qpos0[m.eq_qpos2[id]];
+                const real* c = ka->m.eq_polycoef + 5 * id;
+                real q1 = qpos[ka->m.eq_qpos1[id]] - ka->m.qpos0[ka->m.eq_qpos1[id]], q2 = qpos[ka->m.eq_qpos2[id]] - ka->m.qpos0[ka->m.eq_qpos2[id]];
                 real poly = c[0] + q2 * (c[1] + q2 * (c[2] + q2 * (c[3] + q2 * c[4])));
                 real dpoly = c[1] + q2 * (2 * c[2] + q2 * (3 * c[3] + q2 * 4 * c[4]));
-                int d1 = m.eq_dof1[id], d2 = m.eq_dof2[id];
+                int d1 = ka->m.eq_dof1[id], d2 = ka->m.eq_dof2[id];
                 tA = dof_tree_()[d1];
                 pos = q1 - poly;
                 diag0 = dof_invweight0_()[d1] + dof_invweight0_()[d2];
                 j1 = d1 - tree_dofadr_()[tA]; v1 = 1;
                 j2 = d2 - tree_dofadr_()[tA]; v2 = -dpoly;   // both joints of a gripper live in the same tree
-                for (int k = 0; k < 2; k++) solref[k] = m.eq_solref[2 * id + k];
-                for (int k = 0; k < 5; k++) solimp[k] = m.eq_solimp[5 * id + k];
+                for (int k = 0; k < 2; k++) solref[k] = ka->m.eq_solref[2 * id + k];
+                for (int k = 0; k < 5; k++) solimp[k] = ka->m.eq_solimp[5 * id + k];
             } else if (type == R_FLOSS) {
                 int d = floss_dof_()[id];
                 tA = dof_tree_()[d];
                 diag0 = dof_invweight0_()[d];
                 floss = dof_frictionloss_()[d];
                 j1 = d - tree_dofadr_()[tA]; v1 = 1;
-                for (int k = 0; k < 2; k++) solref[k] = m.dof_solref[2 * d + k];
-                for (int k = 0; k < 5; k++) solimp[k] = m.dof_solimp[5 * d + k];
+                for (int k = 0; k < 2; k++) solref[k] = ka->m.dof_solref[2 * d + k];
+                for (int k = 0; k < 5; k++) solimp[k] = ka->m.dof_solimp[5 * d + k];
             } else if (type == R_LIMIT) {
                 int j = id, d = jnt_dofadr_()[j];
                 real q = qpos[jnt_qposadr_()[j]];
@@ -992,11 +1015,11 @@ struct Env {
                 margin = jnt_margin_()[j];
                 diag0 = dof_invweight0_()[d];
                 j1 = d - tree_dofadr_()[tA]; v1 = sub == 0 ? real(1) : real(-1);
-                for (int k = 0; k < 2; k++) solref[k] = m.jnt_solref[2 * j + k];
-                for (int k = 0; k < 5; k++) solimp[k] = m.jnt_solimp[5 * j + k];
+                for (int k = 0; k < 2; k++) solref[k] = ka->m.jnt_solref[2 * j + k];
+                for (int k = 0; k < 5; k++) solimp[k] = ka->m.jnt_solimp[5 * j + k];
             } else {
                 int c = id, p = cpair[c];
-                int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1], b1 = geom_body_()[g1], b2 = geom_body_()[g2];
+                int g1 = ka->m.pair_geom[2 * p], g2 = ka->m.pair_geom[2 * p + 1], b1 = geom_body_()[g1], b2 = geom_body_()[g2];
                 int t1 = body_tree_()[b1], t2 = body_tree_()[b2];
                 tA = t1 >= 0 ? t1 : t2;
                 tB = (t1 >= 0 && t2 >= 0 && t2 != t1) ? t2 : -1;
@@ -1017,25 +1040,25 @@ struct Env {
                     J[TREE_W + k] = b;
                 }
                 pos = sub == 0 ? cdist[c] : real(0);
-                margin = m.pair_margin[p] - m.pair_gap[p];
+                margin = ka->m.pair_margin[p] - ka->m.pair_gap[p];
                 diag0 = body_invweight0_()[2 * b1] + body_invweight0_()[2 * b2];
-                for (int k = 0; k < 2; k++) solref[k] = m.pair_solref[2 * p + k];
-                for (int k = 0; k < 5; k++) solimp[k] = m.pair_solimp[5 * p + k];
+                for (int k = 0; k < 2; k++) solref[k] = ka->m.pair_solref[2 * p + k];
+                for (int k = 0; k < 5; k++) solimp[k] = ka->m.pair_solimp[5 * p + k];
             }
             (void)valid;
 #pragma unroll
             for (int k = 0; k < TREE_W; k++) J[k] += (k == j1 ? v1 : real(0)) + (k == j2 ? v2 : real(0));
             // K, B, impedance, R [EXT: mj_makeImpedance]
             real dmax = tclamp(solimp[1], real(0.0001), real(0.9999));
-            real tc = tmax(solref[0], 2 * m.timestep), dr = solref[1];
+            real tc = tmax(solref[0], 2 * ka->m.timestep), dr = solref[1];
             real K = real(1) / tmax(real(1e-15), dmax * dmax * tc * tc * dr * dr), Bd = real(2) / tmax(real(1e-15), dmax * tc);
             real imp, R;
             if (type == R_CONTACT && sub > 0) {
                 int c = id, p = cpair[c];
                 real imp0 = impedance(solimp, cdist[c], margin);
                 real R0 = tmax(real(1e-15), (1 - imp0) * diag0 / imp0);
-                real R1 = R0 / tmax(real(1e-15), m.impratio);
-                real mu0 = m.pair_friction[5 * p], mur = m.pair_friction[5 * p + sub - 1];
+                real R1 = R0 / tmax(real(1e-15), ka->m.impratio);
+                real mu0 = ka->m.pair_friction[5 * p], mur = ka->m.pair_friction[5 * p + sub - 1];
                 R = sub == 1 ? R1 : R1 * mu0 * mu0 / tmax(real(1e-15), mur * mur);
                 imp = imp0;
                 K = 0;
@@ -1097,8 +1120,8 @@ struct Env {
         }
         GSYNC();
         // --- Gauss-Seidel groups: the leading non-contact rows in packs of GRP_MAX, then one group per contact ---
-        int* gI = ii + lay.gI;
-        real* gA = r + lay.gA;
+        int* gI = ii + ka->lay.gI;
+        real* gA = r + ka->lay.gA;
         const int nlead = misc[4];   // number of equality / dry-friction / limit rows (they precede the contacts)
         int ngrp = 0;
         for (int base = 0; base < nefc; base += G) {
@@ -1107,13 +1130,13 @@ struct Env {
             int cnt = 0, isc = 0;
             if (i < nefc) {
                 if (i < nlead) { head = (i % GRP_MAX) == 0; cnt = nlead - i < GRP_MAX ? nlead - i : GRP_MAX; }
-                else { int meta = rmeta[i]; head = ((meta >> 12) & 255) == 0; cnt = m.pair_condim[cpair[(meta >> 2) & 1023]]; isc = 1; }
+                else { int meta = rmeta[i]; head = ((meta >> 12) & 255) == 0; cnt = ka->m.pair_condim[cpair[(meta >> 2) & 1023]]; isc = 1; }
             }
             int tot, rk = group_rank<G>(head, grp, lane, &tot);
-            if (head && ngrp + rk < lay.maxgrp) gI[ngrp + rk] = i | (cnt << 16) | (isc << 24);
+            if (head && ngrp + rk < ka->lay.maxgrp) gI[ngrp + rk] = i | (cnt << 16) | (isc << 24);
             ngrp += tot;
         }
-        if (ngrp > lay.maxgrp) ngrp = lay.maxgrp;
+        if (ngrp > ka->lay.maxgrp) ngrp = ka->lay.maxgrp;
         if (lane == 0) misc[5] = ngrp;
         GSYNC();
         // couplings A_rs = J_r . B_s (r > s) inside each group, one pair per lane
@@ -1147,38 +1170,39 @@ struct Env {
 
     // ---- P8 ------------------------------------------------------------------------------------
     __device__ void solve(int pgs_iters, int solver, int newton_iters, real newton_tol, real scale) {
-        int *misc = ii + lay.misc, *rmeta = ii + lay.rmeta, *cefc = ii + lay.cefc, *rowI = ii + lay.rowI;
-        real *qacc = r + lay.qacc, *as = r + lay.asm_, *rowS = r + lay.rowS, *rJ = r + lay.rJ, *fcon = r + lay.fcon;
+        PHASE_BEGIN();
+        int *misc = ii + ka->lay.misc, *rmeta = ii + ka->lay.rmeta, *cefc = ii + ka->lay.cefc, *rowI = ii + ka->lay.rowI;
+        real *qacc = r + ka->lay.qacc, *as = r + ka->lay.asm_, *rowS = r + ka->lay.rowS, *rJ = r + ka->lay.rJ, *fcon = r + ka->lay.fcon;
         int nefc = misc[1], ncon = misc[0];
-        real* Minv = r + lay.Minv;
+        real* Minv = r + ka->lay.Minv;
         if (solver == 1) {
             // ---- primal Newton (the reference's MuJoCo default), then the noslip sweeps on the dual ----
-            real* warm = r + lay.warm;
-            for (int k = lane; k < m.nv; k += G) qacc[k] = warm[k];
+            real* warm = r + ka->lay.warm;
+            for (int k = lane; k < ka->m.nv; k += G) qacc[k] = warm[k];
             GSYNC();
             NewtonArgs<real> A;
             A.rowS = (LDS_PTR(real))rowS; A.rowI = (LDS_PTR(const int))rowI; A.rmeta = (LDS_PTR(const int))rmeta; A.rJ = (LDS_PTR(const real))rJ;
-            A.M = (LDS_PTR(const real))(r + lay.M); A.a = (LDS_PTR(real))qacc; A.as = (LDS_PTR(const real))as;
-            A.H = (LDS_PTR(real))(r + lay.nH); A.g = (LDS_PTR(real))(r + lay.ng); A.dl = (LDS_PTR(real))(r + lay.ndl); A.jv = (LDS_PTR(real))(r + lay.njv);
-            A.czone = (LDS_PTR(const int))(ii + lay.czone); A.cefc = (LDS_PTR(const int))cefc;
-            A.prof = profiling ? (LDS_PTR(int))(ii + lay.nprof) : (LDS_PTR(int))nullptr;
+            A.M = (LDS_PTR(const real))(r + ka->lay.M); A.a = (LDS_PTR(real))qacc; A.as = (LDS_PTR(const real))as;
+            A.H = (LDS_PTR(real))(r + ka->lay.nH); A.g = (LDS_PTR(real))(r + ka->lay.ng); A.dl = (LDS_PTR(real))(r + ka->lay.ndl); A.jv = (LDS_PTR(real))(r + ka->lay.njv);
+            A.czone = (LDS_PTR(const int))(ii + ka->lay.czone); A.cefc = (LDS_PTR(const int))cefc;
+            A.prof = profiling ? (LDS_PTR(int))(ii + ka->lay.nprof) : (LDS_PTR(int))nullptr;
             A.tree_dofadr = (LDS_PTR(const int))tree_dofadr_(); A.tree_dofnum = (LDS_PTR(const int))tree_dofnum_();
             A.tree_madr = (LDS_PTR(const int))tree_madr_(); A.dof_tree = (LDS_PTR(const int))dof_tree_();
-            A.nv = m.nv; A.nefc = nefc; A.ncon = ncon; A.nlead = misc[4]; A.ntree = m.ntree; A.iters = newton_iters;
+            A.nv = ka->m.nv; A.nefc = nefc; A.ncon = ncon; A.nlead = misc[4]; A.ntree = ka->m.ntree; A.iters = newton_iters;
             A.tol = newton_tol; A.scale = scale; A.ls_tol = sizeof(real) == 8 ? real(1e-10) : real(1e-4);
             int used = newton_solve<real>(A);
             nit_sum += used; nit_max = used > nit_max ? used : nit_max;
             GSYNC();
             long long tn0 = profiling ? __builtin_readcyclecounter() : 0;
             pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const real))rJ, (LDS_PTR(const real))Minv, (LDS_PTR(real))qacc,
-                             (LDS_PTR(const int))(ii + lay.gI), (LDS_PTR(const real))(r + lay.gA), misc[5], 0, m.noslip_iters);
-            if (profiling && lane == 0) (ii + lay.nprof)[6] += (int)(__builtin_readcyclecounter() - tn0);
+                             (LDS_PTR(const int))(ii + ka->lay.gI), (LDS_PTR(const real))(r + ka->lay.gA), misc[5], 0, ka->m.noslip_iters);
+            if (profiling && lane == 0) (ii + ka->lay.nprof)[6] += (int)(__builtin_readcyclecounter() - tn0);
         } else {
         // warm-start forces of friction blocks back onto their cones (one contact per lane)
         for (int c = lane; c < ncon; c += G) {
             int first = cefc[c];
             if (first < 0) continue;
-            int dim = m.pair_condim[(ii + lay.cpair)[c]];
+            int dim = ka->m.pair_condim[(ii + ka->lay.cpair)[c]];
             real fn = rowS[8 * first + 6], s2 = 0;
             for (int s = 1; s < dim; s++) { real t = rowS[8 * (first + s) + 6] * rowS[8 * (first + s) + 7]; s2 += t * t; }
             if (s2 > fn * fn) { real sc = fn / sqrt(s2); for (int s = 1; s < dim; s++) rowS[8 * (first + s) + 6] *= sc; }
@@ -1186,7 +1210,7 @@ struct Env {
         GSYNC();
         // qacc = qacc_smooth + M^-1 J^T f : generalized force per dof first, then the per-tree inverse
         jt_force(fcon, nefc);
-        for (int k = lane; k < m.nv; k += G) {
+        for (int k = lane; k < ka->m.nv; k += G) {
             int t = dof_tree_()[k], a0 = tree_dofadr_()[t], kk = k - a0, n = tree_dofnum_()[t];
             real s = as[k];
             for (int j = 0; j < n; j++) s += Minv[64 * t + 8 * kk + j] * fcon[a0 + j];
@@ -1196,7 +1220,7 @@ struct Env {
         // Gauss-Seidel sweeps (+ noslip sweeps) in the register-resident wave kernel
         static_assert(G == 64, "the solver maps one env to one wavefront");
         pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const real))rJ, (LDS_PTR(const real))Minv, (LDS_PTR(real))qacc,
-                         (LDS_PTR(const int))(ii + lay.gI), (LDS_PTR(const real))(r + lay.gA), misc[5], pgs_iters, m.noslip_iters);
+                         (LDS_PTR(const int))(ii + ka->lay.gI), (LDS_PTR(const real))(r + ka->lay.gA), misc[5], pgs_iters, ka->m.noslip_iters);
         }
         GSYNC();
         // qfrc_constraint = J^T f
@@ -1205,9 +1229,9 @@ struct Env {
 
     // out = J^T f: one row per lane, scattered over the row's two dof windows with returnless LDS atomics
     __device__ void jt_force(real* out, int nefc) {
-        int* rowI = ii + lay.rowI;
-        real *rowS = r + lay.rowS, *rJ = r + lay.rJ;
-        for (int k = lane; k < m.nv; k += G) out[k] = 0;
+        int* rowI = ii + ka->lay.rowI;
+        real *rowS = r + ka->lay.rowS, *rJ = r + ka->lay.rJ;
+        for (int k = lane; k < ka->m.nv; k += G) out[k] = 0;
         GSYNC();
         for (int i = lane; i < nefc; i += G) {
             const real f = rowS[8 * i + 6];
@@ -1224,12 +1248,13 @@ struct Env {
 
     // ---- P9 ------------------------------------------------------------------------------------
     __device__ void euler() {
-        real *qpos = r + lay.qpos, *qvel = r + lay.qvel, *warm = r + lay.warm, *qacc = r + lay.qacc, *fsm = r + lay.fsm, *fcon = r + lay.fcon;
-        real *M = r + lay.M, *L = r + lay.L, *tmp = r + lay.bias;
-        real h = m.timestep;
-        for (int i = lane; i < m.nv; i += G) { tmp[i] = fsm[i] + fcon[i]; warm[i] = qacc[i]; }
+        PHASE_BEGIN();
+        real *qpos = r + ka->lay.qpos, *qvel = r + ka->lay.qvel, *warm = r + ka->lay.warm, *qacc = r + ka->lay.qacc, *fsm = r + ka->lay.fsm, *fcon = r + ka->lay.fcon;
+        real *M = r + ka->lay.M, *L = r + ka->lay.L, *tmp = r + ka->lay.bias;
+        real h = ka->m.timestep;
+        for (int i = lane; i < ka->m.nv; i += G) { tmp[i] = fsm[i] + fcon[i]; warm[i] = qacc[i]; }
         GSYNC();
-        for (int t = lane; t < m.ntree; t += G) {
+        for (int t = lane; t < ka->m.ntree; t += G) {
             int n = tree_dofnum_()[t], a0 = tree_dofadr_()[t];
             real* Mb = M + tree_madr_()[t];
             for (int i = 0; i < n; i++) Mb[i * n + i] += h * dof_damping_()[a0 + i];   // M is rebuilt next substep
@@ -1238,7 +1263,7 @@ struct Env {
             for (int i = 0; i < n; i++) qvel[a0 + i] += h * tmp[a0 + i];
         }
         GSYNC();
-        for (int j = lane; j < m.njnt; j += G) {
+        for (int j = lane; j < ka->m.njnt; j += G) {
             int qa = jnt_qposadr_()[j], da = jnt_dofadr_()[j];
             if (jnt_type_()[j] == J_FREE) {
                 for (int k = 0; k < 3; k++) qpos[qa + k] += h * qvel[da + k];
@@ -1258,13 +1283,14 @@ struct Env {
     }
 
     __device__ int reward(int* latch) {
-        int *misc = ii + lay.misc, *cpair = ii + lay.cpair;
+        PHASE_BEGIN();
+        int *misc = ii + ka->lay.misc, *cpair = ii + ka->lay.cpair;
         int ncon = misc[0];
         enum { CL = 1, CR = 2, CT = 4, CA = 8, CB = 16, CC = 32, CD = 64 };
         int f = 0;  // bit flags: 0 tl, 1 tr, 2 a_table, 3 b_table, 4 ab, 5 cd, 6 ad, 7 ac
-        int t = m.task_id;
+        int t = ka->m.task_id;
         for (int c = lane; c < ncon; c += G) {
-            int p = cpair[c], c1 = m.geom_class[m.pair_geom[2 * p]], c2 = m.geom_class[m.pair_geom[2 * p + 1]];
+            int p = cpair[c], c1 = ka->m.geom_class[ka->m.pair_geom[2 * p]], c2 = ka->m.geom_class[ka->m.pair_geom[2 * p + 1]];
             if (has_pair(c1, c2, CT, CA)) f |= 4;
             if (has_pair(c1, c2, CT, CB)) f |= 8;
             if (has_pair(c1, c2, CA, CB)) f |= 16;
@@ -1316,7 +1342,7 @@ struct Env {
 
 // WPB wavefronts per block, one env per wavefront; the block shares one LDS copy of the hot model tables
 template <typename real, int G, int WPB>
-__global__ void __launch_bounds__(64 * WPB) k_phys(DevModel<real> mg, Layout lay, MOff mo, const real* __restrict__ img_real, const int* __restrict__ img_int, int N, int nsub, int pgs_iters, const float* __restrict__ action,
+__global__ void __launch_bounds__(64 * WPB) k_phys(KPtr<real> ka, const real* __restrict__ img_real, const int* __restrict__ img_int, int N, int nsub, int pgs_iters, const float* __restrict__ action,
                                              int want_reward, real* __restrict__ g_qpos, real* __restrict__ g_qvel, real* __restrict__ g_ctrl,
                                              real* __restrict__ g_warm, int* __restrict__ g_latch, double* __restrict__ o_agent,
                                              int* __restrict__ o_reward, unsigned char* __restrict__ o_success, int* __restrict__ o_ncon,
@@ -1326,31 +1352,30 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(DevModel<real> mg, Layout lay
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = 0;
     const int env = blockIdx.x * WPB + wave;
     // hot model tables -> LDS, once per block
-    real* lr = reinterpret_cast<real*>(smem + (size_t)WPB * lay.bytes_per_env);
-    int* li = reinterpret_cast<int*>(lr + mo.nreal);
-    for (int i = threadIdx.x; i < mo.nreal; i += 64 * WPB) lr[i] = img_real[i];
-    for (int i = threadIdx.x; i < mo.nint; i += 64 * WPB) li[i] = img_int[i];
+    real* lr = reinterpret_cast<real*>(smem + (size_t)WPB * ka->lay.bytes_per_env);
+    int* li = reinterpret_cast<int*>(lr + ka->mo.nreal);
+    for (int i = threadIdx.x; i < ka->mo.nreal; i += 64 * WPB) lr[i] = img_real[i];
+    for (int i = threadIdx.x; i < ka->mo.nint; i += 64 * WPB) li[i] = img_int[i];
     if (WPB > 1) __syncthreads(); else GSYNC();
-    const DevModel<real>& m = mg;
     if (env >= N) return;  // whole groups drop out together; no block barrier is used below
-    real* r = reinterpret_cast<real*>(smem + (size_t)wave * lay.bytes_per_env);
-    int* ii = reinterpret_cast<int*>(r + lay.nreal);
-    Env<real, G> E(m, lay, r, ii, lane, grp, mo, lr, li);
+    real* r = reinterpret_cast<real*>(smem + (size_t)wave * ka->lay.bytes_per_env);
+    int* ii = reinterpret_cast<int*>(r + ka->lay.nreal);
+    Env<real, G> E(ka, r, ii, lane, grp, lr, li);
 
     // ---- load state (coalesced: consecutive lanes read consecutive words of this env's record) ----
-    for (int i = lane; i < m.nq; i += G) r[lay.qpos + i] = g_qpos[(size_t)env * m.nq + i];
-    for (int i = lane; i < m.nv; i += G) { r[lay.qvel + i] = g_qvel[(size_t)env * m.nv + i]; r[lay.warm + i] = g_warm[(size_t)env * m.nv + i]; }
-    for (int i = lane; i < m.nu; i += G) r[lay.ctrl + i] = g_ctrl[(size_t)env * m.nu + i];
-    if (lane == 0) for (int k = 0; k < 8; k++) { ii[lay.misc + k] = 0; ii[lay.nprof + k] = 0; }
+    for (int i = lane; i < ka->m.nq; i += G) r[ka->lay.qpos + i] = g_qpos[(size_t)env * ka->m.nq + i];
+    for (int i = lane; i < ka->m.nv; i += G) { r[ka->lay.qvel + i] = g_qvel[(size_t)env * ka->m.nv + i]; r[ka->lay.warm + i] = g_warm[(size_t)env * ka->m.nv + i]; }
+    for (int i = lane; i < ka->m.nu; i += G) r[ka->lay.ctrl + i] = g_ctrl[(size_t)env * ka->m.nu + i];
+    if (lane == 0) for (int k = 0; k < 8; k++) { ii[ka->lay.misc + k] = 0; ii[ka->lay.nprof + k] = 0; }
     E.profiling = o_prof != nullptr;
     GSYNC();
     if (action) {
         // env.py:203-215: action -> ctrl, grippers un-normalised (env.py:156-161)
-        const float* a = action + (size_t)env * m.nj;
-        for (int i = lane; i < m.nj; i += G) {
+        const float* a = action + (size_t)env * ka->m.nj;
+        for (int i = lane; i < ka->m.nj; i += G) {
             real v = (real)a[i];
-            if (i == 6 || i == 13) v = v * (m.grip_hi - m.grip_lo) + m.grip_lo;
-            r[lay.ctrl + i] = v;
+            if (i == 6 || i == 13) v = v * (ka->m.grip_hi - ka->m.grip_lo) + ka->m.grip_lo;
+            r[ka->lay.ctrl + i] = v;
         }
         GSYNC();
     }
@@ -1363,28 +1388,28 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(DevModel<real> mg, Layout lay
         PROF(3, E.smooth());
         PROF(4, E.collide());
         PROF(5, E.make_constraints());
-        PROF(6, E.solve(pgs_iters, m.solver, m.newton_iters, m.newton_tol, m.nscale));
+        PROF(6, E.solve(pgs_iters, ka->m.solver, ka->m.newton_iters, ka->m.newton_tol, ka->m.nscale));
         PROF(7, E.euler());
     }
     if (o_prof && lane == 0) {
         for (int k = 0; k < 8; k++) o_prof[(size_t)env * 18 + k] = tp[k];
         o_prof[(size_t)env * 18 + 8] = E.t_broad; o_prof[(size_t)env * 18 + 9] = E.t_narrow;
-        for (int k = 0; k < 8; k++) o_prof[(size_t)env * 18 + 10 + k] = ii[lay.nprof + k];   // Newton: init, grad, hess, chol, search, final, noslip
+        for (int k = 0; k < 8; k++) o_prof[(size_t)env * 18 + 10 + k] = ii[ka->lay.nprof + k];   // Newton: init, grad, hess, chol, search, final, noslip
     }
     // trailing refresh of the position-dependent quantities of the final state
-    int nefc_last = ii[lay.misc + 1];
+    int nefc_last = ii[ka->lay.misc + 1];
     E.kinematics();
     E.collide();
 
     // ---- write back ---------------------------------------------------------------------------
     if (nsub > 0) {
-        for (int i = lane; i < m.nq; i += G) g_qpos[(size_t)env * m.nq + i] = r[lay.qpos + i];
-        for (int i = lane; i < m.nv; i += G) { g_qvel[(size_t)env * m.nv + i] = r[lay.qvel + i]; g_warm[(size_t)env * m.nv + i] = r[lay.warm + i]; }
+        for (int i = lane; i < ka->m.nq; i += G) g_qpos[(size_t)env * ka->m.nq + i] = r[ka->lay.qpos + i];
+        for (int i = lane; i < ka->m.nv; i += G) { g_qvel[(size_t)env * ka->m.nv + i] = r[ka->lay.qvel + i]; g_warm[(size_t)env * ka->m.nv + i] = r[ka->lay.warm + i]; }
     }
-    if (action) for (int i = lane; i < m.nu; i += G) g_ctrl[(size_t)env * m.nu + i] = r[lay.ctrl + i];
+    if (action) for (int i = lane; i < ka->m.nu; i += G) g_ctrl[(size_t)env * ka->m.nu + i] = r[ka->lay.ctrl + i];
     if (o_agent)
-        for (int i = lane; i < m.nj; i += G) o_agent[(size_t)env * m.nj + i] = ((double)r[lay.qpos + m.obs_qposadr[i]] - (double)m.obs_offset[i]) * (double)m.obs_scale[i];
-    int ncon = ii[lay.misc + 0];
+        for (int i = lane; i < ka->m.nj; i += G) o_agent[(size_t)env * ka->m.nj + i] = ((double)r[ka->lay.qpos + ka->m.obs_qposadr[i]] - (double)ka->m.obs_offset[i]) * (double)ka->m.obs_scale[i];
+    int ncon = ii[ka->lay.misc + 0];
     if (want_reward) {
         int latch = g_latch[env];
         int rw = E.reward(&latch);
@@ -1395,17 +1420,17 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(DevModel<real> mg, Layout lay
         }
     }
     if (export_contacts)
-    for (int c = lane; c < lay.maxcon; c += G) {
-        int p = c < ncon ? ii[lay.cpair + c] : -1;
-        o_cpairs[((size_t)env * lay.maxcon + c) * 2] = p >= 0 ? m.pair_geom[2 * p] : -1;
-        o_cpairs[((size_t)env * lay.maxcon + c) * 2 + 1] = p >= 0 ? m.pair_geom[2 * p + 1] : -1;
-        o_cdist[(size_t)env * lay.maxcon + c] = c < ncon ? (double)r[lay.cdist + c] : 0.0;
+    for (int c = lane; c < ka->lay.maxcon; c += G) {
+        int p = c < ncon ? ii[ka->lay.cpair + c] : -1;
+        o_cpairs[((size_t)env * ka->lay.maxcon + c) * 2] = p >= 0 ? ka->m.pair_geom[2 * p] : -1;
+        o_cpairs[((size_t)env * ka->lay.maxcon + c) * 2 + 1] = p >= 0 ? ka->m.pair_geom[2 * p + 1] : -1;
+        o_cdist[(size_t)env * ka->lay.maxcon + c] = c < ncon ? (double)r[ka->lay.cdist + c] : 0.0;
     }
     if (lane == 0) {
         o_ncon[env] = ncon;
         bool bad = false;
-        for (int i = 0; i < m.nq; i++) bad |= !(fabs(r[lay.qpos + i]) < real(1e6));
-        o_diag[4 * env] = ncon; o_diag[4 * env + 1] = nefc_last; o_diag[4 * env + 2] = ii[lay.misc + 2]; o_diag[4 * env + 3] = (bad ? 1 : 0) | ((ii[lay.misc + 3] & 0xff) << 8) | ((E.nit_sum & 0xfff) << 16) | ((E.nit_max & 0xf) << 28);
+        for (int i = 0; i < ka->m.nq; i++) bad |= !(fabs(r[ka->lay.qpos + i]) < real(1e6));
+        o_diag[4 * env] = ncon; o_diag[4 * env + 1] = nefc_last; o_diag[4 * env + 2] = ii[ka->lay.misc + 2]; o_diag[4 * env + 3] = (bad ? 1 : 0) | ((ii[ka->lay.misc + 3] & 0xff) << 8) | ((E.nit_sum & 0xfff) << 16) | ((E.nit_max & 0xf) << 28);
     }
 }
 
@@ -1431,6 +1456,8 @@ struct PhysHost {
     MOff moff;
     void* d_img_real = nullptr;
     int* d_img_int = nullptr;
+    void* d_kargs = nullptr;        // KArgs<float|double> in device memory
+    bool kargs_dirty = true;
     template <typename T>
     T* up(const std::vector<T>& v) {
         void* p = nullptr;
@@ -1609,6 +1636,7 @@ struct PhysHost {
 
     void make_layout(int nq, int nv, int nu, int nb, int ng, int msize) {
         Layout& L = lay;
+        kargs_dirty = true;
         int o = 0;
         auto R = [&](int n) { int a = o; o += n; return a; };
         L.qpos = R(nq); L.qvel = R(nv); L.ctrl = R(nu); L.warm = R(nv);
@@ -1690,6 +1718,7 @@ struct PhysHost {
     }
     bool set_option(const char* name, double v) {
         std::string n(name);
+        kargs_dirty = true;
         if (n == "pgs_iters") { pgs_iters = (int)v; return true; }
         if (n == "solver") { if (v != 0 && v != 1) return false; mf.solver = md.solver = (int)v; return true; }
         if (n == "newton_iters") { if (v < 1 || v > 100) return false; mf.newton_iters = md.newton_iters = (int)v; return true; }
@@ -1727,7 +1756,14 @@ struct PhysHost {
         }
         if (shmem > 160 * 1024) { err = "per-block LDS exceeds 160 KiB; lower maxefc/maxcon or raise the group size"; return -1; }
         dim3 grid((N + epb - 1) / epb);
-        hipLaunchKernelGGL(kern, grid, dim3(64 * WPB), shmem, st, m, lay, moff, (const real*)d_img_real, (const int*)d_img_int, N, nsub, pgs_iters, action, (reward || success) && (nsub > 0 || force_reward) ? 1 : 0,
+        if (kargs_dirty) {
+            KArgs<real> ka{m, lay, moff};
+            if (!d_kargs) { if (hipMalloc(&d_kargs, sizeof(KArgs<double>)) != hipSuccess) { err = "hipMalloc(kernel arguments) failed"; return -3; } allocs.push_back(d_kargs); }
+            (void)hipStreamSynchronize(st);
+            if (hipMemcpy(d_kargs, &ka, sizeof(ka), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy(kernel arguments) failed"; return -3; }
+            kargs_dirty = false;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WPB), shmem, st, (KPtr<real>)d_kargs, (const real*)d_img_real, (const int*)d_img_int, N, nsub, pgs_iters, action, (reward || success) && (nsub > 0 || force_reward) ? 1 : 0,
                            (real*)qpos, (real*)qvel, (real*)ctrl, (real*)warm, latch, agent, (int*)reward, (unsigned char*)success, d_ncon,
                            d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof);
         hipError_t e = hipGetLastError();
