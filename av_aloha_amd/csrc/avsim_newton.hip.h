@@ -53,7 +53,6 @@ struct NewtonArgs {
 };
 
 enum { NR_EQ = 0, NR_FLOSS = 1, NR_LIMIT = 2, NR_CONTACT = 3 };
-constexpr int NCH = 2;       // contact chunks of 64 (one contact per lane and chunk)
 constexpr int NVMAX = 48;    // register row of the factorisation
 
 // J_i . v for row i (v in LDS, dof indexed)
@@ -226,7 +225,7 @@ AVS_DEV void nblock(const NewtonArgs<real>& A, int lane, int r0, int dim, bool f
     } while (0)
 
 // cost of the point v (LDS, dof indexed): rows + contacts + 1/2 (v - a_s)^T M (v - a_s)
-template <typename real>
+template <typename real, int NCH>
 AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, LDS_PTR(const real) v) {
     real cs = 0;
     for (int i = lane; i < A.nefc; i += 64) A.rowS[8 * i + 2] = nrow_dot(A, i, v) - A.rowS[8 * i];
@@ -253,13 +252,32 @@ AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, L
     return wave_sum(cs);
 }
 
-template <typename real>
-__device__ __attribute__((noinline)) int newton_solve(NewtonArgs<real> A) {
+// r / ii: the env's real and int LDS regions, li: the block's hot-table image; everything else comes from the layout
+// NCH = contact chunks of 64 (one contact per lane and chunk): 1 when the model's contact cap is <= 64
+template <typename real, int NCH>
+__device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, LDS_PTR(real) r_, LDS_PTR(int) ii_, LDS_PTR(const int) li_, int nefc, int ncon, int nlead,
+                                                      int iters, real tol, real scale, int profiling) {
     const int lane = threadIdx.x & 63;
-    // arguments of a non-kernel function arrive in VGPRs: make the wave-uniform ones scalar again
-    A.nv = __builtin_amdgcn_readfirstlane(A.nv); A.nefc = __builtin_amdgcn_readfirstlane(A.nefc);
-    A.ncon = __builtin_amdgcn_readfirstlane(A.ncon); A.nlead = __builtin_amdgcn_readfirstlane(A.nlead);
-    A.iters = __builtin_amdgcn_readfirstlane(A.iters);
+    NewtonArgs<real> A;
+    {
+        // arguments of a non-kernel function arrive in VGPRs: make the wave-uniform ones scalar again
+        LDS_PTR(real) r = (LDS_PTR(real))__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)r_);
+        LDS_PTR(int) ii = (LDS_PTR(int))__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)ii_);
+        LDS_PTR(const int) li = (LDS_PTR(const int))__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)li_);
+        tol = lane_get(tol, 0); scale = lane_get(scale, 0);
+        const Layout __attribute__((address_space(4)))* L = &ka->lay;
+        const MOff __attribute__((address_space(4)))* O = &ka->mo;
+        A.rowS = r + L->rowS; A.rowI = ii + L->rowI; A.rmeta = ii + L->rmeta; A.rJ = r + L->rJ;
+        A.M = r + L->M; A.a = r + L->qacc; A.as = r + L->asm_;
+        A.H = r + L->nH; A.g = r + L->ng; A.dl = r + L->ndl; A.jv = r + L->njv;
+        A.czone = ii + L->czone; A.cefc = ii + L->cefc;
+        A.prof = profiling ? ii + L->nprof : (LDS_PTR(int))nullptr;
+        A.tree_dofadr = li + O->tree_dofadr; A.tree_dofnum = li + O->tree_dofnum; A.tree_madr = li + O->tree_madr; A.dof_tree = li + O->dof_tree;
+        A.nv = ka->m.nv; A.ntree = ka->m.ntree;
+        A.nefc = __builtin_amdgcn_readfirstlane(nefc); A.ncon = __builtin_amdgcn_readfirstlane(ncon);
+        A.nlead = __builtin_amdgcn_readfirstlane(nlead); A.iters = __builtin_amdgcn_readfirstlane(iters);
+        A.tol = tol; A.scale = scale; A.ls_tol = sizeof(real) == 8 ? real(1e-10) : real(1e-4);
+    }
     const int nv = A.nv, ne = A.nefc;
     int used = 0;
     long long tp0 = A.prof ? __builtin_readcyclecounter() : 0;
@@ -288,9 +306,9 @@ __device__ __attribute__((noinline)) int newton_solve(NewtonArgs<real> A) {
     }
     // ---- start from the warm start (already in a) or from the smooth acceleration, whichever costs less ----
     {
-        const real c0 = ncost(A, lane, con, (LDS_PTR(const real))A.a);
+        const real c0 = ncost<real, NCH>(A, lane, con, (LDS_PTR(const real))A.a);
         NSYNC();
-        const real c1 = ncost(A, lane, con, A.as);
+        const real c1 = ncost<real, NCH>(A, lane, con, A.as);
         if (!(c0 < c1)) {
             for (int k = lane; k < nv; k += 64) A.a[k] = A.as[k];
         }

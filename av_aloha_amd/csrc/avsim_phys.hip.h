@@ -132,6 +132,26 @@ struct Layout {
     int bytes_per_env;
 };
 
+// everything the kernel needs to know about the model: read through a constant-address-space pointer, so that the ~90 table
+// pointers and ~100 offsets are scalar-loaded where they are used instead of being held (and spilled) for the whole kernel
+template <typename real>
+struct KArgs {
+    DevModel<real> m;
+    Layout lay;
+    MOff mo;
+};
+template <typename real>
+using KPtr = const KArgs<real> __attribute__((address_space(4)))*;
+// start of a phase: forget what was loaded through ka so far (keeps the live ranges of model scalars inside one phase)
+#define PHASE_BEGIN()                                                                                  \
+    do {                                                                                               \
+        const unsigned long long p_ = (unsigned long long)ka;                                          \
+        unsigned lo_ = __builtin_amdgcn_readfirstlane((unsigned)p_), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(p_ >> 32)); \
+        asm volatile("" : "+s"(lo_), "+s"(hi_));                                                       \
+        ka = (decltype(ka))(((unsigned long long)hi_ << 32) | lo_);                                    \
+    } while (0)
+
+
 #define GSYNC()                                              \
     do {                                                     \
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); \
@@ -328,25 +348,6 @@ struct SInert {
 };
 
 // spatial inertia of body b about the world origin in world axes
-// everything the kernel needs to know about the model: read through a constant-address-space pointer, so that the ~90 table
-// pointers and ~100 offsets are scalar-loaded where they are used instead of being held (and spilled) for the whole kernel
-template <typename real>
-struct KArgs {
-    DevModel<real> m;
-    Layout lay;
-    MOff mo;
-};
-template <typename real>
-using KPtr = const KArgs<real> __attribute__((address_space(4)))*;
-// start of a phase: forget what was loaded through ka so far (keeps the live ranges of model scalars inside one phase)
-#define PHASE_BEGIN()                                                                                  \
-    do {                                                                                               \
-        const unsigned long long p_ = (unsigned long long)ka;                                          \
-        unsigned lo_ = __builtin_amdgcn_readfirstlane((unsigned)p_), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(p_ >> 32)); \
-        asm volatile("" : "+s"(lo_), "+s"(hi_));                                                       \
-        ka = (decltype(ka))(((unsigned long long)hi_ << 32) | lo_);                                    \
-    } while (0)
-
 template <typename real>
 AVS_DEV void body_inertia(KPtr<real> ka, const real* xmat, const real* xipos, int b, SInert<real>& s) {
     const real* R = xmat + 9 * b;
@@ -1180,17 +1181,9 @@ struct Env {
             real* warm = r + ka->lay.warm;
             for (int k = lane; k < ka->m.nv; k += G) qacc[k] = warm[k];
             GSYNC();
-            NewtonArgs<real> A;
-            A.rowS = (LDS_PTR(real))rowS; A.rowI = (LDS_PTR(const int))rowI; A.rmeta = (LDS_PTR(const int))rmeta; A.rJ = (LDS_PTR(const real))rJ;
-            A.M = (LDS_PTR(const real))(r + ka->lay.M); A.a = (LDS_PTR(real))qacc; A.as = (LDS_PTR(const real))as;
-            A.H = (LDS_PTR(real))(r + ka->lay.nH); A.g = (LDS_PTR(real))(r + ka->lay.ng); A.dl = (LDS_PTR(real))(r + ka->lay.ndl); A.jv = (LDS_PTR(real))(r + ka->lay.njv);
-            A.czone = (LDS_PTR(const int))(ii + ka->lay.czone); A.cefc = (LDS_PTR(const int))cefc;
-            A.prof = profiling ? (LDS_PTR(int))(ii + ka->lay.nprof) : (LDS_PTR(int))nullptr;
-            A.tree_dofadr = (LDS_PTR(const int))tree_dofadr_(); A.tree_dofnum = (LDS_PTR(const int))tree_dofnum_();
-            A.tree_madr = (LDS_PTR(const int))tree_madr_(); A.dof_tree = (LDS_PTR(const int))dof_tree_();
-            A.nv = ka->m.nv; A.nefc = nefc; A.ncon = ncon; A.nlead = misc[4]; A.ntree = ka->m.ntree; A.iters = newton_iters;
-            A.tol = newton_tol; A.scale = scale; A.ls_tol = sizeof(real) == 8 ? real(1e-10) : real(1e-4);
-            int used = newton_solve<real>(A);
+            int used = ka->lay.maxcon <= 64
+                ? newton_solve<real, 1>(ka, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0)
+                : newton_solve<real, 2>(ka, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0);
             nit_sum += used; nit_max = used > nit_max ? used : nit_max;
             GSYNC();
             long long tn0 = profiling ? __builtin_readcyclecounter() : 0;
