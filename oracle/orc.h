@@ -10,8 +10,9 @@
  *    gym_guided_vision/gym_guided_vision/env.py get_reward x5) and are checked against golden
  *    vectors produced by importing that Python (tests/golden/gen_golden.py).
  *  - The physics (env.py:218 -> MuJoCo mj_step, un-vendored third-party C library, mujoco ^3.2.2
- *    per gym_guided_vision/pyproject.toml:11) restates MuJoCo's *documented* pipeline with a
- *    PGS solver as BASELINE.json's north_star asks.  MuJoCo cannot be imported or built here,
+ *    per gym_guided_vision/pyproject.toml:11) restates MuJoCo's *documented* pipeline with the
+ *    Newton solver the reference runs (MuJoCo default) and the PGS solver BASELINE.json's
+ *    north_star names (orc_data.solver).  MuJoCo cannot be imported or built here,
  *    the reference ships no golden trajectories: PARITY UNPINNED at the MuJoCo boundary.
  */
 #ifndef ORC_H
