@@ -1,0 +1,104 @@
+"""BASELINE.json configs 3 and 4 as parity cases at test sizes: contact-rich SewNeedle-3Arms and the
+sharded HookPackage-2Arms rollout whose results must not depend on how the envs are split over GPUs."""
+import numpy as np
+import pytest
+
+from av_aloha_amd.dist import shard_ids
+from av_aloha_amd.env import sample_object_poses
+from orc_env import OrcEnv
+from test_oracle_physics import model_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def make(task, na, N, **opt):
+    from av_aloha_amd.sim import BatchedSim
+    return BatchedSim(task, na, N, options=opt)
+
+
+def poses_for(task, gids, seed0):
+    out = []
+    for g in gids:
+        np.random.seed(seed0 + int(g))       # reference draw order from the global numpy RNG (env.py:513-543 etc.)
+        out.append(sample_object_poses(task))
+    return np.stack(out)
+
+
+def walk_actions(md, gids, T, nj, seed0, close_grippers=False):
+    """Config 4's smooth random walk: default_rng(seed0 + global env id), sigma 0.02 rad per step, clipped to ctrlrange."""
+    h = md["qpos_home"]
+    home = np.concatenate([h[:6], [1.0], h[8:14], [1.0], h[16:23]])[:nj]
+    lo, hi = md["act_ctrlrange"].reshape(-1, 2)[:nj].T.copy()
+    lo[[6, 13]], hi[[6, 13]] = 0.0, 1.0
+    acts = np.empty((T, len(gids), nj), dtype=np.float32)
+    for k, g in enumerate(gids):
+        rng = np.random.default_rng(seed0 + int(g))
+        a = home.copy()
+        for t in range(T):
+            a = np.clip(a + rng.normal(scale=0.02, size=nj), lo, hi)
+            if close_grippers:
+                a[6] = a[13] = 0.0 if t >= 2 else 1.0
+            acts[t, k] = a
+    return acts
+
+
+def rollout(task, na, gids, T, seed_pose, seed_act, **kw):
+    md = model_dict(task, na)
+    nj = 21 if na == 3 else 14
+    sim = make(task, na, len(gids))
+    sim.reset(poses_for(task, gids, seed_pose))
+    acts = walk_actions(md, gids, T, nj, seed_act, **kw)
+    ret = np.zeros(len(gids), dtype=np.float32)
+    for t in range(T):
+        ap, rw, su = sim.step(acts[t])
+        ret += rw
+    q, v, _, _ = sim.get_state()
+    d = sim.diag()
+    sim.close()
+    return q, v, ret, su, d
+
+
+def test_config4_results_do_not_depend_on_the_sharding():
+    """HookPackage-2Arms, 14-D joint actions: the same global env ids stepped as one batch of 16 and as 2 shards of 8
+    (av_aloha_amd.dist.shard_ids, what each rank of bench.py --gpus 2 owns) give bit-identical states and returns."""
+    T, n = 12, 16
+    q, v, ret, su, d = rollout("hook_package", 2, np.arange(n), T, 3000, 3000)
+    assert q.shape[0] == n and (d[:, 2] == 0).all() and ((d[:, 3] & 1) == 0).all()
+    for rank in range(2):
+        ids = shard_ids(rank, 2, n // 2)
+        qs, vs, rs, ss, ds = rollout("hook_package", 2, ids, T, 3000, 3000)
+        assert np.array_equal(qs, q[ids]) and np.array_equal(vs, v[ids])
+        assert np.array_equal(rs, ret[ids]) and np.array_equal(ss, su[ids])
+
+
+def test_config3_sew_needle_contact_rich_vs_oracle():
+    """SewNeedle-3Arms with closing grippers and wandering arms: rows stay under the caps, Newton stays under its iteration
+    cap, and the first envs follow the f64 oracle (Newton both sides) within 1e-4 over 6 env-steps with rewards exact."""
+    T, n = 6, 64
+    task, md = "sew_needle", model_dict("sew_needle", 3)
+    gids = np.arange(n)
+    sim = make(task, 3, n)
+    poses = poses_for(task, gids, 2000)
+    sim.reset(poses)
+    acts = walk_actions(md, gids, T, 21, 2000, close_grippers=True)
+    orcs = []
+    for k in range(3):
+        e = OrcEnv(task, 3)
+        e.d.solver = 1
+        e.reset(poses[k])
+        orcs.append(e)
+    for t in range(T):
+        ap, rw, su = sim.step(acts[t])
+        q, v, _, _ = sim.get_state()
+        for k, e in enumerate(orcs):
+            apo, ro, so = e.env_step(acts[t, k].astype(np.float64))
+            assert np.abs(q[k] - e.qpos).max() < 1e-4, (t, k, np.abs(q[k] - e.qpos).max())
+            assert rw[k] == ro and bool(su[k]) == so
+    d = sim.diag()
+    assert (d[:, 2] == 0).all(), "row / contact caps overflowed"
+    assert ((d[:, 3] & 1) == 0).all(), "NaN state"
+    assert (((d[:, 3] >> 28) & 0xf) <= 8).all()
+    assert d[:, 0].mean() >= 8, "config 3 is meant to be contact-rich"
+    for e in orcs:
+        e.close()
+    sim.close()

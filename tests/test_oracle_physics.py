@@ -184,3 +184,31 @@ def test_determinism():
         outs.append(np.concatenate([e.qpos.copy(), e.qvel.copy()]))
         e.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_newton_solver_reaches_the_pgs_fixed_point():
+    """Both solvers minimise the same convex problem (primal Newton / dual PGS): from identical contact-rich states the
+    Newton acceleration must equal the one of PGS run to convergence; 20 sweeps (the north_star setting) are not converged."""
+    md = model_dict()
+    e = OrcEnv()
+    e.d.solver = 1
+    e.reset(OBJ)
+    a = home_action(md)
+    a[6] = 0.0
+    a[0] += 0.2
+    for _ in range(8):
+        e.env_step(a)
+    assert e.d.ncon >= 8
+    accs = {}
+    for name, solver, sweeps in (("newton", 1, 0), ("pgs20", 0, 20), ("pgs_conv", 0, 20000)):
+        e.d.solver = solver
+        e.d.pgs_iters = max(1, sweeps)
+        e.d.pgs_tol = 0.0
+        e.L.orc_forward(e.dptr)
+        accs[name] = e.arr("qacc", 35).copy()
+        if name == "newton":
+            assert 1 <= e.d.stat_sweeps <= 8          # Newton iterations used
+    scale = np.abs(accs["pgs_conv"]).max()
+    assert np.abs(accs["newton"] - accs["pgs_conv"]).max() < 1e-6 * max(1.0, scale)
+    assert np.abs(accs["pgs20"] - accs["pgs_conv"]).max() > np.abs(accs["newton"] - accs["pgs_conv"]).max()
+    e.close()
