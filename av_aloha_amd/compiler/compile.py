@@ -430,6 +430,22 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
               geom_solref=g_solref, geom_solimp=g_solimp, geom_margin=g_margin, geom_gap=g_gap,
               geom_class=g_class, geom_bcenter=g_bcen, geom_rbound=g_rb)
     md["hull_vert"] = np.concatenate(hull_verts) if hull_verts else np.zeros((0, 3))
+    # half-space form of every hull for the depth ray-caster: rows [nx ny nz d], inside = {x : n.x <= d}, geom-local frame
+    plane_of = {}
+    planes = []
+    for name, (adr, cnt) in hull_info.items():
+        pl = hullmod.hull_planes(md["hull_vert"][adr:adr + cnt])
+        plane_of[(adr, cnt)] = (sum(len(q) for q in planes), len(pl))
+        planes.append(pl)
+    g_hplane = np.zeros((ng, 2), dtype=np.int32)
+    for k in range(ng):
+        if g_type[k] == 7:
+            g_hplane[k] = plane_of[(int(g_hull[k][0]), int(g_hull[k][1]))]
+    md["geom_hplane"] = g_hplane
+    # depth render proxies: the collision geoms stand in for the visual meshes; reward-only pins (group 3, gap=100) and
+    # the 0.6 mm finger pad spheres (inside the finger hulls) are not drawn
+    md["geom_visible"] = np.array([0 if (n.startswith("pin") or n[-3:] in ("_g0", "_g1", "_g2")) else 1 for n in names], dtype=np.int32)
+    md["hull_plane"] = np.concatenate(planes) if planes else np.zeros((0, 4))
 
     # ---- candidate pair list -------------------------------------------------------------
     excl = set()
@@ -619,6 +635,8 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
     md["cam_pos"] = np.array([c["pos"] for c in m.cameras])
     md["cam_quat"] = np.array([c["quat"] for c in m.cameras])
     md["cam_fovy"] = np.array([c["fovy"] for c in m.cameras])
+    # clip planes in metres: <map znear="0.05"/> x <statistic extent="0.6"/> (scene.xml:6,13); zfar = MuJoCo default 50 x extent
+    md["cam_clip"] = np.array([0.05 * 0.6, 50.0 * 0.6])
 
     manifest = {
         "task": task, "task_id": task_id, "num_arms": num_arms,

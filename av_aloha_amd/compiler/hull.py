@@ -60,3 +60,15 @@ def decimate_hull(points, kmax):
         sel.append(i)
     sub = ConvexHull(hv[sel])
     return hv[sel][sub.vertices], err
+
+
+def hull_planes(verts, tol=1e-9):
+    """Facet planes [n, d] (n.x <= d inside, |n| = 1) of the convex hull of `verts`, coplanar triangles merged."""
+    from scipy.spatial import ConvexHull
+    eq = ConvexHull(np.asarray(verts, dtype=np.float64)).equations      # n.x + off <= 0 inside
+    out = []
+    for e in eq:
+        row = np.array([e[0], e[1], e[2], -e[3]])
+        if not any(np.abs(row - o).max() < 1e-7 for o in out):
+            out.append(row)
+    return np.array(out)

@@ -15,6 +15,7 @@
 #include "avsim_ik.hip.h"
 #include "avsim_model.h"
 #include "avsim_phys.hip.h"
+#include "avsim_render.hip.h"
 
 using namespace avs;
 
@@ -44,6 +45,7 @@ struct avsim {
     std::vector<int> obj_qadr, obs_qadr;
     std::vector<double> qpos_home, ctrl_home;
     PhysHost phys;  // device model image + launch configuration (avsim_phys.hip.h)
+    RenderHost render;   // depth renderer (avsim_render.hip.h)
     // device state (real = float, or double with AVSIM_F64_PHYSICS)
     void *d_qpos = nullptr, *d_qvel = nullptr, *d_ctrl = nullptr, *d_warm = nullptr;
     int* d_latch = nullptr;
@@ -304,6 +306,7 @@ int avsim_create(const void* blob, size_t nbytes, int num_envs, int device, uint
         fill_ik(b, h->ik);
         std::string perr;
         if (!h->phys.init(b, num_envs, h->f64, perr)) { g_create_error = perr; return AVSIM_EMODEL; }
+        h->render.build(b, num_envs);
     } catch (const std::exception& ex) {
         g_create_error = std::string("avsim_create: ") + ex.what();
         return AVSIM_EMODEL;
@@ -344,6 +347,7 @@ void avsim_destroy(avsim_t* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->phys.destroy();
+    h->render.destroy();
     for (void* p : {h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, (void*)h->d_latch})
         if (p) (void)hipFree(p);
     for (void* p : h->d_io)
@@ -661,5 +665,29 @@ int avsim_get_diag(avsim_t* h, int32_t* diag) {
     HIPCHK(h, hipMemcpy(diag, h->phys.d_diag, N * 16, hipMemcpyDeviceToHost));
     return AVSIM_OK;
 }
+
+}  // extern "C"
+
+extern "C" {
+
+// E6 (env.py:180-188 get_obs pixels / :195-200 render) as depth images: forward pass of the physics kernel (nsub = 0) exports
+// the body poses, then the two render kernels run on the same stream.
+int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, float* out) {
+    if (!h || !cam_ids || !out) { if (h) h->set_error("avsim_render_depth: bad arguments"); return AVSIM_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    void* dout = nullptr;
+    const size_t bytes = sizeof(float) * (size_t)h->N * ncam * height * width;
+    if ((rc = h->out_begin(7, out, bytes, &dout))) return rc;
+    h->phys.d_xpose = h->render.d_xpose;
+    rc = h->phys.launch(h->stream, h->N, 0, nullptr, h->nj, h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, h->d_latch, nullptr, nullptr, nullptr, h->err);
+    h->phys.d_xpose = nullptr;
+    if (rc) return rc;
+    if ((rc = h->render.launch(h->stream, (const int*)cam_ids, ncam, height, width, (float*)dout, h->err))) return rc < -1 ? AVSIM_EHIP : AVSIM_EINVAL;
+    if ((rc = h->out_end(7, out, bytes))) return rc;
+    return h->finish();
+}
+
+int avsim_camera_count(const avsim_t* h) { return h ? h->render.m.ncam : 0; }
 
 }  // extern "C"

@@ -261,9 +261,9 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, LDS_PT
     NewtonArgs<real> A;
     {
         // arguments of a non-kernel function arrive in VGPRs: make the wave-uniform ones scalar again
-        LDS_PTR(real) r = (LDS_PTR(real))__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)r_);
-        LDS_PTR(int) ii = (LDS_PTR(int))__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)ii_);
-        LDS_PTR(const int) li = (LDS_PTR(const int))__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)li_);
+        LDS_PTR(real) r = (LDS_PTR(real))(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)r_);
+        LDS_PTR(int) ii = (LDS_PTR(int))(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)ii_);
+        LDS_PTR(const int) li = (LDS_PTR(const int))(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)li_);
         tol = lane_get(tol, 0); scale = lane_get(scale, 0);
         const Layout __attribute__((address_space(4)))* L = &ka->lay;
         const MOff __attribute__((address_space(4)))* O = &ka->mo;

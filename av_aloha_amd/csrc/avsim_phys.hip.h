@@ -1339,7 +1339,7 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(KPtr<real> ka, const real* __
                                              int want_reward, real* __restrict__ g_qpos, real* __restrict__ g_qvel, real* __restrict__ g_ctrl,
                                              real* __restrict__ g_warm, int* __restrict__ g_latch, double* __restrict__ o_agent,
                                              int* __restrict__ o_reward, unsigned char* __restrict__ o_success, int* __restrict__ o_ncon,
-                                             int* __restrict__ o_cpairs, double* __restrict__ o_cdist, int* __restrict__ o_diag, int max_reward, int export_contacts, long long* __restrict__ o_prof) {
+                                             int* __restrict__ o_cpairs, double* __restrict__ o_cdist, int* __restrict__ o_diag, int max_reward, int export_contacts, long long* __restrict__ o_prof, float* __restrict__ o_xpose) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(G == 64, "one env per wavefront");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = 0;
@@ -1392,6 +1392,13 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(KPtr<real> ka, const real* __
     // trailing refresh of the position-dependent quantities of the final state
     int nefc_last = ii[ka->lay.misc + 1];
     E.kinematics();
+    if (o_xpose) {   // body poses for the depth renderer (avsim_render.hip.h)
+        for (int b = lane; b < ka->m.nbody; b += G) {
+            float* o = o_xpose + ((size_t)env * ka->m.nbody + b) * 12;
+            for (int k = 0; k < 3; k++) o[k] = (float)r[ka->lay.xpos + 3 * b + k];
+            for (int k = 0; k < 9; k++) o[3 + k] = (float)r[ka->lay.xmat + 9 * b + k];
+        }
+    }
     E.collide();
 
     // ---- write back ---------------------------------------------------------------------------
@@ -1442,6 +1449,7 @@ struct PhysHost {
     int* d_obj_qadr = nullptr;
     int *d_ncon = nullptr, *d_cpairs = nullptr, *d_diag = nullptr;
     long long* d_prof = nullptr;   // optional per-env phase cycle counters (option "profile_phases")
+    float* d_xpose = nullptr;      // when set, the launch also exports body poses float[N][nbody][12] (render path)
     double* d_cdist = nullptr;
 
     std::vector<int> img_int;
@@ -1758,7 +1766,7 @@ struct PhysHost {
         }
         hipLaunchKernelGGL(kern, grid, dim3(64 * WPB), shmem, st, (KPtr<real>)d_kargs, (const real*)d_img_real, (const int*)d_img_int, N, nsub, pgs_iters, action, (reward || success) && (nsub > 0 || force_reward) ? 1 : 0,
                            (real*)qpos, (real*)qvel, (real*)ctrl, (real*)warm, latch, agent, (int*)reward, (unsigned char*)success, d_ncon,
-                           d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof);
+                           d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof, d_xpose);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("physics kernel launch: ") + hipGetErrorString(e); return -3; }
         return 0;

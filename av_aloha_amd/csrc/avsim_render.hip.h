@@ -1,0 +1,421 @@
+// avsim_render.hip.h -- batched depth images of the model's cameras (BASELINE config 5).
+//
+// Stands where the reference renders its cameras through MuJoCo's OpenGL pipeline
+// (gym_guided_vision/gym_guided_vision/env.py:180-188 get_obs "pixels", :195-200 render): one float32 depth image
+// (metres along the optical axis) per env and camera.  Conventions [EXT MuJoCo camera model]: the camera looks along its
+// -z, +y is up, fovy is vertical, clip planes znear*extent / zfar*extent (scene.xml:6,13), back faces culled.  The drawn
+// surfaces are the collision proxies (boxes, spheres, cylinders, decimated convex hulls in half-space form), exactly what
+// oracle/orc_render.c draws.
+//
+// Two kernels.  k_render_geoms: one wavefront per (env, camera) moves every visible geom into the camera frame, projects its
+// vertices to a screen-space box, drops the geoms outside the view and compacts the survivors (ordered ballot) into 28-float
+// records plus a front-to-back order (rank sort on the nearest vertex depth).  k_render_depth: one
+// wavefront per 32 x 8 pixel tile; the tile first culls the camera's records against its own pyramid (screen boxes, one
+// record per lane, ballot masks; then a separating-face test with one hull plane per lane) and walks the survivors front to back, stopping as soon as every pixel of the tile is
+// nearer than the next geom can be; every lane casts its 4 horizontally adjacent rays: the
+// geom record and the hull planes are wave-uniform (scalar loads), the rays differ only in one coordinate, and the result
+// leaves as one 16-byte store per lane (8 lanes = one 128-byte line of the image).  HBM-write bound by construction:
+// 4 B per pixel out, the records (<= 8 KB per camera) come from L2.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "avsim_model.h"
+
+namespace avs {
+
+
+constexpr int REC_W = 28;   // floats per geom record: o_l[3], A[9] (camera dir -> geom frame), c[3], r, size[3], type, plane adr, plane count,
+                            // geom id, pad, screen box xl xr yb yt (units of tan), nearest depth
+constexpr int TILE_W = 32, TILE_H = 8;
+
+struct RenderModel {
+    int ngeom, ncam, nbody, nplane;   // nplane: faces summed over the visible mesh geoms
+    const int *geom_type, *geom_body, *geom_hplane, *geom_hull, *geom_visible, *cam_body;
+    const float *geom_pos, *geom_mat, *geom_size, *geom_bcen, *geom_rbound, *hull_plane, *hull_vert, *cam_pos, *cam_mat, *cam_fovy;
+    float znear, zfar;
+};
+
+__device__ inline void mul33(const float* A, const float* B, float* C) {   // C = A B
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// grid (ncam_sel, N), block 64
+__global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float* __restrict__ xpose, const int* __restrict__ cam_ids, int ncam_sel,
+                                                     int H, int W, float* __restrict__ recs, int* __restrict__ counts, int* __restrict__ order, float* __restrict__ tplanes) {
+    __shared__ float keys[128];
+    const int lane = threadIdx.x, cs = blockIdx.x, env = blockIdx.y, cam = cam_ids[cs];
+    const float* xb = xpose + (size_t)env * m.nbody * 12;
+    // camera pose in the world
+    float Rc[9], pc[3];
+    {
+        const int b = m.cam_body[cam];
+        const float *pb = xb + 12 * b, *Rb = pb + 3, *cp = m.cam_pos + 3 * cam;
+        mul33(Rb, m.cam_mat + 9 * cam, Rc);
+#pragma unroll
+        for (int i = 0; i < 3; i++) pc[i] = pb[i] + Rb[3 * i] * cp[0] + Rb[3 * i + 1] * cp[1] + Rb[3 * i + 2] * cp[2];
+    }
+    const float scale = 2.0f * tanf(0.5f * m.cam_fovy[cam] * 0.017453292519943295f) / (float)H;
+    const float tx = 0.5f * W * scale, ty = 0.5f * H * scale, sx = sqrtf(1 + tx * tx), sy = sqrtf(1 + ty * ty);
+    float* out = recs + ((size_t)env * ncam_sel + cs) * m.ngeom * REC_W;
+    int base = 0;
+    for (int g0 = 0; g0 < m.ngeom; g0 += 64) {
+        const int g = g0 + lane;
+        bool keep = false;
+        float rec[REC_W];
+        if (g < m.ngeom && m.geom_visible[g]) {
+            const int b = m.geom_body[g];
+            const float *pb = xb + 12 * b, *Rb = pb + 3, *gp = m.geom_pos + 3 * g, *bc = m.geom_bcen + 3 * g;
+            float Rg[9], pg[3], rel[3];
+            mul33(Rb, m.geom_mat + 9 * g, Rg);
+#pragma unroll
+            for (int i = 0; i < 3; i++) { pg[i] = pb[i] + Rb[3 * i] * gp[0] + Rb[3 * i + 1] * gp[1] + Rb[3 * i + 2] * gp[2]; rel[i] = pc[i] - pg[i]; }
+            // camera origin in the geom frame, and A = Rg^T Rc (camera-frame direction -> geom frame)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                rec[k] = Rg[k] * rel[0] + Rg[3 + k] * rel[1] + Rg[6 + k] * rel[2];
+#pragma unroll
+                for (int j = 0; j < 3; j++) rec[3 + 3 * k + j] = Rg[k] * Rc[j] + Rg[3 + k] * Rc[3 + j] + Rg[6 + k] * Rc[6 + j];
+            }
+            // bounding sphere centre in the camera frame
+            float cw[3], c[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) cw[i] = pg[i] + Rg[3 * i] * bc[0] + Rg[3 * i + 1] * bc[1] + Rg[3 * i + 2] * bc[2] - pc[i];
+#pragma unroll
+            for (int j = 0; j < 3; j++) c[j] = Rc[j] * cw[0] + Rc[3 + j] * cw[1] + Rc[6 + j] * cw[2];
+            const float r = m.geom_rbound[g] * 1.0001f + 1e-6f;
+            rec[12] = c[0]; rec[13] = c[1]; rec[14] = c[2]; rec[15] = r;
+            rec[16] = m.geom_size[3 * g]; rec[17] = m.geom_size[3 * g + 1]; rec[18] = m.geom_size[3 * g + 2];
+            rec[19] = __int_as_float(m.geom_type[g]);
+            rec[20] = __int_as_float(m.geom_hplane[2 * g]); rec[21] = __int_as_float(m.geom_hplane[2 * g + 1]);
+            rec[22] = __int_as_float(g); rec[23] = 0;
+            // screen box of the geom's vertices (hull vertices, box corners, bounding box of spheres / cylinders)
+            float bx0 = 1e30f, bx1 = -1e30f, by0 = 1e30f, by1 = -1e30f, zmin = 1e30f;
+            bool crossing = false;
+            const int type = m.geom_type[g];
+            const int nvert = type == 7 ? m.geom_hull[2 * g + 1] : 8;
+            const float* hv = m.hull_vert + 3 * (size_t)m.geom_hull[2 * g];
+            const float ex = type == 6 ? rec[16] : rec[16], ey = type == 6 ? rec[17] : rec[16], ez = type == 6 ? rec[18] : (type == 5 ? rec[17] : rec[16]);
+            for (int k = 0; k < nvert; k++) {
+                float pl[3];
+                if (type == 7) { pl[0] = hv[3 * k]; pl[1] = hv[3 * k + 1]; pl[2] = hv[3 * k + 2]; }
+                else { pl[0] = (k & 1) ? ex : -ex; pl[1] = (k & 2) ? ey : -ey; pl[2] = (k & 4) ? ez : -ez; }
+                const float d0 = pl[0] - rec[0], d1 = pl[1] - rec[1], d2 = pl[2] - rec[2];
+                // p_c = A^T (p_l - o_l)
+                const float xc = rec[3] * d0 + rec[6] * d1 + rec[9] * d2, yc = rec[4] * d0 + rec[7] * d1 + rec[10] * d2, zc = rec[5] * d0 + rec[8] * d1 + rec[11] * d2;
+                const float depth = -zc;
+                if (depth < 0.5f * m.znear) { crossing = true; continue; }
+                const float iz = 1.0f / depth;
+                bx0 = fminf(bx0, xc * iz); bx1 = fmaxf(bx1, xc * iz); by0 = fminf(by0, yc * iz); by1 = fmaxf(by1, yc * iz);
+                zmin = fminf(zmin, depth);
+            }
+            if (crossing) { bx0 = by0 = -1e30f; bx1 = by1 = 1e30f; zmin = 0; }
+            const float pad = 1e-4f;
+            rec[24] = bx0 - pad; rec[25] = bx1 + pad; rec[26] = by0 - pad; rec[27] = by1 + pad; rec[23] = zmin * 0.9999f - 1e-5f;
+            keep = (c[2] - r < -m.znear) && rec[24] <= tx && rec[25] >= -tx && rec[26] <= ty && rec[27] >= -ty;
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (keep) {
+            const int k = base + __popcll(bal & ((1ull << lane) - 1ull));
+#pragma unroll
+            for (int q = 0; q < REC_W; q++) out[k * REC_W + q] = rec[q];
+            keys[k] = rec[23];
+        }
+        base += __popcll(bal);
+    }
+    if (lane == 0) counts[(size_t)env * ncam_sel + cs] = base;
+    __syncthreads();
+    // front-to-back order by rank sort on the nearest depth (ties by index)
+    int* ord = order + ((size_t)env * ncam_sel + cs) * m.ngeom;
+    for (int i = lane; i < base; i += 64) {
+        const float ki = keys[i];
+        int rank = 0;
+        for (int j = 0; j < base; j++) { const float kj = keys[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
+        ord[rank] = i;
+    }
+    // faces of the kept hulls in camera-ray form: for the ray (x, y, -1) t through the camera, n.v = a x + b y - c and the
+    // crossing is t = no / n.v with no = d - n.o_l.  One face per lane; the record's plane address becomes the offset here.
+    float* tp = tplanes + ((size_t)env * ncam_sel + cs) * m.nplane * 4;
+    int poff = 0;
+    for (int k = 0; k < base; k++) {
+        const float* rk = out + k * REC_W;
+        if (__float_as_int(rk[19]) != 7) continue;
+        const int adr = __float_as_int(rk[20]), np = __float_as_int(rk[21]);
+        for (int p = lane; p < np; p += 64) {
+            const float* n = m.hull_plane + 4 * (size_t)(adr + p);
+            float4 q;
+            q.x = n[0] * rk[3] + n[1] * rk[6] + n[2] * rk[9];
+            q.y = n[0] * rk[4] + n[1] * rk[7] + n[2] * rk[10];
+            q.z = n[0] * rk[5] + n[1] * rk[8] + n[2] * rk[11];
+            q.w = n[3] - (n[0] * rk[0] + n[1] * rk[1] + n[2] * rk[2]);
+            reinterpret_cast<float4*>(tp)[poff + p] = q;
+        }
+        if (lane == 0) out[k * REC_W + 20] = __int_as_float(poff);
+        poff += np;
+    }
+}
+
+// max over the 64 lanes, broadcast: DPP butterflies inside each row of 16, then four v_readlane
+__device__ inline float wave_max(float x) {
+#define AVS_DPP_MAX(ctrl) x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false)))
+    AVS_DPP_MAX(0xB1);    // quad_perm [1,0,3,2]
+    AVS_DPP_MAX(0x4E);    // quad_perm [2,3,0,1]
+    AVS_DPP_MAX(0x141);   // row_half_mirror
+    AVS_DPP_MAX(0x140);   // row_mirror
+#undef AVS_DPP_MAX
+    const int xi = __builtin_bit_cast(int, x);
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)), b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)), d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+// parametric interval of the ray t * v from origin o (geom frame) inside the convex geom; v differs per pixel
+__device__ inline bool ray_prim(int type, const float* sz, const float* o, const float* v, float* t0) {
+    float lo = -1e30f, hi = 1e30f;
+    if (type == 2) {   // sphere
+        const float a = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], b = o[0] * v[0] + o[1] * v[1] + o[2] * v[2];
+        const float c = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] - sz[0] * sz[0], disc = b * b - a * c;
+        if (disc < 0) return false;
+        const float s = sqrtf(disc), ia = 1.0f / a;
+        lo = (-b - s) * ia; hi = (-b + s) * ia;
+    } else if (type == 6) {   // box
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (v[k] == 0) { if (fabsf(o[k]) > sz[k]) return false; continue; }
+            const float iv = 1.0f / v[k];
+            float ta = (-sz[k] - o[k]) * iv, tb = (sz[k] - o[k]) * iv;
+            if (ta > tb) { const float t = ta; ta = tb; tb = t; }
+            lo = fmaxf(lo, ta); hi = fminf(hi, tb);
+        }
+    } else {   // cylinder: axis z, radius sz[0], half height sz[1]
+        const float a = v[0] * v[0] + v[1] * v[1], b = o[0] * v[0] + o[1] * v[1], c = o[0] * o[0] + o[1] * o[1] - sz[0] * sz[0];
+        if (a > 0) {
+            const float disc = b * b - a * c;
+            if (disc < 0) return false;
+            const float s = sqrtf(disc), ia = 1.0f / a;
+            lo = (-b - s) * ia; hi = (-b + s) * ia;
+        } else if (c > 0) return false;
+        if (v[2] == 0) { if (fabsf(o[2]) > sz[1]) return false; }
+        else {
+            const float iv = 1.0f / v[2];
+            float ta = (-sz[1] - o[2]) * iv, tb = (sz[1] - o[2]) * iv;
+            if (ta > tb) { const float t = ta; ta = tb; tb = t; }
+            lo = fmaxf(lo, ta); hi = fminf(hi, tb);
+        }
+    }
+    if (lo > hi) return false;
+    *t0 = lo;
+    return true;
+}
+
+// grid (tiles_x * tiles_y, ncam_sel, N), block 64: lane -> 4 pixels (x0 .. x0+3, y)
+__global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ recs, const int* __restrict__ counts, const int* __restrict__ order,
+                                                     const float4* __restrict__ tplanes, int nplane,
+                                                     const float* __restrict__ cam_fovy, const int* __restrict__ cam_ids, int ncam_sel, int ngeom, int H,
+                                                     int W, float znear, float zfar, float* __restrict__ out) {
+    const int lane = threadIdx.x, cs = blockIdx.y, env = blockIdx.z;
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tx0 = (blockIdx.x % tiles_x) * TILE_W, ty0 = (blockIdx.x / tiles_x) * TILE_H;
+    const int px = tx0 + 4 * (lane & 7), py = ty0 + (lane >> 3);
+    const float scale = 2.0f * tanf(0.5f * cam_fovy[cam_ids[cs]] * 0.017453292519943295f) / (float)H;
+    const float* R = recs + ((size_t)env * ncam_sel + cs) * ngeom * REC_W;
+    const int cnt = counts[(size_t)env * ncam_sel + cs];
+    const int* ord = order + ((size_t)env * ncam_sel + cs) * ngeom;
+    // tile pyramid: x in [xl, xr], y in [yb, yt] at z = -1
+    const int x1 = tx0 + TILE_W < W ? tx0 + TILE_W : W, y1 = ty0 + TILE_H < H ? ty0 + TILE_H : H;
+    const float xl = (tx0 - 0.5f * W) * scale, xr = (x1 - 0.5f * W) * scale, yt = -(ty0 - 0.5f * H) * scale, yb = -(y1 - 0.5f * H) * scale;
+    const float dy = -(py + 0.5f - 0.5f * H) * scale;
+    float dx[4], best[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { dx[q] = (px + q + 0.5f - 0.5f * W) * scale; best[q] = (px + q < W && py < H) ? zfar : 0.0f; }
+    float far = zfar;    // farthest current depth over the tile's pixels (off-image pixels count as 0)
+    for (int k0 = 0; k0 < cnt; k0 += 64) {
+        bool hit = false;
+        int mine = 0;
+        if (k0 + lane < cnt) {
+            mine = ord[k0 + lane];
+            const float* bb = R + (size_t)mine * REC_W + 24;
+            hit = bb[0] <= xr && bb[1] >= xl && bb[2] <= yt && bb[3] >= yb;
+        }
+        unsigned long long mask = __ballot(hit);
+        while (mask) {
+            const int pos = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int k = __builtin_amdgcn_readlane(mine, pos);
+            const float* rec = R + (size_t)k * REC_W;    // wave-uniform: scalar loads
+            // front to back: nothing behind this geom's nearest vertex can win once every pixel of the tile is nearer
+            if (rec[23] >= far) { mask = 0; k0 = cnt; break; }
+            const float o[3] = {rec[0], rec[1], rec[2]};
+            const int type = __float_as_int(rec[19]);
+            if (type == 7) {
+                // separating face: one hull plane per lane; the tile's pyramid misses the hull if the camera and all four
+                // corner rays are on the outer side of some face (tight for the long frame bars that cross the camera plane)
+                const float4* P = tplanes + ((size_t)env * ncam_sel + cs) * nplane + __float_as_int(rec[20]);
+                const int np = __float_as_int(rec[21]);
+                bool sep = false;
+                for (int p = lane; p < np; p += 64) {
+                    const float4 f = P[p];
+                    sep = sep || (f.w < 0 && f.x * xl + f.y * yt - f.z >= 0 && f.x * xr + f.y * yt - f.z >= 0 && f.x * xl + f.y * yb - f.z >= 0 &&
+                                  f.x * xr + f.y * yb - f.z >= 0);
+                }
+                if (__any(sep)) continue;
+            }
+            if (type == 7) {
+                const float4* P = tplanes + ((size_t)env * ncam_sel + cs) * nplane + __float_as_int(rec[20]);
+                const int np = __float_as_int(rec[21]);
+                // the camera is outside a face iff no < 0 (wave-uniform).  Pass 1, faces seen from outside: the entry is the
+                // largest crossing, a ray that does not approach such a face misses.  Pass 2, the other faces: the entry
+                // point must lie behind them (lo * n.v <= no; no division).
+                float lo[4];
+                bool ok[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { lo[q] = -1e30f; ok[q] = true; }
+                for (int p = 0; p < np; p++) {
+                    const float4 f = P[p];
+                    if (!(f.w < 0)) continue;
+                    const float nb = f.y * dy - f.z;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float nv = nb + f.x * dx[q];
+                        const float t = f.w * __builtin_amdgcn_rcpf(nv);
+                        ok[q] = ok[q] && nv < 0;
+                        lo[q] = fmaxf(lo[q], t);
+                    }
+                }
+                for (int p = 0; p < np; p++) {
+                    const float4 f = P[p];
+                    if (f.w < 0) continue;
+                    const float nb = f.y * dy - f.z;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) ok[q] = ok[q] && lo[q] * (nb + f.x * dx[q]) <= f.w;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (ok[q] && lo[q] >= znear && lo[q] < best[q]) best[q] = lo[q];
+                far = wave_max(fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3])));
+            } else {
+                // direction in the geom frame: A (dx, dy, -1)
+                float vb[3], va[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) { va[i] = rec[3 + 3 * i]; vb[i] = rec[3 + 3 * i + 1] * dy - rec[3 + 3 * i + 2]; }
+                const float sz[3] = {rec[16], rec[17], rec[18]};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float v[3] = {vb[0] + va[0] * dx[q], vb[1] + va[1] * dx[q], vb[2] + va[2] * dx[q]};
+                    float t0;
+                    if (ray_prim(type, sz, o, v, &t0) && t0 >= znear && t0 < best[q]) best[q] = t0;
+                }
+                far = wave_max(fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3])));
+            }
+        }
+    }
+    if (py < H) {
+        float* dst = out + (((size_t)env * ncam_sel + cs) * H + py) * W + px;
+        if (px + 3 < W && (W & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(best[0], best[1], best[2], best[3]);
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (px + q < W) dst[q] = best[q];
+        }
+    }
+}
+
+// host side: float image of the geoms / cameras, scratch buffers, launches
+struct RenderHost {
+    RenderModel m{};
+    std::vector<void*> allocs;
+    float* d_xpose = nullptr;       // [N][nbody][12] body poses written by the physics kernel's forward pass
+    float* d_recs = nullptr;
+    int* d_counts = nullptr;
+    int* d_order = nullptr;
+    float* d_tplanes = nullptr;     // [N][ncam][nplane][4] hull faces in camera-ray form
+    int* d_cam_ids = nullptr;
+    size_t recs_cap = 0;
+    int N = 0;
+
+    template <typename T>
+    T* up(const std::vector<T>& v) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (v.size() ? v.size() : 1) * sizeof(T)) != hipSuccess) throw std::runtime_error("hipMalloc failed while uploading the render model");
+        if (v.size() && hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("hipMemcpy failed while uploading the render model");
+        allocs.push_back(p);
+        return (T*)p;
+    }
+    static std::vector<float> tofloat(const std::vector<double>& v) { return std::vector<float>(v.begin(), v.end()); }
+    static void quat2mat(const double* q, double* R) {
+        double w = q[0], x = q[1], y = q[2], z = q[3];
+        R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+        R[3] = 2 * (x * y + w * z); R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * (y * z - w * x);
+        R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = w * w - x * x - y * y + z * z;
+    }
+    void build(const Blob& b, int N_) {
+        N = N_;
+        m.ngeom = b.scalar("ngeom"); m.nbody = b.scalar("nbody");
+        auto cam_body = b.i("cam_body");
+        m.ncam = (int)cam_body.size();
+        m.geom_type = up(b.i("geom_type")); m.geom_body = up(b.i("geom_body")); m.geom_hplane = up(b.i("geom_hplane")); m.geom_hull = up(b.i("geom_hull"));
+        m.geom_visible = up(b.i("geom_visible")); m.cam_body = up(cam_body);
+        auto gq = b.f("geom_quat"), cq = b.f("cam_quat");
+        std::vector<double> gm(9 * m.ngeom), cm(9 * m.ncam);
+        for (int g = 0; g < m.ngeom; g++) quat2mat(&gq[4 * g], &gm[9 * g]);
+        for (int c = 0; c < m.ncam; c++) quat2mat(&cq[4 * c], &cm[9 * c]);
+        m.geom_pos = up(tofloat(b.f("geom_pos"))); m.geom_mat = up(tofloat(gm)); m.geom_size = up(tofloat(b.f("geom_size")));
+        m.geom_bcen = up(tofloat(b.f("geom_bcenter"))); m.geom_rbound = up(tofloat(b.f("geom_rbound")));
+        {   // capacity of one camera's face list: every visible mesh geom brings its own copy (geoms share hulls)
+            auto hp = b.i("geom_hplane"); auto gt = b.i("geom_type"); auto gv = b.i("geom_visible");
+            m.nplane = 0;
+            for (int g = 0; g < m.ngeom; g++) if (gt[g] == 7 && gv[g]) m.nplane += hp[2 * g + 1];
+        }
+        m.hull_plane = up(tofloat(b.f("hull_plane"))); m.hull_vert = up(tofloat(b.f("hull_vert"))); m.cam_pos = up(tofloat(b.f("cam_pos"))); m.cam_mat = up(tofloat(cm));
+        m.cam_fovy = up(tofloat(b.f("cam_fovy")));
+        auto clip = b.f("cam_clip");
+        m.znear = (float)clip[0]; m.zfar = (float)clip[1];
+        d_xpose = up(std::vector<float>((size_t)N * m.nbody * 12, 0.0f));
+    }
+    void destroy() {
+        for (void* p : allocs) (void)hipFree(p);
+        allocs.clear();
+        if (d_recs) (void)hipFree(d_recs);
+        if (d_counts) (void)hipFree(d_counts);
+        if (d_order) (void)hipFree(d_order);
+        if (d_tplanes) (void)hipFree(d_tplanes);
+        if (d_cam_ids) (void)hipFree(d_cam_ids);
+        d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; d_cam_ids = nullptr; recs_cap = 0;
+    }
+    // d_out: device float[N][ncam_sel][H][W]; body poses must already be in d_xpose (same stream)
+    int launch(hipStream_t st, const int* cam_ids_host, int ncam_sel, int H, int W, float* d_out, std::string& err) {
+        if (ncam_sel < 1 || ncam_sel > 16 || H < 1 || W < 1 || H > 4096 || W > 4096) { err = "avsim_render_depth: bad camera count or image size"; return -1; }
+        for (int c = 0; c < ncam_sel; c++)
+            if (cam_ids_host[c] < 0 || cam_ids_host[c] >= m.ncam) { err = "avsim_render_depth: camera index out of range"; return -1; }
+        const size_t need = (size_t)N * ncam_sel * m.ngeom * REC_W;
+        if (need > recs_cap) {
+            if (d_recs) (void)hipFree(d_recs);
+            if (d_counts) (void)hipFree(d_counts);
+            if (d_order) (void)hipFree(d_order);
+            if (d_tplanes) (void)hipFree(d_tplanes);
+            d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; recs_cap = 0;
+            if (hipMalloc((void**)&d_recs, need * sizeof(float)) != hipSuccess || hipMalloc((void**)&d_counts, (size_t)N * 16 * sizeof(int)) != hipSuccess ||
+                hipMalloc((void**)&d_order, (size_t)N * ncam_sel * m.ngeom * sizeof(int)) != hipSuccess ||
+                hipMalloc((void**)&d_tplanes, (size_t)N * ncam_sel * (m.nplane + 1) * 4 * sizeof(float)) != hipSuccess) {
+                err = "hipMalloc(render records) failed";
+                return -3;
+            }
+            recs_cap = need;
+        }
+        if (!d_cam_ids && hipMalloc((void**)&d_cam_ids, 16 * sizeof(int)) != hipSuccess) { err = "hipMalloc(camera ids) failed"; return -3; }
+        if (hipMemcpyAsync(d_cam_ids, cam_ids_host, ncam_sel * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { err = "camera id copy failed"; return -3; }
+        hipLaunchKernelGGL(k_render_geoms, dim3(ncam_sel, N), dim3(64), 0, st, m, (const float*)d_xpose, (const int*)d_cam_ids, ncam_sel, H, W, d_recs, d_counts, d_order, d_tplanes);
+        const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
+        hipLaunchKernelGGL(k_render_depth, dim3(tiles, ncam_sel, N), dim3(64), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, m.nplane, m.cam_fovy,
+                           (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, d_out);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { err = std::string("render kernel launch: ") + hipGetErrorString(e); return -3; }
+        return 0;
+    }
+};
+
+}  // namespace avs

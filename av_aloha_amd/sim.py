@@ -79,6 +79,15 @@ class BatchedSim:
         self.h.check(self.h.L.avsim_get_contacts(self.h.h, ncon.ctypes.data, pairs.ctypes.data, dist.ctypes.data))
         return ncon, pairs, dist
 
+    def render_depth(self, cameras, height, width):
+        """Depth images float32 [N, len(cameras), height, width] (metres along the optical axis) of the named cameras
+        (names from the manifest's camera table, or indices) at the current state."""
+        names = self.manifest["camera_names"]
+        ids = np.array([names.index(c) if isinstance(c, str) else int(c) for c in cameras], dtype=np.int32)
+        out = np.empty((self.N, len(ids), height, width), dtype=np.float32)
+        self.h.check(self.h.L.avsim_render_depth(self.h.h, ids.ctypes.data, len(ids), height, width, out.ctypes.data))
+        return out
+
     def diag(self):
         d = np.empty((self.N, 4), dtype=np.int32)
         self.h.check(self.h.L.avsim_get_diag(self.h.h, d.ctypes.data))

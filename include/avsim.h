@@ -106,6 +106,14 @@ int avsim_get_diag(avsim_t* h, int32_t* diag);
  * init / gradient / Hessian / factorisation / line search / final forces / noslip cycles, one spare */
 int avsim_get_phase_cycles(avsim_t* h, int64_t* out);
 
+/* Replaces the camera part of get_obs / render (gym_guided_vision/gym_guided_vision/env.py:180-188, :195-200; MuJoCo OpenGL
+ * renderer) by depth images (BASELINE config 5): out = float32[N][ncam][height][width], metres along the optical axis of
+ * camera cam_ids[c] (index into the model's camera table, manifest "camera_names"; avsim_camera_count entries), row 0 = top,
+ * pixels that see nothing = far plane (30 m).  Drawn are the collision proxies of the current state.  `out` is a host or a
+ * device pointer according to AVSIM_IO_DEVICE; cam_ids is always a host pointer. */
+int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, float* out);
+int avsim_camera_count(const avsim_t* h);
+
 /* stream / timing helpers (HIP events on the stream the kernels are launched on) */
 int avsim_sync(avsim_t* h);
 int avsim_set_stream(avsim_t* h, void* hip_stream);

@@ -62,6 +62,10 @@ typedef struct {
     const int *ik_n, *ik_qadr;
     const double *ik_w0, *ik_p0, *ik_site0, *ik_range;
     void* blob; /* owned copy */
+    /* depth render (orc_render.c): hull half-spaces, visibility, cameras */
+    int ncam;
+    const int *geom_hplane, *geom_visible, *cam_body;
+    const double *hull_plane, *cam_pos, *cam_quat, *cam_fovy, *cam_clip;
 } orc_model;
 
 typedef struct {
@@ -104,6 +108,10 @@ orc_model* orc_model_load(const void* blob, size_t nbytes);
 void orc_model_free(orc_model* m);
 orc_data* orc_data_new(const orc_model* m);
 void orc_data_free(orc_data* d);
+
+/* depth image of camera `cam` at the current state (positions must be fresh: orc_forward / orc_step): float32 metres along
+ * the optical axis, out[H][W] row 0 = top; returns the number of pixels that hit a geom */
+int orc_render_depth(const orc_data* d, int cam, int H, int W, float* out);
 
 /* env-level (env.py:203-249): reset to home pose with given object free-joint poses (nobj x 7) */
 void orc_reset(orc_data* d, const double* obj_qpos);

@@ -78,5 +78,14 @@ class OrcEnv:
         names = self.man["geom_names"]
         return [(names[c.geom1], names[c.geom2], c.dist, c.efc_adr) for c in list(self.d.contact)[: self.d.ncon]]
 
+    def render_depth(self, cam, H, W):
+        """cam: name or index into the manifest's camera table; float32 [H, W] metres along the optical axis."""
+        ci = self.man["camera_names"].index(cam) if isinstance(cam, str) else int(cam)
+        out = np.empty((H, W), dtype=np.float32)
+        self.L.orc_render_depth.restype = C.c_int
+        hits = self.L.orc_render_depth(self.dptr, ci, H, W, out.ctypes.data_as(C.c_void_p))
+        assert hits >= 0
+        return out
+
     def close(self):
         self.L.orc_data_free(self.dptr)
