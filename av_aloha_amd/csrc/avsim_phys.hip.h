@@ -1426,7 +1426,7 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(KPtr<real> ka, const real* __
         o_cpairs[((size_t)env * ka->lay.maxcon + c) * 2 + 1] = p >= 0 ? ka->m.pair_geom[2 * p + 1] : -1;
         o_cdist[(size_t)env * ka->lay.maxcon + c] = c < ncon ? (double)r[ka->lay.cdist + c] : 0.0;
     }
-    if (lane == 0) {
+    if (lane == 0 && !o_xpose) {   // the render path's pose-export pass leaves the step diagnostics alone
         o_ncon[env] = ncon;
         bool bad = false;
         for (int i = 0; i < ka->m.nq; i++) bad |= !(fabs(r[ka->lay.qpos + i]) < real(1e6));

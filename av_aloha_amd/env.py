@@ -7,8 +7,9 @@ of gym_guided_vision/gym_guided_vision/__init__.py:4-101, so callers written aga
 `num_arms`) keep working.  Physics, IK, reward and observation gathering all run in libavsim's HIP
 kernels; this file only holds host-side glue (action/observation packing, object-pose sampling).
 
-Differences a caller can see (DESIGN.md lists them): `cameras` must be empty this round (the RGB/depth
-render path is a later row of SURVEY.md section 8f); envs can be batched with `num_envs > 1`.
+Differences a caller can see (DESIGN.md lists them): RGB `pixels` observations are not built, so `cameras` must be empty;
+`render_depth()` returns float32 depth images of the same cameras instead (BASELINE config 5); envs can be batched with
+`num_envs > 1`.
 """
 from __future__ import annotations
 
@@ -99,7 +100,8 @@ class GuidedVisionEnv(_EnvBase):
         assert all([camera in CAMERAS for camera in cameras]), f"Invalid camera names: {cameras}"
         if len(cameras) != 0:
             raise NotImplementedError(
-                "camera observations are not built yet (SURVEY.md 8f: render path); construct the env with cameras=[]")
+                "RGB camera observations are not built (SURVEY.md 8f rank 3); construct the env with cameras=[] and use "
+                "render_depth(cameras, height, width) for depth images of the same cameras")
         if self.task is None:
             raise NotImplementedError("use one of the task classes or make_sim_env()")
         self.cameras = list(cameras)
@@ -177,7 +179,17 @@ class GuidedVisionEnv(_EnvBase):
         self._refresh_agent_pos()
 
     def render(self):
-        raise NotImplementedError("render(): the render path is a later row of SURVEY.md section 8f")
+        raise NotImplementedError("render(): RGB rendering is a later row of SURVEY.md section 8f; see render_depth()")
+
+    def render_depth(self, cameras=("zed_cam_left", "zed_cam_right", "wrist_cam_left", "wrist_cam_right"), height=None, width=None):
+        """Depth images (float32 metres along the optical axis, far plane 30 m) of the named cameras at the current state:
+        {camera: [H, W]} for one env, {camera: [num_envs, H, W]} for a batch.  Stands where the reference's get_obs renders
+        `pixels` (env.py:180-188); sizes default to observation_height x observation_width."""
+        assert all(c in CAMERAS for c in cameras), f"Invalid camera names: {cameras}"
+        h = self.observation_height if height is None else height
+        w = self.observation_width if width is None else width
+        img = self.sim.render_depth(list(cameras), h, w)
+        return {c: self._squeeze(img[:, i]) for i, c in enumerate(cameras)}
 
     def hide_middle_arm(self):
         raise NotImplementedError("choose num_arms at construction (2-arm models carry the hidden middle arm, env.py:394-395)")
