@@ -157,3 +157,40 @@ def test_newton_f64_parity_other_tasks(task):
         np.testing.assert_allclose(qpos[0], ref[t][0], atol=1e-8, err_msg=f"{task} qpos step {t}")
         assert rw[0] == ref[t][3]
     sim.close()
+
+
+def test_staged_rewards_and_success_match_the_oracle():
+    """Non-zero rewards on the device: the stick laid across the slot (reward 3: stick-slot contact, not on the table,
+    env.py:583-584) and the stick dropped into the slot so that the pin boxes overlap (reward 4 = max_reward -> is_success,
+    env.py:585-586, :224), each stepped on the device and in the oracle from the same set_qpos state."""
+    md = model_dict()
+    home = md["qpos_home"].copy()
+    a = home_action(md).astype(np.float32).astype(np.float64)
+    cases = {"across": ([0.0, 0.12, 0.0], [0.0, 0.12, 0.0401]), "inserted": ([0.0, 0.12, 0.0], [0.0, 0.12, 0.0005])}
+    sim = make(N=2, solver=1)
+    assert sim.max_reward == 4
+    orcs = []
+    q = np.repeat(home[None], 2, 0)
+    for k, (slot, stick) in enumerate(cases.values()):
+        q[k, 23:26] = slot
+        q[k, 30:33] = stick
+        if k == 0:
+            q[k, 33:37] = [np.sqrt(0.5), 0.0, 0.0, np.sqrt(0.5)]     # turned 90 deg about z: bridges the two slot walls
+        e = OrcEnv("slot_insertion", 3)
+        e.d.solver = 1
+        e.reset(OBJ)
+        e.L.orc_set_qpos(e.dptr, q[k].ctypes.data_as(__import__("ctypes").c_void_p))
+        orcs.append(e)
+    sim.reset(np.repeat(OBJ[None], 2, 0))
+    sim.set_qpos(q)
+    seen = set()
+    for t in range(6):
+        ap, rw, su = sim.step(np.repeat(a[None], 2, 0))
+        for k, e in enumerate(orcs):
+            apo, ro, so = e.env_step(a)
+            assert rw[k] == ro and bool(su[k]) == so, (t, k, rw[k], ro)
+            seen.add((k, int(rw[k]), bool(su[k])))
+    assert (0, 3, False) in seen and (1, 4, True) in seen, seen
+    for e in orcs:
+        e.close()
+    sim.close()
