@@ -106,3 +106,13 @@ def test_single_process_gather_is_identity():
     assert shard_ids(1, 4, 8).tolist() == list(range(8, 16))
     r, s = gather_episode_stats(torch.arange(5, dtype=torch.float32), torch.tensor([0, 1, 0, 1, 1]))
     assert r.tolist() == [0, 1, 2, 3, 4] and s.tolist() == [0, 1, 0, 1, 1]
+
+
+def test_mat2quat_host_port_matches_the_reference_vectors():
+    """av_aloha_amd.sim_env.mat2quat_xyzw (used for the obs 'poses' of the Cartesian env) vs the vectors produced by the
+    reference's transform_utils.mat2quat (tests/golden/so3_helpers.npz, gen_golden.py:96)."""
+    import os
+    from av_aloha_amd.sim_env import mat2quat_xyzw
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "so3_helpers.npz"))
+    q = mat2quat_xyzw(g["quat2mat"])
+    assert np.abs(q - g["mat2quat"]).max() < 1e-12
