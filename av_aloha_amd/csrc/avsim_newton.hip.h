@@ -60,7 +60,7 @@ template <typename real>
 AVS_DEV real nrow_dot(const NewtonArgs<real>& A, int i, LDS_PTR(const real) v) {
     const int ra = A.rowI[i];
     const int a0 = ra & 63, nA = (ra >> 6) & 15, b0 = (ra >> 13) & 63, nB = (ra >> 19) & 15;
-    LDS_PTR(const real) J = A.rJ + ROW_W * i;
+    LDS_PTR(const real) J = A.rJ + ROW_S * i;
     real s = 0;
 #pragma unroll
     for (int k = 0; k < TREE_W; k++) {
@@ -187,10 +187,10 @@ template <typename real>
 AVS_DEV void nblock(const NewtonArgs<real>& A, int lane, int r0, int dim, bool full, const real* w, const real* c1, const real* c2, real s1, real s2) {
     const int ra = A.rowI[r0], t = lane & 15, gq = nslot_dof(ra, t);
     const int nu = ((ra >> 19) & 15) > 0 ? 4 : 2;
-    LDS_PTR(const real) J = A.rJ + ROW_W * r0;
+    LDS_PTR(const real) J = A.rJ + ROW_S * r0;
     real Jt[6], y1t = 0, y2t = 0;
 #pragma unroll
-    for (int p = 0; p < 6; p++) Jt[p] = p < dim ? J[ROW_W * p + t] : real(0);
+    for (int p = 0; p < 6; p++) Jt[p] = p < dim ? J[ROW_S * p + t] : real(0);
     if (full) {
 #pragma unroll
         for (int p = 0; p < 6; p++) { y1t += c1[p] * Jt[p]; y2t += c2[p] * Jt[p]; }
@@ -201,7 +201,7 @@ AVS_DEV void nblock(const NewtonArgs<real>& A, int lane, int r0, int dim, bool f
         const int s = (lane >> 4) + 4 * u, gp = nslot_dof(ra, s);
         real Js[6], acc = 0;
 #pragma unroll
-        for (int p = 0; p < 6; p++) Js[p] = p < dim ? J[ROW_W * p + s] : real(0);
+        for (int p = 0; p < 6; p++) Js[p] = p < dim ? J[ROW_S * p + s] : real(0);
 #pragma unroll
         for (int p = 0; p < 6; p++) acc += w[p] * Js[p] * Jt[p];
         if (full) {
@@ -228,9 +228,9 @@ AVS_DEV void nblock(const NewtonArgs<real>& A, int lane, int r0, int dim, bool f
 template <typename real, int NCH>
 AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, LDS_PTR(const real) v) {
     real cs = 0;
-    for (int i = lane; i < A.nefc; i += 64) A.rowS[8 * i + 2] = nrow_dot(A, i, v) - A.rowS[8 * i];
+    for (int i = lane; i < A.nefc; i += 64) A.rowS[RS_S * i + 2] = nrow_dot(A, i, v) - A.rowS[RS_S * i];
     NSYNC();
-    for (int i = lane; i < A.nlead; i += 64) cs += nrow_scalar_cost<real>(A.rmeta[i] & 3, A.rowS[8 * i + 2], A.rowS[8 * i + 1], A.rowS[8 * i + 5]);
+    for (int i = lane; i < A.nlead; i += 64) cs += nrow_scalar_cost<real>(A.rmeta[i] & 3, A.rowS[RS_S * i + 2], A.rowS[RS_S * i + 1], A.rowS[RS_S * i + 5]);
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         if (ch * 64 >= A.ncon) break;
@@ -238,7 +238,7 @@ AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, L
         if (c.head >= 0) {
             real jar[6], f[6], w[6], c1[6], c2[6], cc, s1, s2;
 #pragma unroll
-            for (int j = 0; j < 6; j++) jar[j] = j < c.dim ? A.rowS[8 * (c.head + j) + 2] : real(0);
+            for (int j = 0; j < 6; j++) jar[j] = j < c.dim ? A.rowS[RS_S * (c.head + j) + 2] : real(0);
             ncone(c, jar, f, &cc, w, c1, c2, &s1, &s2);
             cs += cc;
         }
@@ -295,9 +295,9 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, LDS_PT
         if (c.head >= 0) {
 #pragma unroll
             for (int j = 0; j < 6; j++)
-                if (j < c.dim) { c.D[j] = real(1) / A.rowS[8 * (c.head + j) + 1]; if (j > 0) c.S[j] = real(1) / A.rowS[8 * (c.head + j) + 7]; }
+                if (j < c.dim) { c.D[j] = real(1) / A.rowS[RS_S * (c.head + j) + 1]; if (j > 0) c.S[j] = real(1) / A.rowS[RS_S * (c.head + j) + 7]; }
             if (c.dim > 1) {
-                const real R0 = A.rowS[8 * c.head + 1], R1 = A.rowS[8 * (c.head + 1) + 1];
+                const real R0 = A.rowS[RS_S * c.head + 1], R1 = A.rowS[RS_S * (c.head + 1) + 1];
                 c.mu = c.S[1] * sqrt(R1 / R0);
                 c.S[0] = c.mu;
                 c.Dm = (real(1) / R0) / tmax(real(1e-15), c.mu * c.mu * (1 + c.mu * c.mu));
@@ -320,12 +320,12 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, LDS_PT
     for (int it = 0; it < A.iters; it++) {
         used++;
         // ---- residuals, forces (-> rowS.f), curvature of the scalar rows (-> jv) ----
-        for (int i = lane; i < ne; i += 64) A.rowS[8 * i + 2] = nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[8 * i];
+        for (int i = lane; i < ne; i += 64) A.rowS[RS_S * i + 2] = nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[RS_S * i];
         NSYNC();
         for (int i = lane; i < A.nlead; i += 64) {
             real f, h;
-            nrow_scalar<real>(A.rmeta[i] & 3, A.rowS[8 * i + 2], A.rowS[8 * i + 1], A.rowS[8 * i + 5], &f, &h);
-            A.rowS[8 * i + 6] = f;
+            nrow_scalar<real>(A.rmeta[i] & 3, A.rowS[RS_S * i + 2], A.rowS[RS_S * i + 1], A.rowS[RS_S * i + 5], &f, &h);
+            A.rowS[RS_S * i + 6] = f;
             A.jv[i] = h;
         }
 #pragma unroll
@@ -336,10 +336,10 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, LDS_PT
             if (c.head >= 0) {
                 real jar[6], f[6], cc;
 #pragma unroll
-                for (int j = 0; j < 6; j++) jar[j] = j < c.dim ? A.rowS[8 * (c.head + j) + 2] : real(0);
+                for (int j = 0; j < 6; j++) jar[j] = j < c.dim ? A.rowS[RS_S * (c.head + j) + 2] : real(0);
                 zone[ch] = ncone(c, jar, f, &cc, cw[ch], cc1[ch], cc2[ch], &cs1[ch], &cs2[ch]);
 #pragma unroll
-                for (int j = 0; j < 6; j++) if (j < c.dim) A.rowS[8 * (c.head + j) + 6] = f[j];
+                for (int j = 0; j < 6; j++) if (j < c.dim) A.rowS[RS_S * (c.head + j) + 6] = f[j];
             }
         }
         // ---- gradient g = M (a - a_s) - J^T f ----
@@ -351,10 +351,10 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, LDS_PT
         }
         NSYNC();
         for (int i = lane; i < ne; i += 64) {
-            const real f = A.rowS[8 * i + 6];
+            const real f = A.rowS[RS_S * i + 6];
             if (f == 0) continue;
             const int ra = A.rowI[i];
-            LDS_PTR(const real) J = A.rJ + ROW_W * i;
+            LDS_PTR(const real) J = A.rJ + ROW_S * i;
 #pragma unroll
             for (int s = 0; s < ROW_W; s++) {
                 const int dof = nslot_dof(ra, s);
@@ -469,7 +469,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, LDS_PT
 #pragma unroll
             for (int j = 0; j < 6; j++) {
                 const bool on = con[ch].head >= 0 && j < con[ch].dim;
-                cj0[ch][j] = on ? A.rowS[8 * (con[ch].head + j) + 2] : real(0);
+                cj0[ch][j] = on ? A.rowS[RS_S * (con[ch].head + j) + 2] : real(0);
                 cjv[ch][j] = on ? A.jv[con[ch].head + j] : real(0);
             }
         real alpha = 0, lo = 0, hi = -1, dphi0 = 0;
@@ -478,7 +478,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, LDS_PT
             for (int i = lane; i < A.nlead; i += 64) {
                 real f, h;
                 const real jvi = A.jv[i];
-                nrow_scalar<real>(A.rmeta[i] & 3, A.rowS[8 * i + 2] + alpha * jvi, A.rowS[8 * i + 1], A.rowS[8 * i + 5], &f, &h);
+                nrow_scalar<real>(A.rmeta[i] & 3, A.rowS[RS_S * i + 2] + alpha * jvi, A.rowS[RS_S * i + 1], A.rowS[RS_S * i + 5], &f, &h);
                 gsum -= f * jvi;
                 hsum += h * jvi * jvi;
             }
@@ -518,12 +518,12 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, LDS_PT
         if (sqrt(st2) * A.scale < real(1e-2) * A.tol) break;
     }
     // ---- forces at the solution ----
-    for (int i = lane; i < ne; i += 64) A.rowS[8 * i + 2] = nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[8 * i];
+    for (int i = lane; i < ne; i += 64) A.rowS[RS_S * i + 2] = nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[RS_S * i];
     NSYNC();
     for (int i = lane; i < A.nlead; i += 64) {
         real f, h;
-        nrow_scalar<real>(A.rmeta[i] & 3, A.rowS[8 * i + 2], A.rowS[8 * i + 1], A.rowS[8 * i + 5], &f, &h);
-        A.rowS[8 * i + 6] = f;
+        nrow_scalar<real>(A.rmeta[i] & 3, A.rowS[RS_S * i + 2], A.rowS[RS_S * i + 1], A.rowS[RS_S * i + 5], &f, &h);
+        A.rowS[RS_S * i + 6] = f;
     }
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
@@ -532,10 +532,10 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, LDS_PT
         if (c.head >= 0) {
             real jar[6], f[6], w[6], c1[6], c2[6], cc, s1, s2;
 #pragma unroll
-            for (int j = 0; j < 6; j++) jar[j] = j < c.dim ? A.rowS[8 * (c.head + j) + 2] : real(0);
+            for (int j = 0; j < 6; j++) jar[j] = j < c.dim ? A.rowS[RS_S * (c.head + j) + 2] : real(0);
             ncone(c, jar, f, &cc, w, c1, c2, &s1, &s2);
 #pragma unroll
-            for (int j = 0; j < 6; j++) if (j < c.dim) A.rowS[8 * (c.head + j) + 6] = f[j];
+            for (int j = 0; j < 6; j++) if (j < c.dim) A.rowS[RS_S * (c.head + j) + 6] = f[j];
         }
     }
     NSYNC();

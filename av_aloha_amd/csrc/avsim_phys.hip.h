@@ -28,6 +28,10 @@ enum { J_FREE = 0, J_BALL = 1, J_SLIDE = 2, J_HINGE = 3 };
 enum { R_EQ = 0, R_FLOSS = 1, R_LIMIT = 2, R_CONTACT = 3 };
 constexpr int TREE_W = 8;     // max dofs of one kinematic tree (8, 8, 7, 6, 6 here)
 constexpr int ROW_W = 2 * TREE_W;
+// LDS strides of the per-row records: odd, so that the row-per-lane loops (lane i reads word k of row i) spread over all 32
+// banks instead of hammering 2 (stride 16) or 4 (stride 8) of them
+constexpr int ROW_S = ROW_W + 1;   // Jacobian row: 16 words used
+constexpr int RS_S = 9;            // solver record: 8 words used
 constexpr int CAND_MAX = 64;   // exact broad-phase survivors per substep (narrow-phase work list)
 constexpr int NEAR_MAX = 192;  // Verlet neighbour list: pairs within reach + skin, rebuilt when a geom moved > skin/2
 
@@ -263,19 +267,19 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         const int row0 = start + d, row1 = start + 4 + d;
         const int adr0 = ((ra0 >> sh) & 63) + k8, adr1 = ((ra1 >> sh) & 63) + k8;
         const bool in0 = d < cnt && k8 < ((ra0 >> (sh + 6)) & 15), in1 = 4 + d < cnt && k8 < ((ra1 >> (sh + 6)) & 15);
-        const real J0 = rJ[ROW_W * row0 + l16], q0 = q[in0 ? adr0 : 0];
-        const real J1 = rJ[ROW_W * row1 + l16], q1 = q[in1 ? adr1 : 0];
+        const real J0 = rJ[ROW_S * row0 + l16], q0 = q[in0 ? adr0 : 0];
+        const real J1 = rJ[ROW_S * row1 + l16], q1 = q[in1 ? adr1 : 0];
         real B0 = 0, B1 = 0;
         {
             LDS_PTR(const real) Mi0 = Minv + 64 * ((ra0 >> (sh + 10)) & 7) + 8 * k8;
             LDS_PTR(const real) Mi1 = Minv + 64 * ((ra1 >> (sh + 10)) & 7) + 8 * k8;
-            LDS_PTR(const real) Jw0 = rJ + ROW_W * row0 + w8;
-            LDS_PTR(const real) Jw1 = rJ + ROW_W * row1 + w8;
+            LDS_PTR(const real) Jw0 = rJ + ROW_S * row0 + w8;
+            LDS_PTR(const real) Jw1 = rJ + ROW_S * row1 + w8;
 #pragma unroll
             for (int j = 0; j < TREE_W; j++) { B0 += Mi0[j] * Jw0[j]; B1 += Mi1[j] * Jw1[j]; }
         }
         const bool mine = lane < cnt;
-        LDS_PTR(real) S = rowS + 8 * (start + (mine ? lane : 0));
+        LDS_PTR(real) S = rowS + RS_S * (start + (mine ? lane : 0));
         const real aref = S[0], R = S[1], inv2 = S[2], inv3 = S[3], lo = S[4], hi = S[5], f0 = S[6], muinv = S[7];
         real a[GRP_MAX - 1];
 #pragma unroll
@@ -1093,7 +1097,7 @@ struct Env {
                 dg += J[k] * sa + J[TREE_W + k] * sb;
             }
 #pragma unroll
-            for (int k = 0; k < ROW_W; k++) rJ[ROW_W * i + k] = J[k];
+            for (int k = 0; k < ROW_W; k++) rJ[ROW_S * i + k] = J[k];
             // warm start: force implied by last step's acceleration, f = -D (J qacc_ws - aref), made feasible per row
             const int a0 = tree_dofadr_()[tA], nA = tree_dofnum_()[tA], b0 = tB >= 0 ? tree_dofadr_()[tB] : 0, nB = tB >= 0 ? tree_dofnum_()[tB] : 0;
             real jw = 0;
@@ -1113,7 +1117,7 @@ struct Env {
             }
             real f = -(jw - aref) / R;
             f = tmin(tmax(f, lo), hi);
-            real* S = rowS + 8 * i;
+            real* S = rowS + RS_S * i;
             S[0] = aref; S[1] = R; S[2] = real(1) / (dg + R); S[3] = ns ? real(1) / tmax(dg, real(1e-15)) : real(0);
             S[4] = lo; S[5] = hi; S[6] = f; S[7] = muinv;
             rowI[i] = a0 | (nA << 6) | (tA << 10) | ((b0 | (nB << 6) | ((tB >= 0 ? tB : 0) << 10)) << 13);
@@ -1158,8 +1162,8 @@ struct Env {
                         if (((rs >> (13 * ws + 6)) & 15) == 0 || ((rs >> (13 * ws + 10)) & 7) != tr) continue;
                         for (int k = 0; k < TREE_W; k++) {
                             real t = 0;
-                            for (int j = 0; j < TREE_W; j++) t += Minv[64 * tr + 8 * k + j] * rJ[ROW_W * is + TREE_W * ws + j];
-                            v += rJ[ROW_W * ir + TREE_W * wr + k] * t;
+                            for (int j = 0; j < TREE_W; j++) t += Minv[64 * tr + 8 * k + j] * rJ[ROW_S * is + TREE_W * ws + j];
+                            v += rJ[ROW_S * ir + TREE_W * wr + k] * t;
                         }
                     }
                 }
@@ -1196,9 +1200,9 @@ struct Env {
             int first = cefc[c];
             if (first < 0) continue;
             int dim = ka->m.pair_condim[(ii + ka->lay.cpair)[c]];
-            real fn = rowS[8 * first + 6], s2 = 0;
-            for (int s = 1; s < dim; s++) { real t = rowS[8 * (first + s) + 6] * rowS[8 * (first + s) + 7]; s2 += t * t; }
-            if (s2 > fn * fn) { real sc = fn / sqrt(s2); for (int s = 1; s < dim; s++) rowS[8 * (first + s) + 6] *= sc; }
+            real fn = rowS[RS_S * first + 6], s2 = 0;
+            for (int s = 1; s < dim; s++) { real t = rowS[RS_S * (first + s) + 6] * rowS[RS_S * (first + s) + 7]; s2 += t * t; }
+            if (s2 > fn * fn) { real sc = fn / sqrt(s2); for (int s = 1; s < dim; s++) rowS[RS_S * (first + s) + 6] *= sc; }
         }
         GSYNC();
         // qacc = qacc_smooth + M^-1 J^T f : generalized force per dof first, then the per-tree inverse
@@ -1227,13 +1231,13 @@ struct Env {
         for (int k = lane; k < ka->m.nv; k += G) out[k] = 0;
         GSYNC();
         for (int i = lane; i < nefc; i += G) {
-            const real f = rowS[8 * i + 6];
+            const real f = rowS[RS_S * i + 6];
             if (f == 0) continue;
             const int ra = rowI[i];
 #pragma unroll
             for (int s = 0; s < ROW_W; s++) {
                 const int dof = nslot_dof(ra, s);
-                if (dof >= 0) __hip_atomic_fetch_add(out + dof, rJ[ROW_W * i + s] * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (dof >= 0) __hip_atomic_fetch_add(out + dof, rJ[ROW_S * i + s] * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         GSYNC();
@@ -1657,8 +1661,8 @@ struct PhysHost {
         L.cinert = a; a += 10 * nb; L.cvel = a; a += 6 * nb; L.cacc = a; a += 6 * nb; L.cfrc = a; a += 6 * nb;
         int bq = o;
         L.cdist = bq; bq += maxcon; L.cpos = bq; bq += 3 * maxcon; L.cnrm = bq; bq += 3 * maxcon;
-        bq = (bq + 3) & ~3; L.rJ = bq; bq += ROW_W * maxefc;
-        bq = (bq + 3) & ~3; L.rowS = bq; bq += 8 * maxefc;
+        bq = (bq + 3) & ~3; L.rJ = bq; bq += ROW_S * maxefc;
+        bq = (bq + 3) & ~3; L.rowS = bq; bq += RS_S * maxefc;
         L.maxgrp = maxefc / 3 + 8; L.gA = bq; bq += 16 * L.maxgrp;
         o = a > bq ? a : bq;
         L.nreal = (o + 3) & ~3;
@@ -1725,7 +1729,7 @@ struct PhysHost {
         if (n == "newton_iters") { if (v < 1 || v > 100) return false; mf.newton_iters = md.newton_iters = (int)v; return true; }
         if (n == "newton_tol") { if (v < 0) return false; mf.newton_tol = (float)v; md.newton_tol = v; return true; }
         if (n == "export_contacts") { export_contacts = v != 0; return true; }
-        if (n == "waves_per_block") { int x = (int)v; if (x == 0 || x == 1 || x == 2 || x == 4) { wpb_override = x; return true; } return false; }
+        if (n == "waves_per_block") { int x = (int)v; if (x >= 0 && x <= 6) { wpb_override = x; return true; } return false; }
         if (n == "profile_phases") {
             if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * 18, 0));
             if (v == 0) d_prof = nullptr;
@@ -1783,7 +1787,10 @@ struct PhysHost {
         size_t tables = (size_t)moff.nreal * 4 + (size_t)moff.nint * 4;
         int wpb = (int)((160 * 1024 - tables) / (size_t)lay.bytes_per_env);
         if (wpb_override > 0) wpb = wpb_override;
+        if (wpb >= 6) return launch_t<float, 64, 6>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
+        if (wpb >= 5) return launch_t<float, 64, 5>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
         if (wpb >= 4) return launch_t<float, 64, 4>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
+        if (wpb >= 3) return launch_t<float, 64, 3>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
         if (wpb >= 2) return launch_t<float, 64, 2>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
         return launch_t<float, 64, 1>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
     }
