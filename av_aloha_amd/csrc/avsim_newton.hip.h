@@ -33,7 +33,7 @@ struct NewtonArgs {
     LDS_PTR(real) rowS;          // 8 reals per row: aref, R, [Newton: J a - aref], 1/diag|0, lo, hi, force, 1/friction
     LDS_PTR(const int) rowI;     // dof windows of the row: (adr 6 | n 4 | tree 3) x 2
     LDS_PTR(const int) rmeta;    // type 2 | id 10 | sub 8 | tree ids
-    LDS_PTR(const real) rJ;      // 16 reals per row
+    const real* rJ;              // 16 reals per row, global memory (L2-resident scratch of this env)
     LDS_PTR(const real) M;       // per-tree dense blocks
     LDS_PTR(real) a;             // qacc (in: start point, out: solution)
     LDS_PTR(const real) as;      // qacc_smooth
@@ -60,7 +60,7 @@ template <typename real>
 AVS_DEV real nrow_dot(const NewtonArgs<real>& A, int i, LDS_PTR(const real) v) {
     const int ra = A.rowI[i];
     const int a0 = ra & 63, nA = (ra >> 6) & 15, b0 = (ra >> 13) & 63, nB = (ra >> 19) & 15;
-    LDS_PTR(const real) J = A.rJ + ROW_S * i;
+    const real* J = A.rJ + ROW_S * i;
     real s = 0;
 #pragma unroll
     for (int k = 0; k < TREE_W; k++) {
@@ -187,7 +187,7 @@ template <typename real>
 AVS_DEV void nblock(const NewtonArgs<real>& A, int lane, int r0, int dim, bool full, const real* w, const real* c1, const real* c2, real s1, real s2) {
     const int ra = A.rowI[r0], t = lane & 15, gq = nslot_dof(ra, t);
     const int nu = ((ra >> 19) & 15) > 0 ? 4 : 2;
-    LDS_PTR(const real) J = A.rJ + ROW_S * r0;
+    const real* J = A.rJ + ROW_S * r0;
     real Jt[6], y1t = 0, y2t = 0;
 #pragma unroll
     for (int p = 0; p < 6; p++) Jt[p] = p < dim ? J[ROW_S * p + t] : real(0);
@@ -255,7 +255,7 @@ AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, L
 // r / ii: the env's real and int LDS regions, li: the block's hot-table image; everything else comes from the layout
 // NCH = contact chunks of 64 (one contact per lane and chunk): 1 when the model's contact cap is <= 64
 template <typename real, int NCH>
-__device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, LDS_PTR(real) r_, LDS_PTR(int) ii_, LDS_PTR(const int) li_, int nefc, int ncon, int nlead,
+__device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, const real* rows, LDS_PTR(real) r_, LDS_PTR(int) ii_, LDS_PTR(const int) li_, int nefc, int ncon, int nlead,
                                                       int iters, real tol, real scale, int profiling) {
     const int lane = threadIdx.x & 63;
     NewtonArgs<real> A;
@@ -267,7 +267,11 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, LDS_PT
         tol = lane_get(tol, 0); scale = lane_get(scale, 0);
         const Layout __attribute__((address_space(4)))* L = &ka->lay;
         const MOff __attribute__((address_space(4)))* O = &ka->mo;
-        A.rowS = r + L->rowS; A.rowI = ii + L->rowI; A.rmeta = ii + L->rmeta; A.rJ = r + L->rJ;
+        A.rowS = r + L->rowS; A.rowI = ii + L->rowI; A.rmeta = ii + L->rmeta;
+        {   // the row pointer is wave-uniform: back to SGPRs
+            const unsigned long long p_ = (unsigned long long)rows;
+            A.rJ = (const real*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p_));
+        }
         A.M = r + L->M; A.a = r + L->qacc; A.as = r + L->asm_;
         A.H = r + L->nH; A.g = r + L->ng; A.dl = r + L->ndl; A.jv = r + L->njv;
         A.czone = ii + L->czone; A.cefc = ii + L->cefc;
@@ -354,7 +358,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, LDS_PT
             const real f = A.rowS[RS_S * i + 6];
             if (f == 0) continue;
             const int ra = A.rowI[i];
-            LDS_PTR(const real) J = A.rJ + ROW_S * i;
+            const real* J = A.rJ + ROW_S * i;
 #pragma unroll
             for (int s = 0; s < ROW_W; s++) {
                 const int dof = nslot_dof(ra, s);

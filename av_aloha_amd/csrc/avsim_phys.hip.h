@@ -28,9 +28,9 @@ enum { J_FREE = 0, J_BALL = 1, J_SLIDE = 2, J_HINGE = 3 };
 enum { R_EQ = 0, R_FLOSS = 1, R_LIMIT = 2, R_CONTACT = 3 };
 constexpr int TREE_W = 8;     // max dofs of one kinematic tree (8, 8, 7, 6, 6 here)
 constexpr int ROW_W = 2 * TREE_W;
-// LDS strides of the per-row records: odd, so that the row-per-lane loops (lane i reads word k of row i) spread over all 32
-// banks instead of hammering 2 (stride 16) or 4 (stride 8) of them
-constexpr int ROW_S = ROW_W + 1;   // Jacobian row: 16 words used
+// LDS stride of the per-row solver record: odd, so that the row-per-lane loops (lane i reads word k of row i) spread over
+// all 32 banks instead of hammering 4 of them (stride 8)
+constexpr int ROW_S = ROW_W;       // Jacobian rows live in global memory (L2-resident scratch): 64-byte rows, no banks to dodge
 constexpr int RS_S = 9;            // solver record: 8 words used
 constexpr int CAND_MAX = 64;   // exact broad-phase survivors per substep (narrow-phase work list)
 constexpr int NEAR_MAX = 192;  // Verlet neighbour list: pairs within reach + skin, rebuilt when a geom moved > skin/2
@@ -62,6 +62,9 @@ struct DevModel {
     // pairs
     const int *pair_geom, *pair_condim;
     const real *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
+    // constraint Jacobian rows of every env: real[N][maxefc][16], rewritten each substep (kept out of LDS so that more envs
+    // fit on a CU; the working set of the resident envs stays in L2)
+    real* rJ_glob;
     // observation
     const int* obs_qposadr;
     const real *obs_offset, *obs_scale;
@@ -128,7 +131,7 @@ struct Layout {
     // scratch union U, phase A
     int cinert, cvel, cacc, cfrc;
     // phase B
-    int cdist, cpos, cnrm, rJ, rowS, gA;
+    int cdist, cpos, cnrm, rowS, gA, scr;   // scr: narrow-phase scratch (overlays rowS / gA, 32 lanes x 56 words)
     // ints
     int cand, nearl, cpair, cefc, rmeta, rowI, gI, czone, misc, nprof, nint;
     int maxgrp;
@@ -243,7 +246,7 @@ constexpr int GRP_MAX = 6;   // rows per Gauss-Seidel group (a condim-6 contact 
 // B = J M^-1 is not stored: each lane rebuilds its entry from the tree's dense 8x8 inverse (Minv) and the row's J window.
 // ------------------------------------------------------------------------------------------------
 template <typename real>
-__device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const real) rJ, LDS_PTR(const real) Minv,
+__device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, const real* __restrict__ rJ, LDS_PTR(const real) Minv,
                                                      LDS_PTR(real) q, LDS_PTR(const int) gI, LDS_PTR(const real) gA, int ngrp, int iters,
                                                      int noslip_iters) {
     const int lane = threadIdx.x & 63, d = lane >> 4, l16 = lane & 15, sh = l16 < TREE_W ? 0 : 13, k8 = l16 & (TREE_W - 1), w8 = l16 & TREE_W;
@@ -273,8 +276,8 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         {
             LDS_PTR(const real) Mi0 = Minv + 64 * ((ra0 >> (sh + 10)) & 7) + 8 * k8;
             LDS_PTR(const real) Mi1 = Minv + 64 * ((ra1 >> (sh + 10)) & 7) + 8 * k8;
-            LDS_PTR(const real) Jw0 = rJ + ROW_S * row0 + w8;
-            LDS_PTR(const real) Jw1 = rJ + ROW_S * row1 + w8;
+            const real* Jw0 = rJ + ROW_S * row0 + w8;
+            const real* Jw1 = rJ + ROW_S * row1 + w8;
 #pragma unroll
             for (int j = 0; j < TREE_W; j++) { B0 += Mi0[j] * Jw0[j]; B1 += Mi1[j] * Jw1[j]; }
         }
@@ -457,6 +460,7 @@ AVS_DEV int has_pair(int c1, int c2, int a, int b) { return ((c1 & a) && (c2 & b
 template <typename real, int G>
 struct Env {
     KPtr<real> ka;   // model, LDS layout and table offsets: one struct in constant memory, re-read per phase (PHASE_BEGIN)
+    int env = 0;                    // global env index (row buffer addressing)
     int nit_sum = 0, nit_max = 0;   // Newton iterations over the launch's substeps (diagnostics)
     bool profiling = false;
     real* r;  // real region of this env
@@ -468,6 +472,7 @@ struct Env {
     __device__ Env(KPtr<real> ka_, real* r_, int* i_, int lane_, int grp_, const real* lr_, const int* li_)
         : ka(ka_), r(r_), ii(i_), lane(lane_), grp(grp_), lr(lr_), li(li_) {}
     // hot model tables live in LDS (copied once per block); the accessors rebuild the pointer from the kernarg offset
+    AVS_DEV real* rows_() const { return ka->m.rJ_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
     AVS_DEV const int* body_parent_() const { return li + ka->mo.body_parent; }
     AVS_DEV const int* body_jntadr_() const { return li + ka->mo.body_jntadr; }
     AVS_DEV const int* body_jntnum_() const { return li + ka->mo.body_jntnum; }
@@ -864,12 +869,13 @@ struct Env {
         real *cdist = r + ka->lay.cdist, *cpos = r + ka->lay.cpos, *cnrm = r + ka->lay.cnrm;
         int* cpair = ii + ka->lay.cpair;
         int ncon = 0, ovf = 0;
-        for (int base = 0; base < ncand; base += G) {
+        // 32 candidate pairs per pass: the per-lane LDS scratch (polygon work space + results, 56 words) overlays the solver
+        // records, which are not live during collision
+        for (int base = 0; base < ncand; base += 32) {
             int ci = base + lane, n = 0, p = 0;
-            // per-lane LDS scratch (polygon work space + results): the row storage is not live during collision
-            LDS_PTR(real) scr = (LDS_PTR(real))(r + ka->lay.rJ + 56 * lane);
+            LDS_PTR(real) scr = (LDS_PTR(real))(r + ka->lay.scr + 56 * (lane & 31));
             int keepmask = 0;
-            if (ci < ncand) {
+            if (lane < 32 && ci < ncand) {
                 p = cand[ci];
                 Shape<real> a, b;
                 load_shape(ka->m.pair_geom[2 * p], a);
@@ -977,7 +983,7 @@ struct Env {
         if (lane == 0) { misc[1] = nefc; if (ovf) misc[2] |= 2; }
         GSYNC();
         // --- fill rows (one row per lane) ---
-        real *rJ = r + ka->lay.rJ, *rowS = r + ka->lay.rowS, *warm = r + ka->lay.warm, *Minv = r + ka->lay.Minv;
+        real *rJ = rows_(), *rowS = r + ka->lay.rowS, *warm = r + ka->lay.warm, *Minv = r + ka->lay.Minv;
         int* rowI = ii + ka->lay.rowI;
         real* Lm = r + ka->lay.L;
         for (int i = lane; i < nefc; i += G) {
@@ -1177,7 +1183,7 @@ struct Env {
     __device__ void solve(int pgs_iters, int solver, int newton_iters, real newton_tol, real scale) {
         PHASE_BEGIN();
         int *misc = ii + ka->lay.misc, *rmeta = ii + ka->lay.rmeta, *cefc = ii + ka->lay.cefc, *rowI = ii + ka->lay.rowI;
-        real *qacc = r + ka->lay.qacc, *as = r + ka->lay.asm_, *rowS = r + ka->lay.rowS, *rJ = r + ka->lay.rJ, *fcon = r + ka->lay.fcon;
+        real *qacc = r + ka->lay.qacc, *as = r + ka->lay.asm_, *rowS = r + ka->lay.rowS, *rJ = rows_(), *fcon = r + ka->lay.fcon;
         int nefc = misc[1], ncon = misc[0];
         real* Minv = r + ka->lay.Minv;
         if (solver == 1) {
@@ -1186,12 +1192,12 @@ struct Env {
             for (int k = lane; k < ka->m.nv; k += G) qacc[k] = warm[k];
             GSYNC();
             int used = ka->lay.maxcon <= 64
-                ? newton_solve<real, 1>(ka, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0)
-                : newton_solve<real, 2>(ka, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0);
+                ? newton_solve<real, 1>(ka, (const real*)rJ, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0)
+                : newton_solve<real, 2>(ka, (const real*)rJ, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0);
             nit_sum += used; nit_max = used > nit_max ? used : nit_max;
             GSYNC();
             long long tn0 = profiling ? __builtin_readcyclecounter() : 0;
-            pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const real))rJ, (LDS_PTR(const real))Minv, (LDS_PTR(real))qacc,
+            pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (const real*)rJ, (LDS_PTR(const real))Minv, (LDS_PTR(real))qacc,
                              (LDS_PTR(const int))(ii + ka->lay.gI), (LDS_PTR(const real))(r + ka->lay.gA), misc[5], 0, ka->m.noslip_iters);
             if (profiling && lane == 0) (ii + ka->lay.nprof)[6] += (int)(__builtin_readcyclecounter() - tn0);
         } else {
@@ -1216,7 +1222,7 @@ struct Env {
         GSYNC();
         // Gauss-Seidel sweeps (+ noslip sweeps) in the register-resident wave kernel
         static_assert(G == 64, "the solver maps one env to one wavefront");
-        pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const real))rJ, (LDS_PTR(const real))Minv, (LDS_PTR(real))qacc,
+        pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (const real*)rJ, (LDS_PTR(const real))Minv, (LDS_PTR(real))qacc,
                          (LDS_PTR(const int))(ii + ka->lay.gI), (LDS_PTR(const real))(r + ka->lay.gA), misc[5], pgs_iters, ka->m.noslip_iters);
         }
         GSYNC();
@@ -1227,7 +1233,7 @@ struct Env {
     // out = J^T f: one row per lane, scattered over the row's two dof windows with returnless LDS atomics
     __device__ void jt_force(real* out, int nefc) {
         int* rowI = ii + ka->lay.rowI;
-        real *rowS = r + ka->lay.rowS, *rJ = r + ka->lay.rJ;
+        real *rowS = r + ka->lay.rowS, *rJ = rows_();
         for (int k = lane; k < ka->m.nv; k += G) out[k] = 0;
         GSYNC();
         for (int i = lane; i < nefc; i += G) {
@@ -1358,6 +1364,7 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(KPtr<real> ka, const real* __
     real* r = reinterpret_cast<real*>(smem + (size_t)wave * ka->lay.bytes_per_env);
     int* ii = reinterpret_cast<int*>(r + ka->lay.nreal);
     Env<real, G> E(ka, r, ii, lane, grp, lr, li);
+    E.env = env;
 
     // ---- load state (coalesced: consecutive lanes read consecutive words of this env's record) ----
     for (int i = lane; i < ka->m.nq; i += G) r[ka->lay.qpos + i] = g_qpos[(size_t)env * ka->m.nq + i];
@@ -1639,14 +1646,14 @@ struct PhysHost {
         d_img_int = up(img_int);
     }
 
-    void make_layout(int nq, int nv, int nu, int nb, int ng, int msize) {
+    void make_layout(int nq, int nv, int nu, int nb, int ng, int msize, int ntree) {
         Layout& L = lay;
         kargs_dirty = true;
         int o = 0;
         auto R = [&](int n) { int a = o; o += n; return a; };
         L.qpos = R(nq); L.qvel = R(nv); L.ctrl = R(nu); L.warm = R(nv);
         L.xpos = R(3 * nb); L.xmat = R(9 * nb); L.xipos = R(3 * nb); L.cdof = R(6 * nv); L.gcen = R(3 * ng); L.gref = R(3 * ng);
-        L.M = R(msize); L.L = R(msize); o = (o + 3) & ~3; L.Minv = R(64 * 8);
+        L.M = R(msize); L.L = R(msize); o = (o + 3) & ~3; L.Minv = R(64 * ntree);
         L.bias = R(nv); L.fsm = R(nv); L.asm_ = R(nv); L.qacc = R(nv); L.fcon = R(nv);
         // Newton scratch (packed Hessian, gradient, direction, per-row J.dl) lives over xpos..gcen where it fits: every
         // position-derived quantity is dead between make_constraints and the next substep's kinematics
@@ -1661,9 +1668,9 @@ struct PhysHost {
         L.cinert = a; a += 10 * nb; L.cvel = a; a += 6 * nb; L.cacc = a; a += 6 * nb; L.cfrc = a; a += 6 * nb;
         int bq = o;
         L.cdist = bq; bq += maxcon; L.cpos = bq; bq += 3 * maxcon; L.cnrm = bq; bq += 3 * maxcon;
-        bq = (bq + 3) & ~3; L.rJ = bq; bq += ROW_S * maxefc;
-        bq = (bq + 3) & ~3; L.rowS = bq; bq += RS_S * maxefc;
+        bq = (bq + 3) & ~3; L.rowS = bq; L.scr = bq; bq += RS_S * maxefc;
         L.maxgrp = maxefc / 3 + 8; L.gA = bq; bq += 16 * L.maxgrp;
+        if (bq < L.scr + 32 * 56) bq = L.scr + 32 * 56;
         o = a > bq ? a : bq;
         L.nreal = (o + 3) & ~3;
         int io = 0;
@@ -1676,9 +1683,15 @@ struct PhysHost {
         L.bytes_per_env = (int)((L.nreal * rs + (size_t)L.nint * 4 + 15) & ~(size_t)15);
     }
 
-    int dims[6] = {0, 0, 0, 0, 0, 0};
+    int dims[7] = {0, 0, 0, 0, 0, 0, 0};
     size_t lds_bytes() const { return (size_t)lay.bytes_per_env + (size_t)moff.nreal * (f64 ? 8 : 4) + (size_t)moff.nint * 4; }   // WPB = 1 figure
+    void* d_rows = nullptr;
     void alloc_contacts() {
+        if (d_rows) (void)hipFree(d_rows);
+        d_rows = nullptr;
+        if (hipMalloc(&d_rows, (size_t)N * maxefc * ROW_S * (f64 ? 8 : 4)) != hipSuccess) throw std::runtime_error("hipMalloc of the constraint row buffer failed");
+        mf.rJ_glob = (float*)d_rows; md.rJ_glob = (double*)d_rows;
+        kargs_dirty = true;
         if (d_cpairs) (void)hipFree(d_cpairs);
         if (d_cdist) (void)hipFree(d_cdist);
         d_cpairs = nullptr; d_cdist = nullptr;
@@ -1700,8 +1713,8 @@ struct PhysHost {
             static const int cap_efc[5] = {176, 176, 240, 336, 192}, cap_con[5] = {48, 48, 56, 72, 48};
             maxefc = cap_efc[b.scalar("task_id")];
             maxcon = cap_con[b.scalar("task_id")];
-            dims[0] = b.scalar("nq"); dims[1] = b.scalar("nv"); dims[2] = b.scalar("nu"); dims[3] = b.scalar("nbody"); dims[4] = b.scalar("ngeom"); dims[5] = ms;
-            make_layout(dims[0], dims[1], dims[2], dims[3], dims[4], dims[5]);
+            dims[0] = b.scalar("nq"); dims[1] = b.scalar("nv"); dims[2] = b.scalar("nu"); dims[3] = b.scalar("nbody"); dims[4] = b.scalar("ngeom"); dims[5] = ms; dims[6] = b.scalar("ntree");
+            make_layout(dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], dims[6]);
             d_qpos_home = up(b.f("qpos_home"));
             d_ctrl_home = up(b.f("ctrl_home"));
             d_obj_qadr = up(b.i("objects_qposadr"));
@@ -1719,7 +1732,8 @@ struct PhysHost {
         allocs.clear();
         if (d_cpairs) (void)hipFree(d_cpairs);
         if (d_cdist) (void)hipFree(d_cdist);
-        d_cpairs = nullptr; d_cdist = nullptr;
+        if (d_rows) (void)hipFree(d_rows);
+        d_cpairs = nullptr; d_cdist = nullptr; d_rows = nullptr;
     }
     bool set_option(const char* name, double v) {
         std::string n(name);
@@ -1740,7 +1754,7 @@ struct PhysHost {
             if (x < 16 || x > 1000) return false;
             (void)hipDeviceSynchronize();
             if (n == "maxefc") maxefc = x; else maxcon = x;
-            make_layout(dims[0], dims[1], dims[2], dims[3], dims[4], dims[5]);
+            make_layout(dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], dims[6]);
             try { alloc_contacts(); } catch (...) { return false; }
             return true;
         }
