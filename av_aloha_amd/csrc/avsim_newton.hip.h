@@ -41,8 +41,7 @@ struct NewtonArgs {
     LDS_PTR(real) g;             // gradient nv; MUST be H + nv(nv+1)/2 (the factorisation reads it as row nv)
     LDS_PTR(real) dl;            // search direction nv
     LDS_PTR(real) jv;            // per row: J dl (line search) / curvature of the scalar rows (Hessian phase)
-    LDS_PTR(const int) cefc;     // first row of contact c, or -1
-    LDS_PTR(const int) czone;    // per contact-head row: dim << 8
+    LDS_PTR(const int) cefc;     // contact c: first row | rows << 16, or -1
     LDS_PTR(const int) tree_dofadr;
     LDS_PTR(const int) tree_dofnum;
     LDS_PTR(const int) tree_madr;
@@ -274,7 +273,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, const 
         }
         A.M = r + L->M; A.a = r + L->qacc; A.as = r + L->asm_;
         A.H = r + L->nH; A.g = r + L->ng; A.dl = r + L->ndl; A.jv = r + L->njv;
-        A.czone = ii + L->czone; A.cefc = ii + L->cefc;
+        A.cefc = ii + L->cefc;
         A.prof = profiling ? ii + L->nprof : (LDS_PTR(int))nullptr;
         A.tree_dofadr = li + O->tree_dofadr; A.tree_dofnum = li + O->tree_dofnum; A.tree_madr = li + O->tree_madr; A.dof_tree = li + O->dof_tree;
         A.nv = ka->m.nv; A.ntree = ka->m.ntree;
@@ -291,8 +290,9 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, const 
     for (int ch = 0; ch < NCH; ch++) {
         NCon<real>& c = con[ch];
         const int ci = ch * 64 + lane;
-        c.head = ci < A.ncon ? A.cefc[ci] : -1;
-        c.dim = c.head >= 0 ? (A.czone[c.head] >> 8) : 0;
+        const int ce = ci < A.ncon ? A.cefc[ci] : -1;
+        c.head = ce >= 0 ? (ce & 0xffff) : -1;
+        c.dim = ce >= 0 ? (ce >> 16) : 0;
         c.mu = 0; c.Dm = 0;
 #pragma unroll
         for (int j = 0; j < 6; j++) { c.S[j] = 0; c.D[j] = 0; }

@@ -65,6 +65,9 @@ struct DevModel {
     // constraint Jacobian rows of every env: real[N][maxefc][16], rewritten each substep (kept out of LDS so that more envs
     // fit on a CU; the working set of the resident envs stays in L2)
     real* rJ_glob;
+    real* gA_glob;      // intra-group couplings real[N][maxgrp][16] (write once per substep, read by the Gauss-Seidel sweeps)
+    int* near_glob;     // Verlet neighbour lists int[N][NEAR_MAX] (rebuilt when a geom moved more than skin / 2)
+    real* gref_glob;    // geom centres at the last rebuild, real[N][ngeom][3]
     // observation
     const int* obs_qposadr;
     const real *obs_offset, *obs_scale;
@@ -127,13 +130,13 @@ struct MOff {
 
 // per-env LDS layout (offsets in reals / ints)
 struct Layout {
-    int qpos, qvel, ctrl, warm, xpos, xmat, xipos, cdof, gcen, gref, M, L, Minv, bias, fsm, asm_, qacc, fcon, nH, ng, ndl, njv, U, nreal;
+    int qpos, qvel, ctrl, warm, xpos, xmat, xipos, cdof, gcen, M, L, Minv, bias, fsm, asm_, qacc, fcon, nH, ng, ndl, njv, U, nreal;
     // scratch union U, phase A
     int cinert, cvel, cacc, cfrc;
     // phase B
-    int cdist, cpos, cnrm, rowS, gA, scr;   // scr: narrow-phase scratch (overlays rowS / gA, 32 lanes x 56 words)
+    int cdist, cpos, cnrm, rowS, scr;   // scr: narrow-phase scratch (overlays rowS, 32 lanes x 56 words)
     // ints
-    int cand, nearl, cpair, cefc, rmeta, rowI, gI, czone, misc, nprof, nint;
+    int cand, cpair, cefc, rmeta, rowI, gI, misc, nprof, nint;
     int maxgrp;
     int maxcon, maxefc;
     int bytes_per_env;
@@ -247,7 +250,7 @@ constexpr int GRP_MAX = 6;   // rows per Gauss-Seidel group (a condim-6 contact 
 // ------------------------------------------------------------------------------------------------
 template <typename real>
 __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, const real* __restrict__ rJ, LDS_PTR(const real) Minv,
-                                                     LDS_PTR(real) q, LDS_PTR(const int) gI, LDS_PTR(const real) gA, int ngrp, int iters,
+                                                     LDS_PTR(real) q, LDS_PTR(const int) gI, const real* __restrict__ gA, int ngrp, int iters,
                                                      int noslip_iters) {
     const int lane = threadIdx.x & 63, d = lane >> 4, l16 = lane & 15, sh = l16 < TREE_W ? 0 : 13, k8 = l16 & (TREE_W - 1), w8 = l16 & TREE_W;
     const int lr = lane < GRP_MAX ? lane : 0;          // row slot owned in the sequential phase
@@ -473,6 +476,9 @@ struct Env {
         : ka(ka_), r(r_), ii(i_), lane(lane_), grp(grp_), lr(lr_), li(li_) {}
     // hot model tables live in LDS (copied once per block); the accessors rebuild the pointer from the kernarg offset
     AVS_DEV real* rows_() const { return ka->m.rJ_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
+    AVS_DEV real* coup_() const { return ka->m.gA_glob + (size_t)env * ka->lay.maxgrp * 16; }
+    AVS_DEV int* near_() const { return ka->m.near_glob + (size_t)env * NEAR_MAX; }
+    AVS_DEV real* gref_() const { return ka->m.gref_glob + (size_t)env * ka->m.ngeom * 3; }
     AVS_DEV const int* body_parent_() const { return li + ka->mo.body_parent; }
     AVS_DEV const int* body_jntadr_() const { return li + ka->mo.body_jntadr; }
     AVS_DEV const int* body_jntnum_() const { return li + ka->mo.body_jntnum; }
@@ -795,8 +801,8 @@ struct Env {
         int ncand = 0;
         long long tb0 = __builtin_readcyclecounter();
         const real skin = real(0.05);
-        real* gref = r + ka->lay.gref;
-        int* nearl = ii + ka->lay.nearl;
+        real* gref = gref_();
+        int* nearl = near_();
         // pair test with extra reach `pad` (0 = exact broad phase)
         auto pair_hit = [&](int p, real pad) -> bool {
             int g1 = ka->m.pair_geom[2 * p], g2 = ka->m.pair_geom[2 * p + 1];
@@ -966,10 +972,9 @@ struct Env {
             if (c < ncon) {
                 int first = nefc + off;
                 if (dim > 0 && first + dim <= ka->lay.maxefc) {
-                    cefc[c] = first;
+                    cefc[c] = first | (dim << 16);   // first row | rows
                     myend = first + dim;
                     for (int s = 0; s < dim; s++) rmeta[first + s] = R_CONTACT | (c << 2) | (s << 12) | (dim << 20);
-                    (ii + ka->lay.czone)[first] = dim << 8;
                 } else {
                     cefc[c] = -1;
                     if (dim > 0) ovf = 1;
@@ -1132,7 +1137,7 @@ struct Env {
         GSYNC();
         // --- Gauss-Seidel groups: the leading non-contact rows in packs of GRP_MAX, then one group per contact ---
         int* gI = ii + ka->lay.gI;
-        real* gA = r + ka->lay.gA;
+        real* gA = coup_();
         const int nlead = misc[4];   // number of equality / dry-friction / limit rows (they precede the contacts)
         int ngrp = 0;
         for (int base = 0; base < nefc; base += G) {
@@ -1198,13 +1203,14 @@ struct Env {
             GSYNC();
             long long tn0 = profiling ? __builtin_readcyclecounter() : 0;
             pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (const real*)rJ, (LDS_PTR(const real))Minv, (LDS_PTR(real))qacc,
-                             (LDS_PTR(const int))(ii + ka->lay.gI), (LDS_PTR(const real))(r + ka->lay.gA), misc[5], 0, ka->m.noslip_iters);
+                             (LDS_PTR(const int))(ii + ka->lay.gI), (const real*)coup_(), misc[5], 0, ka->m.noslip_iters);
             if (profiling && lane == 0) (ii + ka->lay.nprof)[6] += (int)(__builtin_readcyclecounter() - tn0);
         } else {
         // warm-start forces of friction blocks back onto their cones (one contact per lane)
         for (int c = lane; c < ncon; c += G) {
             int first = cefc[c];
             if (first < 0) continue;
+            first &= 0xffff;
             int dim = ka->m.pair_condim[(ii + ka->lay.cpair)[c]];
             real fn = rowS[RS_S * first + 6], s2 = 0;
             for (int s = 1; s < dim; s++) { real t = rowS[RS_S * (first + s) + 6] * rowS[RS_S * (first + s) + 7]; s2 += t * t; }
@@ -1223,7 +1229,7 @@ struct Env {
         // Gauss-Seidel sweeps (+ noslip sweeps) in the register-resident wave kernel
         static_assert(G == 64, "the solver maps one env to one wavefront");
         pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (const real*)rJ, (LDS_PTR(const real))Minv, (LDS_PTR(real))qacc,
-                         (LDS_PTR(const int))(ii + ka->lay.gI), (LDS_PTR(const real))(r + ka->lay.gA), misc[5], pgs_iters, ka->m.noslip_iters);
+                         (LDS_PTR(const int))(ii + ka->lay.gI), (const real*)coup_(), misc[5], pgs_iters, ka->m.noslip_iters);
         }
         GSYNC();
         // qfrc_constraint = J^T f
@@ -1652,7 +1658,7 @@ struct PhysHost {
         int o = 0;
         auto R = [&](int n) { int a = o; o += n; return a; };
         L.qpos = R(nq); L.qvel = R(nv); L.ctrl = R(nu); L.warm = R(nv);
-        L.xpos = R(3 * nb); L.xmat = R(9 * nb); L.xipos = R(3 * nb); L.cdof = R(6 * nv); L.gcen = R(3 * ng); L.gref = R(3 * ng);
+        L.xpos = R(3 * nb); L.xmat = R(9 * nb); L.xipos = R(3 * nb); L.cdof = R(6 * nv); L.gcen = R(3 * ng);
         L.M = R(msize); L.L = R(msize); o = (o + 3) & ~3; L.Minv = R(64 * ntree);
         L.bias = R(nv); L.fsm = R(nv); L.asm_ = R(nv); L.qacc = R(nv); L.fcon = R(nv);
         // Newton scratch (packed Hessian, gradient, direction, per-row J.dl) lives over xpos..gcen where it fits: every
@@ -1669,28 +1675,43 @@ struct PhysHost {
         int bq = o;
         L.cdist = bq; bq += maxcon; L.cpos = bq; bq += 3 * maxcon; L.cnrm = bq; bq += 3 * maxcon;
         bq = (bq + 3) & ~3; L.rowS = bq; L.scr = bq; bq += RS_S * maxefc;
-        L.maxgrp = maxefc / 3 + 8; L.gA = bq; bq += 16 * L.maxgrp;
+        L.maxgrp = maxefc / 3 + 8;
         if (bq < L.scr + 32 * 56) bq = L.scr + 32 * 56;
         o = a > bq ? a : bq;
         L.nreal = (o + 3) & ~3;
         int io = 0;
         auto Iq = [&](int n) { int x = io; io += n; return x; };
-        L.cand = Iq(CAND_MAX); L.nearl = Iq(NEAR_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.czone = Iq(maxefc); L.misc = Iq(8); L.nprof = Iq(8);
+        L.cand = Iq(CAND_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.misc = Iq(8); L.nprof = Iq(8);
         L.nint = (io + 3) & ~3;
         L.maxcon = maxcon;
         L.maxefc = maxefc;
         size_t rs = f64 ? 8 : 4;
         L.bytes_per_env = (int)((L.nreal * rs + (size_t)L.nint * 4 + 15) & ~(size_t)15);
+        if (getenv("AVSIM_DEBUG_LAYOUT"))
+            fprintf(stderr, "avsim layout: %d reals + %d ints = %d B per env (U at %d: phase A %d, phase B %d words); tables %zu B\n", L.nreal, L.nint,
+                    L.bytes_per_env, L.U, a - L.U, bq - L.U, (size_t)moff.nreal * rs + (size_t)moff.nint * 4);
     }
 
     int dims[7] = {0, 0, 0, 0, 0, 0, 0};
     size_t lds_bytes() const { return (size_t)lay.bytes_per_env + (size_t)moff.nreal * (f64 ? 8 : 4) + (size_t)moff.nint * 4; }   // WPB = 1 figure
     void* d_rows = nullptr;
+    void* d_coup = nullptr;
+    int* d_near = nullptr;
+    void* d_gref = nullptr;
     void alloc_contacts() {
         if (d_rows) (void)hipFree(d_rows);
         d_rows = nullptr;
         if (hipMalloc(&d_rows, (size_t)N * maxefc * ROW_S * (f64 ? 8 : 4)) != hipSuccess) throw std::runtime_error("hipMalloc of the constraint row buffer failed");
         mf.rJ_glob = (float*)d_rows; md.rJ_glob = (double*)d_rows;
+        if (d_coup) (void)hipFree(d_coup);
+        if (d_near) (void)hipFree(d_near);
+        if (d_gref) (void)hipFree(d_gref);
+        d_coup = nullptr; d_near = nullptr; d_gref = nullptr;
+        if (hipMalloc(&d_gref, (size_t)N * dims[4] * 3 * (f64 ? 8 : 4)) != hipSuccess) throw std::runtime_error("hipMalloc of the Verlet reference buffer failed");
+        mf.gref_glob = (float*)d_gref; md.gref_glob = (double*)d_gref;
+        if (hipMalloc(&d_coup, (size_t)N * lay.maxgrp * 16 * (f64 ? 8 : 4)) != hipSuccess || hipMalloc((void**)&d_near, (size_t)N * NEAR_MAX * 4) != hipSuccess)
+            throw std::runtime_error("hipMalloc of the coupling / neighbour buffers failed");
+        mf.gA_glob = (float*)d_coup; md.gA_glob = (double*)d_coup; mf.near_glob = d_near; md.near_glob = d_near;
         kargs_dirty = true;
         if (d_cpairs) (void)hipFree(d_cpairs);
         if (d_cdist) (void)hipFree(d_cdist);
@@ -1733,7 +1754,10 @@ struct PhysHost {
         if (d_cpairs) (void)hipFree(d_cpairs);
         if (d_cdist) (void)hipFree(d_cdist);
         if (d_rows) (void)hipFree(d_rows);
-        d_cpairs = nullptr; d_cdist = nullptr; d_rows = nullptr;
+        if (d_coup) (void)hipFree(d_coup);
+        if (d_near) (void)hipFree(d_near);
+        if (d_gref) (void)hipFree(d_gref);
+        d_cpairs = nullptr; d_cdist = nullptr; d_rows = nullptr; d_coup = nullptr; d_near = nullptr; d_gref = nullptr;
     }
     bool set_option(const char* name, double v) {
         std::string n(name);
@@ -1743,7 +1767,7 @@ struct PhysHost {
         if (n == "newton_iters") { if (v < 1 || v > 100) return false; mf.newton_iters = md.newton_iters = (int)v; return true; }
         if (n == "newton_tol") { if (v < 0) return false; mf.newton_tol = (float)v; md.newton_tol = v; return true; }
         if (n == "export_contacts") { export_contacts = v != 0; return true; }
-        if (n == "waves_per_block") { int x = (int)v; if (x >= 0 && x <= 6) { wpb_override = x; return true; } return false; }
+        if (n == "waves_per_block") { int x = (int)v; if (x >= 0 && x <= 8) { wpb_override = x; return true; } return false; }
         if (n == "profile_phases") {
             if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * 18, 0));
             if (v == 0) d_prof = nullptr;
@@ -1801,6 +1825,8 @@ struct PhysHost {
         size_t tables = (size_t)moff.nreal * 4 + (size_t)moff.nint * 4;
         int wpb = (int)((160 * 1024 - tables) / (size_t)lay.bytes_per_env);
         if (wpb_override > 0) wpb = wpb_override;
+        if (wpb >= 8) return launch_t<float, 64, 8>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
+        if (wpb >= 7) return launch_t<float, 64, 7>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
         if (wpb >= 6) return launch_t<float, 64, 6>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
         if (wpb >= 5) return launch_t<float, 64, 5>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
         if (wpb >= 4) return launch_t<float, 64, 4>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
