@@ -533,84 +533,143 @@ struct Env {
 
 
     // ---- P1 ------------------------------------------------------------------------------------
+    // P1.  One body per lane: every lane builds its body's transform relative to the parent from its joint coordinate, then
+    // the chains are multiplied out by pointer jumping (3 rounds for the 8-deep arms) instead of one lane walking each chain.
+    // cdof (one dof per lane), inertial frames and geom centres follow from the world poses in parallel.
     __device__ void kinematics() {
         PHASE_BEGIN();
         real *xpos = r + ka->lay.xpos, *xmat = r + ka->lay.xmat, *xipos = r + ka->lay.xipos, *cdof = r + ka->lay.cdof, *qpos = r + ka->lay.qpos;
-        for (int i = lane; i < 6 * ka->m.nv; i += G) cdof[i] = 0;
-        // bodies welded to the world: constant poses (the Newton scratch overlays this region during the solve)
-        for (int b = lane; b < ka->m.nbody; b += G) {
-            for (int k = 0; k < 3; k++) { xpos[3 * b + k] = ka->m.static_xpos[3 * b + k]; xipos[3 * b + k] = 0; }
-            for (int k = 0; k < 9; k++) xmat[9 * b + k] = ka->m.static_xmat[9 * b + k];
-        }
-        GSYNC();
-        for (int t = lane; t < ka->m.ntree; t += G) {
-            for (int bi = tree_bodyadr_()[t]; bi < tree_bodyadr_()[t + 1]; bi++) {
-                int b = tree_bodylist_()[bi], p = body_parent_()[b], ja = body_jntadr_()[b], jn = body_jntnum_()[b];
-                real pos[3], quat[4], R[9];
-                if (jn == 1 && jnt_type_()[ja] == J_FREE) {
-                    int qa = jnt_qposadr_()[ja], da = jnt_dofadr_()[ja];
+        int* anc = ii + ka->lay.cand;        // ancestor still to be folded in (-1: the pose is final); collide's list is idle here
+        const int nb = ka->m.nbody;
+        // local transforms; children of world-welded bodies and free bodies are already in world coordinates
+        for (int b = lane; b < nb; b += G) {
+            real R[9], pos[3];
+            int a = -1;
+            if (body_tree_()[b] < 0) {
+                for (int k = 0; k < 3; k++) pos[k] = ka->m.static_xpos[3 * b + k];
+                for (int k = 0; k < 9; k++) R[k] = ka->m.static_xmat[9 * b + k];
+            } else {
+                const int p = body_parent_()[b], ja = body_jntadr_()[b], jn = body_jntnum_()[b];
+                const int jt = jn > 0 ? jnt_type_()[ja] : -1;
+                if (jt == J_FREE) {
+                    const int qa = jnt_qposadr_()[ja];
+                    real quat[4];
                     for (int k = 0; k < 3; k++) pos[k] = qpos[qa + k];
                     for (int k = 0; k < 4; k++) quat[k] = qpos[qa + 3 + k];
                     quatnorm(quat);
                     quat2mat(quat, R);
-                    for (int k = 0; k < 3; k++) {
-                        cdof[6 * (da + k) + 3 + k] = 1;
-                        real w[3] = {R[k], R[3 + k], R[6 + k]}, c[3];
-                        cross3(pos, w, c);
-                        for (int q = 0; q < 3; q++) { cdof[6 * (da + 3 + k) + q] = w[q]; cdof[6 * (da + 3 + k) + 3 + q] = c[q]; }
-                    }
                 } else {
-                    real t3[3], pq[4], bp[3] = {body_pos_()[3 * b], body_pos_()[3 * b + 1], body_pos_()[3 * b + 2]};
-                    // parent pose: LDS for dynamic parents, constants for static ones (copied to LDS at launch)
-                    mulmat(xmat + 9 * p, bp, t3);
-                    for (int k = 0; k < 3; k++) pos[k] = xpos[3 * p + k] + t3[k];
-                    // parent quaternion is not stored: carry orientation as a matrix product instead
-                    real Rb[9], Rl[9];
-                    real bq[4] = {body_quat_()[4 * b], body_quat_()[4 * b + 1], body_quat_()[4 * b + 2], body_quat_()[4 * b + 3]};
+                    real Rl[9], bq[4] = {body_quat_()[4 * b], body_quat_()[4 * b + 1], body_quat_()[4 * b + 2], body_quat_()[4 * b + 3]};
                     quat2mat(bq, Rl);
-                    const real* Rp = xmat + 9 * p;
-                    for (int i = 0; i < 3; i++)
-                        for (int j = 0; j < 3; j++) Rb[3 * i + j] = Rp[3 * i] * Rl[j] + Rp[3 * i + 1] * Rl[3 + j] + Rp[3 * i + 2] * Rl[6 + j];
-                    (void)pq;
-                    for (int j = ja; j < ja + jn; j++) {
-                        real ax[3] = {jnt_axis_()[3 * j], jnt_axis_()[3 * j + 1], jnt_axis_()[3 * j + 2]};
-                        real jp[3] = {jnt_pos_()[3 * j], jnt_pos_()[3 * j + 1], jnt_pos_()[3 * j + 2]};
-                        real axis[3], anchor[3];
-                        mulmat(Rb, ax, axis);
-                        mulmat(Rb, jp, anchor);
-                        for (int k = 0; k < 3; k++) anchor[k] += pos[k];
-                        real q = qpos[jnt_qposadr_()[j]];
-                        int dof = jnt_dofadr_()[j];
-                        if (jnt_type_()[j] == J_HINGE) {
-                            real c[3];
-                            cross3(anchor, axis, c);
-                            for (int k = 0; k < 3; k++) { cdof[6 * dof + k] = axis[k]; cdof[6 * dof + 3 + k] = c[k]; }
-                            // Rb <- Rb * Rot(ax, q)  (Rodrigues in the joint's local frame)
-                            real s = sin(q), co = cos(q), oc = 1 - co;
-                            real Rq[9] = {co + ax[0] * ax[0] * oc, ax[0] * ax[1] * oc - ax[2] * s, ax[0] * ax[2] * oc + ax[1] * s,
-                                          ax[1] * ax[0] * oc + ax[2] * s, co + ax[1] * ax[1] * oc, ax[1] * ax[2] * oc - ax[0] * s,
-                                          ax[2] * ax[0] * oc - ax[1] * s, ax[2] * ax[1] * oc + ax[0] * s, co + ax[2] * ax[2] * oc};
-                            real Rn[9];
-                            for (int i = 0; i < 3; i++)
-                                for (int jj = 0; jj < 3; jj++)
-                                    Rn[3 * i + jj] = Rb[3 * i] * Rq[jj] + Rb[3 * i + 1] * Rq[3 + jj] + Rb[3 * i + 2] * Rq[6 + jj];
-                            for (int k = 0; k < 9; k++) Rb[k] = Rn[k];
-                            mulmat(Rb, jp, t3);
-                            for (int k = 0; k < 3; k++) pos[k] = anchor[k] - t3[k];
-                        } else {
-                            for (int k = 0; k < 3; k++) { cdof[6 * dof + 3 + k] = axis[k]; pos[k] += axis[k] * q; }
-                        }
+                    for (int k = 0; k < 3; k++) pos[k] = body_pos_()[3 * b + k];
+                    for (int k = 0; k < 9; k++) R[k] = Rl[k];
+                    if (jt == J_HINGE) {
+                        const real q = qpos[jnt_qposadr_()[ja]];
+                        const real ax[3] = {jnt_axis_()[3 * ja], jnt_axis_()[3 * ja + 1], jnt_axis_()[3 * ja + 2]};
+                        const real jp[3] = {jnt_pos_()[3 * ja], jnt_pos_()[3 * ja + 1], jnt_pos_()[3 * ja + 2]};
+                        const real sn = sin(q), co = cos(q), oc = 1 - co;
+                        const real Rq[9] = {co + ax[0] * ax[0] * oc, ax[0] * ax[1] * oc - ax[2] * sn, ax[0] * ax[2] * oc + ax[1] * sn,
+                                            ax[1] * ax[0] * oc + ax[2] * sn, co + ax[1] * ax[1] * oc, ax[1] * ax[2] * oc - ax[0] * sn,
+                                            ax[2] * ax[0] * oc - ax[1] * sn, ax[2] * ax[1] * oc + ax[0] * sn, co + ax[2] * ax[2] * oc};
+                        for (int i = 0; i < 3; i++)
+                            for (int j = 0; j < 3; j++) R[3 * i + j] = Rl[3 * i] * Rq[j] + Rl[3 * i + 1] * Rq[3 + j] + Rl[3 * i + 2] * Rq[6 + j];
+                        // the joint anchor stays put: pos = body_pos + Rl jp - (Rl Rq) jp
+                        real t0[3], t1[3];
+                        mulmat(Rl, jp, t0);
+                        mulmat(R, jp, t1);
+                        for (int k = 0; k < 3; k++) pos[k] += t0[k] - t1[k];
+                    } else if (jt == J_SLIDE) {
+                        const real q = qpos[jnt_qposadr_()[ja]];
+                        const real ax[3] = {jnt_axis_()[3 * ja], jnt_axis_()[3 * ja + 1], jnt_axis_()[3 * ja + 2]};
+                        real t0[3];
+                        mulmat(Rl, ax, t0);
+                        for (int k = 0; k < 3; k++) pos[k] += t0[k] * q;
                     }
-                    for (int k = 0; k < 9; k++) R[k] = Rb[k];
+                    if (body_tree_()[p] < 0) {      // parent welded to the world: fold its constant pose in right away
+                        const real* Rp = ka->m.static_xmat + 9 * p;
+                        real Rn[9], t0[3];
+                        for (int i = 0; i < 3; i++)
+                            for (int j = 0; j < 3; j++) Rn[3 * i + j] = Rp[3 * i] * R[j] + Rp[3 * i + 1] * R[3 + j] + Rp[3 * i + 2] * R[6 + j];
+                        mulmat(Rp, pos, t0);
+                        for (int k = 0; k < 3; k++) pos[k] = ka->m.static_xpos[3 * p + k] + t0[k];
+                        for (int k = 0; k < 9; k++) R[k] = Rn[k];
+                    } else a = p;
                 }
-                for (int k = 0; k < 3; k++) xpos[3 * b + k] = pos[k];
-                for (int k = 0; k < 9; k++) xmat[9 * b + k] = R[k];
-                real ip[3] = {body_ipos_()[3 * b], body_ipos_()[3 * b + 1], body_ipos_()[3 * b + 2]}, t3[3];
-                mulmat(R, ip, t3);
-                for (int k = 0; k < 3; k++) xipos[3 * b + k] = pos[k] + t3[k];
             }
+            for (int k = 0; k < 3; k++) xpos[3 * b + k] = pos[k];
+            for (int k = 0; k < 9; k++) xmat[9 * b + k] = R[k];
+            anc[b] = a;
         }
         GSYNC();
+        // pointer jumping: T_b <- T_anc(b) T_b, anc(b) <- anc(anc(b)), until every chain reaches its root
+        for (int round = 0; round < 6; round++) {
+            bool any = false;
+            real Ra[9], pa[3];
+            int a = -1, aa = -1;
+            const int b = lane;
+            if (b < nb) {
+                a = anc[b];
+                if (a >= 0) {
+                    any = true;
+                    aa = anc[a];
+                    for (int k = 0; k < 9; k++) Ra[k] = xmat[9 * a + k];
+                    for (int k = 0; k < 3; k++) pa[k] = xpos[3 * a + k];
+                }
+            }
+            if (!__any(any)) break;
+            GSYNC();
+            if (a >= 0) {
+                real R[9], pos[3], Rn[9], t0[3];
+                for (int k = 0; k < 9; k++) R[k] = xmat[9 * b + k];
+                for (int k = 0; k < 3; k++) pos[k] = xpos[3 * b + k];
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) Rn[3 * i + j] = Ra[3 * i] * R[j] + Ra[3 * i + 1] * R[3 + j] + Ra[3 * i + 2] * R[6 + j];
+                mulmat(Ra, pos, t0);
+                for (int k = 0; k < 3; k++) xpos[3 * b + k] = pa[k] + t0[k];
+                for (int k = 0; k < 9; k++) xmat[9 * b + k] = Rn[k];
+                anc[b] = aa;
+            }
+            GSYNC();
+        }
+        // inertial frames (one body per lane), cdof (one dof per lane), geom centres (one geom per lane)
+        for (int b = lane; b < nb; b += G) {
+            real t3[3] = {0, 0, 0};
+            if (body_tree_()[b] >= 0) {
+                const real ip[3] = {body_ipos_()[3 * b], body_ipos_()[3 * b + 1], body_ipos_()[3 * b + 2]};
+                mulmat(xmat + 9 * b, ip, t3);
+                for (int k = 0; k < 3; k++) t3[k] += xpos[3 * b + k];
+            }
+            for (int k = 0; k < 3; k++) xipos[3 * b + k] = t3[k];
+        }
+        for (int d = lane; d < ka->m.nv; d += G) {
+            const int j = dof_jnt_()[d], b = dof_body_()[d], jt = jnt_type_()[j], k = d - jnt_dofadr_()[j];
+            const real *R = xmat + 9 * b, *pos = xpos + 3 * b;
+            real cd[6] = {0, 0, 0, 0, 0, 0};
+            if (jt == J_FREE) {
+                if (k < 3) cd[3 + k] = 1;
+                else {
+                    const real w[3] = {R[k - 3], R[3 + k - 3], R[6 + k - 3]};
+                    real c[3];
+                    cross3(pos, w, c);
+                    for (int q = 0; q < 3; q++) { cd[q] = w[q]; cd[3 + q] = c[q]; }
+                }
+            } else {
+                const real ax[3] = {jnt_axis_()[3 * j], jnt_axis_()[3 * j + 1], jnt_axis_()[3 * j + 2]};
+                real axis[3];
+                mulmat(R, ax, axis);
+                if (jt == J_HINGE) {
+                    const real jp[3] = {jnt_pos_()[3 * j], jnt_pos_()[3 * j + 1], jnt_pos_()[3 * j + 2]};
+                    real anchor[3], c[3];
+                    mulmat(R, jp, anchor);
+                    for (int q = 0; q < 3; q++) anchor[q] += pos[q];
+                    cross3(anchor, axis, c);
+                    for (int q = 0; q < 3; q++) { cd[q] = axis[q]; cd[3 + q] = c[q]; }
+                } else {
+                    for (int q = 0; q < 3; q++) cd[3 + q] = axis[q];
+                }
+            }
+            for (int q = 0; q < 6; q++) cdof[6 * d + q] = cd[q];
+        }
         real* gcen = r + ka->lay.gcen;
         for (int g = lane; g < ka->m.ngeom; g += G) {
             if (geom_static_()[g]) continue;
@@ -1511,6 +1570,8 @@ struct PhysHost {
         auto dof_body = I("dof_body");
         int nb = m.nbody, nv = m.nv, nt = m.ntree;
         for (int t = 0; t < nt; t++) if (tree_dofnum[t] > TREE_W) throw std::runtime_error("kinematic tree with more than 8 dofs");
+        if (nb > 64) throw std::runtime_error("more than 64 bodies (kinematics maps one body per lane)");
+        { auto jn = I("body_jntnum"); for (int bb = 0; bb < nb; bb++) if (jn[bb] > 1) throw std::runtime_error("body with more than one joint"); }
         // bodies of each tree, in id order; static poses
         std::vector<int> tba(nt + 1, 0), tbl;
         for (int t = 0; t < nt; t++) {
