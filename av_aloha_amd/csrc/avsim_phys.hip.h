@@ -43,7 +43,7 @@ struct DevModel {
     int solver, newton_iters;     // 0 = PGS (dual), 1 = Newton (primal, the reference's default solver)
     real newton_tol, nscale;      // MuJoCo tolerance and 1/(meaninertia*nv) scaling of the termination tests
     // bodies
-    const int *body_parent, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_tree, *body_dofmask;
+    const int *body_parent, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_tree, *body_dofmask, *body_last;
     const real *body_pos, *body_quat, *body_mass, *body_ipos, *body_inertia, *body_invweight0, *static_xpos, *static_xmat;
     const int *tree_bodyadr, *tree_bodylist, *tree_dofadr, *tree_dofnum, *tree_madr;
     // joints / dofs
@@ -82,6 +82,7 @@ struct MOff {
     int body_dofnum;
     int body_tree;
     int body_dofmask;
+    int body_last;
     int tree_bodyadr;
     int tree_bodylist;
     int tree_dofadr;
@@ -486,6 +487,7 @@ struct Env {
     AVS_DEV const int* body_dofnum_() const { return li + ka->mo.body_dofnum; }
     AVS_DEV const int* body_tree_() const { return li + ka->mo.body_tree; }
     AVS_DEV const int* body_dofmask_() const { return li + ka->mo.body_dofmask; }
+    AVS_DEV const int* body_last_() const { return li + ka->mo.body_last; }
     AVS_DEV const int* tree_bodyadr_() const { return li + ka->mo.tree_bodyadr; }
     AVS_DEV const int* tree_bodylist_() const { return li + ka->mo.tree_bodylist; }
     AVS_DEV const int* tree_dofadr_() const { return li + ka->mo.tree_dofadr; }
@@ -533,6 +535,60 @@ struct Env {
 
 
     // ---- P1 ------------------------------------------------------------------------------------
+    // ---- per-tree dense linear algebra on the whole wave: lane 8 t + i owns row i of tree t's block (<= 8 trees of <= 8 dofs) ----
+    // Cholesky of every tree block at once: L L^T = A (+ add on the diagonal); the multipliers travel by ds_bpermute inside the
+    // tree's 8 lanes.  L goes to Ldst in the same n x n layout as A.  Padded lanes carry an identity row.
+    __device__ void tree_chol(const real* A, real* Ldst, const real* diag_add, real diag_scale) {
+        const int t = lane >> 3, i = lane & 7, gb = lane & ~7;
+        const bool act = t < ka->m.ntree;
+        const int n = act ? tree_dofnum_()[t] : 0, base = act ? tree_madr_()[t] : 0, a0 = act ? tree_dofadr_()[t] : 0;
+        real row[TREE_W];
+#pragma unroll
+        for (int k = 0; k < TREE_W; k++) row[k] = (i < n && k <= i) ? A[base + i * n + k] : (k == i ? real(1) : real(0));
+        if (diag_add && i < n) {
+#pragma unroll
+            for (int k = 0; k < TREE_W; k++) if (k == i) row[k] += diag_scale * diag_add[a0 + i];
+        }
+#pragma unroll
+        for (int j = 0; j < TREE_W; j++) {
+            const real d = sqrt(tmax(__shfl(row[j], gb | j, 64), real(1e-30)));
+            const real lij = i == j ? d : row[j] / d;
+            row[j] = lij;
+            const real mul = i > j ? lij : real(0);
+#pragma unroll
+            for (int k = j + 1; k < TREE_W; k++) row[k] -= mul * __shfl(lij, gb | k, 64);
+        }
+        if (i < n) {
+#pragma unroll
+            for (int k = 0; k < TREE_W; k++) if (k <= i) Ldst[base + i * n + k] = row[k];
+        }
+    }
+    // solves L L^T x = b for every tree: lane 8 t + i passes b_i and gets x_i (L read from LDS)
+    __device__ real tree_solve(const real* L, real x) {
+        const int t = lane >> 3, i = lane & 7, gb = lane & ~7;
+        const bool act = t < ka->m.ntree;
+        const int n = act ? tree_dofnum_()[t] : 0, base = act ? tree_madr_()[t] : 0;
+        real row[TREE_W], col[TREE_W];
+#pragma unroll
+        for (int k = 0; k < TREE_W; k++) {
+            row[k] = (i < n && k < i) ? L[base + i * n + k] : real(0);
+            col[k] = (k < n && k > i) ? L[base + k * n + i] : real(0);
+        }
+        const real dinv = i < n ? real(1) / L[base + i * n + i] : real(1);
+        if (!(i < n)) x = 0;
+#pragma unroll
+        for (int j = 0; j < TREE_W; j++) {
+            const real yj = __shfl(x * dinv, gb | j, 64);
+            x = i == j ? yj : x - row[j] * yj;
+        }
+#pragma unroll
+        for (int j = TREE_W - 1; j >= 0; j--) {
+            const real xj = __shfl(x * dinv, gb | j, 64);
+            x = i == j ? xj : x - col[j] * xj;
+        }
+        return x;
+    }
+
     // P1.  One body per lane: every lane builds its body's transform relative to the parent from its joint coordinate, then
     // the chains are multiplied out by pointer jumping (3 rounds for the 8-deep arms) instead of one lane walking each chain.
     // cdof (one dof per lane), inertial frames and geom centres follow from the world poses in parallel.
@@ -696,12 +752,19 @@ struct Env {
         }
         for (int i = lane; i < ka->m.msize; i += G) M[i] = 0;
         GSYNC();
-        for (int t = lane; t < ka->m.ntree; t += G)
-            for (int bi = tree_bodyadr_()[t + 1] - 1; bi > tree_bodyadr_()[t]; bi--) {
-                int b = tree_bodylist_()[bi], p = body_parent_()[b];
-                if (body_tree_()[p] != t) continue;
-                for (int k = 0; k < 10; k++) ci[10 * p + k] += ci[10 * b + k];
-            }
+        // composite inertias: bodies are numbered depth first, so the subtree of body p is the id range p .. body_last[p]
+        {
+            real acc[10];
+            const int p = lane < ka->m.nbody ? lane : 0;
+            const bool dyn = lane < ka->m.nbody && body_tree_()[p] >= 0;
+            for (int k = 0; k < 10; k++) acc[k] = 0;
+            if (dyn)
+                for (int d = p; d <= body_last_()[p]; d++)
+                    for (int k = 0; k < 10; k++) acc[k] += ci[10 * d + k];
+            GSYNC();
+            if (dyn)
+                for (int k = 0; k < 10; k++) ci[10 * p + k] = acc[k];
+        }
         GSYNC();
         for (int e = lane; e < ka->m.nment; e += G) {
             int i = ment_i_()[e], j = ment_j_()[e], t = dof_tree_()[i], n = tree_dofnum_()[t], a = tree_dofadr_()[t];
@@ -715,7 +778,7 @@ struct Env {
             Mb[(j - a) * n + (i - a)] = v;
         }
         GSYNC();
-        for (int t = lane; t < ka->m.ntree; t += G) chol_block(M + tree_madr_()[t], L + tree_madr_()[t], tree_dofnum_()[t]);
+        tree_chol(M, L, (const real*)nullptr, real(0));
         GSYNC();
         // dense per-tree inverse (8x8, zero padded): B = J M^-1 is formed on the fly from it, so rows store only J
         real* Minv = r + ka->lay.Minv;
@@ -826,7 +889,14 @@ struct Env {
             as[i] = f;
         }
         GSYNC();
-        for (int t = lane; t < ka->m.ntree; t += G) chol_solve_block(r + ka->lay.L + tree_madr_()[t], as + tree_dofadr_()[t], tree_dofnum_()[t]);
+        {
+            const int t = lane >> 3, i = lane & 7;
+            const bool mine = t < ka->m.ntree && i < tree_dofnum_()[t];
+            const int k = mine ? tree_dofadr_()[t] + i : 0;
+            const real x = tree_solve(r + ka->lay.L, mine ? as[k] : real(0));
+            GSYNC();
+            if (mine) as[k] = x;
+        }
         GSYNC();
     }
 
@@ -1322,13 +1392,15 @@ struct Env {
         real h = ka->m.timestep;
         for (int i = lane; i < ka->m.nv; i += G) { tmp[i] = fsm[i] + fcon[i]; warm[i] = qacc[i]; }
         GSYNC();
-        for (int t = lane; t < ka->m.ntree; t += G) {
-            int n = tree_dofnum_()[t], a0 = tree_dofadr_()[t];
-            real* Mb = M + tree_madr_()[t];
-            for (int i = 0; i < n; i++) Mb[i * n + i] += h * dof_damping_()[a0 + i];   // M is rebuilt next substep
-            chol_block(Mb, L + tree_madr_()[t], n);
-            chol_solve_block(L + tree_madr_()[t], tmp + a0, n);
-            for (int i = 0; i < n; i++) qvel[a0 + i] += h * tmp[a0 + i];
+        // (M + h diag(damping)) qacc_d = qfrc: factor and solve all trees at once (M itself is rebuilt next substep)
+        tree_chol(M, L, dof_damping_(), h);
+        GSYNC();
+        {
+            const int t = lane >> 3, i = lane & 7;
+            const bool mine = t < ka->m.ntree && i < tree_dofnum_()[t];
+            const int k = mine ? tree_dofadr_()[t] + i : 0;
+            const real x = tree_solve(L, mine ? tmp[k] : real(0));
+            if (mine) qvel[k] += h * x;
         }
         GSYNC();
         for (int j = lane; j < ka->m.njnt; j += G) {
@@ -1571,6 +1643,7 @@ struct PhysHost {
         int nb = m.nbody, nv = m.nv, nt = m.ntree;
         for (int t = 0; t < nt; t++) if (tree_dofnum[t] > TREE_W) throw std::runtime_error("kinematic tree with more than 8 dofs");
         if (nb > 64) throw std::runtime_error("more than 64 bodies (kinematics maps one body per lane)");
+        if (nt > 8) throw std::runtime_error("more than 8 kinematic trees (the per-tree solves map 8 lanes to a tree)");
         { auto jn = I("body_jntnum"); for (int bb = 0; bb < nb; bb++) if (jn[bb] > 1) throw std::runtime_error("body with more than one joint"); }
         // bodies of each tree, in id order; static poses
         std::vector<int> tba(nt + 1, 0), tbl;
@@ -1625,6 +1698,14 @@ struct PhysHost {
         m.nlimited = (int)lj.size();
         m.body_parent = up(body_parent); moff.body_parent = (int)img_int.size(); { auto v_ = body_parent; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.body_jntadr = up(I("body_jntadr")); moff.body_jntadr = (int)img_int.size(); { auto v_ = I("body_jntadr"); img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.body_jntnum = up(I("body_jntnum")); moff.body_jntnum = (int)img_int.size(); { auto v_ = I("body_jntnum"); img_int.insert(img_int.end(), v_.begin(), v_.end()); }
         m.body_dofadr = up(body_dofadr); moff.body_dofadr = (int)img_int.size(); { auto v_ = body_dofadr; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.body_dofnum = up(body_dofnum); moff.body_dofnum = (int)img_int.size(); { auto v_ = body_dofnum; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.body_tree = up(body_tree); moff.body_tree = (int)img_int.size(); { auto v_ = body_tree; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.body_dofmask = up(mask); moff.body_dofmask = (int)img_int.size(); { auto v_ = mask; img_int.insert(img_int.end(), v_.begin(), v_.end()); }
+        {   // bodies are numbered depth first: the subtree of body p is the id range p .. body_last[p] (checked)
+            std::vector<int> last(nb);
+            for (int bb = 0; bb < nb; bb++) last[bb] = bb;
+            for (int bb = nb - 1; bb > 0; bb--) { int pp = body_parent[bb]; if (last[bb] > last[pp]) last[pp] = last[bb]; }
+            for (int bb = 1; bb < nb; bb++) { int pp = body_parent[bb]; if (!(pp < bb && bb <= last[pp])) throw std::runtime_error("bodies are not in depth-first order"); }
+            for (int pp = 0; pp < nb; pp++) for (int d = pp + 1; d <= last[pp]; d++) { int a = d; while (a > pp) a = body_parent[a]; if (a != pp) throw std::runtime_error("bodies are not in depth-first order"); }
+            m.body_last = up(last); moff.body_last = (int)img_int.size(); img_int.insert(img_int.end(), last.begin(), last.end());
+        }
         m.body_pos = upr<real>(bpos); moff.body_pos = (int)img_real.size(); { auto v_ = bpos; img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.body_quat = upr<real>(bquat); moff.body_quat = (int)img_real.size(); { auto v_ = bquat; img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.body_mass = upr<real>(F("body_mass")); moff.body_mass = (int)img_real.size(); { auto v_ = F("body_mass"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.body_ipos = upr<real>(F("body_ipos")); moff.body_ipos = (int)img_real.size(); { auto v_ = F("body_ipos"); img_real.insert(img_real.end(), v_.begin(), v_.end()); }
         m.body_inertia = upr<real>(F("body_inertia")); moff.body_inertia = (int)img_real.size(); { auto v_ = F("body_inertia"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.body_invweight0 = upr<real>(F("body_invweight0")); moff.body_invweight0 = (int)img_real.size(); { auto v_ = F("body_invweight0"); img_real.insert(img_real.end(), v_.begin(), v_.end()); }
         m.static_xpos = upr<real>(sx); m.static_xmat = upr<real>(sm);
