@@ -812,55 +812,82 @@ struct Env {
     }
 
     // ---- P5 bias -------------------------------------------------------------------------------
+    // Recursive Newton-Euler without the recursion: in world coordinates about the origin the body velocity is the plain sum of
+    // cdof_j qvel_j over the ancestor dofs (body_dofmask), the bias acceleration the sum of cdof_dot_j qvel_j over the same
+    // dofs, and the joint torque the projection of the inertial forces summed over the subtree (a contiguous id range).
     __device__ void rne_bias() {
         PHASE_BEGIN();
         real *xmat = r + ka->lay.xmat, *xipos = r + ka->lay.xipos, *cdof = r + ka->lay.cdof, *qvel = r + ka->lay.qvel;
-        real *cvel = r + ka->lay.cvel, *cacc = r + ka->lay.cacc, *cfrc = r + ka->lay.cfrc, *bias = r + ka->lay.bias;
-        for (int t = lane; t < ka->m.ntree; t += G) {
-            int b0 = tree_bodyadr_()[t], b1 = tree_bodyadr_()[t + 1];
-            for (int bi = b0; bi < b1; bi++) {
-                int b = tree_bodylist_()[bi], p = body_parent_()[b];
-                real v[6], a[6];
-                if (body_tree_()[p] == t) { for (int k = 0; k < 6; k++) { v[k] = cvel[6 * p + k]; a[k] = cacc[6 * p + k]; } }
-                else { for (int k = 0; k < 6; k++) { v[k] = 0; a[k] = 0; } a[3] = -ka->m.gravity[0]; a[4] = -ka->m.gravity[1]; a[5] = -ka->m.gravity[2]; }
-                int da = body_dofadr_()[b], dn = body_dofnum_()[b], j = 0;
-                while (j < dn) {
-                    int dof = da + j;
-                    if (jnt_type_()[dof_jnt_()[dof]] == J_FREE) {
-                        for (int k = 0; k < 3; k++)
-                            for (int q = 0; q < 6; q++) v[q] += cdof[6 * (dof + k) + q] * qvel[dof + k];
-                        real dot[3][6];
-                        for (int k = 0; k < 3; k++) cross_motion(v, cdof + 6 * (dof + 3 + k), dot[k]);
-                        for (int k = 0; k < 3; k++)
-                            for (int q = 0; q < 6; q++) { a[q] += dot[k][q] * qvel[dof + 3 + k]; v[q] += cdof[6 * (dof + 3 + k) + q] * qvel[dof + 3 + k]; }
-                        j += 6;
-                    } else {
-                        real dot[6];
-                        cross_motion(v, cdof + 6 * dof, dot);
-                        for (int q = 0; q < 6; q++) { a[q] += dot[q] * qvel[dof]; v[q] += cdof[6 * dof + q] * qvel[dof]; }
-                        j += 1;
+        real *cvel = r + ka->lay.cvel, *cfrc = r + ka->lay.cfrc, *bias = r + ka->lay.bias;
+        real* cdd = r + ka->lay.cinert;     // cdof_dot_j qvel_j per dof (the composite inertias are no longer needed)
+        const int nb = ka->m.nbody;
+        // body velocities
+        for (int b = lane; b < nb; b += G) {
+            real v[6] = {0, 0, 0, 0, 0, 0};
+            const int t = body_tree_()[b];
+            if (t >= 0) {
+                const int a0 = tree_dofadr_()[t], n = tree_dofnum_()[t], mask = body_dofmask_()[b];
+                for (int k = 0; k < n; k++)
+                    if ((mask >> k) & 1) {
+                        const real qd = qvel[a0 + k];
+                        for (int q = 0; q < 6; q++) v[q] += cdof[6 * (a0 + k) + q] * qd;
                     }
+            }
+            for (int q = 0; q < 6; q++) cvel[6 * b + q] = v[q];
+        }
+        GSYNC();
+        // cdof_dot_j qvel_j: v x cdof_j with v the body's velocity (hinge / slide; the joint's own term drops out of the cross
+        // product), or the translational part of a free body's velocity for its three rotational dofs
+        for (int d = lane; d < ka->m.nv; d += G) {
+            const int j = dof_jnt_()[d], b = dof_body_()[d];
+            real o[6] = {0, 0, 0, 0, 0, 0};
+            if (jnt_type_()[j] == J_FREE) {
+                const int d0 = jnt_dofadr_()[j];
+                if (d - d0 >= 3) {
+                    real vt[6] = {0, 0, 0, 0, 0, 0};
+                    for (int k = 0; k < 3; k++)
+                        for (int q = 0; q < 6; q++) vt[q] += cdof[6 * (d0 + k) + q] * qvel[d0 + k];
+                    cross_motion(vt, cdof + 6 * d, o);
                 }
-                SInert<real> s;
-                body_inertia(ka, xmat, xipos, b, s);
-                real sv[10] = {s.m, s.h[0], s.h[1], s.h[2], s.I[0], s.I[1], s.I[2], s.I[3], s.I[4], s.I[5]};
+            } else {
+                cross_motion(cvel + 6 * b, cdof + 6 * d, o);
+            }
+            const real qd = qvel[d];
+            for (int q = 0; q < 6; q++) cdd[6 * d + q] = o[q] * qd;
+        }
+        GSYNC();
+        // inertial force of every body: I a + v x* (I v)
+        for (int b = lane; b < nb; b += G) {
+            const int t = body_tree_()[b];
+            real f[6] = {0, 0, 0, 0, 0, 0};
+            if (t >= 0) {
+                real a[6] = {0, 0, 0, -ka->m.gravity[0], -ka->m.gravity[1], -ka->m.gravity[2]}, v[6];
+                const int a0 = tree_dofadr_()[t], n = tree_dofnum_()[t], mask = body_dofmask_()[b];
+                for (int k = 0; k < n; k++)
+                    if ((mask >> k) & 1)
+                        for (int q = 0; q < 6; q++) a[q] += cdd[6 * (a0 + k) + q];
+                for (int q = 0; q < 6; q++) v[q] = cvel[6 * b + q];
+                SInert<real> si;
+                body_inertia(ka, xmat, xipos, b, si);
+                const real sv[10] = {si.m, si.h[0], si.h[1], si.h[2], si.I[0], si.I[1], si.I[2], si.I[3], si.I[4], si.I[5]};
                 real Ia[6], Iv[6], vIv[6];
                 inert_mul(sv, a, Ia);
                 inert_mul(sv, v, Iv);
                 cross_force(v, Iv, vIv);
-                for (int k = 0; k < 6; k++) { cvel[6 * b + k] = v[k]; cacc[6 * b + k] = a[k]; cfrc[6 * b + k] = Ia[k] + vIv[k]; }
+                for (int q = 0; q < 6; q++) f[q] = Ia[q] + vIv[q];
             }
-            for (int bi = b1 - 1; bi > b0; bi--) {
-                int b = tree_bodylist_()[bi], p = body_parent_()[b];
-                if (body_tree_()[p] != t) continue;
-                for (int k = 0; k < 6; k++) cfrc[6 * p + k] += cfrc[6 * b + k];
-            }
-            int a0 = tree_dofadr_()[t];
-            for (int i = a0; i < a0 + tree_dofnum_()[t]; i++) {
-                real s = 0;
-                for (int k = 0; k < 6; k++) s += cdof[6 * i + k] * cfrc[6 * dof_body_()[i] + k];
-                bias[i] = s;
-            }
+            for (int q = 0; q < 6; q++) cfrc[6 * b + q] = f[q];
+        }
+        GSYNC();
+        // joint torques: cdof_i . (forces of the subtree of dof i's body)
+        for (int i = lane; i < ka->m.nv; i += G) {
+            const int b = dof_body_()[i];
+            real f[6] = {0, 0, 0, 0, 0, 0};
+            for (int d = b; d <= body_last_()[b]; d++)
+                for (int q = 0; q < 6; q++) f[q] += cfrc[6 * d + q];
+            real sacc = 0;
+            for (int q = 0; q < 6; q++) sacc += cdof[6 * i + q] * f[q];
+            bias[i] = sacc;
         }
         GSYNC();
     }
