@@ -65,6 +65,7 @@ struct DevModel {
     // constraint Jacobian rows of every env: real[N][maxefc][16], rewritten each substep (kept out of LDS so that more envs
     // fit on a CU; the working set of the resident envs stays in L2)
     real* rJ_glob;
+    real* rB_glob;      // rows of J M^-1, same layout (the Gauss-Seidel sweeps apply force changes through them)
     real* gA_glob;      // intra-group couplings real[N][maxgrp][16] (write once per substep, read by the Gauss-Seidel sweeps)
     int* near_glob;     // Verlet neighbour lists int[N][NEAR_MAX] (rebuilt when a geom moved more than skin / 2)
     real* gref_glob;    // geom centres at the last rebuild, real[N][ngeom][3]
@@ -247,20 +248,21 @@ constexpr int GRP_MAX = 6;   // rows per Gauss-Seidel group (a condim-6 contact 
 // A contact is exactly one group, so the elliptic-cone projection of its friction block is local to the group.
 // Separate noinline function: the sweep loop gets its own register allocation.
 // rowI[i] = two 13-bit dof windows of row i: first dof (6) | count (4) | kinematic tree (3).
-// B = J M^-1 is not stored: each lane rebuilds its entry from the tree's dense 8x8 inverse (Minv) and the row's J window.
+// B = J M^-1 is read from the global row scratch next to J (written by the row's lane in make_constraints).
 // ------------------------------------------------------------------------------------------------
 template <typename real>
-__device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, const real* __restrict__ rJ, LDS_PTR(const real) Minv,
+__device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, const real* __restrict__ rJ, const real* __restrict__ rB,
                                                      LDS_PTR(real) q, LDS_PTR(const int) gI, const real* __restrict__ gA, int ngrp, int iters,
                                                      int noslip_iters) {
-    const int lane = threadIdx.x & 63, d = lane >> 4, l16 = lane & 15, sh = l16 < TREE_W ? 0 : 13, k8 = l16 & (TREE_W - 1), w8 = l16 & TREE_W;
+    // lane 8 d + k serves row d of the group (d < 6) and dof slot k of BOTH of the row's tree windows
+    const int lane = threadIdx.x & 63, d = lane >> 3, k8 = lane & 7, dr = d < GRP_MAX ? d : 0;
     const int lr = lane < GRP_MAX ? lane : 0;          // row slot owned in the sequential phase
     const int tri = lr * (lr - 1) / 2;                 // offset of that row in the packed lower triangle
     if (ngrp <= 0) return;
     // software pipeline: group headers two groups ahead, row windows one group ahead
     int gi = __builtin_amdgcn_readfirstlane(gI[0]);
     int gin = __builtin_amdgcn_readfirstlane(gI[ngrp > 1 ? 1 : 0]);
-    int ra0 = rowI[(gi & 0xffff) + d], ra1 = rowI[(gi & 0xffff) + 4 + d];
+    int ra = rowI[(gi & 0xffff) + dr];
     const int total = (iters + noslip_iters) * ngrp;
     int g = 0, it = 0;
     for (int step = 0; step < total; step++) {
@@ -268,23 +270,18 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         const int start = gi & 0xffff, cnt = (gi >> 16) & 15;
         const bool contact = (gi >> 24) & 1;
         const int g1 = g + 1 < ngrp ? g + 1 : 0, g2 = g1 + 1 < ngrp ? g1 + 1 : 0;
-        // ---- issue every LDS read of this group (and the look-ahead ones) in one batch ----
+        // ---- issue every read of this group (and the look-ahead ones) in one batch ----
         const int ginn_v = gI[g2];
-        const int ra0n = rowI[(gin & 0xffff) + d], ra1n = rowI[(gin & 0xffff) + 4 + d];
-        const int row0 = start + d, row1 = start + 4 + d;
-        const int adr0 = ((ra0 >> sh) & 63) + k8, adr1 = ((ra1 >> sh) & 63) + k8;
-        const bool in0 = d < cnt && k8 < ((ra0 >> (sh + 6)) & 15), in1 = 4 + d < cnt && k8 < ((ra1 >> (sh + 6)) & 15);
-        const real J0 = rJ[ROW_S * row0 + l16], q0 = q[in0 ? adr0 : 0];
-        const real J1 = rJ[ROW_S * row1 + l16], q1 = q[in1 ? adr1 : 0];
-        real B0 = 0, B1 = 0;
-        {
-            LDS_PTR(const real) Mi0 = Minv + 64 * ((ra0 >> (sh + 10)) & 7) + 8 * k8;
-            LDS_PTR(const real) Mi1 = Minv + 64 * ((ra1 >> (sh + 10)) & 7) + 8 * k8;
-            const real* Jw0 = rJ + ROW_S * row0 + w8;
-            const real* Jw1 = rJ + ROW_S * row1 + w8;
-#pragma unroll
-            for (int j = 0; j < TREE_W; j++) { B0 += Mi0[j] * Jw0[j]; B1 += Mi1[j] * Jw1[j]; }
-        }
+        const int ran = rowI[(gin & 0xffff) + dr];
+        const bool inr = d < cnt;
+        const int row = start + (inr ? d : 0);
+        const int adrA = (ra & 63) + k8, adrB = ((ra >> 13) & 63) + k8;
+        const bool inA = inr && k8 < ((ra >> 6) & 15), inB = inr && k8 < ((ra >> 19) & 15);
+        const real* Jr = rJ + ROW_S * row + k8;
+        const real* Br = rB + ROW_S * row + k8;
+        const real JA = inA ? Jr[0] : real(0), JB = inB ? Jr[TREE_W] : real(0);
+        const real BA = inA ? Br[0] : real(0), BB = inB ? Br[TREE_W] : real(0);
+        const real qA = q[inA ? adrA : 0], qB = q[inB ? adrB : 0];
         const bool mine = lane < cnt;
         LDS_PTR(real) S = rowS + RS_S * (start + (mine ? lane : 0));
         const real aref = S[0], R = S[1], inv2 = S[2], inv3 = S[3], lo = S[4], hi = S[5], f0 = S[6], muinv = S[7];
@@ -293,10 +290,9 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         for (int s = 0; s < GRP_MAX - 1; s++) a[s] = gA[16 * g + tri + s];
 #pragma unroll
         for (int s = 0; s < GRP_MAX - 1; s++) a[s] = (mine && s < lane) ? a[s] : real(0);
-        // ---- row residual dot products: one matrix row per 16-lane DPP row, two passes ----
-        real x0 = row16_sum(in0 ? J0 * q0 : real(0)), x1 = row16_sum(in1 ? J1 * q1 : real(0));
-        const real y0 = __shfl(x0, 16 * (lane & 3), 64), y1 = __shfl(x1, 16 * (lane & 3), 64);
-        const real dot = lane < 4 ? y0 : y1;
+        // ---- row residuals J_r . qacc: every row is summed over its 8 lanes, lane r then fetches row r's sum ----
+        const real x = oct_sum(JA * qA + JB * qB);
+        const real dot = __shfl(x, 8 * lr, 64);
         // ---- sequential relaxation on lanes 0..cnt-1 (lane r = row start + r) ----
         const real inv = noslip ? inv3 : inv2;
         real res = dot - aref + (noslip ? real(0) : R * f0);
@@ -320,16 +316,15 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         }
         if (mine) S[6] = f;
         const real delta = mine ? f - f0 : real(0);
-        // ---- qacc += B_r^T delta_r, 4 rows per pass ----
-        const real dd0 = __shfl(delta, d, 64), dd1 = __shfl(delta, 4 + d, 64);
-        if (in0) __hip_atomic_fetch_add(q + adr0, B0 * dd0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (in1) __hip_atomic_fetch_add(q + adr1, B1 * dd1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // ---- qacc += B_r^T delta_r ----
+        const real dd = __shfl(delta, d, 64);
+        if (inA) __hip_atomic_fetch_add(q + adrA, BA * dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (inB) __hip_atomic_fetch_add(q + adrB, BB * dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         gi = gin;
         gin = __builtin_amdgcn_readfirstlane(ginn_v);
-        ra0 = ra0n;
-        ra1 = ra1n;
+        ra = ran;
         g = g1;
         if (g1 == 0) it++;
     }
@@ -338,6 +333,16 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
 }  // namespace avs
 #include "avsim_newton.hip.h"
 namespace avs {
+
+// one 16-word row record to global memory in 16-byte pieces (rows are 64- / 128-byte aligned)
+AVS_DEV void store_row16(float* dst, const float* v) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) reinterpret_cast<float4*>(dst)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+AVS_DEV void store_row16(double* dst, const double* v) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) reinterpret_cast<double2*>(dst)[q] = make_double2(v[2 * q], v[2 * q + 1]);
+}
 
 template <int G>
 AVS_DEV unsigned long long group_mask(int grp) {
@@ -477,6 +482,7 @@ struct Env {
         : ka(ka_), r(r_), ii(i_), lane(lane_), grp(grp_), lr(lr_), li(li_) {}
     // hot model tables live in LDS (copied once per block); the accessors rebuild the pointer from the kernarg offset
     AVS_DEV real* rows_() const { return ka->m.rJ_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
+    AVS_DEV real* rowsB_() const { return ka->m.rB_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
     AVS_DEV real* coup_() const { return ka->m.gA_glob + (size_t)env * ka->lay.maxgrp * 16; }
     AVS_DEV int* near_() const { return ka->m.near_glob + (size_t)env * NEAR_MAX; }
     AVS_DEV real* gref_() const { return ka->m.gref_glob + (size_t)env * ka->m.ngeom * 3; }
@@ -1252,6 +1258,7 @@ struct Env {
             const real aref = -Bd * vel - K * imp * (pos - margin);
             // B = J M^-1 per tree (dense 8x8 inverse), diag = J B^T
             real dg = 0;
+            real Bv[ROW_W];
 #pragma unroll
             for (int k = 0; k < TREE_W; k++) {
                 real sa = 0, sb = 0;
@@ -1262,9 +1269,11 @@ struct Env {
                     for (int j = 0; j < TREE_W; j++) sb += Minv[64 * tB + 8 * k + j] * J[TREE_W + j];
                 }
                 dg += J[k] * sa + J[TREE_W + k] * sb;
+                Bv[k] = sa;
+                Bv[TREE_W + k] = sb;
             }
-#pragma unroll
-            for (int k = 0; k < ROW_W; k++) rJ[ROW_S * i + k] = J[k];
+            store_row16(rJ + ROW_S * i, J);
+            store_row16(rowsB_() + ROW_S * i, Bv);
             // warm start: force implied by last step's acceleration, f = -D (J qacc_ws - aref), made feasible per row
             const int a0 = tree_dofadr_()[tA], nA = tree_dofnum_()[tA], b0 = tB >= 0 ? tree_dofadr_()[tB] : 0, nB = tB >= 0 ? tree_dofnum_()[tB] : 0;
             real jw = 0;
@@ -1358,7 +1367,7 @@ struct Env {
             nit_sum += used; nit_max = used > nit_max ? used : nit_max;
             GSYNC();
             long long tn0 = profiling ? __builtin_readcyclecounter() : 0;
-            pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (const real*)rJ, (LDS_PTR(const real))Minv, (LDS_PTR(real))qacc,
+            pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (const real*)rJ, (const real*)rowsB_(), (LDS_PTR(real))qacc,
                              (LDS_PTR(const int))(ii + ka->lay.gI), (const real*)coup_(), misc[5], 0, ka->m.noslip_iters);
             if (profiling && lane == 0) (ii + ka->lay.nprof)[6] += (int)(__builtin_readcyclecounter() - tn0);
         } else {
@@ -1384,7 +1393,7 @@ struct Env {
         GSYNC();
         // Gauss-Seidel sweeps (+ noslip sweeps) in the register-resident wave kernel
         static_assert(G == 64, "the solver maps one env to one wavefront");
-        pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (const real*)rJ, (LDS_PTR(const real))Minv, (LDS_PTR(real))qacc,
+        pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (const real*)rJ, (const real*)rowsB_(), (LDS_PTR(real))qacc,
                          (LDS_PTR(const int))(ii + ka->lay.gI), (const real*)coup_(), misc[5], pgs_iters, ka->m.noslip_iters);
         }
         GSYNC();
@@ -1870,8 +1879,9 @@ struct PhysHost {
     void alloc_contacts() {
         if (d_rows) (void)hipFree(d_rows);
         d_rows = nullptr;
-        if (hipMalloc(&d_rows, (size_t)N * maxefc * ROW_S * (f64 ? 8 : 4)) != hipSuccess) throw std::runtime_error("hipMalloc of the constraint row buffer failed");
+        if (hipMalloc(&d_rows, (size_t)N * maxefc * ROW_S * (f64 ? 8 : 4) * 2) != hipSuccess) throw std::runtime_error("hipMalloc of the constraint row buffers failed");
         mf.rJ_glob = (float*)d_rows; md.rJ_glob = (double*)d_rows;
+        mf.rB_glob = mf.rJ_glob + (size_t)N * maxefc * ROW_S; md.rB_glob = md.rJ_glob + (size_t)N * maxefc * ROW_S;
         if (d_coup) (void)hipFree(d_coup);
         if (d_near) (void)hipFree(d_near);
         if (d_gref) (void)hipFree(d_gref);
