@@ -33,7 +33,7 @@ struct NewtonArgs {
     LDS_PTR(real) rowS;          // 8 reals per row: aref, R, [Newton: J a - aref], 1/diag|0, lo, hi, force, 1/friction
     LDS_PTR(const int) rowI;     // dof windows of the row: (adr 6 | n 4 | tree 3) x 2
     LDS_PTR(const int) rmeta;    // type 2 | id 10 | sub 8 | tree ids
-    const real* rJ;              // 16 reals per row, global memory (L2-resident scratch of this env)
+    GLB_PTR(const real) rJ;      // 16 reals per row, global memory (L2-resident scratch of this env)
     LDS_PTR(const real) M;       // per-tree dense blocks
     LDS_PTR(real) a;             // qacc (in: start point, out: solution)
     LDS_PTR(const real) as;      // qacc_smooth
@@ -59,7 +59,7 @@ template <typename real>
 AVS_DEV real nrow_dot(const NewtonArgs<real>& A, int i, LDS_PTR(const real) v) {
     const int ra = A.rowI[i];
     const int a0 = ra & 63, nA = (ra >> 6) & 15, b0 = (ra >> 13) & 63, nB = (ra >> 19) & 15;
-    const real* J = A.rJ + ROW_S * i;
+    GLB_PTR(const real) J = A.rJ + ROW_S * i;
     real s = 0;
 #pragma unroll
     for (int k = 0; k < TREE_W; k++) {
@@ -186,7 +186,7 @@ template <typename real>
 AVS_DEV void nblock(const NewtonArgs<real>& A, int lane, int r0, int dim, bool full, const real* w, const real* c1, const real* c2, real s1, real s2) {
     const int ra = A.rowI[r0], t = lane & 15, gq = nslot_dof(ra, t);
     const int nu = ((ra >> 19) & 15) > 0 ? 4 : 2;
-    const real* J = A.rJ + ROW_S * r0;
+    GLB_PTR(const real) J = A.rJ + ROW_S * r0;
     real Jt[6], y1t = 0, y2t = 0;
 #pragma unroll
     for (int p = 0; p < 6; p++) Jt[p] = p < dim ? J[ROW_S * p + t] : real(0);
@@ -254,7 +254,7 @@ AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, L
 // r / ii: the env's real and int LDS regions, li: the block's hot-table image; everything else comes from the layout
 // NCH = contact chunks of 64 (one contact per lane and chunk): 1 when the model's contact cap is <= 64
 template <typename real, int NCH>
-__device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, const real* rows, LDS_PTR(real) r_, LDS_PTR(int) ii_, LDS_PTR(const int) li_, int nefc, int ncon, int nlead,
+__device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PTR(const real) rows, LDS_PTR(real) r_, LDS_PTR(int) ii_, LDS_PTR(const int) li_, int nefc, int ncon, int nlead,
                                                       int iters, real tol, real scale, int profiling) {
     const int lane = threadIdx.x & 63;
     NewtonArgs<real> A;
@@ -269,14 +269,14 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, const 
         A.rowS = r + L->rowS; A.rowI = ii + L->rowI; A.rmeta = ii + L->rmeta;
         {   // the row pointer is wave-uniform: back to SGPRs
             const unsigned long long p_ = (unsigned long long)rows;
-            A.rJ = (const real*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p_));
+            A.rJ = (GLB_PTR(const real))(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p_));
         }
         A.M = r + L->M; A.a = r + L->qacc; A.as = r + L->asm_;
         A.H = r + L->nH; A.g = r + L->ng; A.dl = r + L->ndl; A.jv = r + L->njv;
         A.cefc = ii + L->cefc;
         A.prof = profiling ? ii + L->nprof : (LDS_PTR(int))nullptr;
         A.tree_dofadr = li + O->tree_dofadr; A.tree_dofnum = li + O->tree_dofnum; A.tree_madr = li + O->tree_madr; A.dof_tree = li + O->dof_tree;
-        A.nv = ka->m.nv; A.ntree = ka->m.ntree;
+        A.nv = __builtin_amdgcn_readfirstlane(ka->m.nv); A.ntree = __builtin_amdgcn_readfirstlane(ka->m.ntree);
         A.nefc = __builtin_amdgcn_readfirstlane(nefc); A.ncon = __builtin_amdgcn_readfirstlane(ncon);
         A.nlead = __builtin_amdgcn_readfirstlane(nlead); A.iters = __builtin_amdgcn_readfirstlane(iters);
         A.tol = tol; A.scale = scale; A.ls_tol = sizeof(real) == 8 ? real(1e-10) : real(1e-4);
@@ -358,7 +358,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, const 
             const real f = A.rowS[RS_S * i + 6];
             if (f == 0) continue;
             const int ra = A.rowI[i];
-            const real* J = A.rJ + ROW_S * i;
+            GLB_PTR(const real) J = A.rJ + ROW_S * i;
 #pragma unroll
             for (int s = 0; s < ROW_W; s++) {
                 const int dof = nslot_dof(ra, s);
@@ -424,12 +424,12 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, const 
                 // L_ij for the rows below, d on the diagonal, y_j = (L^-1 (-g))_j from lane nv ("row nv" is g's storage)
                 if (lane >= j && lane <= nv) A.H[rbase + j] = lane == j ? d : lij;
 #pragma unroll
-                for (int mb = 1; mb < NVMAX; mb += 4) {
+                for (int mb = 1; mb < NVMAX; mb += 8) {
                     if (j + mb <= nv - 1) {          // wave-uniform: the rest of the row is past the matrix
 #pragma unroll
-                        for (int mm = 0; mm < 4; mm++) {
+                        for (int mm = 0; mm < 8; mm++) {
                             const int m = mb + mm;
-                            if (m < NVMAX) row[m - 1] = row[m] - lij * lane_get(lij, j + m);
+                            if (m < NVMAX) row[m - 1] = row[m] - lij * lane_get(lij, (j + m) & 63);
                         }
                     }
                 }

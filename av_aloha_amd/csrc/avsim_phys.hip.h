@@ -201,6 +201,7 @@ AVS_DEV double wave_sum(double x) {
 }
 
 #define LDS_PTR(T) __attribute__((address_space(3))) T*
+#define GLB_PTR(T) __attribute__((address_space(1))) T*   // global memory, so that loads are global_load, not flat_load
 
 // ------------------------------------------------------------------------------------------------
 // P8 inner loop, one env per wave (G == 64): projected Gauss-Seidel with the acceleration vector held in
@@ -251,8 +252,8 @@ constexpr int GRP_MAX = 6;   // rows per Gauss-Seidel group (a condim-6 contact 
 // B = J M^-1 is read from the global row scratch next to J (written by the row's lane in make_constraints).
 // ------------------------------------------------------------------------------------------------
 template <typename real>
-__device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, const real* __restrict__ rJ, const real* __restrict__ rB,
-                                                     LDS_PTR(real) q, LDS_PTR(const int) gI, const real* __restrict__ gA, int ngrp, int iters,
+__device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
+                                                     LDS_PTR(real) q, LDS_PTR(const int) gI, GLB_PTR(const real) gA, int ngrp, int iters,
                                                      int noslip_iters) {
     // lane 8 d + k serves row d of the group (d < 6) and dof slot k of BOTH of the row's tree windows
     const int lane = threadIdx.x & 63, d = lane >> 3, k8 = lane & 7, dr = d < GRP_MAX ? d : 0;
@@ -277,8 +278,8 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         const int row = start + (inr ? d : 0);
         const int adrA = (ra & 63) + k8, adrB = ((ra >> 13) & 63) + k8;
         const bool inA = inr && k8 < ((ra >> 6) & 15), inB = inr && k8 < ((ra >> 19) & 15);
-        const real* Jr = rJ + ROW_S * row + k8;
-        const real* Br = rB + ROW_S * row + k8;
+        GLB_PTR(const real) Jr = rJ + ROW_S * row + k8;
+        GLB_PTR(const real) Br = rB + ROW_S * row + k8;
         const real JA = inA ? Jr[0] : real(0), JB = inB ? Jr[TREE_W] : real(0);
         const real BA = inA ? Br[0] : real(0), BB = inB ? Br[TREE_W] : real(0);
         const real qA = q[inA ? adrA : 0], qB = q[inB ? adrB : 0];
@@ -335,13 +336,15 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
 namespace avs {
 
 // one 16-word row record to global memory in 16-byte pieces (rows are 64- / 128-byte aligned)
-AVS_DEV void store_row16(float* dst, const float* v) {
+typedef float avs_v4f __attribute__((ext_vector_type(4)));
+typedef double avs_v2d __attribute__((ext_vector_type(2)));
+AVS_DEV void store_row16(GLB_PTR(float) dst, const float* v) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) reinterpret_cast<float4*>(dst)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    for (int q = 0; q < 4; q++) { avs_v4f t = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; ((GLB_PTR(avs_v4f))dst)[q] = t; }
 }
-AVS_DEV void store_row16(double* dst, const double* v) {
+AVS_DEV void store_row16(GLB_PTR(double) dst, const double* v) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) reinterpret_cast<double2*>(dst)[q] = make_double2(v[2 * q], v[2 * q + 1]);
+    for (int q = 0; q < 8; q++) { avs_v2d t = {v[2 * q], v[2 * q + 1]}; ((GLB_PTR(avs_v2d))dst)[q] = t; }
 }
 
 template <int G>
@@ -481,11 +484,11 @@ struct Env {
     __device__ Env(KPtr<real> ka_, real* r_, int* i_, int lane_, int grp_, const real* lr_, const int* li_)
         : ka(ka_), r(r_), ii(i_), lane(lane_), grp(grp_), lr(lr_), li(li_) {}
     // hot model tables live in LDS (copied once per block); the accessors rebuild the pointer from the kernarg offset
-    AVS_DEV real* rows_() const { return ka->m.rJ_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
-    AVS_DEV real* rowsB_() const { return ka->m.rB_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
-    AVS_DEV real* coup_() const { return ka->m.gA_glob + (size_t)env * ka->lay.maxgrp * 16; }
-    AVS_DEV int* near_() const { return ka->m.near_glob + (size_t)env * NEAR_MAX; }
-    AVS_DEV real* gref_() const { return ka->m.gref_glob + (size_t)env * ka->m.ngeom * 3; }
+    AVS_DEV GLB_PTR(real) rows_() const { return (GLB_PTR(real))ka->m.rJ_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
+    AVS_DEV GLB_PTR(real) rowsB_() const { return (GLB_PTR(real))ka->m.rB_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
+    AVS_DEV GLB_PTR(real) coup_() const { return (GLB_PTR(real))ka->m.gA_glob + (size_t)env * ka->lay.maxgrp * 16; }
+    AVS_DEV GLB_PTR(int) near_() const { return (GLB_PTR(int))ka->m.near_glob + (size_t)env * NEAR_MAX; }
+    AVS_DEV GLB_PTR(real) gref_() const { return (GLB_PTR(real))ka->m.gref_glob + (size_t)env * ka->m.ngeom * 3; }
     AVS_DEV const int* body_parent_() const { return li + ka->mo.body_parent; }
     AVS_DEV const int* body_jntadr_() const { return li + ka->mo.body_jntadr; }
     AVS_DEV const int* body_jntnum_() const { return li + ka->mo.body_jntnum; }
@@ -963,8 +966,8 @@ struct Env {
         int ncand = 0;
         long long tb0 = __builtin_readcyclecounter();
         const real skin = real(0.05);
-        real* gref = gref_();
-        int* nearl = near_();
+        GLB_PTR(real) gref = gref_();
+        GLB_PTR(int) nearl = near_();
         // pair test with extra reach `pad` (0 = exact broad phase)
         auto pair_hit = [&](int p, real pad) -> bool {
             int g1 = ka->m.pair_geom[2 * p], g2 = ka->m.pair_geom[2 * p + 1];
@@ -990,8 +993,7 @@ struct Env {
         if (misc[7]) {
             for (int g = lane; g < ka->m.ngeom; g += G)
                 if (!geom_static_()[g]) {
-                    real d[3];
-                    sub3(gcen + 3 * g, gref + 3 * g, d);
+                    const real d[3] = {gcen[3 * g] - gref[3 * g], gcen[3 * g + 1] - gref[3 * g + 1], gcen[3 * g + 2] - gref[3 * g + 2]};
                     moved |= dot3(d, d) > real(0.25) * skin * skin;
                 }
         }
@@ -1150,7 +1152,8 @@ struct Env {
         if (lane == 0) { misc[1] = nefc; if (ovf) misc[2] |= 2; }
         GSYNC();
         // --- fill rows (one row per lane) ---
-        real *rJ = rows_(), *rowS = r + ka->lay.rowS, *warm = r + ka->lay.warm, *Minv = r + ka->lay.Minv;
+        GLB_PTR(real) rJ = rows_();
+        real *rowS = r + ka->lay.rowS, *warm = r + ka->lay.warm, *Minv = r + ka->lay.Minv;
         int* rowI = ii + ka->lay.rowI;
         real* Lm = r + ka->lay.L;
         for (int i = lane; i < nefc; i += G) {
@@ -1302,7 +1305,7 @@ struct Env {
         GSYNC();
         // --- Gauss-Seidel groups: the leading non-contact rows in packs of GRP_MAX, then one group per contact ---
         int* gI = ii + ka->lay.gI;
-        real* gA = coup_();
+        GLB_PTR(real) gA = coup_();
         const int nlead = misc[4];   // number of equality / dry-friction / limit rows (they precede the contacts)
         int ngrp = 0;
         for (int base = 0; base < nefc; base += G) {
@@ -1353,7 +1356,8 @@ struct Env {
     __device__ void solve(int pgs_iters, int solver, int newton_iters, real newton_tol, real scale) {
         PHASE_BEGIN();
         int *misc = ii + ka->lay.misc, *rmeta = ii + ka->lay.rmeta, *cefc = ii + ka->lay.cefc, *rowI = ii + ka->lay.rowI;
-        real *qacc = r + ka->lay.qacc, *as = r + ka->lay.asm_, *rowS = r + ka->lay.rowS, *rJ = rows_(), *fcon = r + ka->lay.fcon;
+        real *qacc = r + ka->lay.qacc, *as = r + ka->lay.asm_, *rowS = r + ka->lay.rowS, *fcon = r + ka->lay.fcon;
+        GLB_PTR(real) rJ = rows_();
         int nefc = misc[1], ncon = misc[0];
         real* Minv = r + ka->lay.Minv;
         if (solver == 1) {
@@ -1362,13 +1366,13 @@ struct Env {
             for (int k = lane; k < ka->m.nv; k += G) qacc[k] = warm[k];
             GSYNC();
             int used = ka->lay.maxcon <= 64
-                ? newton_solve<real, 1>(ka, (const real*)rJ, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0)
-                : newton_solve<real, 2>(ka, (const real*)rJ, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0);
+                ? newton_solve<real, 1>(ka, (GLB_PTR(const real))rJ, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0)
+                : newton_solve<real, 2>(ka, (GLB_PTR(const real))rJ, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0);
             nit_sum += used; nit_max = used > nit_max ? used : nit_max;
             GSYNC();
             long long tn0 = profiling ? __builtin_readcyclecounter() : 0;
-            pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (const real*)rJ, (const real*)rowsB_(), (LDS_PTR(real))qacc,
-                             (LDS_PTR(const int))(ii + ka->lay.gI), (const real*)coup_(), misc[5], 0, ka->m.noslip_iters);
+            pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (GLB_PTR(const real))rJ, (GLB_PTR(const real))rowsB_(), (LDS_PTR(real))qacc,
+                             (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], 0, ka->m.noslip_iters);
             if (profiling && lane == 0) (ii + ka->lay.nprof)[6] += (int)(__builtin_readcyclecounter() - tn0);
         } else {
         // warm-start forces of friction blocks back onto their cones (one contact per lane)
@@ -1393,8 +1397,8 @@ struct Env {
         GSYNC();
         // Gauss-Seidel sweeps (+ noslip sweeps) in the register-resident wave kernel
         static_assert(G == 64, "the solver maps one env to one wavefront");
-        pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (const real*)rJ, (const real*)rowsB_(), (LDS_PTR(real))qacc,
-                         (LDS_PTR(const int))(ii + ka->lay.gI), (const real*)coup_(), misc[5], pgs_iters, ka->m.noslip_iters);
+        pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (GLB_PTR(const real))rJ, (GLB_PTR(const real))rowsB_(), (LDS_PTR(real))qacc,
+                         (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], pgs_iters, ka->m.noslip_iters);
         }
         GSYNC();
         // qfrc_constraint = J^T f
@@ -1404,7 +1408,8 @@ struct Env {
     // out = J^T f: one row per lane, scattered over the row's two dof windows with returnless LDS atomics
     __device__ void jt_force(real* out, int nefc) {
         int* rowI = ii + ka->lay.rowI;
-        real *rowS = r + ka->lay.rowS, *rJ = rows_();
+        real* rowS = r + ka->lay.rowS;
+        GLB_PTR(real) rJ = rows_();
         for (int k = lane; k < ka->m.nv; k += G) out[k] = 0;
         GSYNC();
         for (int i = lane; i < nefc; i += G) {
