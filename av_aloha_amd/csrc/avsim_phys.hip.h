@@ -155,13 +155,26 @@ struct KArgs {
 template <typename real>
 using KPtr = const KArgs<real> __attribute__((address_space(4)))*;
 // start of a phase: forget what was loaded through ka so far (keeps the live ranges of model scalars inside one phase)
-#define PHASE_BEGIN()                                                                                  \
+#define PHASE_LAUNDER()                                                                                \
     do {                                                                                               \
         const unsigned long long p_ = (unsigned long long)ka;                                          \
         unsigned lo_ = __builtin_amdgcn_readfirstlane((unsigned)p_), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(p_ >> 32)); \
         asm volatile("" : "+s"(lo_), "+s"(hi_));                                                       \
         ka = (decltype(ka))(((unsigned long long)hi_ << 32) | lo_);                                    \
     } while (0)
+// the env's LDS regions through pointers whose provenance (LDS) is visible inside a non-inlined member function: without it
+// every access through the members `r` / `ii` is a flat_load / flat_store
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AVS_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
+#else
+#define AVS_ASSUME_LDS(p) ((void)(p))
+#endif
+#define LDS_BASES()                                                                       \
+    real* const r = this->r; AVS_ASSUME_LDS(r);     \
+    int* const ii = this->ii; AVS_ASSUME_LDS(ii);   \
+    (void)r; (void)ii
+#define PHASE_BEGIN() PHASE_LAUNDER(); LDS_BASES()
+
 
 
 #define GSYNC()                                              \
@@ -484,63 +497,65 @@ struct Env {
     __device__ Env(KPtr<real> ka_, real* r_, int* i_, int lane_, int grp_, const real* lr_, const int* li_)
         : ka(ka_), r(r_), ii(i_), lane(lane_), grp(grp_), lr(lr_), li(li_) {}
     // hot model tables live in LDS (copied once per block); the accessors rebuild the pointer from the kernarg offset
+    AVS_DEV const int* LI() const { const int* p = li; AVS_ASSUME_LDS(p); return p; }
+    AVS_DEV const real* LR() const { const real* p = lr; AVS_ASSUME_LDS(p); return p; }
     AVS_DEV GLB_PTR(real) rows_() const { return (GLB_PTR(real))ka->m.rJ_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
     AVS_DEV GLB_PTR(real) rowsB_() const { return (GLB_PTR(real))ka->m.rB_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
     AVS_DEV GLB_PTR(real) coup_() const { return (GLB_PTR(real))ka->m.gA_glob + (size_t)env * ka->lay.maxgrp * 16; }
     AVS_DEV GLB_PTR(int) near_() const { return (GLB_PTR(int))ka->m.near_glob + (size_t)env * NEAR_MAX; }
     AVS_DEV GLB_PTR(real) gref_() const { return (GLB_PTR(real))ka->m.gref_glob + (size_t)env * ka->m.ngeom * 3; }
-    AVS_DEV const int* body_parent_() const { return li + ka->mo.body_parent; }
-    AVS_DEV const int* body_jntadr_() const { return li + ka->mo.body_jntadr; }
-    AVS_DEV const int* body_jntnum_() const { return li + ka->mo.body_jntnum; }
-    AVS_DEV const int* body_dofadr_() const { return li + ka->mo.body_dofadr; }
-    AVS_DEV const int* body_dofnum_() const { return li + ka->mo.body_dofnum; }
-    AVS_DEV const int* body_tree_() const { return li + ka->mo.body_tree; }
-    AVS_DEV const int* body_dofmask_() const { return li + ka->mo.body_dofmask; }
-    AVS_DEV const int* body_last_() const { return li + ka->mo.body_last; }
-    AVS_DEV const int* tree_bodyadr_() const { return li + ka->mo.tree_bodyadr; }
-    AVS_DEV const int* tree_bodylist_() const { return li + ka->mo.tree_bodylist; }
-    AVS_DEV const int* tree_dofadr_() const { return li + ka->mo.tree_dofadr; }
-    AVS_DEV const int* tree_dofnum_() const { return li + ka->mo.tree_dofnum; }
-    AVS_DEV const int* tree_madr_() const { return li + ka->mo.tree_madr; }
-    AVS_DEV const int* jnt_type_() const { return li + ka->mo.jnt_type; }
-    AVS_DEV const int* jnt_qposadr_() const { return li + ka->mo.jnt_qposadr; }
-    AVS_DEV const int* jnt_dofadr_() const { return li + ka->mo.jnt_dofadr; }
-    AVS_DEV const int* jnt_actfrclimited_() const { return li + ka->mo.jnt_actfrclimited; }
-    AVS_DEV const int* limited_jnt_() const { return li + ka->mo.limited_jnt; }
-    AVS_DEV const int* dof_body_() const { return li + ka->mo.dof_body; }
-    AVS_DEV const int* dof_parent_() const { return li + ka->mo.dof_parent; }
-    AVS_DEV const int* dof_tree_() const { return li + ka->mo.dof_tree; }
-    AVS_DEV const int* dof_jnt_() const { return li + ka->mo.dof_jnt; }
-    AVS_DEV const int* floss_dof_() const { return li + ka->mo.floss_dof; }
-    AVS_DEV const int* ment_i_() const { return li + ka->mo.ment_i; }
-    AVS_DEV const int* ment_j_() const { return li + ka->mo.ment_j; }
-    AVS_DEV const int* act_dof_() const { return li + ka->mo.act_dof; }
-    AVS_DEV const int* act_qposadr_() const { return li + ka->mo.act_qposadr; }
-    AVS_DEV const int* act_ctrllimited_() const { return li + ka->mo.act_ctrllimited; }
-    AVS_DEV const int* geom_type_() const { return li + ka->mo.geom_type; }
-    AVS_DEV const int* geom_body_() const { return li + ka->mo.geom_body; }
-    AVS_DEV const int* geom_static_() const { return li + ka->mo.geom_static; }
-    AVS_DEV const real* body_pos_() const { return lr + ka->mo.body_pos; }
-    AVS_DEV const real* body_quat_() const { return lr + ka->mo.body_quat; }
-    AVS_DEV const real* body_mass_() const { return lr + ka->mo.body_mass; }
-    AVS_DEV const real* body_ipos_() const { return lr + ka->mo.body_ipos; }
-    AVS_DEV const real* body_inertia_() const { return lr + ka->mo.body_inertia; }
-    AVS_DEV const real* body_invweight0_() const { return lr + ka->mo.body_invweight0; }
-    AVS_DEV const real* jnt_pos_() const { return lr + ka->mo.jnt_pos; }
-    AVS_DEV const real* jnt_axis_() const { return lr + ka->mo.jnt_axis; }
-    AVS_DEV const real* jnt_range_() const { return lr + ka->mo.jnt_range; }
-    AVS_DEV const real* jnt_actfrcrange_() const { return lr + ka->mo.jnt_actfrcrange; }
-    AVS_DEV const real* jnt_margin_() const { return lr + ka->mo.jnt_margin; }
-    AVS_DEV const real* dof_armature_() const { return lr + ka->mo.dof_armature; }
-    AVS_DEV const real* dof_damping_() const { return lr + ka->mo.dof_damping; }
-    AVS_DEV const real* dof_frictionloss_() const { return lr + ka->mo.dof_frictionloss; }
-    AVS_DEV const real* dof_invweight0_() const { return lr + ka->mo.dof_invweight0; }
-    AVS_DEV const real* act_kp_() const { return lr + ka->mo.act_kp; }
-    AVS_DEV const real* act_kv_() const { return lr + ka->mo.act_kv; }
-    AVS_DEV const real* act_gear_() const { return lr + ka->mo.act_gear; }
-    AVS_DEV const real* act_ctrlrange_() const { return lr + ka->mo.act_ctrlrange; }
-    AVS_DEV const real* geom_cpos_() const { return lr + ka->mo.geom_cpos; }
-    AVS_DEV const real* geom_rbound_() const { return lr + ka->mo.geom_rbound; }
+    AVS_DEV const int* body_parent_() const { return LI() + ka->mo.body_parent; }
+    AVS_DEV const int* body_jntadr_() const { return LI() + ka->mo.body_jntadr; }
+    AVS_DEV const int* body_jntnum_() const { return LI() + ka->mo.body_jntnum; }
+    AVS_DEV const int* body_dofadr_() const { return LI() + ka->mo.body_dofadr; }
+    AVS_DEV const int* body_dofnum_() const { return LI() + ka->mo.body_dofnum; }
+    AVS_DEV const int* body_tree_() const { return LI() + ka->mo.body_tree; }
+    AVS_DEV const int* body_dofmask_() const { return LI() + ka->mo.body_dofmask; }
+    AVS_DEV const int* body_last_() const { return LI() + ka->mo.body_last; }
+    AVS_DEV const int* tree_bodyadr_() const { return LI() + ka->mo.tree_bodyadr; }
+    AVS_DEV const int* tree_bodylist_() const { return LI() + ka->mo.tree_bodylist; }
+    AVS_DEV const int* tree_dofadr_() const { return LI() + ka->mo.tree_dofadr; }
+    AVS_DEV const int* tree_dofnum_() const { return LI() + ka->mo.tree_dofnum; }
+    AVS_DEV const int* tree_madr_() const { return LI() + ka->mo.tree_madr; }
+    AVS_DEV const int* jnt_type_() const { return LI() + ka->mo.jnt_type; }
+    AVS_DEV const int* jnt_qposadr_() const { return LI() + ka->mo.jnt_qposadr; }
+    AVS_DEV const int* jnt_dofadr_() const { return LI() + ka->mo.jnt_dofadr; }
+    AVS_DEV const int* jnt_actfrclimited_() const { return LI() + ka->mo.jnt_actfrclimited; }
+    AVS_DEV const int* limited_jnt_() const { return LI() + ka->mo.limited_jnt; }
+    AVS_DEV const int* dof_body_() const { return LI() + ka->mo.dof_body; }
+    AVS_DEV const int* dof_parent_() const { return LI() + ka->mo.dof_parent; }
+    AVS_DEV const int* dof_tree_() const { return LI() + ka->mo.dof_tree; }
+    AVS_DEV const int* dof_jnt_() const { return LI() + ka->mo.dof_jnt; }
+    AVS_DEV const int* floss_dof_() const { return LI() + ka->mo.floss_dof; }
+    AVS_DEV const int* ment_i_() const { return LI() + ka->mo.ment_i; }
+    AVS_DEV const int* ment_j_() const { return LI() + ka->mo.ment_j; }
+    AVS_DEV const int* act_dof_() const { return LI() + ka->mo.act_dof; }
+    AVS_DEV const int* act_qposadr_() const { return LI() + ka->mo.act_qposadr; }
+    AVS_DEV const int* act_ctrllimited_() const { return LI() + ka->mo.act_ctrllimited; }
+    AVS_DEV const int* geom_type_() const { return LI() + ka->mo.geom_type; }
+    AVS_DEV const int* geom_body_() const { return LI() + ka->mo.geom_body; }
+    AVS_DEV const int* geom_static_() const { return LI() + ka->mo.geom_static; }
+    AVS_DEV const real* body_pos_() const { return LR() + ka->mo.body_pos; }
+    AVS_DEV const real* body_quat_() const { return LR() + ka->mo.body_quat; }
+    AVS_DEV const real* body_mass_() const { return LR() + ka->mo.body_mass; }
+    AVS_DEV const real* body_ipos_() const { return LR() + ka->mo.body_ipos; }
+    AVS_DEV const real* body_inertia_() const { return LR() + ka->mo.body_inertia; }
+    AVS_DEV const real* body_invweight0_() const { return LR() + ka->mo.body_invweight0; }
+    AVS_DEV const real* jnt_pos_() const { return LR() + ka->mo.jnt_pos; }
+    AVS_DEV const real* jnt_axis_() const { return LR() + ka->mo.jnt_axis; }
+    AVS_DEV const real* jnt_range_() const { return LR() + ka->mo.jnt_range; }
+    AVS_DEV const real* jnt_actfrcrange_() const { return LR() + ka->mo.jnt_actfrcrange; }
+    AVS_DEV const real* jnt_margin_() const { return LR() + ka->mo.jnt_margin; }
+    AVS_DEV const real* dof_armature_() const { return LR() + ka->mo.dof_armature; }
+    AVS_DEV const real* dof_damping_() const { return LR() + ka->mo.dof_damping; }
+    AVS_DEV const real* dof_frictionloss_() const { return LR() + ka->mo.dof_frictionloss; }
+    AVS_DEV const real* dof_invweight0_() const { return LR() + ka->mo.dof_invweight0; }
+    AVS_DEV const real* act_kp_() const { return LR() + ka->mo.act_kp; }
+    AVS_DEV const real* act_kv_() const { return LR() + ka->mo.act_kv; }
+    AVS_DEV const real* act_gear_() const { return LR() + ka->mo.act_gear; }
+    AVS_DEV const real* act_ctrlrange_() const { return LR() + ka->mo.act_ctrlrange; }
+    AVS_DEV const real* geom_cpos_() const { return LR() + ka->mo.geom_cpos; }
+    AVS_DEV const real* geom_rbound_() const { return LR() + ka->mo.geom_rbound; }
 
 
     // ---- P1 ------------------------------------------------------------------------------------
@@ -937,6 +952,7 @@ struct Env {
     }
 
     __device__ void load_shape(int g, Shape<real>& s) {
+        LDS_BASES();
         real *xpos = r + ka->lay.xpos, *xmat = r + ka->lay.xmat, *gcen = r + ka->lay.gcen;
         s.type = geom_type_()[g];
         for (int k = 0; k < 3; k++) s.size[k] = ka->m.geom_size[3 * g + k];
@@ -1407,6 +1423,8 @@ struct Env {
 
     // out = J^T f: one row per lane, scattered over the row's two dof windows with returnless LDS atomics
     __device__ void jt_force(real* out, int nefc) {
+        LDS_BASES();
+        AVS_ASSUME_LDS(out);
         int* rowI = ii + ka->lay.rowI;
         real* rowS = r + ka->lay.rowS;
         GLB_PTR(real) rJ = rows_();
