@@ -17,7 +17,7 @@ struct Shape {
     T size[3];
     T pos[3];      // world position of the geom frame
     T mat[9];      // geom->world rotation, row-major
-    const T* hull; // hull vertices in the geom frame (global memory)
+    GLB_PTR(const T) hull; // hull vertices in the geom frame (global memory)
     int nh;
     T center[3];   // an interior point (world)
     T lc[3], lh[3]; // local bounding box: centre and half extents in the geom frame

@@ -43,25 +43,94 @@ struct DevModel {
     int solver, newton_iters;     // 0 = PGS (dual), 1 = Newton (primal, the reference's default solver)
     real newton_tol, nscale;      // MuJoCo tolerance and 1/(meaninertia*nv) scaling of the termination tests
     // bodies
-    const int *body_parent, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_tree, *body_dofmask, *body_last;
-    const real *body_pos, *body_quat, *body_mass, *body_ipos, *body_inertia, *body_invweight0, *static_xpos, *static_xmat;
-    const int *tree_bodyadr, *tree_bodylist, *tree_dofadr, *tree_dofnum, *tree_madr;
+    GLB_PTR(const int) body_parent;
+    GLB_PTR(const int) body_jntadr;
+    GLB_PTR(const int) body_jntnum;
+    GLB_PTR(const int) body_dofadr;
+    GLB_PTR(const int) body_dofnum;
+    GLB_PTR(const int) body_tree;
+    GLB_PTR(const int) body_dofmask;
+    GLB_PTR(const int) body_last;
+    GLB_PTR(const real) body_pos;
+    GLB_PTR(const real) body_quat;
+    GLB_PTR(const real) body_mass;
+    GLB_PTR(const real) body_ipos;
+    GLB_PTR(const real) body_inertia;
+    GLB_PTR(const real) body_invweight0;
+    GLB_PTR(const real) static_xpos;
+    GLB_PTR(const real) static_xmat;
+    GLB_PTR(const int) tree_bodyadr;
+    GLB_PTR(const int) tree_bodylist;
+    GLB_PTR(const int) tree_dofadr;
+    GLB_PTR(const int) tree_dofnum;
+    GLB_PTR(const int) tree_madr;
     // joints / dofs
-    const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_actfrclimited, *limited_jnt;
-    const real *jnt_pos, *jnt_axis, *jnt_range, *jnt_actfrcrange, *jnt_solref, *jnt_solimp, *jnt_margin;
-    const int *dof_body, *dof_parent, *dof_tree, *dof_jnt, *floss_dof, *ment_i, *ment_j;
-    const real *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0, *dof_solref, *dof_solimp;
+    GLB_PTR(const int) jnt_type;
+    GLB_PTR(const int) jnt_qposadr;
+    GLB_PTR(const int) jnt_dofadr;
+    GLB_PTR(const int) jnt_actfrclimited;
+    GLB_PTR(const int) limited_jnt;
+    GLB_PTR(const real) jnt_pos;
+    GLB_PTR(const real) jnt_axis;
+    GLB_PTR(const real) jnt_range;
+    GLB_PTR(const real) jnt_actfrcrange;
+    GLB_PTR(const real) jnt_solref;
+    GLB_PTR(const real) jnt_solimp;
+    GLB_PTR(const real) jnt_margin;
+    GLB_PTR(const int) dof_body;
+    GLB_PTR(const int) dof_parent;
+    GLB_PTR(const int) dof_tree;
+    GLB_PTR(const int) dof_jnt;
+    GLB_PTR(const int) floss_dof;
+    GLB_PTR(const int) ment_i;
+    GLB_PTR(const int) ment_j;
+    GLB_PTR(const real) dof_armature;
+    GLB_PTR(const real) dof_damping;
+    GLB_PTR(const real) dof_frictionloss;
+    GLB_PTR(const real) dof_invweight0;
+    GLB_PTR(const real) dof_solref;
+    GLB_PTR(const real) dof_solimp;
     // actuators, equalities
-    const int *act_dof, *act_qposadr, *act_ctrllimited;
-    const real *act_kp, *act_kv, *act_gear, *act_ctrlrange;
-    const int *eq_dof1, *eq_dof2, *eq_qpos1, *eq_qpos2;
-    const real *eq_polycoef, *eq_solref, *eq_solimp, *qpos0;
+    GLB_PTR(const int) act_dof;
+    GLB_PTR(const int) act_qposadr;
+    GLB_PTR(const int) act_ctrllimited;
+    GLB_PTR(const real) act_kp;
+    GLB_PTR(const real) act_kv;
+    GLB_PTR(const real) act_gear;
+    GLB_PTR(const real) act_ctrlrange;
+    GLB_PTR(const int) eq_dof1;
+    GLB_PTR(const int) eq_dof2;
+    GLB_PTR(const int) eq_qpos1;
+    GLB_PTR(const int) eq_qpos2;
+    GLB_PTR(const real) eq_polycoef;
+    GLB_PTR(const real) eq_solref;
+    GLB_PTR(const real) eq_solimp;
+    GLB_PTR(const real) qpos0;
     // geoms
-    const int *geom_type, *geom_body, *geom_hull, *geom_class, *geom_static;
-    const real *geom_pos, *geom_mat, *geom_size, *geom_cpos, *geom_rbound, *geom_xpos0, *geom_xmat0, *geom_cen0, *geom_aabb0, *geom_lbox, *hull_vert;
+    GLB_PTR(const int) geom_type;
+    GLB_PTR(const int) geom_body;
+    GLB_PTR(const int) geom_hull;
+    GLB_PTR(const int) geom_class;
+    GLB_PTR(const int) geom_static;
+    GLB_PTR(const real) geom_pos;
+    GLB_PTR(const real) geom_mat;
+    GLB_PTR(const real) geom_size;
+    GLB_PTR(const real) geom_cpos;
+    GLB_PTR(const real) geom_rbound;
+    GLB_PTR(const real) geom_xpos0;
+    GLB_PTR(const real) geom_xmat0;
+    GLB_PTR(const real) geom_cen0;
+    GLB_PTR(const real) geom_aabb0;
+    GLB_PTR(const real) geom_lbox;
+    GLB_PTR(const real) hull_vert;
     // pairs
-    const int *pair_geom, *pair_condim;
-    const real *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
+    GLB_PTR(const int) pair_geom;
+    GLB_PTR(const int) pair_condim;
+    GLB_PTR(const real) pair_friction;
+    GLB_PTR(const real) pair_solref;
+    GLB_PTR(const real) pair_solimp;
+    GLB_PTR(const real) pair_margin;
+    GLB_PTR(const real) pair_gap;
     // constraint Jacobian rows of every env: real[N][maxefc][16], rewritten each substep (kept out of LDS so that more envs
     // fit on a CU; the working set of the resident envs stays in L2)
     real* rJ_glob;
@@ -70,8 +139,9 @@ struct DevModel {
     int* near_glob;     // Verlet neighbour lists int[N][NEAR_MAX] (rebuilt when a geom moved more than skin / 2)
     real* gref_glob;    // geom centres at the last rebuild, real[N][ngeom][3]
     // observation
-    const int* obs_qposadr;
-    const real *obs_offset, *obs_scale;
+    GLB_PTR(const int) obs_qposadr;
+    GLB_PTR(const real) obs_offset;
+    GLB_PTR(const real) obs_scale;
 };
 
 struct MOff {
@@ -214,7 +284,6 @@ AVS_DEV double wave_sum(double x) {
 }
 
 #define LDS_PTR(T) __attribute__((address_space(3))) T*
-#define GLB_PTR(T) __attribute__((address_space(1))) T*   // global memory, so that loads are global_load, not flat_load
 
 // ------------------------------------------------------------------------------------------------
 // P8 inner loop, one env per wave (G == 64): projected Gauss-Seidel with the acceleration vector held in
@@ -383,7 +452,7 @@ struct SInert {
 template <typename real>
 AVS_DEV void body_inertia(KPtr<real> ka, const real* xmat, const real* xipos, int b, SInert<real>& s) {
     const real* R = xmat + 9 * b;
-    const real* Ib = ka->m.body_inertia + 6 * b;
+    GLB_PTR(const real) Ib = ka->m.body_inertia + 6 * b;
     real I3[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]}, T[9], Ic[9];
 #pragma unroll
     for (int i = 0; i < 3; i++)
@@ -666,7 +735,7 @@ struct Env {
                         for (int k = 0; k < 3; k++) pos[k] += t0[k] * q;
                     }
                     if (body_tree_()[p] < 0) {      // parent welded to the world: fold its constant pose in right away
-                        const real* Rp = ka->m.static_xmat + 9 * p;
+                        GLB_PTR(const real) Rp = ka->m.static_xmat + 9 * p;
                         real Rn[9], t0[3];
                         for (int i = 0; i < 3; i++)
                             for (int j = 0; j < 3; j++) Rn[3 * i + j] = Rp[3 * i] * R[j] + Rp[3 * i + 1] * R[3 + j] + Rp[3 * i + 2] * R[6 + j];
@@ -968,7 +1037,7 @@ struct Env {
             mulmat(xmat + 9 * b, gp, t3);
             for (int k = 0; k < 3; k++) { s.pos[k] = xpos[3 * b + k] + t3[k]; s.center[k] = gcen[3 * g + k]; }
             const real* Rb = xmat + 9 * b;
-            const real* Rg = ka->m.geom_mat + 9 * g;
+            GLB_PTR(const real) Rg = ka->m.geom_mat + 9 * g;
             for (int i = 0; i < 3; i++)
                 for (int j = 0; j < 3; j++) s.mat[3 * i + j] = Rb[3 * i] * Rg[j] + Rb[3 * i + 1] * Rg[3 + j] + Rb[3 * i + 2] * Rg[6 + j];
         }
@@ -1099,6 +1168,7 @@ struct Env {
 
     // Jacobian entry of body b's point p for tree-local dof slot k of tree t (translational row along ax, or rotational)
     AVS_DEV real jac_entry(int b, int t, int k, const real* p, const real* ax, bool rot) const {
+        LDS_BASES();
         if (body_tree_()[b] != t || !((body_dofmask_()[b] >> k) & 1)) return real(0);
         const real* cd = r + ka->lay.cdof + 6 * (tree_dofadr_()[t] + k);
         if (rot) return ax[0] * cd[0] + ax[1] * cd[1] + ax[2] * cd[2];
@@ -1184,7 +1254,7 @@ struct Env {
             real solref[2], solimp[5];
             bool valid = true;
             if (type == R_EQ) {
-                const real* c = ka->m.eq_polycoef + 5 * id;
+                GLB_PTR(const real) c = ka->m.eq_polycoef + 5 * id;
                 real q1 = qpos[ka->m.eq_qpos1[id]] - ka->m.qpos0[ka->m.eq_qpos1[id]], q2 = qpos[ka->m.eq_qpos2[id]] - ka->m.qpos0[ka->m.eq_qpos2[id]];
                 real poly = c[0] + q2 * (c[1] + q2 * (c[2] + q2 * (c[3] + q2 * c[4])));
                 real dpoly = c[1] + q2 * (2 * c[2] + q2 * (3 * c[3] + q2 * 4 * c[4]));
@@ -1666,17 +1736,25 @@ struct PhysHost {
     int* d_img_int = nullptr;
     void* d_kargs = nullptr;        // KArgs<float|double> in device memory
     bool kargs_dirty = true;
+    // device pointer that converts to the plain and to the global-address-space pointer types
     template <typename T>
-    T* up(const std::vector<T>& v) {
+    struct DevPtr {
+        T* p;
+        operator T*() const { return p; }
+        operator GLB_PTR(T)() const { return (GLB_PTR(T))p; }
+        operator GLB_PTR(const T)() const { return (GLB_PTR(const T))p; }
+    };
+    template <typename T>
+    DevPtr<T> up(const std::vector<T>& v) {
         void* p = nullptr;
         size_t n = (v.size() ? v.size() : 1) * sizeof(T);
         if (hipMalloc(&p, n) != hipSuccess) throw std::runtime_error("hipMalloc failed while uploading the model");
         if (v.size() && hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("hipMemcpy failed while uploading the model");
         allocs.push_back(p);
-        return (T*)p;
+        return DevPtr<T>{(T*)p};
     }
     template <typename real>
-    const real* upr(const std::vector<double>& v) {
+    DevPtr<real> upr(const std::vector<double>& v) {
         std::vector<real> w(v.begin(), v.end());
         return up(w);
     }
