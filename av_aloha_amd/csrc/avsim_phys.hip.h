@@ -342,37 +342,51 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
     const int lr = lane < GRP_MAX ? lane : 0;          // row slot owned in the sequential phase
     const int tri = lr * (lr - 1) / 2;                 // offset of that row in the packed lower triangle
     if (ngrp <= 0) return;
-    // software pipeline: group headers two groups ahead, row windows one group ahead
+    // software pipeline: group headers three groups ahead, row windows two ahead, the J / J M^-1 entries (global memory, L2
+    // latency) one group ahead, so that a step only waits for LDS
+    auto jb_load = [&](int hdr, int win, real& ja, real& jb, real& ba, real& bb) {
+        const int st = hdr & 0xffff, cn = (hdr >> 16) & 15;
+        const bool in = d < cn;
+        const int rw = st + (in ? d : 0);
+        const bool a = in && k8 < ((win >> 6) & 15), b = in && k8 < ((win >> 19) & 15);
+        GLB_PTR(const real) Jr = rJ + ROW_S * rw + k8;
+        GLB_PTR(const real) Br = rB + ROW_S * rw + k8;
+        ja = a ? Jr[0] : real(0); jb = b ? Jr[TREE_W] : real(0);
+        ba = a ? Br[0] : real(0); bb = b ? Br[TREE_W] : real(0);
+    };
     int gi = __builtin_amdgcn_readfirstlane(gI[0]);
     int gin = __builtin_amdgcn_readfirstlane(gI[ngrp > 1 ? 1 : 0]);
-    int ra = rowI[(gi & 0xffff) + dr];
+    int ginn = __builtin_amdgcn_readfirstlane(gI[ngrp > 2 ? 2 : (ngrp > 1 ? 0 : 0)]);
+    int ra = rowI[(gi & 0xffff) + dr], ran = rowI[(gin & 0xffff) + dr];
+    real JA, JB, BA, BB;
+    jb_load(gi, ra, JA, JB, BA, BB);
+    real ac[GRP_MAX - 1];
+#pragma unroll
+    for (int s = 0; s < GRP_MAX - 1; s++) ac[s] = gA[tri + s];
     const int total = (iters + noslip_iters) * ngrp;
     int g = 0, it = 0;
     for (int step = 0; step < total; step++) {
         const bool noslip = it >= iters;
         const int start = gi & 0xffff, cnt = (gi >> 16) & 15;
         const bool contact = (gi >> 24) & 1;
-        const int g1 = g + 1 < ngrp ? g + 1 : 0, g2 = g1 + 1 < ngrp ? g1 + 1 : 0;
-        // ---- issue every read of this group (and the look-ahead ones) in one batch ----
-        const int ginn_v = gI[g2];
-        const int ran = rowI[(gin & 0xffff) + dr];
+        const int g1 = g + 1 < ngrp ? g + 1 : 0, g2 = g1 + 1 < ngrp ? g1 + 1 : 0, g3 = g2 + 1 < ngrp ? g2 + 1 : 0;
+        // ---- issue the look-ahead reads and this group's LDS reads in one batch ----
+        const int ginnn_v = gI[g3];
+        const int rann = rowI[(ginn & 0xffff) + dr];
+        real JAn, JBn, BAn, BBn;
+        jb_load(gin, ran, JAn, JBn, BAn, BBn);
         const bool inr = d < cnt;
-        const int row = start + (inr ? d : 0);
         const int adrA = (ra & 63) + k8, adrB = ((ra >> 13) & 63) + k8;
         const bool inA = inr && k8 < ((ra >> 6) & 15), inB = inr && k8 < ((ra >> 19) & 15);
-        GLB_PTR(const real) Jr = rJ + ROW_S * row + k8;
-        GLB_PTR(const real) Br = rB + ROW_S * row + k8;
-        const real JA = inA ? Jr[0] : real(0), JB = inB ? Jr[TREE_W] : real(0);
-        const real BA = inA ? Br[0] : real(0), BB = inB ? Br[TREE_W] : real(0);
         const real qA = q[inA ? adrA : 0], qB = q[inB ? adrB : 0];
         const bool mine = lane < cnt;
         LDS_PTR(real) S = rowS + RS_S * (start + (mine ? lane : 0));
         const real aref = S[0], R = S[1], inv2 = S[2], inv3 = S[3], lo = S[4], hi = S[5], f0 = S[6], muinv = S[7];
-        real a[GRP_MAX - 1];
+        real a[GRP_MAX - 1], an[GRP_MAX - 1];
 #pragma unroll
-        for (int s = 0; s < GRP_MAX - 1; s++) a[s] = gA[16 * g + tri + s];
+        for (int s = 0; s < GRP_MAX - 1; s++) an[s] = gA[16 * g1 + tri + s];      // next group's couplings (global memory)
 #pragma unroll
-        for (int s = 0; s < GRP_MAX - 1; s++) a[s] = (mine && s < lane) ? a[s] : real(0);
+        for (int s = 0; s < GRP_MAX - 1; s++) a[s] = (mine && s < lane) ? ac[s] : real(0);
         // ---- row residuals J_r . qacc: every row is summed over its 8 lanes, lane r then fetches row r's sum ----
         const real x = oct_sum(JA * qA + JB * qB);
         const real dot = __shfl(x, 8 * lr, 64);
@@ -406,8 +420,13 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         gi = gin;
-        gin = __builtin_amdgcn_readfirstlane(ginn_v);
+        gin = ginn;
+        ginn = __builtin_amdgcn_readfirstlane(ginnn_v);
         ra = ran;
+        ran = rann;
+        JA = JAn; JB = JBn; BA = BAn; BB = BBn;
+#pragma unroll
+        for (int s = 0; s < GRP_MAX - 1; s++) ac[s] = an[s];
         g = g1;
         if (g1 == 0) it++;
     }
