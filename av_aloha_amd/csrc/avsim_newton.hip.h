@@ -520,6 +520,8 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         st2 = wave_sum(st2);
         NSYNC();
         if (sqrt(st2) * A.scale < real(1e-2) * A.tol) break;
+        // MuJoCo's improvement test [EXT]: the cost decrease of this iteration, -alpha phi'(0) / 2 to second order, scaled
+        if (real(-0.5) * alpha * dphi0 * A.scale < A.tol) break;
     }
     // ---- forces at the solution ----
     for (int i = lane; i < ne; i += 64) A.rowS[RS_S * i + 2] = nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[RS_S * i];

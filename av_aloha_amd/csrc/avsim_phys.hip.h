@@ -32,8 +32,9 @@ constexpr int ROW_W = 2 * TREE_W;
 // all 32 banks instead of hammering 4 of them (stride 8)
 constexpr int ROW_S = ROW_W;       // Jacobian rows live in global memory (L2-resident scratch): 64-byte rows, no banks to dodge
 constexpr int RS_S = 9;            // solver record: 8 words used
-constexpr int CAND_MAX = 64;   // exact broad-phase survivors per substep (narrow-phase work list)
-constexpr int NEAR_MAX = 192;  // Verlet neighbour list: pairs within reach + skin, rebuilt when a geom moved > skin/2
+constexpr int CAND_MAX = 256;  // exact broad-phase survivors per substep (narrow-phase work list, global scratch)
+constexpr int ANC_MAX = 64;    // LDS ints of the kinematics' pointer-jumping table (one per body)
+constexpr int NEAR_MAX = 512;  // Verlet neighbour list: pairs within reach + skin, rebuilt when a geom moved > skin/2
 
 template <typename real>
 struct DevModel {
@@ -106,6 +107,7 @@ struct DevModel {
     GLB_PTR(const real) eq_solref;
     GLB_PTR(const real) eq_solimp;
     GLB_PTR(const real) qpos0;
+    GLB_PTR(const real) qpos_home;   // state an env falls back to when its simulation diverges
     // geoms
     GLB_PTR(const int) geom_type;
     GLB_PTR(const int) geom_body;
@@ -137,6 +139,7 @@ struct DevModel {
     real* rB_glob;      // rows of J M^-1, same layout (the Gauss-Seidel sweeps apply force changes through them)
     real* gA_glob;      // intra-group couplings real[N][maxgrp][16] (write once per substep, read by the Gauss-Seidel sweeps)
     int* near_glob;     // Verlet neighbour lists int[N][NEAR_MAX] (rebuilt when a geom moved more than skin / 2)
+    int* cand_glob;     // exact broad-phase survivors int[N][CAND_MAX]
     real* gref_glob;    // geom centres at the last rebuild, real[N][ngeom][3]
     // observation
     GLB_PTR(const int) obs_qposadr;
@@ -574,6 +577,7 @@ template <typename real, int G>
 struct Env {
     KPtr<real> ka;   // model, LDS layout and table offsets: one struct in constant memory, re-read per phase (PHASE_BEGIN)
     int env = 0;                    // global env index (row buffer addressing)
+    int diverged = 0;               // the state left the representable range during this launch and was put back to the home pose
     int nit_sum = 0, nit_max = 0;   // Newton iterations over the launch's substeps (diagnostics)
     bool profiling = false;
     real* r;  // real region of this env
@@ -591,6 +595,7 @@ struct Env {
     AVS_DEV GLB_PTR(real) rowsB_() const { return (GLB_PTR(real))ka->m.rB_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
     AVS_DEV GLB_PTR(real) coup_() const { return (GLB_PTR(real))ka->m.gA_glob + (size_t)env * ka->lay.maxgrp * 16; }
     AVS_DEV GLB_PTR(int) near_() const { return (GLB_PTR(int))ka->m.near_glob + (size_t)env * NEAR_MAX; }
+    AVS_DEV GLB_PTR(int) cand_() const { return (GLB_PTR(int))ka->m.cand_glob + (size_t)env * CAND_MAX; }
     AVS_DEV GLB_PTR(real) gref_() const { return (GLB_PTR(real))ka->m.gref_glob + (size_t)env * ka->m.ngeom * 3; }
     AVS_DEV const int* body_parent_() const { return LI() + ka->mo.body_parent; }
     AVS_DEV const int* body_jntadr_() const { return LI() + ka->mo.body_jntadr; }
@@ -1066,7 +1071,8 @@ struct Env {
     __device__ void collide() {
         PHASE_BEGIN();
         real* gcen = r + ka->lay.gcen;
-        int *cand = ii + ka->lay.cand, *misc = ii + ka->lay.misc;
+        int* misc = ii + ka->lay.misc;
+        GLB_PTR(int) cand = cand_();
         int ncand = 0;
         long long tb0 = __builtin_readcyclecounter();
         const real skin = real(0.05);
@@ -1510,6 +1516,23 @@ struct Env {
         jt_force(fcon, nefc);
     }
 
+    // MuJoCo's mj_checkPos / mj_checkVel [EXT]: a state with NaN / Inf / huge entries is unusable; MuJoCo warns and resets
+    // the data, dm_control raises PhysicsError.  Batched: the env goes back to the home pose (default object poses), zero
+    // velocity, and the launch reports it through the NaN flag of avsim_get_diag; its neighbours are not affected.
+    __device__ void check_divergence() {
+        LDS_BASES();
+        real *qpos = r + ka->lay.qpos, *qvel = r + ka->lay.qvel, *warm = r + ka->lay.warm;
+        bool bad = false;
+        for (int i = lane; i < ka->m.nq; i += G) bad |= !(fabs(qpos[i]) < real(1e6));
+        for (int i = lane; i < ka->m.nv; i += G) bad |= !(fabs(qvel[i]) < real(1e6));
+        if (!__any(bad)) return;
+        diverged = 1;
+        for (int i = lane; i < ka->m.nq; i += G) qpos[i] = ka->m.qpos_home[i];
+        for (int i = lane; i < ka->m.nv; i += G) { qvel[i] = 0; warm[i] = 0; }
+        if (lane == 0) (ii + ka->lay.misc)[7] = 0;      // the Verlet list is stale
+        GSYNC();
+    }
+
     // out = J^T f: one row per lane, scattered over the row's two dof windows with returnless LDS atomics
     __device__ void jt_force(real* out, int nefc) {
         LDS_BASES();
@@ -1679,6 +1702,7 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(KPtr<real> ka, const real* __
         PROF(5, E.make_constraints());
         PROF(6, E.solve(pgs_iters, ka->m.solver, ka->m.newton_iters, ka->m.newton_tol, ka->m.nscale));
         PROF(7, E.euler());
+        E.check_divergence();
     }
     if (o_prof && lane == 0) {
         for (int k = 0; k < 8; k++) o_prof[(size_t)env * 18 + k] = tp[k];
@@ -1724,9 +1748,9 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(KPtr<real> ka, const real* __
     }
     if (lane == 0 && !o_xpose) {   // the render path's pose-export pass leaves the step diagnostics alone
         o_ncon[env] = ncon;
-        bool bad = false;
+        bool bad = E.diverged != 0;
         for (int i = 0; i < ka->m.nq; i++) bad |= !(fabs(r[ka->lay.qpos + i]) < real(1e6));
-        o_diag[4 * env] = ncon; o_diag[4 * env + 1] = nefc_last; o_diag[4 * env + 2] = ii[ka->lay.misc + 2]; o_diag[4 * env + 3] = (bad ? 1 : 0) | ((ii[ka->lay.misc + 3] & 0xff) << 8) | ((E.nit_sum & 0xfff) << 16) | ((E.nit_max & 0xf) << 28);
+        o_diag[4 * env] = ncon; o_diag[4 * env + 1] = nefc_last; o_diag[4 * env + 2] = ii[ka->lay.misc + 2]; o_diag[4 * env + 3] = (bad ? 1 : 0) | ((ii[ka->lay.misc + 3] & 0xff) << 8) | ((E.nit_sum & 0xfff) << 16) | ((E.nit_max < 15 ? E.nit_max : 15) << 28);
     }
 }
 
@@ -1789,7 +1813,7 @@ struct PhysHost {
         auto opt = F("opt");
         m.timestep = (real)opt[0]; m.gravity[0] = (real)opt[1]; m.gravity[1] = (real)opt[2]; m.gravity[2] = (real)opt[3];
         m.impratio = (real)opt[4]; m.noslip_iters = (int)opt[5];
-        m.solver = 1; m.newton_iters = 8; m.newton_tol = sizeof(real) == 8 ? (real)1e-8 : (real)1e-6;
+        m.solver = 1; m.newton_iters = 30; m.newton_tol = sizeof(real) == 8 ? (real)1e-8 : (real)1e-6;
         m.nscale = (real)(1.0 / ((opt.size() > 7 && opt[7] > 0 ? opt[7] : 1.0) * std::max(1, m.nv)));
         auto gr = F("grip_range");
         m.grip_lo = (real)gr[0]; m.grip_hi = (real)gr[1];
@@ -1880,6 +1904,7 @@ struct PhysHost {
         m.eq_dof1 = up(I("eq_dof1")); m.eq_dof2 = up(I("eq_dof2")); m.eq_qpos1 = up(I("eq_qpos1")); m.eq_qpos2 = up(I("eq_qpos2"));
         m.eq_polycoef = upr<real>(F("eq_polycoef")); m.eq_solref = upr<real>(F("eq_solref")); m.eq_solimp = upr<real>(F("eq_solimp"));
         m.qpos0 = upr<real>(F("qpos0"));
+        m.qpos_home = upr<real>(F("qpos_home"));
         // geoms: local rotation matrices, interior point in the body frame, world constants for static geoms
         auto gbody = I("geom_body");
         auto gpos = F("geom_pos"), gquat = F("geom_quat"), gbc = F("geom_bcenter");
@@ -1979,7 +2004,7 @@ struct PhysHost {
         L.nreal = (o + 3) & ~3;
         int io = 0;
         auto Iq = [&](int n) { int x = io; io += n; return x; };
-        L.cand = Iq(CAND_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.misc = Iq(8); L.nprof = Iq(8);
+        L.cand = Iq(ANC_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.misc = Iq(8); L.nprof = Iq(8);
         L.nint = (io + 3) & ~3;
         L.maxcon = maxcon;
         L.maxefc = maxefc;
@@ -2008,9 +2033,9 @@ struct PhysHost {
         d_coup = nullptr; d_near = nullptr; d_gref = nullptr;
         if (hipMalloc(&d_gref, (size_t)N * dims[4] * 3 * (f64 ? 8 : 4)) != hipSuccess) throw std::runtime_error("hipMalloc of the Verlet reference buffer failed");
         mf.gref_glob = (float*)d_gref; md.gref_glob = (double*)d_gref;
-        if (hipMalloc(&d_coup, (size_t)N * lay.maxgrp * 16 * (f64 ? 8 : 4)) != hipSuccess || hipMalloc((void**)&d_near, (size_t)N * NEAR_MAX * 4) != hipSuccess)
+        if (hipMalloc(&d_coup, (size_t)N * lay.maxgrp * 16 * (f64 ? 8 : 4)) != hipSuccess || hipMalloc((void**)&d_near, (size_t)N * (NEAR_MAX + CAND_MAX) * 4) != hipSuccess)
             throw std::runtime_error("hipMalloc of the coupling / neighbour buffers failed");
-        mf.gA_glob = (float*)d_coup; md.gA_glob = (double*)d_coup; mf.near_glob = d_near; md.near_glob = d_near;
+        mf.gA_glob = (float*)d_coup; md.gA_glob = (double*)d_coup; mf.near_glob = d_near; md.near_glob = d_near; mf.cand_glob = md.cand_glob = d_near + (size_t)N * NEAR_MAX;
         kargs_dirty = true;
         if (d_cpairs) (void)hipFree(d_cpairs);
         if (d_cdist) (void)hipFree(d_cdist);

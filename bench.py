@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--pgs-iters", type=int, default=20)
     ap.add_argument("--solver", choices=["pgs", "newton"], default="newton")
-    ap.add_argument("--newton-iters", type=int, default=8)
+    ap.add_argument("--newton-iters", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--render", default="", help="HxW: also render depth images of the 4 zed/wrist cameras every step (BASELINE configs[4]); off by default")
     args = ap.parse_args()

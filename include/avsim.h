@@ -96,8 +96,9 @@ int avsim_get_state(avsim_t* h, double* qpos, double* qvel, double* ctrl, double
 int avsim_set_state(avsim_t* h, const double* qpos, const double* qvel, const double* ctrl, const double* warmstart);
 /* contacts of the current state, env.py:436-441 view: ncon int32[N], geom pairs int32[N][cap][2], dist double[N][cap] */
 int avsim_get_contacts(avsim_t* h, int32_t* ncon, int32_t* geom_pairs, double* dist);
-/* per-env diagnostics of the last step: int32[N][4] = {ncon, nefc, overflow flags, packed}; packed = nan flag (bit 0) |
- * broad-phase survivors (bits 8-15) | Newton iterations summed over the substeps (bits 16-27) | their maximum (bits 28-31) */
+/* per-env diagnostics of the last step: int32[N][4] = {ncon, nefc, overflow flags, packed}; packed = divergence flag (bit 0: the state became NaN / Inf / > 1e6 during the step and the env was put back to the
+ * home pose with zero velocity, as MuJoCo resets its data on a bad state) |
+ * broad-phase survivors (bits 8-15) | Newton iterations summed over the substeps (bits 16-27) | their maximum, saturated at 15 (bits 28-31) */
 int avsim_get_diag(avsim_t* h, int32_t* diag);
 
 /* debug: shader-clock cycles each env's wave spent in the 8 phases (kinematics, CRB, RNE, smooth, collide, rows,

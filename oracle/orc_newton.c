@@ -230,6 +230,8 @@ void orc_solve_newton(orc_data* d) {
         double step2 = 0;
         for (int i = 0; i < nv; i++) { a[i] += alpha * dl[i]; step2 += alpha * dl[i] * alpha * dl[i]; }
         if (sqrt(step2) * d->pgs_scale < 1e-2 * d->newton_tol) break;
+        /* MuJoCo's improvement test [EXT]: the cost decrease of this iteration, -alpha phi'(0) / 2 to second order, scaled */
+        if (-0.5 * alpha * dphi0 * d->pgs_scale < d->newton_tol) break;
     }
     /* forces and qfrc_constraint at the solution */
     for (int i = 0; i < ne; i++) { double s = -d->efc_aref[i]; for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)i * nv + k] * a[k]; jar[i] = s; }
