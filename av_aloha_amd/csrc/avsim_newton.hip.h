@@ -321,6 +321,12 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
     NPROF(0);
     int zone[NCH];
     real cw[NCH][6], cc1[NCH][6], cc2[NCH][6], cs1[NCH], cs2[NCH];
+    // the Hessian depends only on the active set while no contact sits in the cone's middle zone: remember the set the
+    // last factorisation was made for and skip assembly + factorisation when an iteration finds it unchanged
+    bool have_L = false;
+    unsigned long long sig_lead = 0, sig_z1[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) sig_z1[ch] = 0;
     for (int it = 0; it < A.iters; it++) {
         used++;
         // ---- residuals, forces (-> rowS.f), curvature of the scalar rows (-> jv) ----
@@ -371,69 +377,100 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         gn2 = wave_sum(gn2);
         NPROF(1);
         if (sqrt(gn2) * A.scale < A.tol) break;
-        // ---- Hessian: packed lower triangle ----
-        for (int e = lane; e < nv * (nv + 1) / 2; e += 64) A.H[e] = 0;
-        NSYNC();
-        for (int e = lane; e < nv * TREE_W; e += 64) {           // M blocks
-            const int k = e >> 3, j8 = e & 7, t = A.dof_tree[k], a0 = A.tree_dofadr[t], n = A.tree_dofnum[t], kk = k - a0;
-            if (j8 < n && j8 <= kk) A.H[k * (k + 1) / 2 + a0 + j8] = A.M[A.tree_madr[t] + kk * n + j8];
-        }
-        NSYNC();
-        {
-            real w1[6] = {0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < A.nlead; i++) {
-                w1[0] = lane_get(A.jv[i], 0);
-                if (w1[0] != 0) nblock<real>(A, lane, i, 1, false, w1, w1, w1, real(0), real(0));
-            }
-        }
+        // ---- active set now: scalar rows with curvature, contacts in the bottom / middle zone ----
+        unsigned long long cur_lead = __ballot(lane < A.nlead && A.jv[lane < A.nlead ? lane : 0] != 0), cur_z1[NCH];
+        bool middle = false, same = have_L && A.nlead <= 64 && cur_lead == sig_lead;
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) {
+            cur_z1[ch] = 0;
             if (ch * 64 >= A.ncon) break;
-            const int nc = A.ncon - ch * 64 < 64 ? A.ncon - ch * 64 : 64;
-            for (int c = 0; c < nc; c++) {
-                const int zn = __builtin_amdgcn_readlane(zone[ch], c);
-                if (zn == 0) continue;
-                const int head = __builtin_amdgcn_readlane(con[ch].head, c), dim = __builtin_amdgcn_readlane(con[ch].dim, c);
-                real w[6], c1[6], c2[6];
-#pragma unroll
-                for (int p = 0; p < 6; p++) { w[p] = lane_get(cw[ch][p], c); c1[p] = lane_get(cc1[ch][p], c); c2[p] = lane_get(cc2[ch][p], c); }
-                nblock<real>(A, lane, head, dim, zn == 2, w, c1, c2, lane_get(cs1[ch], c), lane_get(cs2[ch], c));
-            }
+            cur_z1[ch] = __ballot(zone[ch] == 1);
+            middle = middle || __ballot(zone[ch] == 2) != 0;
+            same = same && cur_z1[ch] == sig_z1[ch];
         }
-        NSYNC();
-        NPROF(2);
-        // ---- Cholesky + forward substitution in registers: lane i = row i, lane nv = -g ----
-        {
-            // g sits right behind the packed triangle (NewtonArgs contract), i.e. it is "row nv" of the same array
-            real row[NVMAX];
-            const int rbase = lane * (lane + 1) / 2;
-            const real sgn = lane == nv ? real(-1) : real(1);
-#pragma unroll
-            for (int k = 0; k < NVMAX; k++) {
-                const bool ok = lane <= nv && k <= lane && k < nv;
-                const real v = A.H[ok ? rbase + k : 0];
-                row[k] = ok ? sgn * v : real(0);
+        if (!(same && !middle)) {
+            // ---- Hessian: packed lower triangle ----
+            for (int e = lane; e < nv * (nv + 1) / 2; e += 64) A.H[e] = 0;
+            NSYNC();
+            for (int e = lane; e < nv * TREE_W; e += 64) {           // M blocks
+                const int k = e >> 3, j8 = e & 7, t = A.dof_tree[k], a0 = A.tree_dofadr[t], n = A.tree_dofnum[t], kk = k - a0;
+                if (j8 < n && j8 <= kk) A.H[k * (k + 1) / 2 + a0 + j8] = A.M[A.tree_madr[t] + kk * n + j8];
             }
-            for (int j = 0; j < nv; j++) {
-                // pivot: d = sqrt(H_jj), column j = row[0] / d.  f32 takes the hardware rsq (1 ulp), f64 the exact pair
-                const real piv = tmax(lane_get(row[0], j), real(1e-30));
-                real d, rinv;
-                if (sizeof(real) == 4) { rinv = (real)__builtin_amdgcn_rsqf((float)piv); d = piv * rinv; }
-                else { d = sqrt(piv); rinv = real(1) / d; }
-                const real lij = row[0] * rinv;
-                // L_ij for the rows below, d on the diagonal, y_j = (L^-1 (-g))_j from lane nv ("row nv" is g's storage)
-                if (lane >= j && lane <= nv) A.H[rbase + j] = lane == j ? d : lij;
-#pragma unroll
-                for (int mb = 1; mb < NVMAX; mb += 8) {
-                    if (j + mb <= nv - 1) {          // wave-uniform: the rest of the row is past the matrix
-#pragma unroll
-                        for (int mm = 0; mm < 8; mm++) {
-                            const int m = mb + mm;
-                            if (m < NVMAX) row[m - 1] = row[m] - lij * lane_get(lij, (j + m) & 63);
+            NSYNC();
+            {
+                real w1[6] = {0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < A.nlead; i++) {
+                    w1[0] = lane_get(A.jv[i], 0);
+                    if (w1[0] != 0) nblock<real>(A, lane, i, 1, false, w1, w1, w1, real(0), real(0));
+                }
+            }
+    #pragma unroll
+            for (int ch = 0; ch < NCH; ch++) {
+                if (ch * 64 >= A.ncon) break;
+                const int nc = A.ncon - ch * 64 < 64 ? A.ncon - ch * 64 : 64;
+                for (int c = 0; c < nc; c++) {
+                    const int zn = __builtin_amdgcn_readlane(zone[ch], c);
+                    if (zn == 0) continue;
+                    const int head = __builtin_amdgcn_readlane(con[ch].head, c), dim = __builtin_amdgcn_readlane(con[ch].dim, c);
+                    real w[6], c1[6], c2[6];
+    #pragma unroll
+                    for (int p = 0; p < 6; p++) { w[p] = lane_get(cw[ch][p], c); c1[p] = lane_get(cc1[ch][p], c); c2[p] = lane_get(cc2[ch][p], c); }
+                    nblock<real>(A, lane, head, dim, zn == 2, w, c1, c2, lane_get(cs1[ch], c), lane_get(cs2[ch], c));
+                }
+            }
+            NSYNC();
+            NPROF(2);
+            // ---- Cholesky + forward substitution in registers: lane i = row i, lane nv = -g ----
+            {
+                // g sits right behind the packed triangle (NewtonArgs contract), i.e. it is "row nv" of the same array
+                real row[NVMAX];
+                const int rbase = lane * (lane + 1) / 2;
+                const real sgn = lane == nv ? real(-1) : real(1);
+    #pragma unroll
+                for (int k = 0; k < NVMAX; k++) {
+                    const bool ok = lane <= nv && k <= lane && k < nv;
+                    const real v = A.H[ok ? rbase + k : 0];
+                    row[k] = ok ? sgn * v : real(0);
+                }
+                for (int j = 0; j < nv; j++) {
+                    // pivot: d = sqrt(H_jj), column j = row[0] / d.  f32 takes the hardware rsq (1 ulp), f64 the exact pair
+                    const real piv = tmax(lane_get(row[0], j), real(1e-30));
+                    real d, rinv;
+                    if (sizeof(real) == 4) { rinv = (real)__builtin_amdgcn_rsqf((float)piv); d = piv * rinv; }
+                    else { d = sqrt(piv); rinv = real(1) / d; }
+                    const real lij = row[0] * rinv;
+                    // L_ij for the rows below, d on the diagonal, y_j = (L^-1 (-g))_j from lane nv ("row nv" is g's storage)
+                    if (lane >= j && lane <= nv) A.H[rbase + j] = lane == j ? d : lij;
+    #pragma unroll
+                    for (int mb = 1; mb < NVMAX; mb += 8) {
+                        if (j + mb <= nv - 1) {          // wave-uniform: the rest of the row is past the matrix
+    #pragma unroll
+                            for (int mm = 0; mm < 8; mm++) {
+                                const int m = mb + mm;
+                                if (m < NVMAX) row[m - 1] = row[m] - lij * lane_get(lij, (j + m) & 63);
+                            }
                         }
                     }
                 }
             }
+            have_L = !middle && A.nlead <= 64;
+            sig_lead = cur_lead;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) sig_z1[ch] = cur_z1[ch];
+        } else {
+            // same Hessian as last time: forward substitution L y = -g with the stored factor (lane i holds y_i)
+            real x = lane < nv ? -A.g[lane] : real(0);
+            const real dinv = lane < nv ? real(1) / A.H[lane * (lane + 1) / 2 + lane] : real(0);
+            real Lnext = (lane > 0 && lane < nv) ? A.H[lane * (lane + 1) / 2] : real(0);
+            for (int j = 0; j < nv; j++) {
+                const real Lc = Lnext;
+                if (j + 1 < nv) Lnext = (lane > j + 1 && lane < nv) ? A.H[lane * (lane + 1) / 2 + j + 1] : real(0);
+                const real yj = lane_get(x * dinv, j);
+                if (lane == j) x = yj;
+                else if (lane > j) x -= Lc * yj;
+            }
+            NSYNC();
+            if (lane < nv) A.g[lane] = x;
         }
         NSYNC();
         NPROF(3);
