@@ -261,10 +261,10 @@ template <typename T> AVS_DEV T sel3(const T* v, int k) { return k == 0 ? v[0] :
 template <typename T> AVS_DEV void col3(const T* M, int k, T* o) { o[0] = sel3(M, k); o[1] = sel3(M + 3, k); o[2] = sel3(M + 6, k); }
 
 // box-box: 15-axis SAT then reference-face clipping (face contact, <=4 points) or closest edge points.
-// `scr` = 56 words of per-lane LDS scratch: clipped polygon while working (dynamic indexing would otherwise spill it
-// to scratch memory), results on return: dist [0,4), pos [4,16), common normal [16,19).
+// `work` = 56 words of LDS scratch for the clipped polygon (dynamic indexing would otherwise spill it to scratch memory),
+// `scr` = the lane's 20-word result slot: dist [0,4), pos [4,16), common normal [16,19).
 template <typename T>
-__device__ int box_box(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr) {
+__device__ int box_box(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, AVS_LDS(T) work) {
     const T *Ra = a.mat, *Rb = b.mat;
     T p[3], pa[3], pb[3];
     sub3(b.pos, a.pos, p);
@@ -370,9 +370,9 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr) {
     if (fabs(li[2]) > fabs(sel3(li, k))) k = 2;
     T sgn = sel3(li, k) > 0 ? T(-1) : T(1);
     int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
-    AVS_LDS(T) poly = scr;          // [8][3]
-    AVS_LDS(T) tmp = scr + 24;      // [8][3]
-    AVS_LDS(T) dep = scr + 48;      // [8]
+    AVS_LDS(T) poly = work;          // [8][3]
+    AVS_LDS(T) tmp = work + 24;      // [8][3]
+    AVS_LDS(T) dep = work + 48;      // [8]
     int np = 4;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -476,12 +476,12 @@ AVS_DEV bool boxes_separated(const Shape<T>& a, const Shape<T>& b) {
     return false;
 }
 
-// dispatch; up to 4 contacts written to the lane's LDS scratch: dist [0,4), pos [4,16), common normal [16,19)
+// dispatch for every pair that is not box-box (those go through box_box with their own work area); at most one contact,
+// written to the lane's result slot: dist [0], pos [4,7), normal [16,19)
 template <typename T>
 __device__ int narrow(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr) {
     int ta = a.type, tb = b.type;
     if (boxes_separated(a, b)) return 0;
-    if (ta == G_BOX && tb == G_BOX) return box_box(a, b, scr);
     T dist[1], pos[3], nrm[3];
     int n;
     if (ta == G_SPHERE && tb == G_SPHERE) n = sphere_sphere(a, b, dist, pos, nrm);

@@ -209,7 +209,7 @@ struct Layout {
     // scratch union U, phase A
     int cinert, cvel, cacc, cfrc;
     // phase B
-    int cdist, cpos, cnrm, rowS, scr;   // scr: narrow-phase scratch (overlays rowS, 32 lanes x 56 words)
+    int cdist, cpos, cnrm, rowS, scr;   // scr: narrow-phase scratch (overlays rowS: 64 result slots of 20 words + 9 box work areas)
     // ints
     int cand, cpair, cefc, rmeta, rowI, gI, misc, nprof, nint;
     int maxgrp;
@@ -1149,18 +1149,36 @@ struct Env {
         real *cdist = r + ka->lay.cdist, *cpos = r + ka->lay.cpos, *cnrm = r + ka->lay.cnrm;
         int* cpair = ii + ka->lay.cpair;
         int ncon = 0, ovf = 0;
-        // 32 candidate pairs per pass: the per-lane LDS scratch (polygon work space + results, 56 words) overlays the solver
-        // records, which are not live during collision
-        for (int base = 0; base < ncand; base += 32) {
-            int ci = base + lane, n = 0, p = 0;
-            LDS_PTR(real) scr = (LDS_PTR(real))(r + ka->lay.scr + 56 * (lane & 31));
-            int keepmask = 0;
-            if (lane < 32 && ci < ncand) {
-                p = cand[ci];
+        // 64 candidate pairs per pass, one per lane, each with a 20-word result slot in LDS (the solver records, not live
+        // during collision).  Box-box pairs go first, NBOX at a time through the polygon work areas behind the slots, then
+        // everything else: the wave executes the clipping code and the MPR code once each instead of both in every pass.
+        constexpr int NBOX = 9;
+        for (int base = 0; base < ncand; base += G) {
+            const int ci = base + lane;
+            int n = 0, p = 0, nn = 0;
+            LDS_PTR(real) scr = (LDS_PTR(real))(r + ka->lay.scr + 20 * lane);
+            const bool valid = ci < ncand;
+            if (valid) p = cand[ci];
+            const int ga = ka->m.pair_geom[2 * p], gb = ka->m.pair_geom[2 * p + 1];
+            const bool isbox = valid && geom_type_()[ga] == G_BOX && geom_type_()[gb] == G_BOX;
+            {
+                int nbox, rk = group_rank<G>(isbox, grp, lane, &nbox);
+                for (int b0 = 0; b0 < nbox; b0 += NBOX)
+                    if (isbox && rk >= b0 && rk < b0 + NBOX) {
+                        Shape<real> a, b;
+                        load_shape(ga, a);
+                        load_shape(gb, b);
+                        nn = boxes_separated(a, b) ? 0 : box_box(a, b, scr, (LDS_PTR(real))(r + ka->lay.scr + 20 * G + 56 * (rk - b0)));
+                    }
+            }
+            if (valid && !isbox) {
                 Shape<real> a, b;
-                load_shape(ka->m.pair_geom[2 * p], a);
-                load_shape(ka->m.pair_geom[2 * p + 1], b);
-                int nn = narrow(a, b, scr);
+                load_shape(ga, a);
+                load_shape(gb, b);
+                nn = narrow(a, b, scr);
+            }
+            int keepmask = 0;
+            if (valid) {
                 // drop separated points (margin = 0 here) while keeping order
                 real mg = ka->m.pair_margin[p];
                 for (int k = 0; k < nn; k++)
@@ -1999,7 +2017,7 @@ struct PhysHost {
         L.cdist = bq; bq += maxcon; L.cpos = bq; bq += 3 * maxcon; L.cnrm = bq; bq += 3 * maxcon;
         bq = (bq + 3) & ~3; L.rowS = bq; L.scr = bq; bq += RS_S * maxefc;
         L.maxgrp = maxefc / 3 + 8;
-        if (bq < L.scr + 32 * 56) bq = L.scr + 32 * 56;
+        if (bq < L.scr + 64 * 20 + 9 * 56) bq = L.scr + 64 * 20 + 9 * 56;     // narrow phase: 64 result slots + 9 box work areas
         o = a > bq ? a : bq;
         L.nreal = (o + 3) & ~3;
         int io = 0;
