@@ -287,6 +287,14 @@ __global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ r
                         lo[q] = fmaxf(lo[q], t);
                     }
                 }
+                }
+                // no ray of the tile can still improve on what it already sees: skip the validity pass
+                {
+                    bool need = false;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) need = need || (ok[q] && lo[q] >= znear && lo[q] < best[q]);
+                    if (!__any(need)) continue;
+                }
                 for (int p = 0; p < np; p++) {
                     const float4 f = P[p];
                     if (f.w < 0) continue;
