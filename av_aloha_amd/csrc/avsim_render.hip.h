@@ -287,7 +287,6 @@ __global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ r
                         lo[q] = fmaxf(lo[q], t);
                     }
                 }
-                }
                 // no ray of the tile can still improve on what it already sees: skip the validity pass
                 {
                     bool need = false;
