@@ -35,7 +35,7 @@ constexpr int TILE_W = 32, TILE_H = 8;
 struct RenderModel {
     int ngeom, ncam, nbody, nplane;   // nplane: faces summed over the visible mesh geoms
     const int *geom_type, *geom_body, *geom_hplane, *geom_hull, *geom_visible, *cam_body;
-    const float *geom_pos, *geom_mat, *geom_size, *geom_bcen, *geom_rbound, *hull_plane, *hull_vert, *cam_pos, *cam_mat, *cam_fovy;
+    const float *geom_pos, *geom_mat, *geom_size, *geom_bcen, *geom_rbound, *hull_plane, *hull_vert, *cam_pos, *cam_mat, *cam_fovy;   // cam_fovy: tan(fovy / 2) per camera
     float znear, zfar;
 };
 
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
 #pragma unroll
         for (int i = 0; i < 3; i++) pc[i] = pb[i] + Rb[3 * i] * cp[0] + Rb[3 * i + 1] * cp[1] + Rb[3 * i + 2] * cp[2];
     }
-    const float scale = 2.0f * tanf(0.5f * m.cam_fovy[cam] * 0.017453292519943295f) / (float)H;
+    const float scale = 2.0f * m.cam_fovy[cam] / (float)H;       // cam_fovy holds tan(fovy / 2)
     const float tx = 0.5f * W * scale, ty = 0.5f * H * scale, sx = sqrtf(1 + tx * tx), sy = sqrtf(1 + ty * ty);
     float* out = recs + ((size_t)env * ncam_sel + cs) * m.ngeom * REC_W;
     int base = 0;
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ r
     const int lane = threadIdx.x, cs = blockIdx.y, env = blockIdx.z;
     const int tiles_x = (W + TILE_W - 1) / TILE_W, tx0 = (blockIdx.x % tiles_x) * TILE_W, ty0 = (blockIdx.x / tiles_x) * TILE_H;
     const int px = tx0 + 4 * (lane & 7), py = ty0 + (lane >> 3);
-    const float scale = 2.0f * tanf(0.5f * cam_fovy[cam_ids[cs]] * 0.017453292519943295f) / (float)H;
+    const float scale = 2.0f * cam_fovy[cam_ids[cs]] / (float)H;     // cam_fovy holds tan(fovy / 2)
     const float* R = recs + ((size_t)env * ncam_sel + cs) * ngeom * REC_W;
     const int cnt = counts[(size_t)env * ncam_sel + cs];
     const int* ord = order + ((size_t)env * ncam_sel + cs) * ngeom;
@@ -378,7 +378,12 @@ struct RenderHost {
             for (int g = 0; g < m.ngeom; g++) if (gt[g] == 7 && gv[g]) m.nplane += hp[2 * g + 1];
         }
         m.hull_plane = up(tofloat(b.f("hull_plane"))); m.hull_vert = up(tofloat(b.f("hull_vert"))); m.cam_pos = up(tofloat(b.f("cam_pos"))); m.cam_mat = up(tofloat(cm));
-        m.cam_fovy = up(tofloat(b.f("cam_fovy")));
+        {   // the kernels only need tan(fovy / 2)
+            auto fv = b.f("cam_fovy");
+            std::vector<float> th(fv.size());
+            for (size_t c = 0; c < fv.size(); c++) th[c] = (float)std::tan(0.5 * fv[c] * 3.14159265358979323846 / 180.0);
+            m.cam_fovy = up(th);
+        }
         auto clip = b.f("cam_clip");
         m.znear = (float)clip[0]; m.zfar = (float)clip[1];
         d_xpose = up(std::vector<float>((size_t)N * m.nbody * 12, 0.0f));
