@@ -60,7 +60,13 @@ void avsim_destroy(avsim_t* h);
 const char* avsim_last_error(const avsim_t* h); /* h may be NULL for creation errors */
 int avsim_dims(const avsim_t* h, int32_t dims[AVSIM_NDIMS]);
 
-/* Solver/collision knobs. name: "pgs_iters", "noslip_iters". */
+/* Solver / capacity / debug knobs (returns AVSIM_EINVAL for an unknown name or a value out of range):
+ *   "solver"            0 PGS (BASELINE north_star), 1 Newton (MuJoCo's default, what the reference runs; default)
+ *   "pgs_iters"         Gauss-Seidel sweeps of the PGS solver (default 20); "newton_iters" cap (default 30), "newton_tol"
+ *   "maxefc", "maxcon"  constraint rows / contacts kept per env (per-task defaults 176-336 / 48-72); re-sizes the records
+ *   "waves_per_block"   envs per workgroup, 0 = as many as fit in 160 KiB of LDS (<= 8)
+ *   "export_contacts"   0 skips the per-step contact export (avsim_get_contacts); "kernel_timing" 1 brackets every physics
+ *                       launch with HIP events (avsim_kernel_time); "profile_phases" 1 enables avsim_get_phase_cycles */
 int avsim_set_option(avsim_t* h, const char* name, double value);
 
 /* env.py:228-249 + task reset: envs with mask[i]!=0 (NULL = all) go to the home pose, zero velocity,

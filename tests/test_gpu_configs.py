@@ -161,3 +161,24 @@ def test_soak_all_tasks_stay_finite():
             q, v, _, _ = sim.get_state()
             assert np.isfinite(q).all() and np.isfinite(v).all()
             sim.close()
+
+
+def test_capacity_options_do_not_change_the_results():
+    """maxefc / maxcon only size the per-env records (LDS rows, global row scratch): a run that stays under both settings
+    is bit-identical."""
+    md = model_dict("slot_insertion", 3)
+    n, T = 6, 8
+    acts = walk_actions(md, np.arange(n), T, 21, 42, close_grippers=True)
+    poses = poses_for("slot_insertion", np.arange(n), 42)
+    out = []
+    for opt in ({}, {"maxefc": 240, "maxcon": 64}, {"maxefc": 144, "maxcon": 40, "waves_per_block": 4}):
+        sim = make("slot_insertion", 3, n, **opt)
+        sim.reset(poses)
+        for t in range(T):
+            sim.step(acts[t])
+        q, v, _, _ = sim.get_state()
+        assert (sim.diag()[:, 2] == 0).all()
+        out.append((q.copy(), v.copy()))
+        sim.close()
+    for q, v in out[1:]:
+        assert np.array_equal(q, out[0][0]) and np.array_equal(v, out[0][1])
