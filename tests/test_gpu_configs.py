@@ -182,3 +182,37 @@ def test_capacity_options_do_not_change_the_results():
         sim.close()
     for q, v in out[1:]:
         assert np.array_equal(q, out[0][0]) and np.array_equal(v, out[0][1])
+
+
+def test_masked_reset_touches_only_the_selected_envs():
+    """avsim_reset with a mask (the auto-reset of finished episodes in a batch): masked envs return to the home pose with
+    their new object poses and zero velocity, the others keep their state bit for bit and continue identically."""
+    md = model_dict("slot_insertion", 3)
+    n = 5
+    poses = poses_for("slot_insertion", np.arange(n), 99)
+    acts = walk_actions(md, np.arange(n), 6, 21, 99)
+    sim, ref = make("slot_insertion", 3, n), make("slot_insertion", 3, n)
+    for s in (sim, ref):
+        s.reset(poses)
+        for t in range(3):
+            s.step(acts[t])
+    q0, v0, c0, w0 = sim.get_state()
+    mask = np.array([0, 1, 0, 1, 0], dtype=np.uint8)
+    new_poses = poses_for("slot_insertion", np.arange(n), 1234)
+    sim.reset(new_poses, mask=mask)
+    q1, v1, c1, w1 = sim.get_state()
+    for e in range(n):
+        if mask[e]:
+            assert np.abs(v1[e]).max() == 0 and np.allclose(q1[e, :23], md["qpos_home"][:23])
+            assert np.allclose(q1[e, 23:], new_poses[e].reshape(-1))
+        else:
+            assert np.array_equal(q1[e], q0[e]) and np.array_equal(v1[e], v0[e]) and np.array_equal(w1[e], w0[e])
+    for t in range(3, 6):
+        sim.step(acts[t])
+        ref.step(acts[t])
+    qa, qb = sim.get_state()[0], ref.get_state()[0]
+    for e in range(n):
+        if not mask[e]:
+            assert np.array_equal(qa[e], qb[e])
+    sim.close()
+    ref.close()
