@@ -339,7 +339,7 @@ constexpr int GRP_MAX = 6;   // rows per Gauss-Seidel group (a condim-6 contact 
 template <typename real>
 __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
                                                      LDS_PTR(real) q, LDS_PTR(const int) gI, GLB_PTR(const real) gA, int ngrp, int iters,
-                                                     int noslip_iters) {
+                                                     int noslip_iters, real noslip_tol_scaled) {
     // lane 8 d + k serves row d of the group (d < 6) and dof slot k of BOTH of the row's tree windows
     const int lane = threadIdx.x & 63, d = lane >> 3, k8 = lane & 7, dr = d < GRP_MAX ? d : 0;
     const int lr = lane < GRP_MAX ? lane : 0;          // row slot owned in the sequential phase
@@ -368,6 +368,7 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
     for (int s = 0; s < GRP_MAX - 1; s++) ac[s] = gA[tri + s];
     const int total = (iters + noslip_iters) * ngrp;
     int g = 0, it = 0;
+    real imp = 0;      // improvement of the dual cost over the current noslip sweep
     for (int step = 0; step < total; step++) {
         const bool noslip = it >= iters;
         const int start = gi & 0xffff, cnt = (gi >> 16) & 15;
@@ -416,6 +417,15 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         }
         if (mine) S[6] = f;
         const real delta = mine ? f - f0 : real(0);
+        if (noslip) {
+            // decrease of the dual cost by this group [EXT: costChange in mj_solNoSlip]: -(delta . res0 + 1/2 delta^T A delta),
+            // res0 the residuals before the group moved, A its coupling block (diagonal 1 / inv)
+            real cross = 0;
+#pragma unroll
+            for (int s = 0; s < GRP_MAX - 1; s++) cross += a[s] * lane_get(delta, s);
+            const real mine_c = delta * (dot - aref) + (inv3 != 0 ? real(0.5) * delta * delta / inv3 : real(0)) + delta * cross;
+            imp -= lane_get(oct_sum(mine ? mine_c : real(0)), 0);
+        }
         // ---- qacc += B_r^T delta_r ----
         const real dd = __shfl(delta, d, 64);
         if (inA) __hip_atomic_fetch_add(q + adrA, BA * dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -431,7 +441,12 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
 #pragma unroll
         for (int s = 0; s < GRP_MAX - 1; s++) ac[s] = an[s];
         g = g1;
-        if (g1 == 0) it++;
+        if (g1 == 0) {
+            // end of a sweep; a noslip sweep that improved the cost by less than noslip_tolerance ends the pass [EXT]
+            if (noslip && imp < noslip_tol_scaled) break;
+            imp = 0;
+            it++;
+        }
     }
 }
 
@@ -1501,7 +1516,7 @@ struct Env {
             GSYNC();
             long long tn0 = profiling ? __builtin_readcyclecounter() : 0;
             pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (GLB_PTR(const real))rJ, (GLB_PTR(const real))rowsB_(), (LDS_PTR(real))qacc,
-                             (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], 0, ka->m.noslip_iters);
+                             (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], 0, ka->m.noslip_iters, real(1e-6) / ka->m.nscale);
             if (profiling && lane == 0) (ii + ka->lay.nprof)[6] += (int)(__builtin_readcyclecounter() - tn0);
         } else {
         // warm-start forces of friction blocks back onto their cones (one contact per lane)
@@ -1527,7 +1542,7 @@ struct Env {
         // Gauss-Seidel sweeps (+ noslip sweeps) in the register-resident wave kernel
         static_assert(G == 64, "the solver maps one env to one wavefront");
         pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (GLB_PTR(const real))rJ, (GLB_PTR(const real))rowsB_(), (LDS_PTR(real))qacc,
-                         (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], pgs_iters, ka->m.noslip_iters);
+                         (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], pgs_iters, ka->m.noslip_iters, real(1e-6) / ka->m.nscale);
         }
         GSYNC();
         // qfrc_constraint = J^T f

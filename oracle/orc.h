@@ -101,6 +101,7 @@ typedef struct {
     int newton_iters; double newton_tol;
     int overflow; /* set when ORC_MAXCON / ORC_MAXEFC was hit */
     long stat_narrow; /* narrow-phase calls, for the flop/pair accounting */
+    int stat_noslip;  /* noslip sweeps used by the last solve */
 } orc_data;
 
 /* model / data */

@@ -520,22 +520,29 @@ static void apply_delta(orc_data* d, int i, double delta) {
     for (int k = 0; k < nv; k++) d->qacc[k] += Br[k] * delta;
 }
 
+/* one noslip row update: force -> newf, acceleration follows; *imp collects the decrease of the dual cost,
+ * -(delta res + 1/2 A_ii delta^2) with the residual at the time of the update [EXT: costChange in mj_solNoSlip] */
+static void noslip_set(orc_data* d, int i, double newf, double* imp) {
+    double dl = newf - d->efc_force[i];
+    if (dl == 0) return;
+    *imp -= dl * row_res(d, i, 0) + 0.5 * d->efc_diag[i] * dl * dl;
+    apply_delta(d, i, dl);
+    d->efc_force[i] = newf;
+}
+
 /* scale the friction components of contact rows [i0+1, i0+dim) back onto the elliptic cone */
-static void cone_project(orc_data* d, const orc_contact* c, int i0) {
+static void cone_project(orc_data* d, const orc_contact* c, int i0, double* imp) {
     double fn = d->efc_force[i0], s2 = 0;
     for (int r = 1; r < c->dim; r++) {
         double t = d->efc_force[i0 + r] / fmax(MINVAL, c->friction[r - 1]);
         s2 += t * t;
     }
     if (s2 > fn * fn) {
-        double sc = fn / sqrt(s2);
-        for (int r = 1; r < c->dim; r++) {
-            double nf = d->efc_force[i0 + r] * sc;
-            apply_delta(d, i0 + r, nf - d->efc_force[i0 + r]);
-            d->efc_force[i0 + r] = nf;
-        }
+        double sc = fn / sqrt(s2), dummy = 0;
+        for (int r = 1; r < c->dim; r++) noslip_set(d, i0 + r, d->efc_force[i0 + r] * sc, imp ? imp : &dummy);
     }
 }
+
 
 /* P8: projected Gauss-Seidel on the dual of MuJoCo's soft-constraint problem, carried in acceleration
  * space: qacc = qacc_smooth + M^-1 J^T f is kept current, row residual = J_i qacc - aref_i + R_i f_i. */
@@ -584,7 +591,7 @@ void orc_solve(orc_data* d) {
                 apply_delta(d, i, f - d->efc_force[i]);
                 d->efc_force[i] = f;
                 improvement += 0.5 * (d->efc_diag[i] + d->efc_R[i]) * (f - fprev) * (f - fprev);
-                if (i == c->efc_adr + c->dim - 1 && c->dim > 1) cone_project(d, c, c->efc_adr);
+                if (i == c->efc_adr + c->dim - 1 && c->dim > 1) cone_project(d, c, c->efc_adr, NULL);
                 continue;
             }
             apply_delta(d, i, f - d->efc_force[i]);
@@ -599,26 +606,28 @@ void orc_solve(orc_data* d) {
 void orc_noslip(orc_data* d) {
     const orc_model* m = d->m;
     int nv = m->nv, ne = d->nefc;
-    /* noslip post-pass (aloha_sim.xml:4 noslip_iterations=3): PGS sweeps over dry-friction and contact
-     * friction rows with the regulariser R removed; normal forces are held fixed [EXT: mj_solNoSlip] */
+    /* noslip post-pass (aloha_sim.xml:4 noslip_iterations=3): PGS sweeps over dry-friction and contact friction rows with
+     * the regulariser R removed; normal forces are held fixed.  As in mj_solNoSlip [EXT] a sweep whose scaled improvement of
+     * the dual cost falls below noslip_tolerance (MuJoCo default 1e-6, not set by the reference's XML) ends the pass. */
+    const double noslip_tolerance = 1e-6;
     for (int it = 0; it < m->noslip_iterations; it++) {
+        double imp = 0;
         for (int i = 0; i < ne; i++) {
             int t = d->efc_type[i];
             if (t == ORC_FLOSS) {
                 double f = d->efc_force[i] - row_res(d, i, 0) / fmax(MINVAL, d->efc_diag[i]);
                 if (f > d->efc_floss[i]) f = d->efc_floss[i];
                 if (f < -d->efc_floss[i]) f = -d->efc_floss[i];
-                apply_delta(d, i, f - d->efc_force[i]);
-                d->efc_force[i] = f;
+                noslip_set(d, i, f, &imp);
             } else if (t == ORC_CONTACT) {
                 const orc_contact* c = &d->contact[d->efc_id[i]];
                 if (i == c->efc_adr) continue;
-                double f = d->efc_force[i] - row_res(d, i, 0) / fmax(MINVAL, d->efc_diag[i]);
-                apply_delta(d, i, f - d->efc_force[i]);
-                d->efc_force[i] = f;
-                if (i == c->efc_adr + c->dim - 1) cone_project(d, c, c->efc_adr);
+                noslip_set(d, i, d->efc_force[i] - row_res(d, i, 0) / fmax(MINVAL, d->efc_diag[i]), &imp);
+                if (i == c->efc_adr + c->dim - 1) cone_project(d, c, c->efc_adr, &imp);
             }
         }
+        d->stat_noslip = it + 1;
+        if (imp * d->pgs_scale < noslip_tolerance) break;
     }
     for (int k = 0; k < nv; k++) {
         double s = 0;

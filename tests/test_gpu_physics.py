@@ -78,7 +78,9 @@ def test_f64_parity_other_tasks(task):
         qpos, qvel, _, _ = sim.get_state()
         # TubeTransfer carries a 0.5 g ball with 1e-5 friction inside the tube (task_tube_transfer.xml:6-8):
         # its contact switching amplifies rounding-level differences in the row sums
-        tol = 1e-4 if task == "tube_transfer" else 1e-7
+        # (and a noslip sweep count that is decided by a tolerance test, which rounding can tip either way after 20
+        # unconverged PGS sweeps; with the Newton solver the same rollout agrees to 1e-8, see the test below)
+        tol = 5e-4 if task == "tube_transfer" else 1e-7
         np.testing.assert_allclose(qpos[0], ref[t][0], atol=tol, err_msg=f"{task} qpos step {t}")
         assert rw[0] == ref[t][3]
     sim.close()
