@@ -1477,17 +1477,21 @@ struct Env {
             real v = 0;
             if (rr < cnt) {
                 int ir = start + rr, is = start + ss, ra = rowI[ir], rs = rowI[is];
-                // J_r M^-1 J_s^T over the kinematic trees both rows touch
+                // J_r . (J_s M^-1) over the tree windows the two rows share: the stored rows of J M^-1 are zero-padded, and a
+                // window of row r matches a window of row s iff it is the same kinematic tree
+                GLB_PTR(const real) Jr = rJ + ROW_S * ir;
+                GLB_PTR(const real) Bs = rowsB_() + ROW_S * is;
+#pragma unroll
                 for (int wr = 0; wr < 2; wr++) {
-                    if (((ra >> (13 * wr + 6)) & 15) == 0) continue;
-                    int tr = (ra >> (13 * wr + 10)) & 7;
+                    const bool on_r = ((ra >> (13 * wr + 6)) & 15) != 0;
+                    const int tr = (ra >> (13 * wr + 10)) & 7;
+#pragma unroll
                     for (int ws = 0; ws < 2; ws++) {
-                        if (((rs >> (13 * ws + 6)) & 15) == 0 || ((rs >> (13 * ws + 10)) & 7) != tr) continue;
-                        for (int k = 0; k < TREE_W; k++) {
-                            real t = 0;
-                            for (int j = 0; j < TREE_W; j++) t += Minv[64 * tr + 8 * k + j] * rJ[ROW_S * is + TREE_W * ws + j];
-                            v += rJ[ROW_S * ir + TREE_W * wr + k] * t;
-                        }
+                        const bool match = on_r && ((rs >> (13 * ws + 6)) & 15) != 0 && ((rs >> (13 * ws + 10)) & 7) == tr;
+                        real t = 0;
+#pragma unroll
+                        for (int k = 0; k < TREE_W; k++) t += Jr[TREE_W * wr + k] * Bs[TREE_W * ws + k];
+                        v += match ? t : real(0);
                     }
                 }
             }
