@@ -1,0 +1,79 @@
+"""Rollout / recording harnesses (av_aloha_amd/harness.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from av_aloha_amd import harness
+
+
+def test_preprocess_observation_layout():
+    """eval.py:23-66: images u8 HWC -> f32 CHW / 255 at 480 x 640 under observation.images.<cam>, agent_pos -> observation.state
+    float32 with a leading batch axis."""
+    import torch
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
+    small = rng.integers(0, 256, size=(240, 320, 3), dtype=np.uint8)
+    obs = {"pixels": {"zed_cam_left": img, "wrist_cam_left": small}, "agent_pos": np.arange(21, dtype=np.float64)}
+    out = harness.preprocess_observation(obs)
+    assert set(out) == {"observation.images.zed_cam_left", "observation.images.wrist_cam_left", "observation.state"}
+    a = out["observation.images.zed_cam_left"]
+    assert a.shape == (1, 3, 480, 640) and a.dtype == torch.float32
+    assert torch.equal(a[0], torch.from_numpy(img).permute(2, 0, 1).float() / 255)
+    b = out["observation.images.wrist_cam_left"]
+    assert b.shape == (1, 3, 480, 640) and 0 <= float(b.min()) and float(b.max()) <= 1
+    assert out["observation.state"].shape == (1, 21) and out["observation.state"].dtype == torch.float32
+    with pytest.raises(AssertionError):
+        harness.preprocess_observation({"pixels": {"c": img.astype(np.float32)}, "agent_pos": np.zeros(21)})
+    with pytest.raises(AssertionError):
+        harness.preprocess_observation({"pixels": {"c": np.zeros((3, 480, 640), np.uint8)}, "agent_pos": np.zeros(21)})
+
+
+def test_episode_file_roundtrip(tmp_path):
+    T = 6
+    data = {"/observations/qpos": np.random.rand(T, 21).astype(np.float32), "/observations/qvel": np.random.rand(T, 21).astype(np.float32),
+            "/observations/all_qpos": np.random.rand(T, 37).astype(np.float32), "/action": np.random.rand(T, 21).astype(np.float32)}
+    path = harness.save_episode(data, str(tmp_path), 3)
+    assert os.path.basename(path).startswith("episode_3.")
+    back = harness.load_episode(path)
+    assert set(back) == set(data)
+    for k in data:
+        assert back[k].dtype == np.float32 and np.array_equal(back[k], data[k])
+
+
+@pytest.mark.gpu
+def test_rollout_record_and_replay_on_the_device():
+    from av_aloha_amd.env import make
+    from av_aloha_amd.sim_env import make_sim_env
+    # rollout with a constant "policy": shapes, bookkeeping, batched and single
+    env = make("gym_guided_vision/SlotInsertion-3Arms-v0", cameras=[], num_envs=3)
+    np.random.seed(1)
+    home = None
+
+    def policy(obs):
+        nonlocal home
+        s = obs["observation.state"].numpy()
+        if home is None:
+            home = s.copy()
+        return home
+    res = harness.rollout(env, policy, episode_len=4, num_episodes=2)
+    assert len(res) == 2 and res[0]["success"].shape == (3,) and res[0]["max_reward"] == 4 and res[0]["frames"] == []
+    env.close()
+    # record a short Cartesian episode, check the file layout, replay it through set_qpos
+    cenv = make_sim_env("sim_slot_insertion")
+    np.random.seed(2)
+    obs, _ = cenv.reset()
+    target = np.concatenate([obs["poses"]["left"], [0.0], obs["poses"]["right"], [0.0], obs["poses"]["middle"]])
+    acts = np.repeat(target[None], 5, 0)
+    acts[:, 0] += 0.004 * np.arange(5)
+    ep = harness.record_episode(cenv, acts)
+    assert ep["/observations/qpos"].shape == (6, 21) and ep["/observations/qvel"].shape == (6, 21)
+    assert ep["/observations/all_qpos"].shape == (6, 37) and ep["/action"].shape == (6, 21)
+    assert all(v.dtype == np.float32 for v in ep.values())
+    assert np.allclose(ep["/action"][1:, 6], 1.0) and np.allclose(ep["/action"][1:, 13], 1.0)      # trigger 0 -> gripper open
+    cenv.close()
+    genv = make("gym_guided_vision/SlotInsertion-3Arms-v0", cameras=[])
+    agent, rewards = harness.replay_episode(genv, ep)
+    assert agent.shape == (6, 21) and rewards.shape == (6,)
+    assert np.abs(agent - ep["/observations/qpos"]).max() < 1e-6                                  # same joints, same normalisation
+    genv.close()
