@@ -200,7 +200,7 @@ AVS_DEV void nblock(const NewtonArgs<real>& A, int lane, int r0, int dim, bool f
         const int s = (lane >> 4) + 4 * u, gp = nslot_dof(ra, s);
         real Js[6], acc = 0;
 #pragma unroll
-        for (int p = 0; p < 6; p++) Js[p] = p < dim ? J[ROW_S * p + s] : real(0);
+        for (int p = 0; p < 6; p++) Js[p] = __shfl(Jt[p], (lane & 48) | s, 64);     // J[p][s] sits in the lane of this 16-group whose column is s
 #pragma unroll
         for (int p = 0; p < 6; p++) acc += w[p] * Js[p] * Jt[p];
         if (full) {
