@@ -18,7 +18,10 @@ def gather_episode_stats(ret, success, dist=None):
     pack = torch.stack([ret.to(torch.float32), success.to(torch.float32)], dim=1).contiguous()
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return pack[:, 0].clone(), pack[:, 1].to(torch.int32)
+    dev = pack.device
+    if dist.get_backend() == "gloo" and pack.is_cuda:      # gloo moves host memory only (CPU tests, one-GPU debugging)
+        pack = pack.cpu()
     out = [torch.empty_like(pack) for _ in range(dist.get_world_size())]
     dist.all_gather(out, pack)
-    allp = torch.cat(out, dim=0)
+    allp = torch.cat(out, dim=0).to(dev)
     return allp[:, 0].contiguous(), allp[:, 1].to(torch.int32)

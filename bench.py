@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--solver", choices=["pgs", "newton"], default="newton")
     ap.add_argument("--newton-iters", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for testing the multi-rank path on a one-GPU box together with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing aid: every rank uses cuda:0")
     ap.add_argument("--render", default="", help="HxW: also render depth images of the 4 zed/wrist cameras every step (BASELINE configs[4]); off by default")
     args = ap.parse_args()
 
@@ -153,12 +155,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the simulation path has no CPU fallback")
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     from av_aloha_amd import _ffi
     from av_aloha_amd.build import build_hip
@@ -246,7 +253,7 @@ def main():
     torch.cuda.synchronize()
     diag = diag.cpu().numpy()
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
