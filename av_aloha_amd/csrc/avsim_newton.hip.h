@@ -309,11 +309,14 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         }
     }
     // ---- start from the warm start (already in a) or from the smooth acceleration, whichever costs less ----
+    bool jar_ready = false;
     {
-        const real c0 = ncost<real, NCH>(A, lane, con, (LDS_PTR(const real))A.a);
-        NSYNC();
+        // the warm start is evaluated last: if it wins, its residuals J a - aref are already in place for the first iteration
         const real c1 = ncost<real, NCH>(A, lane, con, A.as);
-        if (!(c0 < c1)) {
+        NSYNC();
+        const real c0 = ncost<real, NCH>(A, lane, con, (LDS_PTR(const real))A.a);
+        jar_ready = c0 < c1;
+        if (!jar_ready) {
             for (int k = lane; k < nv; k += 64) A.a[k] = A.as[k];
         }
         NSYNC();
@@ -330,8 +333,10 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
     for (int it = 0; it < A.iters; it++) {
         used++;
         // ---- residuals, forces (-> rowS.f), curvature of the scalar rows (-> jv) ----
-        for (int i = lane; i < ne; i += 64) A.rowS[RS_S * i + 2] = nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[RS_S * i];
-        NSYNC();
+        if (!(it == 0 && jar_ready)) {
+            for (int i = lane; i < ne; i += 64) A.rowS[RS_S * i + 2] = nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[RS_S * i];
+            NSYNC();
+        }
         for (int i = lane; i < A.nlead; i += 64) {
             real f, h;
             nrow_scalar<real>(A.rmeta[i] & 3, A.rowS[RS_S * i + 2], A.rowS[RS_S * i + 1], A.rowS[RS_S * i + 5], &f, &h);
