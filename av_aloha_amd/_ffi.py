@@ -49,6 +49,7 @@ def lib():
         L.avsim_get_phase_cycles.argtypes = [vp, vp]
         L.avsim_render_depth.argtypes = [vp, vp, i32, i32, i32, vp]
         L.avsim_camera_count.argtypes = [vp]
+        L.avsim_reward_from_pairs.argtypes = [vp, vp, i32, i32, vp, vp]
         L.avsim_sync.argtypes = [vp]
         L.avsim_set_stream.argtypes = [vp, vp]
         L.avsim_event_record.argtypes = [vp, i32]

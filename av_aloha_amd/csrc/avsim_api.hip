@@ -690,4 +690,31 @@ int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height,
 
 int avsim_camera_count(const avsim_t* h) { return h ? h->render.m.ncam : 0; }
 
+// R1 (env.py:425-863, get_reward x5) on caller-supplied contact lists: the class-bit predicate the step kernel applies
+// to its own contacts (reward_pair_flags / reward_from_flags), one thread per list; host pointers
+int avsim_reward_from_pairs(avsim_t* h, const int32_t* geom_pairs, int nsets, int cap, int32_t* latch, int32_t* reward) {
+    if (!h || (!geom_pairs && cap > 0) || !reward || nsets < 0 || cap < 0) { if (h) h->set_error("avsim_reward_from_pairs: bad arguments"); return AVSIM_EINVAL; }
+    if (nsets == 0) return AVSIM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    int *dp = nullptr, *dl = nullptr, *dr = nullptr;
+    const size_t pb = sizeof(int) * (size_t)nsets * (cap ? cap : 1) * 2, nb = sizeof(int) * (size_t)nsets;
+    HIPCHK(h, hipMalloc(&dp, pb + 2 * nb));
+    dl = dp + (pb / sizeof(int)); dr = dl + nsets;
+    hipError_t e = hipSuccess;
+    if (cap) e = hipMemcpyAsync(dp, geom_pairs, sizeof(int) * (size_t)nsets * cap * 2, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = latch ? hipMemcpyAsync(dl, latch, nb, hipMemcpyHostToDevice, h->stream) : hipMemsetAsync(dl, 0, nb, h->stream);
+    if (e == hipSuccess) {
+        GLB_PTR(const int) gc = h->phys.f64 ? h->phys.md.geom_class : h->phys.mf.geom_class;
+        const int ng = h->phys.f64 ? h->phys.md.ngeom : h->phys.mf.ngeom, task = h->phys.f64 ? h->phys.md.task_id : h->phys.mf.task_id;
+        hipLaunchKernelGGL(k_reward_pairs, dim3((nsets + 255) / 256), dim3(256), 0, h->stream, gc, ng, task, dp, nsets, cap, dl, dr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(reward, dr, nb, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && latch) e = hipMemcpyAsync(latch, dl, nb, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(dp);
+    if (e != hipSuccess) { h->set_error("avsim_reward_from_pairs: %s", hipGetErrorString(e)); return AVSIM_EHIP; }
+    return AVSIM_OK;
+}
+
 }  // extern "C"

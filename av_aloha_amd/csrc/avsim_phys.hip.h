@@ -587,6 +587,74 @@ AVS_DEV real impedance(const real* si, real pos, real margin) {
 
 // reward predicates over geom class bits (env.py get_reward x5; compile.py geom_class)
 AVS_DEV int has_pair(int c1, int c2, int a, int b) { return ((c1 & a) && (c2 & b)) || ((c2 & a) && (c1 & b)); }
+// contact-pair predicates of the five get_reward functions (env.py:425-863) on the geom class bits of compile.py: one
+// contact contributes flag bits, the staged reward follows from the OR over all contacts (later rules overwrite earlier)
+AVS_DEV int reward_pair_flags(int c1, int c2, int t) {
+    enum { CL = 1, CR = 2, CT = 4, CA = 8, CB = 16, CC = 32, CD = 64 };
+    int f = 0;  // bit flags: 0 tl, 1 tr, 2 a_table, 3 b_table, 4 ab, 5 cd, 6 ad, 7 ac
+    if (has_pair(c1, c2, CT, CA)) f |= 4;
+    if (has_pair(c1, c2, CT, CB)) f |= 8;
+    if (has_pair(c1, c2, CA, CB)) f |= 16;
+    if (has_pair(c1, c2, CC, CD)) f |= 32;
+    if (has_pair(c1, c2, CA, CD)) f |= 64;
+    if (has_pair(c1, c2, CA, CC)) f |= 128;
+    if (has_pair(c1, c2, CA, CR)) f |= 2;
+    if (t == 0 || t == 3) { if (has_pair(c1, c2, CB, CL)) f |= 1; }
+    else { if (has_pair(c1, c2, CA, CL)) f |= 1; }
+    return f;
+}
+AVS_DEV int reward_from_flags(int f, int t, int* latch) {
+    bool tl = f & 1, tr = f & 2, a_table = f & 4, b_table = f & 8, ab = f & 16, cd = f & 32, ad = f & 64, ac = f & 128;
+    int rw = 0;
+    switch (t) {
+        case 0:
+            if (tl && tr) rw = 1;
+            if (tl && tr && !a_table && !b_table) rw = 2;
+            if (ab && !a_table && !b_table) rw = 3;
+            if (ac) rw = 4;
+            break;
+        case 1:
+            if (tl && tr) rw = 1;
+            if (tl && tr && !a_table) rw = 2;
+            if (ab && !a_table) rw = 3;
+            if (cd) rw = 4;
+            break;
+        case 2:
+            if (cd) *latch = 1;
+            if (tr) rw = 1;
+            if (tr && !a_table) rw = 2;
+            if (ab && !a_table) rw = 3;
+            if (*latch) rw = 4;
+            if (tl && !tr && !a_table && !ad && *latch) rw = 5;
+            break;
+        case 3:
+            if (tl && tr) rw = 1;
+            if (tl && tr && !a_table && !b_table) rw = 2;
+            if (cd) rw = 3;
+            break;
+        default:
+            if (tl && tr) rw = 1;
+            if (tl && tr && !a_table) rw = 2;
+            if (ab && !a_table) rw = 3;
+            if (cd) rw = 4;
+    }
+    return rw;
+}
+// get_reward on explicit contact lists (one thread per list): geom id pairs int[n][cap][2], -1 = unused slot
+__global__ void k_reward_pairs(GLB_PTR(const int) geom_class, int ngeom, int task_id, const int* __restrict__ pairs, int n, int cap, int* __restrict__ latch, int* __restrict__ reward) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int f = 0;
+    for (int c = 0; c < cap; c++) {
+        const int g1 = pairs[((size_t)i * cap + c) * 2], g2 = pairs[((size_t)i * cap + c) * 2 + 1];
+        if (g1 < 0 || g2 < 0 || g1 >= ngeom || g2 >= ngeom) continue;
+        f |= reward_pair_flags(geom_class[g1], geom_class[g2], task_id);
+    }
+    int l = latch ? latch[i] : 0;
+    reward[i] = reward_from_flags(f, task_id, &l);
+    if (latch) latch[i] = l;
+}
+
 
 template <typename real, int G>
 struct Env {
@@ -1634,57 +1702,14 @@ struct Env {
         PHASE_BEGIN();
         int *misc = ii + ka->lay.misc, *cpair = ii + ka->lay.cpair;
         int ncon = misc[0];
-        enum { CL = 1, CR = 2, CT = 4, CA = 8, CB = 16, CC = 32, CD = 64 };
-        int f = 0;  // bit flags: 0 tl, 1 tr, 2 a_table, 3 b_table, 4 ab, 5 cd, 6 ad, 7 ac
-        int t = ka->m.task_id;
+        int f = 0;
+        const int t = ka->m.task_id;
         for (int c = lane; c < ncon; c += G) {
-            int p = cpair[c], c1 = ka->m.geom_class[ka->m.pair_geom[2 * p]], c2 = ka->m.geom_class[ka->m.pair_geom[2 * p + 1]];
-            if (has_pair(c1, c2, CT, CA)) f |= 4;
-            if (has_pair(c1, c2, CT, CB)) f |= 8;
-            if (has_pair(c1, c2, CA, CB)) f |= 16;
-            if (has_pair(c1, c2, CC, CD)) f |= 32;
-            if (has_pair(c1, c2, CA, CD)) f |= 64;
-            if (has_pair(c1, c2, CA, CC)) f |= 128;
-            if (has_pair(c1, c2, CA, CR)) f |= 2;
-            if (t == 0 || t == 3) { if (has_pair(c1, c2, CB, CL)) f |= 1; }
-            else { if (has_pair(c1, c2, CA, CL)) f |= 1; }
+            int p = cpair[c];
+            f |= reward_pair_flags(ka->m.geom_class[ka->m.pair_geom[2 * p]], ka->m.geom_class[ka->m.pair_geom[2 * p + 1]], t);
         }
         for (int o = 1; o < G; o <<= 1) f |= __shfl_xor(f, o, G);
-        bool tl = f & 1, tr = f & 2, a_table = f & 4, b_table = f & 8, ab = f & 16, cd = f & 32, ad = f & 64, ac = f & 128;
-        int rw = 0;
-        switch (t) {
-            case 0:
-                if (tl && tr) rw = 1;
-                if (tl && tr && !a_table && !b_table) rw = 2;
-                if (ab && !a_table && !b_table) rw = 3;
-                if (ac) rw = 4;
-                break;
-            case 1:
-                if (tl && tr) rw = 1;
-                if (tl && tr && !a_table) rw = 2;
-                if (ab && !a_table) rw = 3;
-                if (cd) rw = 4;
-                break;
-            case 2:
-                if (cd) *latch = 1;
-                if (tr) rw = 1;
-                if (tr && !a_table) rw = 2;
-                if (ab && !a_table) rw = 3;
-                if (*latch) rw = 4;
-                if (tl && !tr && !a_table && !ad && *latch) rw = 5;
-                break;
-            case 3:
-                if (tl && tr) rw = 1;
-                if (tl && tr && !a_table && !b_table) rw = 2;
-                if (cd) rw = 3;
-                break;
-            default:
-                if (tl && tr) rw = 1;
-                if (tl && tr && !a_table) rw = 2;
-                if (ab && !a_table) rw = 3;
-                if (cd) rw = 4;
-        }
-        return rw;
+        return reward_from_flags(f, t, latch);
     }
 };
 

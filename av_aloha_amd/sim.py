@@ -88,6 +88,18 @@ class BatchedSim:
         self.h.check(self.h.L.avsim_render_depth(self.h.h, ids.ctypes.data, len(ids), height, width, out.ctypes.data))
         return out
 
+    def reward_from_pairs(self, geom_pairs, latch=None):
+        """The task's get_reward (env.py:425-863) on explicit contact lists: geom_pairs int [nsets, cap, 2] (collision
+        geom ids, negative = empty slot); latch int32 [nsets] is updated in place.  Returns int32 [nsets]."""
+        p = np.ascontiguousarray(geom_pairs, dtype=np.int32)
+        assert p.ndim == 3 and p.shape[2] == 2
+        if latch is not None:
+            assert latch.dtype == np.int32 and latch.shape == (p.shape[0],) and latch.flags.c_contiguous
+        rw = np.empty(p.shape[0], dtype=np.int32)
+        self.h.check(self.h.L.avsim_reward_from_pairs(self.h.h, p.ctypes.data, p.shape[0], p.shape[1],
+                                                      latch.ctypes.data if latch is not None else None, rw.ctypes.data))
+        return rw
+
     def diag(self):
         d = np.empty((self.N, 4), dtype=np.int32)
         self.h.check(self.h.L.avsim_get_diag(self.h.h, d.ctypes.data))

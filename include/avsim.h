@@ -121,6 +121,13 @@ int avsim_get_phase_cycles(avsim_t* h, int64_t* out);
 int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, float* out);
 int avsim_camera_count(const avsim_t* h);
 
+/* get_reward of the handle's task (gym_guided_vision/gym_guided_vision/env.py:425-863, five subclasses) evaluated on
+ * caller-supplied contact lists instead of the simulator's own contacts: geom_pairs = int32[nsets][cap][2], ids into the
+ * model's collision geom table (manifest "geom_names"), a slot with a negative id is empty.  The kernel applies the same
+ * predicate as the step kernel.  latch (may be NULL = all zero) is int32[nsets], read and updated in place (SewNeedle's
+ * threaded_needle, env.py:596); reward = int32[nsets].  All pointers are host pointers. */
+int avsim_reward_from_pairs(avsim_t* h, const int32_t* geom_pairs, int nsets, int cap, int32_t* latch, int32_t* reward);
+
 /* stream / timing helpers (HIP events on the stream the kernels are launched on) */
 int avsim_sync(avsim_t* h);
 int avsim_set_stream(avsim_t* h, void* hip_stream);
