@@ -48,6 +48,7 @@ def lib():
         L.avsim_get_diag.argtypes = [vp, vp]
         L.avsim_get_phase_cycles.argtypes = [vp, vp]
         L.avsim_render_depth.argtypes = [vp, vp, i32, i32, i32, vp]
+        L.avsim_render_rgb.argtypes = [vp, vp, i32, i32, i32, vp]
         L.avsim_camera_count.argtypes = [vp]
         L.avsim_reward_from_pairs.argtypes = [vp, vp, i32, i32, vp, vp]
         L.avsim_sync.argtypes = [vp]

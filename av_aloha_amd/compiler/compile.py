@@ -25,6 +25,23 @@ from .mjcf import parse, quat_mul, quat_to_mat
 
 GEOM_SPHERE, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = 2, 5, 6, 7
 GTYPE = {"sphere": GEOM_SPHERE, "cylinder": GEOM_CYLINDER, "box": GEOM_BOX, "mesh": GEOM_MESH}
+
+
+# material colours of the drawn proxies: an explicit rgba wins, then the material's rgba; the textured table material
+# (scene.xml:39, small_meta_table_diffuse.png) is drawn in one flat colour, and collision geoms without either (robot
+# links, aloha_sim.xml:106-108) take the colour of the visual meshes they stand in for (material "black", aloha_sim.xml:9)
+TABLE_RGBA = (0.55, 0.50, 0.44, 1.0)
+
+
+def geom_colour(m, g):
+    if g.get("rgba_given"):
+        return np.asarray(g["rgba"], dtype=float)
+    mat = g.get("material")
+    if mat is not None and mat in m.materials:
+        return np.asarray(m.materials[mat] if m.materials[mat] is not None else TABLE_RGBA, dtype=float)
+    if g["name"] == "table":
+        return np.asarray(TABLE_RGBA)
+    return np.asarray(m.materials.get("black", (0.15, 0.15, 0.15, 1.0)), dtype=float)
 JTYPE = {"free": 0, "ball": 1, "slide": 2, "hinge": 3}
 
 TASKS = {
@@ -397,8 +414,10 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
     g_prio = np.zeros(ng, dtype=np.int32)
     g_solmix = np.zeros(ng)
     names = []
+    g_rgba = np.zeros((ng, 4))
     for k, gi in enumerate(cg):
         g = m.geoms[gi]
+        g_rgba[k] = geom_colour(m, g)
         g_type[k] = GTYPE[g["type"]]
         g_body[k] = g["body"]
         g_pos[k], g_quat[k] = g["pos"], g["quat"]
@@ -446,6 +465,11 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
     # the 0.6 mm finger pad spheres (inside the finger hulls) are not drawn
     md["geom_visible"] = np.array([0 if (n.startswith("pin") or n[-3:] in ("_g0", "_g1", "_g2")) else 1 for n in names], dtype=np.int32)
     md["hull_plane"] = np.concatenate(planes) if planes else np.zeros((0, 4))
+    md["geom_rgba"] = g_rgba
+    # lights of the colour render (scene.xml:9 headlight, :48 directional light with MuJoCo's default diffuse 0.7) and the
+    # skybox gradient (scene.xml:34): [headlight ambient, headlight diffuse, light diffuse, 0], light direction (world),
+    # sky rgb at the zenith, sky rgb at the nadir
+    md["render_light"] = np.array([0.3, 0.6, 0.7, 0.0,  0.0, 0.0, -1.0, 0.0,  0.3, 0.5, 0.7, 0.0,  0.0, 0.0, 0.0, 0.0])
 
     # ---- candidate pair list -------------------------------------------------------------
     excl = set()

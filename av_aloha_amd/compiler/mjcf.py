@@ -165,6 +165,7 @@ class Model:
         self.option = {}
         self.compiler = {}
         self.meshes = {}      # name -> dict(file, scale)
+        self.materials = {}   # name -> rgba (4,) or None for a textured material
         self.bodies = []      # list of dict, index 0 = world
         self.joints = []
         self.geoms = []
@@ -201,6 +202,8 @@ def parse(path):
             name = me.attrib.get("name", os.path.splitext(os.path.basename(f))[0])
             scale = _floats(me.attrib.get("scale", "1 1 1"), 3)
             m.meshes[name] = {"file": os.path.join(meshdir, f), "scale": scale}
+        for ma in node.findall("material"):
+            m.materials[ma.attrib["name"]] = _floats(ma.attrib["rgba"], 4) if "rgba" in ma.attrib else None
 
     def elem_attrs(tag, node, childclass):
         cls = node.attrib.get("class", childclass)
@@ -291,6 +294,7 @@ def parse(path):
                     "mass": float(a["mass"]) if "mass" in a else None,
                     "density": float(a.get("density", 1000)),
                     "rgba": _floats(a.get("rgba", "0.5 0.5 0.5 1"), 4),
+                    "rgba_given": "rgba" in a, "material": a.get("material"),
                 }
                 # friction may be given with fewer than 3 numbers: pad with defaults
                 fr = np.array([1.0, 0.005, 0.0001])
@@ -351,6 +355,7 @@ def parse(path):
                     "mass": float(a["mass"]) if "mass" in a else None,
                     "density": float(a.get("density", 1000)),
                     "rgba": _floats(a.get("rgba", "0.5 0.5 0.5 1"), 4),
+                    "rgba_given": "rgba" in a, "material": a.get("material"),
                 }
                 fr = np.array([1.0, 0.005, 0.0001])
                 fr[:len(g["friction"])] = g["friction"]

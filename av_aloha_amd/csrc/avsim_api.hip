@@ -672,20 +672,28 @@ extern "C" {
 
 // E6 (env.py:180-188 get_obs pixels / :195-200 render) as depth images: forward pass of the physics kernel (nsub = 0) exports
 // the body poses, then the two render kernels run on the same stream.
-int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, float* out) {
-    if (!h || !cam_ids || !out) { if (h) h->set_error("avsim_render_depth: bad arguments"); return AVSIM_EINVAL; }
+static int render_images(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, void* out, bool rgb) {
+    const char* who = rgb ? "avsim_render_rgb" : "avsim_render_depth";
+    if (!h || !cam_ids || !out) { if (h) h->set_error("%s: bad arguments", who); return AVSIM_EINVAL; }
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     void* dout = nullptr;
-    const size_t bytes = sizeof(float) * (size_t)h->N * ncam * height * width;
+    const size_t bytes = (rgb ? 3 : sizeof(float)) * (size_t)h->N * ncam * height * width;
     if ((rc = h->out_begin(7, out, bytes, &dout))) return rc;
     h->phys.d_xpose = h->render.d_xpose;
     rc = h->phys.launch(h->stream, h->N, 0, nullptr, h->nj, h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, h->d_latch, nullptr, nullptr, nullptr, h->err);
     h->phys.d_xpose = nullptr;
     if (rc) return rc;
-    if ((rc = h->render.launch(h->stream, (const int*)cam_ids, ncam, height, width, (float*)dout, h->err))) return rc < -1 ? AVSIM_EHIP : AVSIM_EINVAL;
+    if ((rc = h->render.launch(h->stream, (const int*)cam_ids, ncam, height, width, dout, rgb, h->err))) return rc < -1 ? AVSIM_EHIP : AVSIM_EINVAL;
     if ((rc = h->out_end(7, out, bytes))) return rc;
     return h->finish();
+}
+int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, float* out) {
+    return render_images(h, cam_ids, ncam, height, width, out, false);
+}
+// E6 as colour images of the same proxies (env.py:180-188 "pixels" u8[H][W][3], :195-200 render)
+int avsim_render_rgb(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, uint8_t* out) {
+    return render_images(h, cam_ids, ncam, height, width, out, true);
 }
 
 int avsim_camera_count(const avsim_t* h) { return h ? h->render.m.ncam : 0; }

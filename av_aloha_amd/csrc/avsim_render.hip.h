@@ -36,6 +36,7 @@ struct RenderModel {
     int ngeom, ncam, nbody, nplane;   // nplane: faces summed over the visible mesh geoms
     const int *geom_type, *geom_body, *geom_hplane, *geom_hull, *geom_visible, *cam_body;
     const float *geom_pos, *geom_mat, *geom_size, *geom_bcen, *geom_rbound, *hull_plane, *hull_vert, *cam_pos, *cam_mat, *cam_fovy;   // cam_fovy: tan(fovy / 2) per camera
+    const float *geom_rgba, *light;   // colour render: material colours; [ambient, headlight, light, -, light dir (world) 4, sky zenith rgb 4, sky nadir rgb 4]
     float znear, zfar;
 };
 
@@ -48,7 +49,8 @@ __device__ inline void mul33(const float* A, const float* B, float* C) {   // C 
 
 // grid (ncam_sel, N), block 64
 __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float* __restrict__ xpose, const int* __restrict__ cam_ids, int ncam_sel,
-                                                     int H, int W, float* __restrict__ recs, int* __restrict__ counts, int* __restrict__ order, float* __restrict__ tplanes) {
+                                                     int H, int W, float* __restrict__ recs, int* __restrict__ counts, int* __restrict__ order, float* __restrict__ tplanes,
+                                                     float* __restrict__ camaux) {
     __shared__ float keys[128];
     const int lane = threadIdx.x, cs = blockIdx.x, env = blockIdx.y, cam = cam_ids[cs];
     const float* xb = xpose + (size_t)env * m.nbody * 12;
@@ -60,6 +62,14 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
         mul33(Rb, m.cam_mat + 9 * cam, Rc);
 #pragma unroll
         for (int i = 0; i < 3; i++) pc[i] = pb[i] + Rb[3 * i] * cp[0] + Rb[3 * i + 1] * cp[1] + Rb[3 * i + 2] * cp[2];
+    }
+    if (lane < 8) {   // colour render: the light's direction and the world's up axis, both in the camera frame
+        const float* L = m.light + 4;
+        const float il = 1.0f / sqrtf(L[0] * L[0] + L[1] * L[1] + L[2] * L[2]);
+        const int j = lane & 3;
+        float v = 0;
+        if (j < 3) v = lane < 4 ? (Rc[j] * L[0] + Rc[3 + j] * L[1] + Rc[6 + j] * L[2]) * il : Rc[6 + j];
+        camaux[((size_t)env * ncam_sel + cs) * 8 + lane] = v;
     }
     const float scale = 2.0f * m.cam_fovy[cam] / (float)H;       // cam_fovy holds tan(fovy / 2)
     const float tx = 0.5f * W * scale, ty = 0.5f * H * scale, sx = sqrtf(1 + tx * tx), sy = sqrtf(1 + ty * ty);
@@ -214,11 +224,15 @@ __device__ inline bool ray_prim(int type, const float* sz, const float* o, const
     return true;
 }
 
-// grid (tiles_x * tiles_y, ncam_sel, N), block 64: lane -> 4 pixels (x0 .. x0+3, y)
+// grid (tiles_x * tiles_y, ncam_sel, N), block 64: lane -> 4 pixels (x0 .. x0+3, y).  RGB: the cast also remembers which record
+// (and hull face) each pixel sees, and an epilogue shades it (flat material colour, Lambert terms of the headlight along
+// the ray and of the scene's directional light, sky gradient where nothing is hit) into u8[H][W][3]
+template <bool RGB>
 __global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ recs, const int* __restrict__ counts, const int* __restrict__ order,
                                                      const float4* __restrict__ tplanes, int nplane,
                                                      const float* __restrict__ cam_fovy, const int* __restrict__ cam_ids, int ncam_sel, int ngeom, int H,
-                                                     int W, float znear, float zfar, float* __restrict__ out) {
+                                                     int W, float znear, float zfar, float* __restrict__ out, const float* __restrict__ geom_rgba, const float* __restrict__ light,
+                                                     const float* __restrict__ camaux, unsigned char* __restrict__ out_rgb) {
     const int lane = threadIdx.x, cs = blockIdx.y, env = blockIdx.z;
     const int tiles_x = (W + TILE_W - 1) / TILE_W, tx0 = (blockIdx.x % tiles_x) * TILE_W, ty0 = (blockIdx.x / tiles_x) * TILE_H;
     const int px = tx0 + 4 * (lane & 7), py = ty0 + (lane >> 3);
@@ -231,8 +245,9 @@ __global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ r
     const float xl = (tx0 - 0.5f * W) * scale, xr = (x1 - 0.5f * W) * scale, yt = -(ty0 - 0.5f * H) * scale, yb = -(y1 - 0.5f * H) * scale;
     const float dy = -(py + 0.5f - 0.5f * H) * scale;
     float dx[4], best[4];
+    int win[4];     // RGB: record index | entry face << 8 of what the pixel sees
 #pragma unroll
-    for (int q = 0; q < 4; q++) { dx[q] = (px + q + 0.5f - 0.5f * W) * scale; best[q] = (px + q < W && py < H) ? zfar : 0.0f; }
+    for (int q = 0; q < 4; q++) { dx[q] = (px + q + 0.5f - 0.5f * W) * scale; best[q] = (px + q < W && py < H) ? zfar : 0.0f; win[q] = -1; }
     float far = zfar;    // farthest current depth over the tile's pixels (off-image pixels count as 0)
     for (int k0 = 0; k0 < cnt; k0 += 64) {
         bool hit = false;
@@ -273,8 +288,9 @@ __global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ r
                 // point must lie behind them (lo * n.v <= no; no division).
                 float lo[4];
                 bool ok[4];
+                int face[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) { lo[q] = -1e30f; ok[q] = true; }
+                for (int q = 0; q < 4; q++) { lo[q] = -1e30f; ok[q] = true; face[q] = 0; }
                 for (int p = 0; p < np; p++) {
                     const float4 f = P[p];
                     if (!(f.w < 0)) continue;
@@ -284,6 +300,7 @@ __global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ r
                         const float nv = nb + f.x * dx[q];
                         const float t = f.w * __builtin_amdgcn_rcpf(nv);
                         ok[q] = ok[q] && nv < 0;
+                        if (RGB) { if (t > lo[q]) face[q] = p; }
                         lo[q] = fmaxf(lo[q], t);
                     }
                 }
@@ -303,7 +320,7 @@ __global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ r
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++)
-                    if (ok[q] && lo[q] >= znear && lo[q] < best[q]) best[q] = lo[q];
+                    if (ok[q] && lo[q] >= znear && lo[q] < best[q]) { best[q] = lo[q]; if (RGB) win[q] = k | (face[q] << 8); }
                 far = wave_max(fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3])));
             } else {
                 // direction in the geom frame: A (dx, dy, -1)
@@ -315,19 +332,82 @@ __global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ r
                 for (int q = 0; q < 4; q++) {
                     const float v[3] = {vb[0] + va[0] * dx[q], vb[1] + va[1] * dx[q], vb[2] + va[2] * dx[q]};
                     float t0;
-                    if (ray_prim(type, sz, o, v, &t0) && t0 >= znear && t0 < best[q]) best[q] = t0;
+                    if (ray_prim(type, sz, o, v, &t0) && t0 >= znear && t0 < best[q]) { best[q] = t0; if (RGB) win[q] = k; }
                 }
                 far = wave_max(fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3])));
             }
         }
     }
-    if (py < H) {
-        float* dst = out + (((size_t)env * ncam_sel + cs) * H + py) * W + px;
-        if (px + 3 < W && (W & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(best[0], best[1], best[2], best[3]);
-        else {
+    if (!RGB) {
+        if (py < H) {
+            float* dst = out + (((size_t)env * ncam_sel + cs) * H + py) * W + px;
+            if (px + 3 < W && (W & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(best[0], best[1], best[2], best[3]);
+            else {
 #pragma unroll
-            for (int q = 0; q < 4; q++) if (px + q < W) dst[q] = best[q];
+                for (int q = 0; q < 4; q++) if (px + q < W) dst[q] = best[q];
+            }
         }
+        return;
+    }
+    if (py >= H) return;
+    const float* aux = camaux + ((size_t)env * ncam_sel + cs) * 8;
+    const float amb = light[0], hd = light[1], ld = light[2];
+    unsigned char col[12];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float idn = rsqrtf(dx[q] * dx[q] + dy * dy + 1.0f);
+        float rgb[3];
+        if (win[q] >= 0) {
+            const int k = win[q] & 255;
+            const float* rec = R + (size_t)k * REC_W;
+            const int type = __float_as_int(rec[19]);
+            float n[3];    // outward normal in the camera frame
+            if (type == 7) {
+                const float4 f = tplanes[((size_t)env * ncam_sel + cs) * nplane + __float_as_int(rec[20]) + (win[q] >> 8)];
+                n[0] = f.x; n[1] = f.y; n[2] = f.z;
+            } else {
+                float p[3], ng[3] = {0, 0, 0};
+                const float t = best[q];
+#pragma unroll
+                for (int i = 0; i < 3; i++) p[i] = rec[i] + t * (rec[3 + 3 * i] * dx[q] + rec[3 + 3 * i + 1] * dy - rec[3 + 3 * i + 2]);
+                if (type == 2) {
+                    const float ir = rsqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+                    ng[0] = p[0] * ir; ng[1] = p[1] * ir; ng[2] = p[2] * ir;
+                } else if (type == 6) {   // the face whose slab the entry point lies on
+                    const float q0 = fabsf(p[0]) / rec[16], q1 = fabsf(p[1]) / rec[17], q2 = fabsf(p[2]) / rec[18];
+                    const int a = (q1 > q0) ? ((q2 > q1) ? 2 : 1) : ((q2 > q0) ? 2 : 0);
+                    ng[a] = p[a] > 0 ? 1.0f : -1.0f;
+                } else {                  // cylinder: cap or side
+                    const float rr = sqrtf(p[0] * p[0] + p[1] * p[1]);
+                    if (fabsf(p[2]) / rec[17] > rr / rec[16]) ng[2] = p[2] > 0 ? 1.0f : -1.0f;
+                    else { ng[0] = p[0] / rr; ng[1] = p[1] / rr; }
+                }
+#pragma unroll
+                for (int j = 0; j < 3; j++) n[j] = rec[3 + j] * ng[0] + rec[6 + j] * ng[1] + rec[9 + j] * ng[2];   // A^T
+            }
+            const float ch = -(n[0] * dx[q] + n[1] * dy - n[2]) * idn, cl = -(n[0] * aux[0] + n[1] * aux[1] + n[2] * aux[2]);
+            const float lum = fminf(1.0f, amb + hd * fmaxf(ch, 0.0f) + ld * fmaxf(cl, 0.0f));
+            const float* c = geom_rgba + 4 * __float_as_int(rec[22]);
+            rgb[0] = c[0] * lum; rgb[1] = c[1] * lum; rgb[2] = c[2] * lum;
+        } else {
+            const float w = 0.5f + 0.5f * (aux[4] * dx[q] + aux[5] * dy - aux[6]) * idn;
+#pragma unroll
+            for (int j = 0; j < 3; j++) rgb[j] = light[12 + j] + (light[8 + j] - light[12 + j]) * w;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) col[3 * q + j] = (unsigned char)(fminf(fmaxf(rgb[j], 0.0f), 1.0f) * 255.0f + 0.5f);
+    }
+    unsigned char* dst = out_rgb + ((((size_t)env * ncam_sel + cs) * H + py) * W + px) * 3;
+    if (px + 3 < W && (W & 3) == 0) {
+        unsigned int w3[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) w3[j] = col[4 * j] | (col[4 * j + 1] << 8) | (col[4 * j + 2] << 16) | ((unsigned)col[4 * j + 3] << 24);
+        unsigned int* d32 = reinterpret_cast<unsigned int*>(dst);
+        d32[0] = w3[0]; d32[1] = w3[1]; d32[2] = w3[2];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (px + q < W) { dst[3 * q] = col[3 * q]; dst[3 * q + 1] = col[3 * q + 1]; dst[3 * q + 2] = col[3 * q + 2]; }
     }
 }
 
@@ -340,6 +420,7 @@ struct RenderHost {
     int* d_counts = nullptr;
     int* d_order = nullptr;
     float* d_tplanes = nullptr;     // [N][ncam][nplane][4] hull faces in camera-ray form
+    float* d_camaux = nullptr;      // [N][16][8] light direction and world up axis in the camera frame
     int* d_cam_ids = nullptr;
     size_t recs_cap = 0;
     int N = 0;
@@ -384,6 +465,8 @@ struct RenderHost {
             for (size_t c = 0; c < fv.size(); c++) th[c] = (float)std::tan(0.5 * fv[c] * 3.14159265358979323846 / 180.0);
             m.cam_fovy = up(th);
         }
+        m.geom_rgba = up(tofloat(b.f("geom_rgba"))); m.light = up(tofloat(b.f("render_light")));
+        d_camaux = up(std::vector<float>((size_t)N * 16 * 8, 0.0f));
         auto clip = b.f("cam_clip");
         m.znear = (float)clip[0]; m.zfar = (float)clip[1];
         d_xpose = up(std::vector<float>((size_t)N * m.nbody * 12, 0.0f));
@@ -398,8 +481,8 @@ struct RenderHost {
         if (d_cam_ids) (void)hipFree(d_cam_ids);
         d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; d_cam_ids = nullptr; recs_cap = 0;
     }
-    // d_out: device float[N][ncam_sel][H][W]; body poses must already be in d_xpose (same stream)
-    int launch(hipStream_t st, const int* cam_ids_host, int ncam_sel, int H, int W, float* d_out, std::string& err) {
+    // d_out: device float[N][ncam_sel][H][W], or (rgb) u8[N][ncam_sel][H][W][3]; body poses must already be in d_xpose (same stream)
+    int launch(hipStream_t st, const int* cam_ids_host, int ncam_sel, int H, int W, void* d_out, bool rgb, std::string& err) {
         if (ncam_sel < 1 || ncam_sel > 16 || H < 1 || W < 1 || H > 4096 || W > 4096) { err = "avsim_render_depth: bad camera count or image size"; return -1; }
         for (int c = 0; c < ncam_sel; c++)
             if (cam_ids_host[c] < 0 || cam_ids_host[c] >= m.ncam) { err = "avsim_render_depth: camera index out of range"; return -1; }
@@ -420,10 +503,14 @@ struct RenderHost {
         }
         if (!d_cam_ids && hipMalloc((void**)&d_cam_ids, 16 * sizeof(int)) != hipSuccess) { err = "hipMalloc(camera ids) failed"; return -3; }
         if (hipMemcpyAsync(d_cam_ids, cam_ids_host, ncam_sel * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { err = "camera id copy failed"; return -3; }
-        hipLaunchKernelGGL(k_render_geoms, dim3(ncam_sel, N), dim3(64), 0, st, m, (const float*)d_xpose, (const int*)d_cam_ids, ncam_sel, H, W, d_recs, d_counts, d_order, d_tplanes);
+        hipLaunchKernelGGL(k_render_geoms, dim3(ncam_sel, N), dim3(64), 0, st, m, (const float*)d_xpose, (const int*)d_cam_ids, ncam_sel, H, W, d_recs, d_counts, d_order, d_tplanes, d_camaux);
         const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
-        hipLaunchKernelGGL(k_render_depth, dim3(tiles, ncam_sel, N), dim3(64), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, m.nplane, m.cam_fovy,
-                           (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, d_out);
+        if (rgb)
+            hipLaunchKernelGGL(k_render_depth<true>, dim3(tiles, ncam_sel, N), dim3(64), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, m.nplane,
+                               m.cam_fovy, (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, (float*)nullptr, m.geom_rgba, m.light, (const float*)d_camaux, (unsigned char*)d_out);
+        else
+            hipLaunchKernelGGL(k_render_depth<false>, dim3(tiles, ncam_sel, N), dim3(64), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, m.nplane,
+                               m.cam_fovy, (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, (float*)d_out, m.geom_rgba, m.light, (const float*)d_camaux, (unsigned char*)nullptr);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("render kernel launch: ") + hipGetErrorString(e); return -3; }
         return 0;

@@ -7,16 +7,17 @@ of gym_guided_vision/gym_guided_vision/__init__.py:4-101, so callers written aga
 `num_arms`) keep working.  Physics, IK, reward and observation gathering all run in libavsim's HIP
 kernels; this file only holds host-side glue (action/observation packing, object-pose sampling).
 
-Differences a caller can see (DESIGN.md lists them): RGB `pixels` observations are not built, so `cameras` must be empty;
-`render_depth()` returns float32 depth images of the same cameras instead (BASELINE config 5); envs can be batched with
-`num_envs > 1`.
+Differences a caller can see (DESIGN.md lists them): the `pixels` observations and `render()` are drawn by the library's
+own ray caster over the collision proxies in flat material colours (no textures / shadows), not by MuJoCo's OpenGL
+renderer; `render_depth()` returns float32 depth images of the same cameras (BASELINE config 5); envs can be batched
+with `num_envs > 1` (every array gains a leading axis).
 """
 from __future__ import annotations
 
 import numpy as np
 
 from . import _ffi
-from .constants import CAMERAS, SIM_DT, SIM_PHYSICS_ENV_STEP_RATIO
+from .constants import CAMERAS, RENDER_CAMERA, SIM_DT, SIM_PHYSICS_ENV_STEP_RATIO
 from .sim import BatchedSim
 
 try:  # gymnasium is optional: the API below does not depend on it
@@ -98,10 +99,6 @@ class GuidedVisionEnv(_EnvBase):
             super().__init__()
         assert num_arms in [2, 3], f"Invalid number of arms: {num_arms}"
         assert all([camera in CAMERAS for camera in cameras]), f"Invalid camera names: {cameras}"
-        if len(cameras) != 0:
-            raise NotImplementedError(
-                "RGB camera observations are not built (SURVEY.md 8f rank 3); construct the env with cameras=[] and use "
-                "render_depth(cameras, height, width) for depth images of the same cameras")
         if self.task is None:
             raise NotImplementedError("use one of the task classes or make_sim_env()")
         self.cameras = list(cameras)
@@ -116,10 +113,13 @@ class GuidedVisionEnv(_EnvBase):
         shape = (self.num_joints,) if self.num_envs == 1 else (self.num_envs, self.num_joints)
         self.action_space = box(low=-np.inf, high=np.inf, shape=shape, dtype=np.float32)
         agent_space = box(low=-np.inf, high=np.inf, shape=shape, dtype=np.float64)
+        ishape = (observation_height, observation_width, 3)
+        ishape = ishape if self.num_envs == 1 else (self.num_envs,) + ishape
+        pix = {c: box(low=0, high=255, shape=ishape, dtype=np.uint8) for c in self.cameras}
         if spaces is not None:
-            self.observation_space = spaces.Dict({"pixels": spaces.Dict({}), "agent_pos": agent_space})
+            self.observation_space = spaces.Dict({"pixels": spaces.Dict(pix), "agent_pos": agent_space})
         else:
-            self.observation_space = {"pixels": {}, "agent_pos": agent_space}
+            self.observation_space = {"pixels": pix, "agent_pos": agent_space}
         self._agent_pos = np.zeros((self.num_envs, self.num_joints))
         self._reward = np.zeros(self.num_envs, dtype=np.int32)
 
@@ -127,8 +127,14 @@ class GuidedVisionEnv(_EnvBase):
     def _squeeze(self, a):
         return a[0] if self.num_envs == 1 else a
 
+    def _pixels(self):
+        if not self.cameras:
+            return {}
+        img = self.sim.render_rgb(self.cameras, self.observation_height, self.observation_width)
+        return {c: self._squeeze(img[:, i]).copy() for i, c in enumerate(self.cameras)}
+
     def _obs(self):
-        return {"pixels": {}, "agent_pos": self._squeeze(self._agent_pos).copy()}
+        return {"pixels": self._pixels(), "agent_pos": self._squeeze(self._agent_pos).copy()}
 
     def _refresh_agent_pos(self):
         ap = np.empty((self.num_envs, self.num_joints))
@@ -179,7 +185,8 @@ class GuidedVisionEnv(_EnvBase):
         self._refresh_agent_pos()
 
     def render(self):
-        raise NotImplementedError("render(): RGB rendering is a later row of SURVEY.md section 8f; see render_depth()")
+        """env.py:195-200: uint8 [225, 300, 3] image of the overhead camera (leading num_envs axis for a batch)."""
+        return self._squeeze(self.sim.render_rgb([RENDER_CAMERA], 225, 300)[:, 0]).copy()
 
     def render_depth(self, cameras=("zed_cam_left", "zed_cam_right", "wrist_cam_left", "wrist_cam_right"), height=None, width=None):
         """Depth images (float32 metres along the optical axis, far plane 30 m) of the named cameras at the current state:

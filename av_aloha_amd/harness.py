@@ -9,7 +9,8 @@
 * `record_episode` / `save_episode` / `load_episode` (record_sim_episodes.py:83-128, :155-212): a scripted Cartesian action
   sequence replaces the VR headset; the episode holds T = len(actions) + 1 time steps with `/observations/qpos` (T, 21),
   `/observations/qvel` (T, 21), `/observations/all_qpos` (T, nq), `/action` (T, 21: the joint-space command with
-  normalised grippers, i.e. obs['control']) as float32 and the attribute sim = True.  Written as HDF5 when h5py is
+  normalised grippers, i.e. obs['control']) as float32, `/observations/images/<cam>` uint8 (T, H, W, 3) for the env's cameras
+  and the attribute sim = True.  Written as HDF5 when h5py is
   importable, otherwise as .npz with the same names (h5py is not installed in this image).
 * `replay_episode` (gym_guided_vision/scripts/replay_sim_episode.py:221-262): set_qpos through `/observations/all_qpos`.
 """
@@ -80,8 +81,11 @@ def record_episode(env, actions23) -> dict:
         ts, _, _, _, _ = env.step(a)
         steps.append(ts)
     stack = lambda f: np.stack([np.asarray(f(s)) for s in steps]).astype(np.float32)
-    return {"/observations/qpos": stack(lambda s: s["joints"]["position"]), "/observations/qvel": stack(lambda s: s["joints"]["velocity"]),
+    data = {"/observations/qpos": stack(lambda s: s["joints"]["position"]), "/observations/qvel": stack(lambda s: s["joints"]["velocity"]),
             "/observations/all_qpos": stack(lambda s: s["qpos"]), "/action": stack(lambda s: s["control"])}
+    for cam in steps[0].get("images", {}):                     # record_sim_episodes.py:197-200: uint8 (T, H, W, 3) per camera
+        data[f"/observations/images/{cam}"] = np.stack([s["images"][cam] for s in steps])
+    return data
 
 
 def save_episode(data: dict, dataset_dir: str, episode_idx: int) -> str:

@@ -88,6 +88,15 @@ class BatchedSim:
         self.h.check(self.h.L.avsim_render_depth(self.h.h, ids.ctypes.data, len(ids), height, width, out.ctypes.data))
         return out
 
+    def render_rgb(self, cameras, height, width):
+        """Colour images uint8 [N, len(cameras), height, width, 3] of the named cameras at the current state (the layout
+        of the reference's "pixels" observation, env.py:180-188)."""
+        names = self.manifest["camera_names"]
+        ids = np.array([names.index(c) if isinstance(c, str) else int(c) for c in cameras], dtype=np.int32)
+        out = np.empty((self.N, len(ids), height, width, 3), dtype=np.uint8)
+        self.h.check(self.h.L.avsim_render_rgb(self.h.h, ids.ctypes.data, len(ids), height, width, out.ctypes.data))
+        return out
+
     def reward_from_pairs(self, geom_pairs, latch=None):
         """The task's get_reward (env.py:425-863) on explicit contact lists: geom_pairs int [nsets, cap, 2] (collision
         geom ids, negative = empty slot); latch int32 [nsets] is updated in place.  Returns int32 [nsets]."""

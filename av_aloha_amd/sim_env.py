@@ -7,7 +7,8 @@ unnorm(1 - trigger) (:300-301) and steps 20 substeps; `step_joints(action[21])` 
 `get_obs()` returns the reference's dictionary (:160-218): joints.position / joints.velocity (fingers normalised by the
 gripper ctrl range), qpos, control, poses.{left,right,middle} = FK of the *commanded* joints as [xyz, quat wxyz], images.
 IK, FK and physics run in libavsim (avsim_step_cartesian, avsim_fk_jac); this file is host glue only.  Rewards are 0 here
-exactly as in the reference (:307).  RGB `images` are not built: `cameras` must be empty (see env.render_depth)."""
+exactly as in the reference (:307).  `images` follow the reference's naming and sizes (:187-203: zed_cam = left | right 720 x 720
+side by side, the others 480 x 640), drawn by the library's proxy ray caster (avsim_render_rgb)."""
 from __future__ import annotations
 
 import numpy as np
@@ -37,14 +38,19 @@ def mat2quat_xyzw(R):
     return q1[..., [1, 2, 3, 0]]
 
 
+CAMERAS = ["zed_cam", "cam_left_wrist", "cam_right_wrist", "cam_high", "cam_low"]      # sim_env.py:22
+_CAMERA_IDS = {"cam_left_wrist": "wrist_cam_left", "cam_right_wrist": "wrist_cam_right", "cam_high": "overhead_cam", "cam_low": "worms_eye_cam"}
+
+
 class GuidedVisionEnv:
     """One env (reference shapes) or a batch (leading axis num_envs)."""
 
     task = None
 
-    def __init__(self, cameras=(), num_envs: int = 1, device: int = 0, f64: bool = False, options: dict | None = None):
-        if len(cameras) != 0:
-            raise NotImplementedError("RGB images are not built; construct with cameras=[] (depth: env.render_depth)")
+    def __init__(self, cameras=CAMERAS, num_envs: int = 1, device: int = 0, f64: bool = False, options: dict | None = None):
+        for camera in cameras:
+            assert camera in CAMERAS, f"Invalid camera name: {camera}"
+        self._cameras = list(cameras)
         if self.task is None:
             raise NotImplementedError("use one of the task classes or make_sim_env()")
         self.num_envs = int(num_envs)
@@ -88,8 +94,18 @@ class GuidedVisionEnv:
             "qpos": self._sq(qpos),
             "control": self._sq(con),
             "poses": {k: self._sq(v) for k, v in poses.items()},
-            "images": {},
+            "images": self._images(),
         }
+
+    def _images(self):
+        images = {}
+        for camera in self._cameras:                               # sim_env.py:187-203
+            if camera == "zed_cam":
+                lr = self.sim.render_rgb(["zed_cam_left", "zed_cam_right"], 720, 720)
+                images["zed_cam"] = self._sq(np.concatenate([lr[:, 0], lr[:, 1]], axis=2))
+            else:
+                images[camera] = self._sq(self.sim.render_rgb([_CAMERA_IDS[camera]], 480, 640)[:, 0]).copy()
+        return images
 
     # ---- gym-style surface (sim_env.py:220-312) ------------------------------------------------------
     def reset(self, seed=None):
@@ -128,7 +144,7 @@ _CLASSES = {"insert_peg": InsertPegEnv, "slot_insertion": SlotInsertionEnv, "sew
             "tube_transfer": TubeTransferEnv, "hook_package": HookPackageEnv}
 
 
-def make_sim_env(task_name, cameras=(), **kw):
+def make_sim_env(task_name, cameras=CAMERAS, **kw):
     """sim_env.py:18-35: keyed on the same substrings, NotImplementedError otherwise."""
     for sub, key in _TASK_OF_SUBSTRING:
         if sub in task_name:

@@ -119,6 +119,14 @@ int avsim_get_phase_cycles(avsim_t* h, int64_t* out);
  * pixels that see nothing = far plane (30 m).  Drawn are the collision proxies of the current state.  `out` is a host or a
  * device pointer according to AVSIM_IO_DEVICE; cam_ids is always a host pointer. */
 int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, float* out);
+
+/* The same cameras as colour images, the layout of the reference's "pixels" observation and of render()
+ * (env.py:180-188, :195-200): out = uint8[N][ncam][height][width][3] (RGB).  Drawn are the collision proxies in their flat
+ * material colours (rgba / material of the MJCF; the textured table in one colour; robot links in the colour of the
+ * visual meshes they stand in for), lit by the scene's headlight (scene.xml:9) and directional light (scene.xml:48) with
+ * Lambert terms, over the skybox gradient (scene.xml:34); no textures, shadows, specular terms or transparency, so the
+ * images are a stand-in for MuJoCo's OpenGL output, not a pixel match.  Pointer conventions as avsim_render_depth. */
+int avsim_render_rgb(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, uint8_t* out);
 int avsim_camera_count(const avsim_t* h);
 
 /* get_reward of the handle's task (gym_guided_vision/gym_guided_vision/env.py:425-863, five subclasses) evaluated on

@@ -66,6 +66,7 @@ typedef struct {
     int ncam;
     const int *geom_hplane, *geom_visible, *cam_body;
     const double *hull_plane, *cam_pos, *cam_quat, *cam_fovy, *cam_clip;
+    const double *geom_rgba, *render_light; /* colour render: material colours, lights + sky (compile.py) */
 } orc_model;
 
 typedef struct {
@@ -113,6 +114,7 @@ void orc_data_free(orc_data* d);
 /* depth image of camera `cam` at the current state (positions must be fresh: orc_forward / orc_step): float32 metres along
  * the optical axis, out[H][W] row 0 = top; returns the number of pixels that hit a geom */
 int orc_render_depth(const orc_data* d, int cam, int H, int W, float* out);
+int orc_render_rgb(const orc_data* d, int cam, int H, int W, unsigned char* out, float* depth);
 
 /* env-level (env.py:203-249): reset to home pose with given object free-joint poses (nobj x 7) */
 void orc_reset(orc_data* d, const double* obj_qpos);

@@ -53,7 +53,7 @@ orc_model* orc_model_load(const void* blob_in, size_t nbytes) {
     LF(qpos0); LF(qpos_home); LF(ctrl_home); LF(obs_offset); LF(obs_scale); LF(grip_range);
     LI(obs_qposadr); LI(obs_dofadr); LI(objects_qposadr);
     LI(ik_n); LI(ik_qadr); LF(ik_w0); LF(ik_p0); LF(ik_site0); LF(ik_range);
-    LI(geom_hplane); LI(geom_visible); LI(cam_body); LF(hull_plane); LF(cam_pos); LF(cam_quat); LF(cam_fovy); LF(cam_clip);
+    LI(geom_hplane); LI(geom_visible); LI(cam_body); LF(hull_plane); LF(cam_pos); LF(cam_quat); LF(cam_fovy); LF(cam_clip); LF(geom_rgba); LF(render_light);
     m->ncam = (int)(find(b, "cam_body")->nbytes / 4);
     m->nobj = (int)(find(b, "objects_qposadr")->nbytes / 4);
     m->nhullvert = (int)(find(b, "hull_vert")->nbytes / 24);

@@ -115,3 +115,108 @@ int orc_render_depth(const orc_data* d, int cam, int H, int W, float* out) {
         }
     return hits;
 }
+
+/* outward unit normal (geom frame) of convex geom g where the ray o + t v enters it at parameter t0 */
+static void entry_normal(const orc_model* m, int g, const double* o, const double* v, double t0, double* n) {
+    const double* sz = m->geom_size + 3 * g;
+    double p[3] = {o[0] + t0 * v[0], o[1] + t0 * v[1], o[2] + t0 * v[2]};
+    n[0] = n[1] = n[2] = 0;
+    switch (m->geom_type[g]) {
+    case ORC_SPHERE: {
+        double r = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+        for (int k = 0; k < 3; k++) n[k] = p[k] / r;
+        break;
+    }
+    case ORC_BOX: { /* the face whose slab the entry point lies on: largest |p_k| / size_k */
+        int a = 0;
+        double best = -1;
+        for (int k = 0; k < 3; k++) { double q = fabs(p[k]) / sz[k]; if (q > best) { best = q; a = k; } }
+        n[a] = p[a] > 0 ? 1 : -1;
+        break;
+    }
+    case ORC_CYLINDER: { /* cap when the entry point is nearer (relatively) to a cap than to the side */
+        double rr = sqrt(p[0] * p[0] + p[1] * p[1]) / sz[0], hh = fabs(p[2]) / sz[1];
+        if (hh > rr) n[2] = p[2] > 0 ? 1 : -1;
+        else { double r = sqrt(p[0] * p[0] + p[1] * p[1]); n[0] = p[0] / r; n[1] = p[1] / r; }
+        break;
+    }
+    case ORC_MESH: { /* the entry face: largest crossing among the faces the ray approaches from outside */
+        const double* P = m->hull_plane + 4 * m->geom_hplane[2 * g];
+        int np = m->geom_hplane[2 * g + 1];
+        double lo = -1e30;
+        for (int k = 0; k < np; k++) {
+            const double* q = P + 4 * k;
+            double nv = q[0] * v[0] + q[1] * v[1] + q[2] * v[2], no = q[3] - (q[0] * o[0] + q[1] * o[1] + q[2] * o[2]);
+            if (nv < 0 && no / nv > lo) { lo = no / nv; n[0] = q[0]; n[1] = q[1]; n[2] = q[2]; }
+        }
+        break;
+    }
+    default: break;
+    }
+}
+
+/* Colour image u8[H][W][3] of camera `cam` (env.py:180-188 pixels, :195-200 render; MuJoCo OpenGL [EXT]): the nearest
+ * proxy surface of orc_render_depth, flat material colour (geom_rgba), Lambert terms of the scene's headlight
+ * (scene.xml:9: ambient 0.3, diffuse 0.6, at the camera, along each pixel's ray) and of its directional light
+ * (scene.xml:48, default diffuse 0.7), sum clamped to 1; rays that hit nothing show the skybox gradient (scene.xml:34)
+ * by the ray's elevation.  No textures, shadows, specular terms, haze or transparency: PARITY UNPINNED against the
+ * reference's pixels.  depth (optional) receives the same values as orc_render_depth. */
+int orc_render_rgb(const orc_data* d, int cam, int H, int W, unsigned char* out, float* depth) {
+    const orc_model* m = d->m;
+    if (cam < 0 || cam >= m->ncam || !m->geom_rgba || !m->render_light) return -1;
+    int b = m->cam_body[cam];
+    double Rl[9], Rc[9], pc[3];
+    quat2mat(m->cam_quat + 4 * cam, Rl);
+    const double *Rb = d->xmat + 9 * b, *pb = d->xpos + 3 * b, *cp = m->cam_pos + 3 * cam;
+    for (int i = 0; i < 3; i++) {
+        pc[i] = pb[i] + Rb[3 * i] * cp[0] + Rb[3 * i + 1] * cp[1] + Rb[3 * i + 2] * cp[2];
+        for (int j = 0; j < 3; j++) Rc[3 * i + j] = Rb[3 * i] * Rl[j] + Rb[3 * i + 1] * Rl[3 + j] + Rb[3 * i + 2] * Rl[6 + j];
+    }
+    const double znear = m->cam_clip[0], zfar = m->cam_clip[1];
+    const double scale = 2.0 * tan(0.5 * m->cam_fovy[cam] * 3.14159265358979323846 / 180.0) / H;
+    const double *L = m->render_light, amb = L[0], hd = L[1], ld = L[2];
+    double ldir[3] = {L[4], L[5], L[6]}, ln = sqrt(ldir[0] * ldir[0] + ldir[1] * ldir[1] + ldir[2] * ldir[2]);
+    for (int k = 0; k < 3; k++) ldir[k] /= ln;
+    int hits = 0;
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            double dc[3] = {(j + 0.5 - 0.5 * W) * scale, -(i + 0.5 - 0.5 * H) * scale, -1.0}, dw[3];
+            for (int k = 0; k < 3; k++) dw[k] = Rc[3 * k] * dc[0] + Rc[3 * k + 1] * dc[1] + Rc[3 * k + 2] * dc[2];
+            double best = zfar, nw[3] = {0, 0, 0};
+            int bg = -1;
+            for (int g = 0; g < m->ngeom; g++) {
+                if (!m->geom_visible[g]) continue;
+                const double *Rg = d->geom_xmat + 9 * g, *pg = d->geom_xpos + 3 * g;
+                double o[3], v[3], rel[3] = {pc[0] - pg[0], pc[1] - pg[1], pc[2] - pg[2]};
+                for (int k = 0; k < 3; k++) {
+                    o[k] = Rg[k] * rel[0] + Rg[3 + k] * rel[1] + Rg[6 + k] * rel[2];
+                    v[k] = Rg[k] * dw[0] + Rg[3 + k] * dw[1] + Rg[6 + k] * dw[2];
+                }
+                double t0, t1;
+                if (!ray_interval(m, g, o, v, &t0, &t1)) continue;
+                if (t0 >= znear && t0 < best) {
+                    double n[3];
+                    best = t0; bg = g;
+                    entry_normal(m, g, o, v, t0, n);
+                    for (int k = 0; k < 3; k++) nw[k] = Rg[3 * k] * n[0] + Rg[3 * k + 1] * n[1] + Rg[3 * k + 2] * n[2];
+                }
+            }
+            double dn = sqrt(dw[0] * dw[0] + dw[1] * dw[1] + dw[2] * dw[2]), rgb[3];
+            if (bg >= 0) {
+                double ch = -(nw[0] * dw[0] + nw[1] * dw[1] + nw[2] * dw[2]) / dn, cl = -(nw[0] * ldir[0] + nw[1] * ldir[1] + nw[2] * ldir[2]);
+                double lum = amb + hd * (ch > 0 ? ch : 0) + ld * (cl > 0 ? cl : 0);
+                if (lum > 1) lum = 1;
+                for (int k = 0; k < 3; k++) rgb[k] = m->geom_rgba[4 * bg + k] * lum;
+                hits++;
+            } else {
+                double w = 0.5 + 0.5 * dw[2] / dn;
+                for (int k = 0; k < 3; k++) rgb[k] = L[12 + k] + (L[8 + k] - L[12 + k]) * w;
+            }
+            for (int k = 0; k < 3; k++) {
+                double c = rgb[k] < 0 ? 0 : (rgb[k] > 1 ? 1 : rgb[k]);
+                out[((size_t)i * W + j) * 3 + k] = (unsigned char)(c * 255.0 + 0.5);
+            }
+            if (depth) depth[(size_t)i * W + j] = (float)best;
+        }
+    return hits;
+}

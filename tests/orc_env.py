@@ -87,5 +87,15 @@ class OrcEnv:
         assert hits >= 0
         return out
 
+    def render_rgb(self, cam, H, W):
+        """uint8 [H, W, 3] colour image and float32 [H, W] depth of the same rays."""
+        ci = self.man["camera_names"].index(cam) if isinstance(cam, str) else int(cam)
+        out = np.empty((H, W, 3), dtype=np.uint8)
+        dep = np.empty((H, W), dtype=np.float32)
+        self.L.orc_render_rgb.restype = C.c_int
+        hits = self.L.orc_render_rgb(self.dptr, ci, H, W, out.ctypes.data_as(C.c_void_p), dep.ctypes.data_as(C.c_void_p))
+        assert hits >= 0
+        return out, dep
+
     def close(self):
         self.L.orc_data_free(self.dptr)

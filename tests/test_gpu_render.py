@@ -75,3 +75,60 @@ def test_depth_full_size_properties_and_ragged_width():
     compare(sim2.render_depth(["overhead_cam"], 60, 80)[0, 0], e2.render_depth("overhead_cam", 60, 80))
     sim2.close()
     e2.close()
+
+
+def compare_rgb(img, ref, frac=0.01):
+    """u8 colour images: +-1 level where both see the same surface; silhouette rays and rays along a box edge / hull
+    ridge may pick the neighbouring face in f32, so up to `frac` of the pixels may differ by more."""
+    bad = (np.abs(img.astype(np.int32) - ref.astype(np.int32)) > 1).any(axis=-1)
+    assert bad.mean() <= frac, f"{bad.sum()} of {bad.size} pixels differ by more than one level"
+    return bad.mean()
+
+
+def test_rgb_matches_oracle_after_motion():
+    from av_aloha_amd.sim import BatchedSim
+    H, W = 60, 80
+    md = model_dict()
+    acts = actions_wiggle(md, 6)
+    sim = BatchedSim("slot_insertion", 3, 2, f64=True, options={"solver": 1})
+    e = OrcEnv()
+    e.d.solver = 1
+    sim.reset(np.repeat(OBJ[None], 2, 0))
+    e.reset(OBJ)
+    for a in acts:
+        sim.step(np.repeat(a[None], 2, 0))
+        e.env_step(a)
+    img = sim.render_rgb(CAMS, H, W)
+    assert img.shape == (2, len(CAMS), H, W, 3) and img.dtype == np.uint8
+    assert np.array_equal(img[0], img[1])
+    dep = sim.render_depth(CAMS, H, W)
+    for ci, cam in enumerate(CAMS):
+        ref, rdep = e.render_rgb(cam, H, W)
+        compare_rgb(img[0, ci], ref)
+        compare(dep[0, ci], rdep)
+        assert len(np.unique(ref.reshape(-1, 3), axis=0)) > 20            # shaded surfaces, not a flat picture
+    # the reference's render() size (env.py:195-200: 225 x 300, overhead camera): odd height, width not a tile multiple
+    big = sim.render_rgb(["overhead_cam"], 225, 300)[0, 0]
+    ref, _ = e.render_rgb("overhead_cam", 225, 300)
+    compare_rgb(big, ref)
+    # a width that is not a multiple of 4 takes the bytewise store path
+    odd = sim.render_rgb(["zed_cam_left"], 33, 50)[0, 0]
+    ref, _ = e.render_rgb("zed_cam_left", 33, 50)
+    compare_rgb(odd, ref, frac=0.02)
+    sim.close()
+    e.close()
+
+
+def test_rgb_objects_have_their_colours():
+    """Known answer: seen from the overhead camera the slot is drawn in its MJCF colour (.8 .4 .4) and the stick in
+    (.4 .8 .4) (task_slot_insertion.xml:7-8, :14): the brightest pixels of each hue have that hue's ratio."""
+    from av_aloha_amd.sim import BatchedSim
+    sim = BatchedSim("slot_insertion", 3, 1)
+    sim.reset(OBJ[None])
+    img = sim.render_rgb(["overhead_cam"], 120, 160)[0, 0].astype(np.int32)
+    r, g, b = img[..., 0], img[..., 1], img[..., 2]
+    red = (r > 1.8 * g) & (np.abs(g - b) <= 1) & (r > 60)
+    green = (g > 1.8 * r) & (np.abs(r - b) <= 1) & (g > 60)
+    assert red.sum() > 20 and green.sum() > 20
+    assert np.all(np.abs(r[red] - 2 * g[red]) <= 2) and np.all(np.abs(g[green] - 2 * r[green]) <= 2)
+    sim.close()

@@ -25,7 +25,7 @@ def fk_pose_oracle(e, arm, q):
 def test_cartesian_step_and_obs_layout_match_the_oracle():
     from av_aloha_amd.sim_env import make_sim_env
     md = model_dict()
-    env = make_sim_env("sim_slot_insertion", num_envs=2, f64=True, options={"solver": 1})
+    env = make_sim_env("sim_slot_insertion", cameras=[], num_envs=2, f64=True, options={"solver": 1})
     np.random.seed(5)
     obs, info = env.reset()
     assert info == "Resetting arms..." and obs["joints"]["position"].shape == (2, 21) and obs["qpos"].shape == (2, 37)

@@ -59,8 +59,19 @@ def test_rollout_record_and_replay_on_the_device():
     res = harness.rollout(env, policy, episode_len=4, num_episodes=2)
     assert len(res) == 2 and res[0]["success"].shape == (3,) and res[0]["max_reward"] == 4 and res[0]["frames"] == []
     env.close()
+    # the registry's default cameras give pixel observations; frames of zed_cam_left are captured (eval.py:111-113)
+    penv = make("gym_guided_vision/SlotInsertion-3Arms-v0", observation_height=120, observation_width=160)
+    home = None
+    res = harness.rollout(penv, policy, episode_len=2)
+    assert len(res[0]["frames"]) == 2 and res[0]["frames"][0].shape == (120, 160, 3) and res[0]["frames"][0].dtype == np.uint8
+    obs, _ = penv.reset()
+    assert list(obs["pixels"]) == ["zed_cam_left", "zed_cam_right", "wrist_cam_left", "wrist_cam_right", "overhead_cam", "worms_eye_cam"]
+    t = harness.preprocess_observation(obs)
+    assert t["observation.images.zed_cam_left"].shape == (1, 3, 480, 640) and 0 <= float(t["observation.images.zed_cam_left"].min())
+    assert penv.render().shape == (225, 300, 3)
+    penv.close()
     # record a short Cartesian episode, check the file layout, replay it through set_qpos
-    cenv = make_sim_env("sim_slot_insertion")
+    cenv = make_sim_env("sim_slot_insertion", cameras=["cam_high"])
     np.random.seed(2)
     obs, _ = cenv.reset()
     target = np.concatenate([obs["poses"]["left"], [0.0], obs["poses"]["right"], [0.0], obs["poses"]["middle"]])
@@ -69,7 +80,9 @@ def test_rollout_record_and_replay_on_the_device():
     ep = harness.record_episode(cenv, acts)
     assert ep["/observations/qpos"].shape == (6, 21) and ep["/observations/qvel"].shape == (6, 21)
     assert ep["/observations/all_qpos"].shape == (6, 37) and ep["/action"].shape == (6, 21)
-    assert all(v.dtype == np.float32 for v in ep.values())
+    assert all(v.dtype == np.float32 for k, v in ep.items() if "/images/" not in k)
+    im = ep["/observations/images/cam_high"]                                                       # record_sim_episodes.py:197-200
+    assert im.shape == (6, 480, 640, 3) and im.dtype == np.uint8 and im.std() > 10 and (im[0] != im[-1]).any()
     assert np.allclose(ep["/action"][1:, 6], 1.0) and np.allclose(ep["/action"][1:, 13], 1.0)      # trigger 0 -> gripper open
     cenv.close()
     genv = make("gym_guided_vision/SlotInsertion-3Arms-v0", cameras=[])
