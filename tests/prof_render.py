@@ -29,3 +29,13 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 gb = out.numel() * 4 / 1e9
 print(f"N={N} {len(ids)} cams {H}x{W}: {dt * 1e3:.2f} ms per render call, {gb:.2f} GB out -> {gb / dt:.1f} GB/s write; hit fraction {(out < 30).float().mean().item():.3f}")
+rgb = torch.empty((N, len(ids), H, W, 3), dtype=torch.uint8, device=dev)
+for _ in range(2):
+    h.check(L.avsim_render_rgb(h.h, ids.ctypes.data, len(ids), H, W, rgb.data_ptr()))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(K):
+    h.check(L.avsim_render_rgb(h.h, ids.ctypes.data, len(ids), H, W, rgb.data_ptr()))
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / K
+print(f"colour: {dt * 1e3:.2f} ms per render call, {rgb.numel() / 1e9:.2f} GB out -> {rgb.numel() / 1e9 / dt:.1f} GB/s write; mean level {rgb.float().mean().item():.1f}")
