@@ -104,6 +104,43 @@ def test_config3_sew_needle_contact_rich_vs_oracle():
     sim.close()
 
 
+def test_config3_scripted_grasp_and_lift():
+    """BASELINE config 3 as written: the right arm reaches for the needle of SewNeedle-3Arms (targets derived from the sampled
+    needle pose, seeds 2000 + i), grasps it top-down and lifts it; GradIK on the measured joints every step
+    (sim_env.py:277-312).  Friction (elliptic cones, noslip) has to carry the needle: at the end most envs score reward 2
+    (gripper on the needle, needle off the table, env.py:666-671) with the needle 10 cm up, and the rollout is contact-rich
+    (at least half of the envs hold >= 8 contacts for >= 100 steps)."""
+    from av_aloha_amd.sim_env import make_sim_env
+    from scripted import grasp_lift_targets
+    n = 256
+    env = make_sim_env("sim_sew_needle", cameras=[], num_envs=n)
+    poses = poses_for("sew_needle", np.arange(n), 2000)
+    env.sim.reset(poses)
+    obs = env.get_obs()
+    home = {k: obs["poses"][k].copy() for k in ("left", "right", "middle")}
+    needle0 = obs["qpos"][:, 30:33].copy()
+    rich = np.zeros(n, dtype=np.int64)
+    flagged = np.zeros(n, dtype=bool)
+    worst = 0
+    for a in grasp_lift_targets(home, needle0 + np.array([0.0, 0.0, 0.01])):
+        _, rw, _ = env.sim.step_cartesian(a)
+        d = env.sim.diag()
+        rich += d[:, 0] >= 8
+        worst = max(worst, int(d[:, 2].max()))
+        flagged |= (d[:, 3] & 1) != 0
+    assert worst == 0, "row / contact caps overflowed"
+    # a needle that is pinched at its edge can be squeezed out of the closing fingers and fly off spinning; the Euler
+    # integrator lets such a free spinning bar run away (as MuJoCo's does [EXT]) until the divergence check resets the env
+    assert flagged.mean() <= 0.10, f"{flagged.sum()} envs were reset by the divergence check"
+    q, v = env.sim.get_state()[:2]
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    lifted = q[:, 32] - needle0[:, 2] > 0.08
+    assert (rich >= 100).mean() >= 0.5, f"contact-rich envs: {(rich >= 100).mean():.2f}"
+    assert lifted.mean() >= 0.7, f"needle lifted in {lifted.mean():.2f} of the envs"
+    assert (rw[lifted] >= 2).all() and (rw >= 2).mean() >= 0.7
+    env.close()
+
+
 def test_divergence_is_contained_and_flagged():
     """MuJoCo resets its data when a state becomes NaN / huge (mj_checkPos / mj_checkVel [EXT]; dm_control raises
     PhysicsError).  Batched counterpart: the env falls back to the home pose with zero velocity, the step reports it in
