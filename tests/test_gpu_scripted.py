@@ -1,0 +1,51 @@
+"""End-to-end task success on the device: a scripted Cartesian policy (tests/scripted.py) solves SlotInsertion-3Arms through the
+same path a teleoperator's actions take (23-D targets -> GradIK on the measured joints -> 20 substeps, sim_env.py:277-312), and
+the staged reward (env.py:546-589) reaches its maximum.  The reference has no scripted policy and no recorded data set: this is the
+build's counterpart of "a recorded episode must reach max_reward" (check_dataset_reward.py), and it needs grasp friction,
+the free-body dynamics of the carried stick and the box-box contacts of the slot walls to be right at the same time."""
+import numpy as np
+import pytest
+
+from scripted import SlotInsertionScript
+from test_gpu_configs import poses_for
+
+pytestmark = pytest.mark.gpu
+
+
+def test_scripted_slot_insertion_reaches_max_reward():
+    from av_aloha_amd import harness
+    from av_aloha_amd.env import make
+    from av_aloha_amd.sim_env import make_sim_env
+    n = 128
+    env = make_sim_env("sim_slot_insertion", cameras=[], num_envs=n)
+    env.sim.reset(poses_for("slot_insertion", np.arange(n), 1000))
+    obs = env.get_obs()
+    home = {k: obs["poses"][k].copy() for k in ("left", "right", "middle")}
+    script = SlotInsertionScript(home, obs["qpos"])
+    best = np.zeros(n, dtype=np.int32)
+    flagged = np.zeros(n, dtype=bool)
+    states = [obs["qpos"].copy()]
+    for t in range(script.steps()):
+        q = env.sim.get_state()[0]
+        _, rw, su = env.sim.step_cartesian(script.action(q))
+        assert np.array_equal(su, rw == 4)                                  # is_success = reward == max_reward (env.py:224)
+        best = np.maximum(best, rw)
+        states.append(env.sim.get_state()[0].copy())
+        d = env.sim.diag()
+        assert (d[:, 2] == 0).all()
+        flagged |= (d[:, 3] & 1) != 0
+    q = states[-1]
+    assert flagged.mean() <= 0.05 and np.isfinite(q).all()      # a stick flung out of a bad grasp may end in a divergence reset
+    done = (rw == 4) & ~flagged
+    assert (best == 4).mean() >= 0.4, f"max reward reached in {(best == 4).mean():.2f} of the envs"
+    assert done.mean() >= 0.35, f"stick left in the slot in {done.mean():.2f} of the envs"
+    # where the pins touch at the end the stick does lie between the slot walls, on the table
+    assert np.abs(q[done, 31] - q[done, 24]).max() < 0.006 and np.abs(q[done, 30] - q[done, 23]).max() < 0.09
+    assert q[done, 32].max() < 0.012
+    env.close()
+    # replaying a solved env's recorded full states through set_qpos reproduces its rewards (replay_sim_episode.py:221-262)
+    k = int(np.nonzero(done)[0][0])
+    genv = make("gym_guided_vision/SlotInsertion-3Arms-v0", cameras=[])
+    _, rewards = harness.replay_episode(genv, {"/observations/all_qpos": np.stack([s[k] for s in states])})
+    assert rewards.max() == genv.max_reward == 4 and rewards[-1] == 4
+    genv.close()
