@@ -1368,6 +1368,9 @@ struct Env {
         real *rowS = r + ka->lay.rowS, *warm = r + ka->lay.warm, *Minv = r + ka->lay.Minv;
         int* rowI = ii + ka->lay.rowI;
         real* Lm = r + ka->lay.L;
+        const int *bmask = body_dofmask_(), *tadr = tree_dofadr_(), *tnum = tree_dofnum_();
+        const real* cdofp = r + ka->lay.cdof;
+        const int nvm = ka->m.nv - 1;
         for (int i = lane; i < nefc; i += G) {
             int meta = rmeta[i], type = meta & 3, id = (meta >> 2) & 1023, sub = (meta >> 12) & 255, dim = meta >> 20;
             real J[ROW_W];   // kept in registers: every index below is a compile-time constant after unrolling
@@ -1422,15 +1425,24 @@ struct Env {
                 real ax[3];
 #pragma unroll
                 for (int q = 0; q < 3; q++) ax[q] = sm == 0 ? n[q] : (sm == 1 ? t1v[q] : t2v[q]);
-                bool rot = sub >= 3;
+                const bool rot = sub >= 3;
+                // entry of dof slot k: the axis' component of the dof's motion at the contact point, signed by which of the
+                // two bodies the dof moves (branch-free: every slot reads its cdof, the body masks select)
+                const int mA = (t1 == tA ? bmask[b1] : 0), pA = (t2 == tA ? bmask[b2] : 0);
+                const int mB = (tB >= 0 && t1 == tB ? bmask[b1] : 0), pB = (tB >= 0 ? bmask[b2] : 0);
+                const int aA = tadr[tA], aB = tadr[tB >= 0 ? tB : tA];
 #pragma unroll
                 for (int k = 0; k < TREE_W; k++) {
-                    real a = 0;
-                    if (k < tree_dofnum_()[tA]) a = jac_entry(b2, tA, k, cp, ax, rot) - jac_entry(b1, tA, k, cp, ax, rot);
-                    J[k] = a;
-                    real b = 0;
-                    if (tB >= 0 && k < tree_dofnum_()[tB]) b = jac_entry(b2, tB, k, cp, ax, rot) - jac_entry(b1, tB, k, cp, ax, rot);
-                    J[TREE_W + k] = b;
+                    const real* ca = cdofp + 6 * (aA + k < nvm ? aA + k : nvm);
+                    const real* cb = cdofp + 6 * (aB + k < nvm ? aB + k : nvm);
+                    real xa[3], xb[3];
+                    cross3(ca, cp, xa);
+                    cross3(cb, cp, xb);
+                    const real ea = rot ? ax[0] * ca[0] + ax[1] * ca[1] + ax[2] * ca[2] : ax[0] * (ca[3] + xa[0]) + ax[1] * (ca[4] + xa[1]) + ax[2] * (ca[5] + xa[2]);
+                    const real eb = rot ? ax[0] * cb[0] + ax[1] * cb[1] + ax[2] * cb[2] : ax[0] * (cb[3] + xb[0]) + ax[1] * (cb[4] + xb[1]) + ax[2] * (cb[5] + xb[2]);
+                    const int sa = ((pA >> k) & 1) - ((mA >> k) & 1), sb = ((pB >> k) & 1) - ((mB >> k) & 1);
+                    J[k] = sa > 0 ? ea : (sa < 0 ? -ea : real(0));
+                    J[TREE_W + k] = sb > 0 ? eb : (sb < 0 ? -eb : real(0));
                 }
                 pos = sub == 0 ? cdist[c] : real(0);
                 margin = ka->m.pair_margin[p] - ka->m.pair_gap[p];
@@ -1463,11 +1475,12 @@ struct Env {
             // velocity along the row, reference acceleration
             real vel = 0;
             {
-                int a0 = tree_dofadr_()[tA], na = tree_dofnum_()[tA], b0 = tB >= 0 ? tree_dofadr_()[tB] : 0, nb = tB >= 0 ? tree_dofnum_()[tB] : 0;
+                // J is zero beyond a tree's dofs: clamped reads instead of per-slot branches
+                const int a0 = tadr[tA], b0 = tadr[tB >= 0 ? tB : tA];
 #pragma unroll
                 for (int k = 0; k < TREE_W; k++) {
-                    if (k < na) vel += J[k] * qvel[a0 + k];
-                    if (k < nb) vel += J[TREE_W + k] * qvel[b0 + k];
+                    vel += J[k] * qvel[a0 + k < nvm ? a0 + k : nvm];
+                    vel += J[TREE_W + k] * qvel[b0 + k < nvm ? b0 + k : nvm];
                 }
             }
             const real aref = -Bd * vel - K * imp * (pos - margin);
@@ -1490,12 +1503,12 @@ struct Env {
             store_row16(rJ + ROW_S * i, J);
             store_row16(rowsB_() + ROW_S * i, Bv);
             // warm start: force implied by last step's acceleration, f = -D (J qacc_ws - aref), made feasible per row
-            const int a0 = tree_dofadr_()[tA], nA = tree_dofnum_()[tA], b0 = tB >= 0 ? tree_dofadr_()[tB] : 0, nB = tB >= 0 ? tree_dofnum_()[tB] : 0;
+            const int a0 = tadr[tA], nA = tnum[tA], b0 = tB >= 0 ? tadr[tB] : 0, nB = tB >= 0 ? tnum[tB] : 0;
             real jw = 0;
 #pragma unroll
             for (int k = 0; k < TREE_W; k++) {
-                if (k < nA) jw += J[k] * warm[a0 + k];
-                if (k < nB) jw += J[TREE_W + k] * warm[b0 + k];
+                jw += J[k] * warm[a0 + k < nvm ? a0 + k : nvm];
+                jw += J[TREE_W + k] * warm[b0 + k < nvm ? b0 + k : nvm];   // (b0 = 0 with J = 0 for one-tree rows)
             }
             const real big = real(1e30);
             real lo = -big, hi = big, muinv = 0;
