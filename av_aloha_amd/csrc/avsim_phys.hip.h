@@ -1151,7 +1151,14 @@ struct Env {
     }
 
     // ---- P3 ------------------------------------------------------------------------------------
-    __device__ void collide() {
+    // out of line, on a copy of the object: the members then live in registers (a callee reached through `this` reloads them
+    // from memory after every store, and the kernel-argument pointer with them: vector loads instead of s_load)
+    __device__ __attribute__((noinline)) void collide() {
+        Env e(*this);
+        e.collide_i();
+        diverged = e.diverged; nit_sum = e.nit_sum; nit_max = e.nit_max; t_broad = e.t_broad; t_narrow = e.t_narrow;
+    }
+    __device__ __attribute__((always_inline)) void collide_i() {
         PHASE_BEGIN();
         real* gcen = r + ka->lay.gcen;
         int* misc = ii + ka->lay.misc;
@@ -1304,7 +1311,14 @@ struct Env {
     }
 
     // ---- P4 ------------------------------------------------------------------------------------
-    __device__ void make_constraints() {
+    // out of line, on a copy of the object: the members then live in registers (a callee reached through `this` reloads them
+    // from memory after every store, and the kernel-argument pointer with them: vector loads instead of s_load)
+    __device__ __attribute__((noinline)) void make_constraints() {
+        Env e(*this);
+        e.make_constraints_i();
+        diverged = e.diverged; nit_sum = e.nit_sum; nit_max = e.nit_max; t_broad = e.t_broad; t_narrow = e.t_narrow;
+    }
+    __device__ __attribute__((always_inline)) void make_constraints_i() {
         PHASE_BEGIN();
         real *qpos = r + ka->lay.qpos, *qvel = r + ka->lay.qvel;
         int *misc = ii + ka->lay.misc, *rmeta = ii + ka->lay.rmeta, *cpair = ii + ka->lay.cpair, *cefc = ii + ka->lay.cefc;
@@ -1582,7 +1596,14 @@ struct Env {
     }
 
     // ---- P8 ------------------------------------------------------------------------------------
-    __device__ void solve(int pgs_iters, int solver, int newton_iters, real newton_tol, real scale) {
+    // out of line, on a copy of the object: the members then live in registers (a callee reached through `this` reloads them
+    // from memory after every store, and the kernel-argument pointer with them: vector loads instead of s_load)
+    __device__ __attribute__((noinline)) void solve(int pgs_iters, int solver, int newton_iters, real newton_tol, real scale) {
+        Env e(*this);
+        e.solve_i(pgs_iters, solver, newton_iters, newton_tol, scale);
+        diverged = e.diverged; nit_sum = e.nit_sum; nit_max = e.nit_max; t_broad = e.t_broad; t_narrow = e.t_narrow;
+    }
+    __device__ __attribute__((always_inline)) void solve_i(int pgs_iters, int solver, int newton_iters, real newton_tol, real scale) {
         PHASE_BEGIN();
         int *misc = ii + ka->lay.misc, *rmeta = ii + ka->lay.rmeta, *cefc = ii + ka->lay.cefc, *rowI = ii + ka->lay.rowI;
         real *qacc = r + ka->lay.qacc, *as = r + ka->lay.asm_, *rowS = r + ka->lay.rowS, *fcon = r + ka->lay.fcon;
@@ -1652,7 +1673,7 @@ struct Env {
     }
 
     // out = J^T f: one row per lane, scattered over the row's two dof windows with returnless LDS atomics
-    __device__ void jt_force(real* out, int nefc) {
+    __device__ __attribute__((always_inline)) void jt_force(real* out, int nefc) {
         LDS_BASES();
         AVS_ASSUME_LDS(out);
         int* rowI = ii + ka->lay.rowI;
