@@ -251,6 +251,73 @@ AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, L
     return wave_sum(cs);
 }
 
+// ---- block-diagonal Hessian: no active row couples two kinematic trees, so H = diag(H_t) and every tree factors on its own.
+// Lane 8 t + i owns row i of tree t (<= 8 trees of <= 8 dofs): eight elimination steps with the multipliers shuffled inside the
+// octet instead of nv serial columns over the whole wave.  L is written back into the packed triangle (the entries a dense
+// factorisation would produce; off-block entries stay zero), so the stored factor serves the later iterations as well.
+template <typename real>
+AVS_DEV void nblock_chol(const NewtonArgs<real>& A, int lane) {
+    const int t = lane >> 3, i = lane & 7, gb = lane & ~7;
+    const bool act = t < A.ntree;
+    const int n = act ? A.tree_dofnum[t] : 0, a0 = act ? A.tree_dofadr[t] : 0;
+    const int rbase = (a0 + i) * (a0 + i + 1) / 2 + a0;
+    real row[TREE_W];
+#pragma unroll
+    for (int k = 0; k < TREE_W; k++) {
+        const bool in = i < n && k <= i;
+        const real v = A.H[in ? rbase + k : 0];
+        row[k] = in ? v : (k == i ? real(1) : real(0));
+    }
+#pragma unroll
+    for (int j = 0; j < TREE_W; j++) {
+        const real piv = tmax(__shfl(row[j], gb | j, 64), real(1e-30));
+        real d, rinv;
+        if (sizeof(real) == 4) { rinv = (real)__builtin_amdgcn_rsqf((float)piv); d = piv * rinv; }
+        else { d = sqrt(piv); rinv = real(1) / d; }
+        const real lij = i == j ? d : row[j] * rinv;
+        row[j] = lij;
+        const real mul = i > j ? lij : real(0);
+#pragma unroll
+        for (int k = j + 1; k < TREE_W; k++) row[k] -= mul * __shfl(lij, gb | k, 64);
+    }
+    if (i < n) {
+#pragma unroll
+        for (int k = 0; k < TREE_W; k++)
+            if (k <= i) A.H[rbase + k] = row[k];
+    }
+}
+// dl = (L L^T)^-1 (-g) with the block factor stored in the packed triangle: both substitutions inside the octets
+template <typename real>
+AVS_DEV void nblock_solve(const NewtonArgs<real>& A, int lane) {
+    const int t = lane >> 3, i = lane & 7, gb = lane & ~7;
+    const bool act = t < A.ntree;
+    const int n = act ? A.tree_dofnum[t] : 0, a0 = act ? A.tree_dofadr[t] : 0;
+    const bool mine = i < n;
+    const int rbase = (a0 + i) * (a0 + i + 1) / 2 + a0;
+    real row[TREE_W], col[TREE_W];
+#pragma unroll
+    for (int k = 0; k < TREE_W; k++) {
+        const bool lo = mine && k < i, up = mine && k < n && k > i;
+        const real a = A.H[lo ? rbase + k : 0], b = A.H[up ? (a0 + k) * (a0 + k + 1) / 2 + a0 + i : 0];
+        row[k] = lo ? a : real(0);
+        col[k] = up ? b : real(0);
+    }
+    const real dg = A.H[mine ? rbase + i : 0];
+    const real dinv = mine ? real(1) / dg : real(1);
+    real x = mine ? -A.g[a0 + i] : real(0);
+#pragma unroll
+    for (int j = 0; j < TREE_W; j++) {
+        const real yj = __shfl(x * dinv, gb | j, 64);
+        x = i == j ? yj : x - row[j] * yj;
+    }
+#pragma unroll
+    for (int j = TREE_W - 1; j >= 0; j--) {
+        const real xj = __shfl(x * dinv, gb | j, 64);
+        x = i == j ? xj : x - col[j] * xj;
+    }
+    if (mine) A.dl[a0 + i] = x;
+}
+
 // r / ii: the env's real and int LDS regions, li: the block's hot-table image; everything else comes from the layout
 // NCH = contact chunks of 64 (one contact per lane and chunk): 1 when the model's contact cap is <= 64
 template <typename real, int NCH>
@@ -283,6 +350,13 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
     }
     const int nv = A.nv, ne = A.nefc;
     int used = 0;
+    // does any row reach into two kinematic trees?  (second dof window non-empty; wave-uniform)
+    bool coupled = false;
+    {
+        bool two = false;
+        for (int i = lane; i < ne; i += 64) two = two || ((A.rowI[i] >> 19) & 15) != 0;
+        coupled = __any(two) != 0 || A.ntree > 8;
+    }
     long long tp0 = A.prof ? __builtin_readcyclecounter() : 0;
     // ---- per-contact constants ----
     NCon<real> con[NCH];
@@ -426,7 +500,8 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
             NSYNC();
             NPROF(2);
             // ---- Cholesky + forward substitution in registers: lane i = row i, lane nv = -g ----
-            {
+            if (!coupled) nblock_chol<real>(A, lane);
+            else {
                 // g sits right behind the packed triangle (NewtonArgs contract), i.e. it is "row nv" of the same array
                 real row[NVMAX];
                 const int rbase = lane * (lane + 1) / 2;
@@ -462,7 +537,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
             sig_lead = cur_lead;
 #pragma unroll
             for (int ch = 0; ch < NCH; ch++) sig_z1[ch] = cur_z1[ch];
-        } else {
+        } else if (coupled) {
             // same Hessian as last time: forward substitution L y = -g with the stored factor (lane i holds y_i)
             real x = lane < nv ? -A.g[lane] : real(0);
             const real dinv = lane < nv ? real(1) / A.H[lane * (lane + 1) / 2 + lane] : real(0);
@@ -480,7 +555,9 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         NSYNC();
         NPROF(3);
         // ---- backward substitution L^T x = y, lane j holds x_j; column entries prefetched one step ahead ----
-        {
+        if (!coupled) {
+            nblock_solve<real>(A, lane);
+        } else {
             real x = lane < nv ? A.g[lane] : real(0);
             const real dinv = lane < nv ? real(1) / A.H[lane * (lane + 1) / 2 + lane] : real(0);
             real Lnext = lane < nv - 1 ? A.H[(nv - 1) * nv / 2 + lane] : real(0);
