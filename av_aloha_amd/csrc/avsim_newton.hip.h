@@ -213,6 +213,56 @@ AVS_DEV void nblock(const NewtonArgs<real>& A, int lane, int r0, int dim, bool f
     }
 }
 
+// The same update for four contacts at once: 16-lane group q of the wave takes the contact whose arguments its lanes carry
+// (group-uniform values), lane t of the group owns column t and walks the rows s itself.  The groups' row loads are in
+// flight together, so a pass over the contacts costs one memory round trip per four contacts instead of one per contact.
+template <typename real>
+AVS_DEV void nblock4(const NewtonArgs<real>& A, int lane, int r0, int dim, bool on, bool full, const real* w, const real* c1, const real* c2, real s1, real s2) {
+    const int ra = A.rowI[on ? r0 : 0], t = lane & 15, gq = on ? nslot_dof(ra, t) : -1;
+    GLB_PTR(const real) J = A.rJ + ROW_S * (on ? r0 : 0);
+    real Jt[6], y1t = 0, y2t = 0;
+#pragma unroll
+    for (int p = 0; p < 6; p++) Jt[p] = (on && p < dim) ? J[ROW_S * p + t] : real(0);
+#pragma unroll
+    for (int p = 0; p < 6; p++) { y1t += c1[p] * Jt[p]; y2t += c2[p] * Jt[p]; }
+    const int smax = __any(on && ((ra >> 19) & 15) > 0) ? 16 : 8;       // rows of the second window only if some contact has one
+    for (int s = 0; s < smax; s++) {
+        const int gp = nslot_dof(ra, s);
+        real Js[6], acc = 0;
+#pragma unroll
+        for (int p = 0; p < 6; p++) Js[p] = __shfl(Jt[p], (lane & 48) | s, 64);
+#pragma unroll
+        for (int p = 0; p < 6; p++) acc += w[p] * Js[p] * Jt[p];
+        real y1s = 0, y2s = 0;
+#pragma unroll
+        for (int p = 0; p < 6; p++) { y1s += c1[p] * Js[p]; y2s += c2[p] * Js[p]; }
+        if (full) acc += s1 * y1s * y1t - s2 * y2s * y2t;
+        if (on && gp >= 0 && gq >= 0 && gq <= gp) __hip_atomic_fetch_add(A.H + gp * (gp + 1) / 2 + gq, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+// scalar rows (equality, dry friction, limits): one row per lane, H += w J^T J over the row's single dof window
+template <typename real>
+AVS_DEV void nlead_rows(const NewtonArgs<real>& A, int lane) {
+    for (int i = lane; i < A.nlead; i += 64) {
+        const real w = A.jv[i];
+        if (w == 0) continue;
+        const int ra = A.rowI[i], a0 = ra & 63, nA = (ra >> 6) & 15;
+        GLB_PTR(const real) J = A.rJ + ROW_S * i;
+        real Jr[TREE_W];
+#pragma unroll
+        for (int k = 0; k < TREE_W; k++) Jr[k] = J[k];
+#pragma unroll
+        for (int k = 0; k < TREE_W; k++) {
+            if (!(k < nA) || Jr[k] == 0) continue;
+#pragma unroll
+            for (int m = 0; m <= k; m++) {
+                if (Jr[m] == 0) continue;
+                __hip_atomic_fetch_add(A.H + (a0 + k) * (a0 + k + 1) / 2 + a0 + m, w * Jr[k] * Jr[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+}
+
 #define NSYNC()                                              \
     do {                                                     \
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); \
@@ -476,25 +526,21 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
                 if (j8 < n && j8 <= kk) A.H[k * (k + 1) / 2 + a0 + j8] = A.M[A.tree_madr[t] + kk * n + j8];
             }
             NSYNC();
-            {
-                real w1[6] = {0, 0, 0, 0, 0, 0};
-                for (int i = 0; i < A.nlead; i++) {
-                    w1[0] = lane_get(A.jv[i], 0);
-                    if (w1[0] != 0) nblock<real>(A, lane, i, 1, false, w1, w1, w1, real(0), real(0));
-                }
-            }
+            nlead_rows<real>(A, lane);
     #pragma unroll
             for (int ch = 0; ch < NCH; ch++) {
                 if (ch * 64 >= A.ncon) break;
                 const int nc = A.ncon - ch * 64 < 64 ? A.ncon - ch * 64 : 64;
-                for (int c = 0; c < nc; c++) {
-                    const int zn = __builtin_amdgcn_readlane(zone[ch], c);
-                    if (zn == 0) continue;
-                    const int head = __builtin_amdgcn_readlane(con[ch].head, c), dim = __builtin_amdgcn_readlane(con[ch].dim, c);
+                for (int c0 = 0; c0 < nc; c0 += 4) {
+                    const int c = c0 + (lane >> 4);                // this 16-lane group's contact
+                    const int zs = __shfl(zone[ch], c & 63, 64);  // every lane takes part: a lane outside the condition could be a source
+                    const int zn = c < nc ? zs : 0;
+                    if (!__any(zn != 0)) continue;
+                    const int head = __shfl(con[ch].head, c & 63, 64), dim = __shfl(con[ch].dim, c & 63, 64);
                     real w[6], c1[6], c2[6];
     #pragma unroll
-                    for (int p = 0; p < 6; p++) { w[p] = lane_get(cw[ch][p], c); c1[p] = lane_get(cc1[ch][p], c); c2[p] = lane_get(cc2[ch][p], c); }
-                    nblock<real>(A, lane, head, dim, zn == 2, w, c1, c2, lane_get(cs1[ch], c), lane_get(cs2[ch], c));
+                    for (int p = 0; p < 6; p++) { w[p] = __shfl(cw[ch][p], c & 63, 64); c1[p] = __shfl(cc1[ch][p], c & 63, 64); c2[p] = __shfl(cc2[ch][p], c & 63, 64); }
+                    nblock4<real>(A, lane, head, dim, zn != 0, zn == 2, w, c1, c2, __shfl(cs1[ch], c & 63, 64), __shfl(cs2[ch], c & 63, 64));
                 }
             }
             NSYNC();
