@@ -386,32 +386,44 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, AVS
         { T pv[3]; mulmatT(rmat, rel, pv); poly[3 * q] = pv[0]; poly[3 * q + 1] = pv[1]; poly[3 * q + 2] = pv[2]; }
     }
     int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+    // Sutherland-Hodgman against the four side planes of the reference face: the two LDS polygons swap roles instead of being
+    // copied back, and the edge's end point becomes the next edge's start point in registers (one LDS read per edge)
+    AVS_LDS(T) src = poly;
+    AVS_LDS(T) dst = tmp;
     for (int side = 0; side < 4; side++) {
         int axis = side < 2 ? a1 : a2;
         T s = (side & 1) ? T(-1) : T(1), lim = sel3(rsize, axis);
         int m = 0;
+        const T P0[3] = {src[0], src[1], src[2]};
+        T P[3] = {P0[0], P0[1], P0[2]};
         for (int q = 0; q < np; q++) {
-            int qn = (q + 1) % np;
-            T P[3] = {poly[3 * q], poly[3 * q + 1], poly[3 * q + 2]}, Qp[3] = {poly[3 * qn], poly[3 * qn + 1], poly[3 * qn + 2]};
+            const bool last = q + 1 >= np;
+            const int qn = last ? 0 : q + 1;
+            T Qp[3] = {src[3 * qn], src[3 * qn + 1], src[3 * qn + 2]};
+            if (last) { Qp[0] = P0[0]; Qp[1] = P0[1]; Qp[2] = P0[2]; }
             T dp = s * sel3(P, axis) - lim, dq = s * sel3(Qp, axis) - lim;
-            if (dp <= 0 && m < 8) { tmp[3 * m] = P[0]; tmp[3 * m + 1] = P[1]; tmp[3 * m + 2] = P[2]; m++; }
+            if (dp <= 0 && m < 8) { dst[3 * m] = P[0]; dst[3 * m + 1] = P[1]; dst[3 * m + 2] = P[2]; m++; }
             if (((dp < 0 && dq > 0) || (dp > 0 && dq < 0)) && m < 8) {
                 T t = dp / (dp - dq);
-                for (int c = 0; c < 3; c++) tmp[3 * m + c] = P[c] + t * (Qp[c] - P[c]);
+                for (int c = 0; c < 3; c++) dst[3 * m + c] = P[c] + t * (Qp[c] - P[c]);
                 m++;
             }
+            P[0] = Qp[0]; P[1] = Qp[1]; P[2] = Qp[2];
         }
         np = m;
-        for (int q = 0; q < 3 * np; q++) poly[q] = tmp[q];
         if (np == 0) return 0;
+        AVS_LDS(T) t_ = src; src = dst; dst = t_;
     }
+    // four swaps: the clipped polygon is back in `poly`, `tmp` is free for the points that lie behind the reference face
     T refax[3];
     col3(rmat, ax, refax);
     T face = dot3(nr, refax) > 0 ? T(1) : T(-1);
     int m = 0;
     for (int q = 0; q < np; q++) {
-        T dq = sel3(rsize, ax) - face * poly[3 * q + ax];
-        if (dq >= 0) { tmp[3 * m] = poly[3 * q]; tmp[3 * m + 1] = poly[3 * q + 1]; tmp[3 * m + 2] = poly[3 * q + 2]; dep[m] = dq; m++; }
+        const T px = src[3 * q], py = src[3 * q + 1], pz = src[3 * q + 2];
+        const T pc[3] = {px, py, pz};
+        T dq = sel3(rsize, ax) - face * sel3(pc, ax);
+        if (dq >= 0) { dst[3 * m] = px; dst[3 * m + 1] = py; dst[3 * m + 2] = pz; dep[m] = dq; m++; }
     }
     if (m == 0) return 0;
     int keep[4], nk = 0;
