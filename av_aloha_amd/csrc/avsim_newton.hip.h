@@ -14,12 +14,15 @@
 //   Hessian   H = M + sum_blocks J_b^T C_b J_b in a packed lower triangle in LDS.  The wave walks the blocks (a scalar
 //             row or a contact) one at a time; the cone block is never formed: in the middle zone
 //                 C = S (Dm n n^T + kappa (I_t - u u^T)) S      n = (1, -mu u),  u = U_t / |U_t|
-//             so J^T C J = sum_p w_p J_p^T J_p + Dm y1 y1^T - kappa y2 y2^T with two 16-vectors y1, y2; every lane owns
-//             <= 4 entries of the block's 16 x 16 dof window and adds them with returnless LDS atomics.
+//             so J^T C J = sum_p w_p J_p^T J_p + Dm y1 y1^T - kappa y2 y2^T with two 16-vectors y1, y2; four contacts per pass
+//             (one per 16-lane group, lane t = column t of the 16 x 16 dof window), returnless LDS atomics; scalar rows
+//             one per lane.
 //   Cholesky  lane i holds row i of H in registers; the column loop is rolled, the register row is rotated by one
 //             entry per column so that the pivot column is always element 0 (static register indices, no scratch);
 //             multipliers travel by v_readlane.  Lane nv carries -g as an extra row, so the forward substitution
-//             comes out of the factorisation; the backward substitution reads L's columns back from LDS.
+//             comes out of the factorisation; the backward substitution reads L's columns back from LDS.  When no row
+//             couples two kinematic trees H is block diagonal: lane 8 t + i then factors / solves tree t's block inside
+//             its octet (nblock_chol / nblock_solve), eight steps instead of nv columns.
 //   search    exact line search: safeguarded 1-D Newton on phi'(alpha); J a and J dl are fixed per iteration, so an
 //             evaluation is a handful of FMAs per lane and two wave-wide DPP sums.
 #pragma once
@@ -180,42 +183,11 @@ AVS_DEV int nslot_dof(int ra, int s) {
     return k < ((ra >> (sh + 6)) & 15) ? ((ra >> sh) & 63) + k : -1;
 }
 
-// H += J_b^T C_b J_b for the block of rows r0 .. r0+dim-1 (every argument wave-uniform).  Lane l owns column
-// t = l & 15 of the block's 16 x 16 dof window and rows (l >> 4) + 4u; lower-triangle entries only.
-template <typename real>
-AVS_DEV void nblock(const NewtonArgs<real>& A, int lane, int r0, int dim, bool full, const real* w, const real* c1, const real* c2, real s1, real s2) {
-    const int ra = A.rowI[r0], t = lane & 15, gq = nslot_dof(ra, t);
-    const int nu = ((ra >> 19) & 15) > 0 ? 4 : 2;
-    GLB_PTR(const real) J = A.rJ + ROW_S * r0;
-    real Jt[6], y1t = 0, y2t = 0;
-#pragma unroll
-    for (int p = 0; p < 6; p++) Jt[p] = p < dim ? J[ROW_S * p + t] : real(0);
-    if (full) {
-#pragma unroll
-        for (int p = 0; p < 6; p++) { y1t += c1[p] * Jt[p]; y2t += c2[p] * Jt[p]; }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        if (u >= nu) continue;
-        const int s = (lane >> 4) + 4 * u, gp = nslot_dof(ra, s);
-        real Js[6], acc = 0;
-#pragma unroll
-        for (int p = 0; p < 6; p++) Js[p] = __shfl(Jt[p], (lane & 48) | s, 64);     // J[p][s] sits in the lane of this 16-group whose column is s
-#pragma unroll
-        for (int p = 0; p < 6; p++) acc += w[p] * Js[p] * Jt[p];
-        if (full) {
-            real y1s = 0, y2s = 0;
-#pragma unroll
-            for (int p = 0; p < 6; p++) { y1s += c1[p] * Js[p]; y2s += c2[p] * Js[p]; }
-            acc += s1 * y1s * y1t - s2 * y2s * y2t;
-        }
-        if (gp >= 0 && gq >= 0 && gq <= gp) __hip_atomic_fetch_add(A.H + gp * (gp + 1) / 2 + gq, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
-
-// The same update for four contacts at once: 16-lane group q of the wave takes the contact whose arguments its lanes carry
-// (group-uniform values), lane t of the group owns column t and walks the rows s itself.  The groups' row loads are in
-// flight together, so a pass over the contacts costs one memory round trip per four contacts instead of one per contact.
+// H += J_b^T C_b J_b for the block of rows r0 .. r0+dim-1 of a contact: C_b = diag(w) + s1 c1 c1^T - s2 c2 c2^T in the cone's
+// middle zone (`full`), diag(w) otherwise.  Lane t of a 16-lane group owns column t of the block's 16 x 16 dof window (two
+// tree windows of 8) and walks the rows s; lower-triangle entries only, added to the packed H by LDS atomics.
+// Four contacts at once: 16-lane group q of the wave takes the contact whose arguments its lanes carry (group-uniform
+// values); the groups' row loads are in flight together, one memory round trip per four contacts.
 template <typename real>
 AVS_DEV void nblock4(const NewtonArgs<real>& A, int lane, int r0, int dim, bool on, bool full, const real* w, const real* c1, const real* c2, real s1, real s2) {
     const int ra = A.rowI[on ? r0 : 0], t = lane & 15, gq = on ? nslot_dof(ra, t) : -1;

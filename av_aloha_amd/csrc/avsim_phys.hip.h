@@ -1299,17 +1299,6 @@ struct Env {
         t_narrow += __builtin_readcyclecounter() - tb1;
     }
 
-    // Jacobian entry of body b's point p for tree-local dof slot k of tree t (translational row along ax, or rotational)
-    AVS_DEV real jac_entry(int b, int t, int k, const real* p, const real* ax, bool rot) const {
-        LDS_BASES();
-        if (body_tree_()[b] != t || !((body_dofmask_()[b] >> k) & 1)) return real(0);
-        const real* cd = r + ka->lay.cdof + 6 * (tree_dofadr_()[t] + k);
-        if (rot) return ax[0] * cd[0] + ax[1] * cd[1] + ax[2] * cd[2];
-        real c[3];
-        cross3(cd, p, c);
-        return ax[0] * (cd[3] + c[0]) + ax[1] * (cd[4] + c[1]) + ax[2] * (cd[5] + c[2]);
-    }
-
     // ---- P4 ------------------------------------------------------------------------------------
     // out of line, on a copy of the object: the members then live in registers (a callee reached through `this` reloads them
     // from memory after every store, and the kernel-argument pointer with them: vector loads instead of s_load)
