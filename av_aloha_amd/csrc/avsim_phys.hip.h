@@ -569,6 +569,9 @@ AVS_DEV void chol_solve_block(const real* L, real* x, int n) {
     }
 }
 
+// x^p for the impedance curve: the models' solimp power is 2 (MuJoCo's default), a product then; pow() only otherwise
+template <typename real>
+AVS_DEV real imp_pow(real x, real p) { return p == real(2) ? x * x : pow(x, p); }
 // solimp impedance [EXT: getimpedance]
 template <typename real>
 AVS_DEV real impedance(const real* si, real pos, real margin) {
@@ -580,8 +583,8 @@ AVS_DEV real impedance(const real* si, real pos, real margin) {
     if (x <= 0) return dmin;
     real y;
     if (power == 1) y = x;
-    else if (x <= mid) y = pow(x / mid, power) * mid;
-    else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);
+    else if (x <= mid) y = imp_pow(x / mid, power) * mid;
+    else y = 1 - imp_pow((1 - x) / (1 - mid), power) * (1 - mid);
     return dmin + y * (dmax - dmin);
 }
 
