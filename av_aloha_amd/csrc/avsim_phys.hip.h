@@ -466,6 +466,18 @@ AVS_DEV void store_row16(GLB_PTR(double) dst, const double* v) {
     for (int q = 0; q < 8; q++) { avs_v2d t = {v[2 * q], v[2 * q + 1]}; ((GLB_PTR(avs_v2d))dst)[q] = t; }
 }
 
+// eight consecutive LDS reals whose address is a multiple of 16 bytes, as two (four) vector reads
+AVS_DEV void lds_load8(const float* p, float* v) {
+    const LDS_PTR(const avs_v4f) q = (LDS_PTR(const avs_v4f))p;
+    const avs_v4f a = q[0], b = q[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+AVS_DEV void lds_load8(const double* p, double* v) {
+    const LDS_PTR(const avs_v2d) q = (LDS_PTR(const avs_v2d))p;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const avs_v2d a = q[k]; v[2 * k] = a.x; v[2 * k + 1] = a.y; }
+}
+
 template <int G>
 AVS_DEV unsigned long long group_mask(int grp) {
     if (G == 64) return ~0ull;
@@ -1452,15 +1464,22 @@ struct Env {
 #pragma unroll
                 for (int k = 0; k < TREE_W; k++) {
                     const real* ca = cdofp + 6 * (aA + k < nvm ? aA + k : nvm);
-                    const real* cb = cdofp + 6 * (aB + k < nvm ? aB + k : nvm);
-                    real xa[3], xb[3];
+                    real xa[3];
                     cross3(ca, cp, xa);
-                    cross3(cb, cp, xb);
                     const real ea = rot ? ax[0] * ca[0] + ax[1] * ca[1] + ax[2] * ca[2] : ax[0] * (ca[3] + xa[0]) + ax[1] * (ca[4] + xa[1]) + ax[2] * (ca[5] + xa[2]);
-                    const real eb = rot ? ax[0] * cb[0] + ax[1] * cb[1] + ax[2] * cb[2] : ax[0] * (cb[3] + xb[0]) + ax[1] * (cb[4] + xb[1]) + ax[2] * (cb[5] + xb[2]);
-                    const int sa = ((pA >> k) & 1) - ((mA >> k) & 1), sb = ((pB >> k) & 1) - ((mB >> k) & 1);
+                    const int sa = ((pA >> k) & 1) - ((mA >> k) & 1);
                     J[k] = sa > 0 ? ea : (sa < 0 ? -ea : real(0));
-                    J[TREE_W + k] = sb > 0 ? eb : (sb < 0 ? -eb : real(0));
+                }
+                if (tB >= 0) {       // second window: contacts between two kinematic trees only
+#pragma unroll
+                    for (int k = 0; k < TREE_W; k++) {
+                        const real* cb = cdofp + 6 * (aB + k < nvm ? aB + k : nvm);
+                        real xb[3];
+                        cross3(cb, cp, xb);
+                        const real eb = rot ? ax[0] * cb[0] + ax[1] * cb[1] + ax[2] * cb[2] : ax[0] * (cb[3] + xb[0]) + ax[1] * (cb[4] + xb[1]) + ax[2] * (cb[5] + xb[2]);
+                        const int sb = ((pB >> k) & 1) - ((mB >> k) & 1);
+                        J[TREE_W + k] = sb > 0 ? eb : (sb < 0 ? -eb : real(0));
+                    }
                 }
                 pos = sub == 0 ? cdist[c] : real(0);
                 margin = ka->m.pair_margin[p] - ka->m.pair_gap[p];
@@ -1507,16 +1526,24 @@ struct Env {
             real Bv[ROW_W];
 #pragma unroll
             for (int k = 0; k < TREE_W; k++) {
-                real sa = 0, sb = 0;
+                real mr[TREE_W], sa = 0;
+                lds_load8(Minv + 64 * tA + 8 * k, mr);          // rows of the 8 x 8 inverse start on 32-byte boundaries
 #pragma unroll
-                for (int j = 0; j < TREE_W; j++) sa += Minv[64 * tA + 8 * k + j] * J[j];
-                if (tB >= 0) {
-#pragma unroll
-                    for (int j = 0; j < TREE_W; j++) sb += Minv[64 * tB + 8 * k + j] * J[TREE_W + j];
-                }
-                dg += J[k] * sa + J[TREE_W + k] * sb;
+                for (int j = 0; j < TREE_W; j++) sa += mr[j] * J[j];
+                dg += J[k] * sa;
                 Bv[k] = sa;
-                Bv[TREE_W + k] = sb;
+                Bv[TREE_W + k] = 0;
+            }
+            if (tB >= 0) {
+#pragma unroll
+                for (int k = 0; k < TREE_W; k++) {
+                    real mr[TREE_W], sb = 0;
+                    lds_load8(Minv + 64 * tB + 8 * k, mr);
+#pragma unroll
+                    for (int j = 0; j < TREE_W; j++) sb += mr[j] * J[TREE_W + j];
+                    dg += J[TREE_W + k] * sb;
+                    Bv[TREE_W + k] = sb;
+                }
             }
             store_row16(rJ + ROW_S * i, J);
             store_row16(rowsB_() + ROW_S * i, Bv);
