@@ -189,25 +189,42 @@ AVS_DEV int nslot_dof(int ra, int s) {
 // Four contacts at once: 16-lane group q of the wave takes the contact whose arguments its lanes carry (group-uniform
 // values); the groups' row loads are in flight together, one memory round trip per four contacts.
 template <typename real>
-AVS_DEV void nblock4(const NewtonArgs<real>& A, int lane, int r0, int dim, bool on, bool full, const real* w, const real* c1, const real* c2, real s1, real s2) {
+AVS_DEV void nblock4(const NewtonArgs<real>& A, int lane, int r0, int dim, bool on, bool full, const real* w, int c, const real* cc1, const real* cc2, real cs1, real cs2) {
     const int ra = A.rowI[on ? r0 : 0], t = lane & 15, gq = on ? nslot_dof(ra, t) : -1;
     GLB_PTR(const real) J = A.rJ + ROW_S * (on ? r0 : 0);
-    real Jt[6], y1t = 0, y2t = 0;
+    real Jt[6];
 #pragma unroll
     for (int p = 0; p < 6; p++) Jt[p] = (on && p < dim) ? J[ROW_S * p + t] : real(0);
+    const int smax = __any(on && ((ra >> 19) & 15) > 0) ? 16 : 8;       // rows of the second window only if some contact has one
+    if (!__any(full)) {
+        // top / bottom zone only: C = diag(w)
+        for (int s = 0; s < smax; s++) {
+            const int gp = nslot_dof(ra, s);
+            real acc = 0;
+#pragma unroll
+            for (int p = 0; p < 6; p++) acc += w[p] * __shfl(Jt[p], (lane & 48) | s, 64) * Jt[p];
+            if (on && gp >= 0 && gq >= 0 && gq <= gp) __hip_atomic_fetch_add(A.H + gp * (gp + 1) / 2 + gq, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    // some contact of this pass is in the middle zone: its rank-two terms come from the owner lane's registers (c1, c2, s1, s2
+    // of contact c live in lane c), fetched only here so that they are not live in the common path
+    real c1[6], c2[6], y1t = 0, y2t = 0;
+#pragma unroll
+    for (int p = 0; p < 6; p++) { c1[p] = __shfl(cc1[p], c & 63, 64); c2[p] = __shfl(cc2[p], c & 63, 64); }
+    const real s1 = __shfl(cs1, c & 63, 64), s2 = __shfl(cs2, c & 63, 64);
 #pragma unroll
     for (int p = 0; p < 6; p++) { y1t += c1[p] * Jt[p]; y2t += c2[p] * Jt[p]; }
-    const int smax = __any(on && ((ra >> 19) & 15) > 0) ? 16 : 8;       // rows of the second window only if some contact has one
     for (int s = 0; s < smax; s++) {
         const int gp = nslot_dof(ra, s);
-        real Js[6], acc = 0;
+        real acc = 0, y1s = 0, y2s = 0;
 #pragma unroll
-        for (int p = 0; p < 6; p++) Js[p] = __shfl(Jt[p], (lane & 48) | s, 64);
-#pragma unroll
-        for (int p = 0; p < 6; p++) acc += w[p] * Js[p] * Jt[p];
-        real y1s = 0, y2s = 0;
-#pragma unroll
-        for (int p = 0; p < 6; p++) { y1s += c1[p] * Js[p]; y2s += c2[p] * Js[p]; }
+        for (int p = 0; p < 6; p++) {
+            const real js = __shfl(Jt[p], (lane & 48) | s, 64);
+            acc += w[p] * js * Jt[p];
+            y1s += c1[p] * js;
+            y2s += c2[p] * js;
+        }
         if (full) acc += s1 * y1s * y1t - s2 * y2s * y2t;
         if (on && gp >= 0 && gq >= 0 && gq <= gp) __hip_atomic_fetch_add(A.H + gp * (gp + 1) / 2 + gq, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -509,10 +526,10 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
                     const int zn = c < nc ? zs : 0;
                     if (!__any(zn != 0)) continue;
                     const int head = __shfl(con[ch].head, c & 63, 64), dim = __shfl(con[ch].dim, c & 63, 64);
-                    real w[6], c1[6], c2[6];
+                    real w[6];
     #pragma unroll
-                    for (int p = 0; p < 6; p++) { w[p] = __shfl(cw[ch][p], c & 63, 64); c1[p] = __shfl(cc1[ch][p], c & 63, 64); c2[p] = __shfl(cc2[ch][p], c & 63, 64); }
-                    nblock4<real>(A, lane, head, dim, zn != 0, zn == 2, w, c1, c2, __shfl(cs1[ch], c & 63, 64), __shfl(cs2[ch], c & 63, 64));
+                    for (int p = 0; p < 6; p++) w[p] = __shfl(cw[ch][p], c & 63, 64);
+                    nblock4<real>(A, lane, head, dim, zn != 0, zn == 2, w, c, cc1[ch], cc2[ch], cs1[ch], cs2[ch]);
                 }
             }
             NSYNC();

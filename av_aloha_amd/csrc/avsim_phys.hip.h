@@ -1168,17 +1168,12 @@ struct Env {
     // ---- P3 ------------------------------------------------------------------------------------
     // out of line, on a copy of the object: the members then live in registers (a callee reached through `this` reloads them
     // from memory after every store, and the kernel-argument pointer with them: vector loads instead of s_load)
-    __device__ __attribute__((noinline)) void collide_ool() {
+    __device__ __attribute__((noinline)) void collide() {
         Env e(*this);
         e.collide_i();
         diverged = e.diverged; nit_sum = e.nit_sum; nit_max = e.nit_max; t_broad = e.t_broad; t_narrow = e.t_narrow;
     }
     // the call goes through a throw-away copy: the caller's object never has its address taken and stays in registers too
-    AVS_DEV void collide() {
-        Env t(*this);
-        t.collide_ool();
-        diverged = t.diverged; nit_sum = t.nit_sum; nit_max = t.nit_max; t_broad = t.t_broad; t_narrow = t.t_narrow;
-    }
     __device__ __attribute__((always_inline)) void collide_i() {
         PHASE_BEGIN();
         real* gcen = r + ka->lay.gcen;
@@ -1323,17 +1318,12 @@ struct Env {
     // ---- P4 ------------------------------------------------------------------------------------
     // out of line, on a copy of the object: the members then live in registers (a callee reached through `this` reloads them
     // from memory after every store, and the kernel-argument pointer with them: vector loads instead of s_load)
-    __device__ __attribute__((noinline)) void make_constraints_ool() {
+    __device__ __attribute__((noinline)) void make_constraints() {
         Env e(*this);
         e.make_constraints_i();
         diverged = e.diverged; nit_sum = e.nit_sum; nit_max = e.nit_max; t_broad = e.t_broad; t_narrow = e.t_narrow;
     }
     // the call goes through a throw-away copy: the caller's object never has its address taken and stays in registers too
-    AVS_DEV void make_constraints() {
-        Env t(*this);
-        t.make_constraints_ool();
-        diverged = t.diverged; nit_sum = t.nit_sum; nit_max = t.nit_max; t_broad = t.t_broad; t_narrow = t.t_narrow;
-    }
     __device__ __attribute__((always_inline)) void make_constraints_i() {
         PHASE_BEGIN();
         real *qpos = r + ka->lay.qpos, *qvel = r + ka->lay.qvel;
@@ -1629,17 +1619,12 @@ struct Env {
     // ---- P8 ------------------------------------------------------------------------------------
     // out of line, on a copy of the object: the members then live in registers (a callee reached through `this` reloads them
     // from memory after every store, and the kernel-argument pointer with them: vector loads instead of s_load)
-    __device__ __attribute__((noinline)) void solve_ool(int pgs_iters, int solver, int newton_iters, real newton_tol, real scale) {
+    __device__ __attribute__((noinline)) void solve(int pgs_iters, int solver, int newton_iters, real newton_tol, real scale) {
         Env e(*this);
         e.solve_i(pgs_iters, solver, newton_iters, newton_tol, scale);
         diverged = e.diverged; nit_sum = e.nit_sum; nit_max = e.nit_max; t_broad = e.t_broad; t_narrow = e.t_narrow;
     }
     // the call goes through a throw-away copy: the caller's object never has its address taken and stays in registers too
-    AVS_DEV void solve(int pgs_iters, int solver, int newton_iters, real newton_tol, real scale) {
-        Env t(*this);
-        t.solve_ool(pgs_iters, solver, newton_iters, newton_tol, scale);
-        diverged = t.diverged; nit_sum = t.nit_sum; nit_max = t.nit_max; t_broad = t.t_broad; t_narrow = t.t_narrow;
-    }
     __device__ __attribute__((always_inline)) void solve_i(int pgs_iters, int solver, int newton_iters, real newton_tol, real scale) {
         PHASE_BEGIN();
         int *misc = ii + ka->lay.misc, *rmeta = ii + ka->lay.rmeta, *cefc = ii + ka->lay.cefc, *rowI = ii + ka->lay.rowI;
