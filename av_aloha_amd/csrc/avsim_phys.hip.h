@@ -430,7 +430,9 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         const real dd = __shfl(delta, d, 64);
         if (inA) __hip_atomic_fetch_add(q + adrA, BA * dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (inB) __hip_atomic_fetch_add(q + adrB, BB * dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        // only this wave touches the env's LDS record, and a wave's LDS operations execute in issue order: a wavefront-scope fence
+        // keeps the compiler from moving the next step's reads above the atomics without draining the look-ahead global loads
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         gi = gin;
         gin = ginn;
