@@ -467,6 +467,243 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, AVS
     return nk;
 }
 
+// ---- box-box on 16 lanes ------------------------------------------------------------------------------------------------
+// The same algorithm as box_box (same expressions, same tie-breaks, bit-identical results), spread over the 16 lanes of a DPP
+// row that all hold the same pair: lane t evaluates separating axis t (15 axes), the winner is chosen by replaying the serial
+// comparison chain on the gathered separations; for a face contact lane q carries polygon vertex q through the four clips
+// (neighbour by shuffle, compaction by ballot + LDS), the depth filter and the output.  Every lane of the row must call it
+// with the same arguments; `g16` = lane & ~15 (first lane of the row), `on` = the row holds a real pair.  Returns the number
+// of contacts (row-uniform); results go to `scr` as in box_box.
+template <typename T> AVS_DEV T sel33(const T (*M)[3], int i, int j) { return sel3(i == 0 ? M[0] : (i == 1 ? M[1] : M[2]), j); }
+template <typename T> AVS_DEV T row_get(T x, int g16, int l) { return __shfl(x, g16 | l, 64); }
+
+template <typename T>
+__device__ int box_box16(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, AVS_LDS(T) work, int lane, bool on) {
+    const int t = lane & 15, g16 = lane & ~15;
+    const unsigned rowmask_sh = g16;
+    const T *Ra = a.mat, *Rb = b.mat;
+    T p[3], pa[3], pb[3];
+    sub3(b.pos, a.pos, p);
+    mulmatT(Ra, p, pa);
+    mulmatT(Rb, p, pb);
+    T R[3][3], Q[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            R[i][j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j];
+            Q[i][j] = fabs(R[i][j]) + T(1e-12);
+        }
+    // ---- this lane's axis ----
+    T sv = T(-1e30);          // separation along axis t
+    bool skip = t >= 15;      // degenerate edge pair (or the idle 16th lane)
+    bool flipv = false;
+    T bnv[3] = {0, 0, 0};
+    if (t < 3) {
+        const int i = t;
+        sv = fabs(sel3(pa, i)) - (sel3(a.size, i) + b.size[0] * sel33(Q, i, 0) + b.size[1] * sel33(Q, i, 1) + b.size[2] * sel33(Q, i, 2));
+        flipv = sel3(pa, i) < 0;
+    } else if (t < 6) {
+        const int j = t - 3;
+        sv = fabs(sel3(pb, j)) - (sel3(b.size, j) + a.size[0] * sel33(Q, 0, j) + a.size[1] * sel33(Q, 1, j) + a.size[2] * sel33(Q, 2, j));
+        flipv = sel3(pb, j) < 0;
+    } else if (t < 15) {
+        const int i = (t - 6) / 3, j = (t - 6) % 3;
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        T c[3] = {sel3(R[0], j), sel3(R[1], j), sel3(R[2], j)}, e[3] = {i == 0 ? T(1) : T(0), i == 1 ? T(1) : T(0), i == 2 ? T(1) : T(0)}, ax[3];
+        cross3(e, c, ax);
+        const T l = sqrt(dot3(ax, ax));
+        if (l < T(1e-8)) skip = true;
+        else {
+            T sep = fabs(dot3(pa, ax)) - (sel3(a.size, i1) * sel33(Q, i2, j) + sel3(a.size, i2) * sel33(Q, i1, j) + sel3(b.size, j1) * sel33(Q, i, j2) + sel3(b.size, j2) * sel33(Q, i, j1));
+            sep /= l;
+            sv = sep;
+            T axn[3] = {ax[0] / l, ax[1] / l, ax[2] / l};
+            flipv = dot3(pa, axn) < 0;
+            mulmat(Ra, axn, bnv);
+        }
+    }
+    // a separating axis anywhere in the row: no contact
+    {
+        const unsigned long long sepm = __ballot(!skip && sv > 0);
+        if ((sepm >> g16) & 0xffffull) return 0;
+    }
+    // ---- the serial comparison chain on the gathered values ----
+    T best = T(-1e30);
+    int code = -1;
+    const T fudge = T(1.05);
+    const unsigned skipm = (unsigned)((__ballot(skip) >> g16) & 0xffffull);
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+        const T sk = row_get(sv, g16, k);
+        if (k < 6) { if (sk > best) { best = sk; code = k; } }
+        else if (!((skipm >> k) & 1u)) { if (sk * fudge > best) { best = sk; code = k; } }
+    }
+    const bool flip = row_get(flipv ? 1 : 0, g16, code) != 0;
+    T bn[3] = {row_get(bnv[0], g16, code), row_get(bnv[1], g16, code), row_get(bnv[2], g16, code)};
+    const T depth = -best;
+    T n[3];
+    if (code < 3) col3(Ra, code, n);
+    else if (code < 6) col3(Rb, code - 3, n);
+    else { n[0] = bn[0]; n[1] = bn[1]; n[2] = bn[2]; }
+    if (flip) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+
+    if (code >= 6) {     // edge-edge: short, every lane computes it, the first lane of the row writes
+        int i = (code - 6) / 3, j = (code - 6) % 3;
+        T pA[3], pB[3], la[3], lb[3];
+        mulmatT(Ra, n, la);
+        mulmatT(Rb, n, lb);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            la[k] = (k == i) ? T(0) : (la[k] > 0 ? a.size[k] : -a.size[k]);
+            lb[k] = (k == j) ? T(0) : (lb[k] > 0 ? -b.size[k] : b.size[k]);
+        }
+        mulmat(Ra, la, pA);
+        mulmat(Rb, lb, pB);
+        for (int k = 0; k < 3; k++) { pA[k] += a.pos[k]; pB[k] += b.pos[k]; }
+        T ua[3], ub[3], w[3];
+        col3(Ra, i, ua);
+        col3(Rb, j, ub);
+        sub3(pB, pA, w);
+        T uaub = dot3(ua, ub), q1 = dot3(ua, w), q2 = -dot3(ub, w), den = 1 - uaub * uaub;
+        T alpha = 0, beta = 0;
+        if (den > T(1e-10)) { alpha = (q1 + uaub * q2) / den; beta = (uaub * q1 + q2) / den; }
+        if (on && t == 0) {
+            for (int k = 0; k < 3; k++) {
+                pA[k] += ua[k] * alpha;
+                pB[k] += ub[k] * beta;
+                scr[4 + k] = T(0.5) * (pA[k] + pB[k]);
+                scr[16 + k] = n[k];
+            }
+            scr[0] = -depth;
+        }
+        return 1;
+    }
+
+    // ---- face contact ----
+    const bool ra = code < 3;
+    T rpos[3], rmat[9], rsize[3], ipos[3], imat[9], isize[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { rpos[q] = ra ? a.pos[q] : b.pos[q]; ipos[q] = ra ? b.pos[q] : a.pos[q]; rsize[q] = ra ? a.size[q] : b.size[q]; isize[q] = ra ? b.size[q] : a.size[q]; }
+#pragma unroll
+    for (int q = 0; q < 9; q++) { rmat[q] = ra ? a.mat[q] : b.mat[q]; imat[q] = ra ? b.mat[q] : a.mat[q]; }
+    T nr[3] = {n[0], n[1], n[2]};
+    if (code >= 3) { nr[0] = -n[0]; nr[1] = -n[1]; nr[2] = -n[2]; }
+    const int ax = code % 3;
+    T li[3];
+    mulmatT(imat, nr, li);
+    int k = 0;
+    if (fabs(li[1]) > fabs(li[0])) k = 1;
+    if (fabs(li[2]) > fabs(sel3(li, k))) k = 2;
+    const T sgn = sel3(li, k) > 0 ? T(-1) : T(1);
+    const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+    (void)k2;
+    AVS_LDS(T) poly = work;          // [8][3]
+    AVS_LDS(T) tmp = work + 24;      // [8][3]
+    AVS_LDS(T) dep = work + 48;      // [8]
+    // vertex q of the incident face, in the reference box's frame (lanes 0..3; the other lanes compute vertex t & 3, unused)
+    T P[3];
+    {
+        const int q = t & 3;
+        const T cs0 = (q == 0 || q == 3) ? T(1) : T(-1), cs1 = (q < 2) ? T(1) : T(-1);
+        T l[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) l[j] = (j == k ? sgn : (j == k1 ? cs0 : cs1)) * isize[j];
+        T wv[3], rel[3];
+        mulmat(imat, l, wv);
+        for (int cc = 0; cc < 3; cc++) rel[cc] = wv[cc] + ipos[cc] - rpos[cc];
+        mulmatT(rmat, rel, P);
+    }
+    int np = 4;
+    const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+    AVS_LDS(T) dst = tmp;
+    for (int side = 0; side < 4; side++) {
+        const int axis = side < 2 ? a1 : a2;
+        const T s = (side & 1) ? T(-1) : T(1), lim = sel3(rsize, axis);
+        const int qn = t + 1 >= np ? 0 : t + 1;
+        const T Qp[3] = {row_get(P[0], g16, qn), row_get(P[1], g16, qn), row_get(P[2], g16, qn)};
+        const T dp = s * sel3(P, axis) - lim, dq = s * sel3(Qp, axis) - lim;
+        const bool live = t < np;
+        const bool e1 = live && dp <= 0, e2 = live && ((dp < 0 && dq > 0) || (dp > 0 && dq < 0));
+        const unsigned m1 = (unsigned)((__ballot(e1) >> g16) & 0xffffull), m2 = (unsigned)((__ballot(e2) >> g16) & 0xffffull);
+        const unsigned below = (1u << t) - 1u;
+        const int off = __popc(m1 & below) + __popc(m2 & below);
+        if (e1 && off < 8) { dst[3 * off] = P[0]; dst[3 * off + 1] = P[1]; dst[3 * off + 2] = P[2]; }
+        if (e2 && off + (e1 ? 1 : 0) < 8) {
+            const int o2 = off + (e1 ? 1 : 0);
+            const T tt = dp / (dp - dq);
+            for (int c = 0; c < 3; c++) dst[3 * o2 + c] = P[c] + tt * (Qp[c] - P[c]);
+        }
+        const int total = __popc(m1) + __popc(m2);
+        np = total < 8 ? total : 8;
+        if (np == 0) return 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int rq = t < np ? t : 0;
+        P[0] = dst[3 * rq]; P[1] = dst[3 * rq + 1]; P[2] = dst[3 * rq + 2];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        dst = dst == tmp ? poly : tmp;
+    }
+    // after four sides `dst` is `tmp` again: points behind the reference face go there, with their depths
+    T refax[3];
+    col3(rmat, ax, refax);
+    const T face = dot3(nr, refax) > 0 ? T(1) : T(-1);
+    int m;
+    {
+        const T dqv = sel3(rsize, ax) - face * sel3(P, ax);
+        const bool kp = t < np && dqv >= 0;
+        const unsigned km = (unsigned)((__ballot(kp) >> g16) & 0xffffull);
+        const int off = __popc(km & ((1u << t) - 1u));
+        if (kp) { tmp[3 * off] = P[0]; tmp[3 * off + 1] = P[1]; tmp[3 * off + 2] = P[2]; dep[off] = dqv; }
+        m = __popc(km);
+        if (m == 0) return 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    int keep[4], nk = 0;
+    if (m <= 4) { for (int q = 0; q < m; q++) keep[nk++] = q; }
+    else {
+        // rare (more than four polygon vertices): every lane replays the serial selection on the LDS copy
+        int i0 = 0;
+        for (int q = 1; q < m; q++) if (dep[q] > dep[i0]) i0 = q;
+        int i1 = i0;
+        T bd = -1;
+        for (int q = 0; q < m; q++) {
+            T dx = tmp[3 * q + a1] - tmp[3 * i0 + a1], dy = tmp[3 * q + a2] - tmp[3 * i0 + a2], dd = dx * dx + dy * dy;
+            if (dd > bd) { bd = dd; i1 = q; }
+        }
+        T ex = tmp[3 * i1 + a1] - tmp[3 * i0 + a1], ey = tmp[3 * i1 + a2] - tmp[3 * i0 + a2];
+        int i2 = -1, i3 = -1;
+        T mx = T(1e-18), mn = T(-1e-18);
+        for (int q = 0; q < m; q++) {
+            T cr = ex * (tmp[3 * q + a2] - tmp[3 * i0 + a2]) - ey * (tmp[3 * q + a1] - tmp[3 * i0 + a1]);
+            if (cr > mx) { mx = cr; i2 = q; }
+            if (cr < mn) { mn = cr; i3 = q; }
+        }
+        keep[nk++] = i0; keep[nk++] = i1;
+        if (i2 >= 0) keep[nk++] = i2;
+        if (i3 >= 0) keep[nk++] = i3;
+        for (int x = 0; x < nk; x++)
+            for (int y = x + 1; y < nk; y++)
+                if (keep[y] < keep[x]) { int tq = keep[x]; keep[x] = keep[y]; keep[y] = tq; }
+    }
+    if (on && t < nk) {          // lane x writes contact x
+        const int q = t == 0 ? keep[0] : (t == 1 ? keep[1] : (t == 2 ? keep[2] : keep[3]));
+        T l[3] = {tmp[3 * q], tmp[3 * q + 1], tmp[3 * q + 2]};
+        const T dq_ = dep[q];
+#pragma unroll
+        for (int j = 0; j < 3; j++) l[j] += (j == ax) ? T(0.5) * dq_ * face : T(0);
+        T wv[3];
+        mulmat(rmat, l, wv);
+        for (int c = 0; c < 3; c++) scr[4 + 3 * t + c] = wv[c] + rpos[c];
+        scr[t] = -dq_;
+    }
+    if (on && t == 0) { for (int c = 0; c < 3; c++) scr[16 + c] = n[c]; }
+    (void)rowmask_sh;
+    return nk;
+}
+
 // conservative cull: separating-axis test of the two local bounding boxes on their 6 face axes
 template <typename T>
 AVS_DEV bool boxes_separated(const Shape<T>& a, const Shape<T>& b) {

@@ -470,12 +470,12 @@ AVS_DEV void store_row16(GLB_PTR(double) dst, const double* v) {
 
 // eight consecutive LDS reals whose address is a multiple of 16 bytes, as two (four) vector reads
 AVS_DEV void lds_load8(const float* p, float* v) {
-    const LDS_PTR(const avs_v4f) q = (LDS_PTR(const avs_v4f))p;
+    LDS_PTR(const avs_v4f) q = (LDS_PTR(const avs_v4f))p;
     const avs_v4f a = q[0], b = q[1];
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 AVS_DEV void lds_load8(const double* p, double* v) {
-    const LDS_PTR(const avs_v2d) q = (LDS_PTR(const avs_v2d))p;
+    LDS_PTR(const avs_v2d) q = (LDS_PTR(const avs_v2d))p;
 #pragma unroll
     for (int k = 0; k < 4; k++) { const avs_v2d a = q[k]; v[2 * k] = a.x; v[2 * k + 1] = a.y; }
 }
@@ -1260,7 +1260,6 @@ struct Env {
         // 64 candidate pairs per pass, one per lane, each with a 20-word result slot in LDS (the solver records, not live
         // during collision).  Box-box pairs go first, NBOX at a time through the polygon work areas behind the slots, then
         // everything else: the wave executes the clipping code and the MPR code once each instead of both in every pass.
-        constexpr int NBOX = 9;
         for (int base = 0; base < ncand; base += G) {
             const int ci = base + lane;
             int n = 0, p = 0, nn = 0;
@@ -1270,14 +1269,30 @@ struct Env {
             const int ga = ka->m.pair_geom[2 * p], gb = ka->m.pair_geom[2 * p + 1];
             const bool isbox = valid && geom_type_()[ga] == G_BOX && geom_type_()[gb] == G_BOX;
             {
+                // box-box pairs, four at a time: every 16-lane row of the wave works on one pair (box_box16), the results land in
+                // the result slot of the lane that owns the pair
                 int nbox, rk = group_rank<G>(isbox, grp, lane, &nbox);
-                for (int b0 = 0; b0 < nbox; b0 += NBOX)
-                    if (isbox && rk >= b0 && rk < b0 + NBOX) {
-                        Shape<real> a, b;
-                        load_shape(ga, a);
-                        load_shape(gb, b);
-                        nn = boxes_separated(a, b) ? 0 : box_box(a, b, scr, (LDS_PTR(real))(r + ka->lay.scr + 20 * G + 56 * (rk - b0)));
+                const int row = lane >> 4;
+                for (int b0 = 0; b0 < nbox; b0 += 4) {
+                    int src = 0;
+                    bool on = false;
+#pragma unroll
+                    for (int gg = 0; gg < 4; gg++) {
+                        const unsigned long long mm = __ballot(isbox && rk == b0 + gg);
+                        if (row == gg && mm != 0) { src = __builtin_ctzll(mm); on = true; }
                     }
+                    const int pga = __shfl(ga, src, 64), pgb = __shfl(gb, src, 64);     // an idle row runs on lane 0's pair, unused
+                    Shape<real> a, b;
+                    load_shape(pga, a);
+                    load_shape(pgb, b);
+                    int n16 = 0;
+                    if (!boxes_separated(a, b))
+                        n16 = box_box16(a, b, (LDS_PTR(real))(r + ka->lay.scr + 20 * src), (LDS_PTR(real))(r + ka->lay.scr + 20 * G + 56 * row), lane, on);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int got = __shfl(on ? n16 : 0, 16 * ((rk - b0) & 3), 64);
+                    if (isbox && rk >= b0 && rk < b0 + 4) nn = got;
+                }
             }
             if (valid && !isbox) {
                 Shape<real> a, b;
