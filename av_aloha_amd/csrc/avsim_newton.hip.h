@@ -357,6 +357,47 @@ AVS_DEV void nblock_solve(const NewtonArgs<real>& A, int lane) {
     if (mine) A.dl[a0 + i] = x;
 }
 
+// Dense factorisation for scenes where a contact couples two trees.  Out of line on purpose: its 48-entry register row would
+// otherwise push the Newton loop's per-contact state out to scratch memory in every solve, coupled or not.
+template <typename real>
+__device__ __attribute__((noinline)) void ndense_chol(LDS_PTR(real) H_, int nv_) {
+    const int lane = threadIdx.x & 63;
+    LDS_PTR(real) H = (LDS_PTR(real))(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)H_);
+    const int nv = __builtin_amdgcn_readfirstlane(nv_);
+    struct { LDS_PTR(real) H; } A = {H};
+
+                // g sits right behind the packed triangle (NewtonArgs contract), i.e. it is "row nv" of the same array
+                real row[NVMAX];
+                const int rbase = lane * (lane + 1) / 2;
+                const real sgn = lane == nv ? real(-1) : real(1);
+    #pragma unroll
+                for (int k = 0; k < NVMAX; k++) {
+                    const bool ok = lane <= nv && k <= lane && k < nv;
+                    const real v = A.H[ok ? rbase + k : 0];
+                    row[k] = ok ? sgn * v : real(0);
+                }
+                for (int j = 0; j < nv; j++) {
+                    // pivot: d = sqrt(H_jj), column j = row[0] / d.  f32 takes the hardware rsq (1 ulp), f64 the exact pair
+                    const real piv = tmax(lane_get(row[0], j), real(1e-30));
+                    real d, rinv;
+                    if (sizeof(real) == 4) { rinv = (real)__builtin_amdgcn_rsqf((float)piv); d = piv * rinv; }
+                    else { d = sqrt(piv); rinv = real(1) / d; }
+                    const real lij = row[0] * rinv;
+                    // L_ij for the rows below, d on the diagonal, y_j = (L^-1 (-g))_j from lane nv ("row nv" is g's storage)
+                    if (lane >= j && lane <= nv) A.H[rbase + j] = lane == j ? d : lij;
+    #pragma unroll
+                    for (int mb = 1; mb < NVMAX; mb += 8) {
+                        if (j + mb <= nv - 1) {          // wave-uniform: the rest of the row is past the matrix
+    #pragma unroll
+                            for (int mm = 0; mm < 8; mm++) {
+                                const int m = mb + mm;
+                                if (m < NVMAX) row[m - 1] = row[m] - lij * lane_get(lij, (j + m) & 63);
+                            }
+                        }
+                    }
+                }
+            }
+
 // r / ii: the env's real and int LDS regions, li: the block's hot-table image; everything else comes from the layout
 // NCH = contact chunks of 64 (one contact per lane and chunk): 1 when the model's contact cap is <= 64
 template <typename real, int NCH>
@@ -536,38 +577,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
             NPROF(2);
             // ---- Cholesky + forward substitution in registers: lane i = row i, lane nv = -g ----
             if (!coupled) nblock_chol<real>(A, lane);
-            else {
-                // g sits right behind the packed triangle (NewtonArgs contract), i.e. it is "row nv" of the same array
-                real row[NVMAX];
-                const int rbase = lane * (lane + 1) / 2;
-                const real sgn = lane == nv ? real(-1) : real(1);
-    #pragma unroll
-                for (int k = 0; k < NVMAX; k++) {
-                    const bool ok = lane <= nv && k <= lane && k < nv;
-                    const real v = A.H[ok ? rbase + k : 0];
-                    row[k] = ok ? sgn * v : real(0);
-                }
-                for (int j = 0; j < nv; j++) {
-                    // pivot: d = sqrt(H_jj), column j = row[0] / d.  f32 takes the hardware rsq (1 ulp), f64 the exact pair
-                    const real piv = tmax(lane_get(row[0], j), real(1e-30));
-                    real d, rinv;
-                    if (sizeof(real) == 4) { rinv = (real)__builtin_amdgcn_rsqf((float)piv); d = piv * rinv; }
-                    else { d = sqrt(piv); rinv = real(1) / d; }
-                    const real lij = row[0] * rinv;
-                    // L_ij for the rows below, d on the diagonal, y_j = (L^-1 (-g))_j from lane nv ("row nv" is g's storage)
-                    if (lane >= j && lane <= nv) A.H[rbase + j] = lane == j ? d : lij;
-    #pragma unroll
-                    for (int mb = 1; mb < NVMAX; mb += 8) {
-                        if (j + mb <= nv - 1) {          // wave-uniform: the rest of the row is past the matrix
-    #pragma unroll
-                            for (int mm = 0; mm < 8; mm++) {
-                                const int m = mb + mm;
-                                if (m < NVMAX) row[m - 1] = row[m] - lij * lane_get(lij, (j + m) & 63);
-                            }
-                        }
-                    }
-                }
-            }
+            else ndense_chol<real>(A.H, nv);
             have_L = !middle && A.nlead <= 64;
             sig_lead = cur_lead;
 #pragma unroll
