@@ -1829,15 +1829,24 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(KPtr<real> ka, const real* __
     long long tp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define PROF(k, stmt) do { if (o_prof) { long long t0_ = __builtin_readcyclecounter(); stmt; tp[k] += __builtin_readcyclecounter() - t0_; } else { stmt; } } while (0)
     for (int s = 0; s < nsub; s++) {
-        PROF(0, E.kinematics());
-        PROF(1, E.crb());
-        PROF(2, E.rne_bias());
-        PROF(3, E.smooth());
+        // E is reached through `this` by the out-of-line phases, so it lives in scratch memory; the phases inlined here run on a
+        // copy that never has its address taken (registers, and dead again before the calls: nothing extra to save around them)
+        {
+            Env<real, G> e(E);
+            PROF(0, e.kinematics());
+            PROF(1, e.crb());
+            PROF(2, e.rne_bias());
+            PROF(3, e.smooth());
+        }
         PROF(4, E.collide());
         PROF(5, E.make_constraints());
         PROF(6, E.solve(pgs_iters, ka->m.solver, ka->m.newton_iters, ka->m.newton_tol, ka->m.nscale));
-        PROF(7, E.euler());
-        E.check_divergence();
+        {
+            Env<real, G> e(E);
+            PROF(7, e.euler());
+            e.check_divergence();
+            E.diverged = e.diverged;
+        }
     }
     if (o_prof && lane == 0) {
         for (int k = 0; k < 8; k++) o_prof[(size_t)env * 18 + k] = tp[k];
