@@ -30,6 +30,27 @@
 
 namespace avs {
 
+// A whole 16-entry row of the global row scratch in four (eight) vector loads issued back to back, then pinned by one empty asm:
+// without it the compiler sinks each element's load into the branch that consumes it (load - wait - use, sixteen times)
+typedef float nv4f __attribute__((ext_vector_type(4)));
+typedef double nv2d __attribute__((ext_vector_type(2)));
+AVS_DEV void load_row16(GLB_PTR(const float) src, float* v) {
+    GLB_PTR(const nv4f) p = (GLB_PTR(const nv4f))src;
+    nv4f a = p[0], b = p[1], c = p[2], d = p[3];
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w; v[12] = d.x; v[13] = d.y; v[14] = d.z; v[15] = d.w;
+}
+AVS_DEV void load_row16(GLB_PTR(const double) src, double* v) {
+    GLB_PTR(const nv2d) p = (GLB_PTR(const nv2d))src;
+    nv2d t[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) t[q] = p[q];
+    asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+#pragma unroll
+    for (int q = 0; q < 8; q++) { v[2 * q] = t[q].x; v[2 * q + 1] = t[q].y; }
+}
+
 template <typename real>
 struct NewtonArgs {
     // LDS views of one env
@@ -523,7 +544,8 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
             const real f = A.rowS[RS_S * i + 6];
             if (f == 0) continue;
             const int ra = A.rowI[i];
-            GLB_PTR(const real) J = A.rJ + ROW_S * i;
+            real J[ROW_W];
+            load_row16(A.rJ + ROW_S * i, J);
 #pragma unroll
             for (int s = 0; s < ROW_W; s++) {
                 const int dof = nslot_dof(ra, s);

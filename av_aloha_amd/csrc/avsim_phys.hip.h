@@ -1724,10 +1724,12 @@ struct Env {
             const real f = rowS[RS_S * i + 6];
             if (f == 0) continue;
             const int ra = rowI[i];
+            real Jr[ROW_W];
+            load_row16((GLB_PTR(const real))rJ + ROW_S * i, Jr);
 #pragma unroll
             for (int s = 0; s < ROW_W; s++) {
                 const int dof = nslot_dof(ra, s);
-                if (dof >= 0) __hip_atomic_fetch_add(out + dof, rJ[ROW_S * i + s] * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (dof >= 0) __hip_atomic_fetch_add(out + dof, Jr[s] * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         GSYNC();
