@@ -305,7 +305,9 @@ AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, L
     for (int k = lane; k < A.nv; k += 64) {
         const int t = A.dof_tree[k], a0 = A.tree_dofadr[t], n = A.tree_dofnum[t], kk = k - a0;
         real sacc = 0;
-        for (int j = 0; j < n; j++) sacc += A.M[A.tree_madr[t] + kk * n + j] * (v[a0 + j] - A.as[a0 + j]);
+        const int mb = A.tree_madr[t] + kk * n;
+#pragma unroll
+        for (int j = 0; j < TREE_W; j++) { const int jj = j < n ? j : 0; const real m = A.M[mb + jj], d = v[a0 + jj] - A.as[a0 + jj]; sacc += j < n ? m * d : real(0); }
         cs += real(0.5) * sacc * (v[k] - A.as[k]);
     }
     return wave_sum(cs);
@@ -536,7 +538,9 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         for (int k = lane; k < nv; k += 64) {
             const int t = A.dof_tree[k], a0 = A.tree_dofadr[t], n = A.tree_dofnum[t], kk = k - a0;
             real s = 0;
-            for (int j = 0; j < n; j++) s += A.M[A.tree_madr[t] + kk * n + j] * (A.a[a0 + j] - A.as[a0 + j]);
+            const int mb = A.tree_madr[t] + kk * n;
+#pragma unroll
+            for (int j = 0; j < TREE_W; j++) { const int jj = j < n ? j : 0; const real m = A.M[mb + jj], d = A.a[a0 + jj] - A.as[a0 + jj]; s += j < n ? m * d : real(0); }
             A.g[k] = s;
         }
         NSYNC();
@@ -645,7 +649,9 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         for (int k = lane; k < nv; k += 64) {
             const int t = A.dof_tree[k], a0 = A.tree_dofadr[t], n = A.tree_dofnum[t], kk = k - a0;
             real s = 0;
-            for (int j = 0; j < n; j++) s += A.M[A.tree_madr[t] + kk * n + j] * A.dl[a0 + j];
+            const int mb = A.tree_madr[t] + kk * n;
+#pragma unroll
+            for (int j = 0; j < TREE_W; j++) { const int jj = j < n ? j : 0; const real m = A.M[mb + jj], d = A.dl[a0 + jj]; s += j < n ? m * d : real(0); }
             q2 += s * A.dl[k];
             q1 += s * (A.a[k] - A.as[k]);
         }
