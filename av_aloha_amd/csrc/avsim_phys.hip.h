@@ -1044,11 +1044,16 @@ struct Env {
             const int t = body_tree_()[b];
             if (t >= 0) {
                 const int a0 = tree_dofadr_()[t], n = tree_dofnum_()[t], mask = body_dofmask_()[b];
-                for (int k = 0; k < n; k++)
-                    if ((mask >> k) & 1) {
-                        const real qd = qvel[a0 + k];
-                        for (int q = 0; q < 6; q++) v[q] += cdof[6 * (a0 + k) + q] * qd;
-                    }
+                // all eight slots unconditionally (reads of an absent slot fall back on the tree's first dof, weight 0): the LDS
+                // reads batch up instead of one branch + wait per ancestor dof
+#pragma unroll
+                for (int k = 0; k < TREE_W; k++) {
+                    const bool on = k < n && ((mask >> k) & 1);
+                    const int d = on ? a0 + k : a0;
+                    const real qd = on ? qvel[d] : real(0);
+#pragma unroll
+                    for (int q = 0; q < 6; q++) v[q] += cdof[6 * d + q] * qd;
+                }
             }
             for (int q = 0; q < 6; q++) cvel[6 * b + q] = v[q];
         }
@@ -1080,9 +1085,13 @@ struct Env {
             if (t >= 0) {
                 real a[6] = {0, 0, 0, -ka->m.gravity[0], -ka->m.gravity[1], -ka->m.gravity[2]}, v[6];
                 const int a0 = tree_dofadr_()[t], n = tree_dofnum_()[t], mask = body_dofmask_()[b];
-                for (int k = 0; k < n; k++)
-                    if ((mask >> k) & 1)
-                        for (int q = 0; q < 6; q++) a[q] += cdd[6 * (a0 + k) + q];
+#pragma unroll
+                for (int k = 0; k < TREE_W; k++) {
+                    const bool on = k < n && ((mask >> k) & 1);
+                    const int d = on ? a0 + k : a0;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) { const real c = cdd[6 * d + q]; a[q] += on ? c : real(0); }
+                }
                 for (int q = 0; q < 6; q++) v[q] = cvel[6 * b + q];
                 SInert<real> si;
                 body_inertia(ka, xmat, xipos, b, si);
