@@ -84,3 +84,44 @@ def test_wrist_and_zed_cameras_move_with_the_arms(env):
     # here only a sanity relation: the two zed cameras are 6 cm apart and see nearly the same depth at the image centre
     zr = env.render_depth("zed_cam_right", 30, 40)
     assert abs(float(z[15, 20]) - float(zr[15, 20])) < 0.05
+
+
+def test_colour_image_known_answers(env):
+    """orc_render_rgb: the depth of the colour pass is the depth pass; a pixel of the table top seen from the overhead camera has
+    the table's flat colour under the analytic light (headlight along the ray + the vertical directional light, scene.xml:9,48);
+    the worm's-eye camera's empty rows show the sky gradient (scene.xml:34); slot and stick keep their MJCF hue."""
+    md = model_dict()
+    H, W = 60, 80
+    img, dep = env.render_rgb("overhead_cam", H, W)
+    assert np.array_equal(dep, env.render_depth("overhead_cam", H, W))
+    pc, Rc, fovy = cam_frame(md, env, "overhead_cam")
+    scale = 2 * np.tan(np.radians(fovy) / 2) / H
+    # a table pixel well away from robots and objects: front edge of the table, image centre column
+    names = env.man["geom_names"]
+    rgba = md["geom_rgba"][names.index("table")]
+    L = md["render_light"]
+    found = False
+    for i in range(H - 1, H // 2, -1):
+        j = W // 2
+        dc = np.array([(j + 0.5 - W / 2) * scale, -(i + 0.5 - H / 2) * scale, -1.0])
+        dw = Rc @ dc
+        t = (-0.0009 - pc[2]) / dw[2]
+        if abs(dep[i, j] - t) < 1e-5:                       # this ray ends on the table top (normal +z)
+            n = np.array([0.0, 0.0, 1.0])
+            lum = min(1.0, L[0] + L[1] * max(0.0, -(n @ dw) / np.linalg.norm(dw)) + L[2] * max(0.0, -(n @ (L[4:7] / np.linalg.norm(L[4:7])))))
+            want = np.floor(np.clip(rgba[:3] * lum, 0, 1) * 255.0 + 0.5)
+            assert np.array_equal(img[i, j].astype(np.float64), want), (i, j, img[i, j], want)
+            found = True
+            break
+    assert found
+    sky, sdep = env.render_rgb("worms_eye_cam", 30, 40)
+    assert sdep[0, 20] == np.float32(md["cam_clip"][1])          # nothing along this ray
+    pcw, Rcw, fw = cam_frame(md, env, "worms_eye_cam")
+    sc = 2 * np.tan(np.radians(fw) / 2) / 30
+    dc = np.array([(20 + 0.5 - 20) * sc, -(0 + 0.5 - 15) * sc, -1.0])
+    dw = Rcw @ dc
+    w = 0.5 + 0.5 * dw[2] / np.linalg.norm(dw)
+    want = np.floor(np.clip(L[12:15] + (L[8:11] - L[12:15]) * w, 0, 1) * 255.0 + 0.5)
+    assert np.array_equal(sky[0, 20].astype(np.float64), want)
+    r, g, b = (img[..., k].astype(np.int32) for k in range(3))
+    assert ((r > 1.8 * g) & (r > 60)).sum() > 5 and ((g > 1.8 * r) & (g > 60)).sum() > 5       # slot (.8 .4 .4), stick (.4 .8 .4)
