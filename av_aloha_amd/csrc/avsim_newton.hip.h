@@ -507,6 +507,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
     unsigned long long sig_lead = 0, sig_z1[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) sig_z1[ch] = 0;
+    bool forces_current = false;
     for (int it = 0; it < A.iters; it++) {
         used++;
         // ---- residuals, forces (-> rowS.f), curvature of the scalar rows (-> jv) ----
@@ -561,7 +562,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         for (int k = lane; k < nv; k += 64) { const real s = A.g[k]; gn2 += s * s; }
         gn2 = wave_sum(gn2);
         NPROF(1);
-        if (sqrt(gn2) * A.scale < A.tol) break;
+        if (sqrt(gn2) * A.scale < A.tol) { forces_current = true; break; }     // residuals and forces were just computed at this a
         // ---- active set now: scalar rows with curvature, contacts in the bottom / middle zone ----
         unsigned long long cur_lead = __ballot(lane < A.nlead && A.jv[lane < A.nlead ? lane : 0] != 0), cur_z1[NCH];
         bool middle = false, same = have_L && A.nlead <= 64 && cur_lead == sig_lead;
@@ -715,25 +716,27 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         // MuJoCo's improvement test [EXT]: the cost decrease of this iteration, -alpha phi'(0) / 2 to second order, scaled
         if (real(-0.5) * alpha * dphi0 * A.scale < A.tol) break;
     }
-    // ---- forces at the solution ----
-    for (int i = lane; i < ne; i += 64) A.rowS[RS_S * i + 2] = nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[RS_S * i];
-    NSYNC();
-    for (int i = lane; i < A.nlead; i += 64) {
-        real f, h;
-        nrow_scalar<real>(A.rmeta[i] & 3, A.rowS[RS_S * i + 2], A.rowS[RS_S * i + 1], A.rowS[RS_S * i + 5], &f, &h);
-        A.rowS[RS_S * i + 6] = f;
-    }
-#pragma unroll
-    for (int ch = 0; ch < NCH; ch++) {
-        if (ch * 64 >= A.ncon) break;
-        const NCon<real>& c = con[ch];
-        if (c.head >= 0) {
-            real jar[6], f[6], w[6], c1[6], c2[6], cc, s1, s2;
-#pragma unroll
-            for (int j = 0; j < 6; j++) jar[j] = j < c.dim ? A.rowS[RS_S * (c.head + j) + 2] : real(0);
-            ncone(c, jar, f, &cc, w, c1, c2, &s1, &s2);
-#pragma unroll
-            for (int j = 0; j < 6; j++) if (j < c.dim) A.rowS[RS_S * (c.head + j) + 6] = f[j];
+    // ---- forces at the solution (already there when the loop ended on the gradient test) ----
+    if (!forces_current) {
+        for (int i = lane; i < ne; i += 64) A.rowS[RS_S * i + 2] = nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[RS_S * i];
+        NSYNC();
+        for (int i = lane; i < A.nlead; i += 64) {
+            real f, h;
+            nrow_scalar<real>(A.rmeta[i] & 3, A.rowS[RS_S * i + 2], A.rowS[RS_S * i + 1], A.rowS[RS_S * i + 5], &f, &h);
+            A.rowS[RS_S * i + 6] = f;
+        }
+    #pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            if (ch * 64 >= A.ncon) break;
+            const NCon<real>& c = con[ch];
+            if (c.head >= 0) {
+                real jar[6], f[6], w[6], c1[6], c2[6], cc, s1, s2;
+    #pragma unroll
+                for (int j = 0; j < 6; j++) jar[j] = j < c.dim ? A.rowS[RS_S * (c.head + j) + 2] : real(0);
+                ncone(c, jar, f, &cc, w, c1, c2, &s1, &s2);
+    #pragma unroll
+                for (int j = 0; j < 6; j++) if (j < c.dim) A.rowS[RS_S * (c.head + j) + 6] = f[j];
+            }
         }
     }
     NSYNC();
