@@ -508,10 +508,16 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) sig_z1[ch] = 0;
     bool forces_current = false;
+    real alpha_prev = 0;
     for (int it = 0; it < A.iters; it++) {
         used++;
         // ---- residuals, forces (-> rowS.f), curvature of the scalar rows (-> jv) ----
-        if (!(it == 0 && jar_ready)) {
+        if (it > 0) {
+            // a moved by alpha dl and the line search left J dl in jv: the residuals follow without touching the rows [EXT: the
+            // same incremental update as MuJoCo's primal solvers]
+            for (int i = lane; i < ne; i += 64) A.rowS[RS_S * i + 2] += alpha_prev * A.jv[i];
+            NSYNC();
+        } else if (!jar_ready) {
             for (int i = lane; i < ne; i += 64) A.rowS[RS_S * i + 2] = nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[RS_S * i];
             NSYNC();
         }
@@ -710,6 +716,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         if (!(dphi0 < 0)) break;
         real st2 = 0;
         for (int k = lane; k < nv; k += 64) { const real s = alpha * A.dl[k]; A.a[k] += s; st2 += s * s; }
+        alpha_prev = alpha;
         st2 = wave_sum(st2);
         NSYNC();
         if (sqrt(st2) * A.scale < real(1e-2) * A.tol) break;
