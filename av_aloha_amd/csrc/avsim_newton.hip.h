@@ -283,13 +283,12 @@ AVS_DEV void nlead_rows(const NewtonArgs<real>& A, int lane) {
         if (A.prof) { const long long t_ = __builtin_readcyclecounter(); if (lane == 0) A.prof[k] += (int)(t_ - tp0); tp0 = t_; } \
     } while (0)
 
-// cost of the point v (LDS, dof indexed): rows + contacts + 1/2 (v - a_s)^T M (v - a_s)
+// cost of the point v (LDS, dof indexed): rows + contacts + 1/2 (v - a_s)^T M (v - a_s).  The row residuals J v - aref are read
+// from word `slot` of the row records: make_constraints leaves them there for the two start candidates (2: warm start, 8: a_s)
 template <typename real, int NCH>
-AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, LDS_PTR(const real) v) {
+AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, LDS_PTR(const real) v, int slot) {
     real cs = 0;
-    for (int i = lane; i < A.nefc; i += 64) A.rowS[RS_S * i + 2] = nrow_dot(A, i, v) - A.rowS[RS_S * i];
-    NSYNC();
-    for (int i = lane; i < A.nlead; i += 64) cs += nrow_scalar_cost<real>(A.rmeta[i] & 3, A.rowS[RS_S * i + 2], A.rowS[RS_S * i + 1], A.rowS[RS_S * i + 5]);
+    for (int i = lane; i < A.nlead; i += 64) cs += nrow_scalar_cost<real>(A.rmeta[i] & 3, A.rowS[RS_S * i + slot], A.rowS[RS_S * i + 1], A.rowS[RS_S * i + 5]);
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         if (ch * 64 >= A.ncon) break;
@@ -297,7 +296,7 @@ AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, L
         if (c.head >= 0) {
             real jar[6], f[6], w[6], c1[6], c2[6], cc, s1, s2;
 #pragma unroll
-            for (int j = 0; j < 6; j++) jar[j] = j < c.dim ? A.rowS[RS_S * (c.head + j) + 2] : real(0);
+            for (int j = 0; j < 6; j++) jar[j] = j < c.dim ? A.rowS[RS_S * (c.head + j) + slot] : real(0);
             ncone(c, jar, f, &cc, w, c1, c2, &s1, &s2);
             cs += cc;
         }
@@ -486,15 +485,14 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         }
     }
     // ---- start from the warm start (already in a) or from the smooth acceleration, whichever costs less ----
-    bool jar_ready = false;
+    // (the residuals of both candidates come with the row records; the winner's end up in word 2 for the first iteration)
+    const bool jar_ready = true;
     {
-        // the warm start is evaluated last: if it wins, its residuals J a - aref are already in place for the first iteration
-        const real c1 = ncost<real, NCH>(A, lane, con, A.as);
-        NSYNC();
-        const real c0 = ncost<real, NCH>(A, lane, con, (LDS_PTR(const real))A.a);
-        jar_ready = c0 < c1;
-        if (!jar_ready) {
+        const real c1 = ncost<real, NCH>(A, lane, con, A.as, 8);
+        const real c0 = ncost<real, NCH>(A, lane, con, (LDS_PTR(const real))A.a, 2);
+        if (!(c0 < c1)) {
             for (int k = lane; k < nv; k += 64) A.a[k] = A.as[k];
+            for (int i = lane; i < ne; i += 64) A.rowS[RS_S * i + 2] = A.rowS[RS_S * i + 8];
         }
         NSYNC();
     }

@@ -1411,7 +1411,8 @@ struct Env {
         GSYNC();
         // --- fill rows (one row per lane) ---
         GLB_PTR(real) rJ = rows_();
-        real *rowS = r + ka->lay.rowS, *warm = r + ka->lay.warm, *Minv = r + ka->lay.Minv;
+        real *rowS = r + ka->lay.rowS, *warm = r + ka->lay.warm, *Minv = r + ka->lay.Minv, *asm_ = r + ka->lay.asm_;
+        const bool newton = ka->m.solver == 1;
         int* rowI = ii + ka->lay.rowI;
         real* Lm = r + ka->lay.L;
         const int *bmask = body_dofmask_(), *tadr = tree_dofadr_(), *tnum = tree_dofnum_();
@@ -1565,11 +1566,14 @@ struct Env {
             store_row16(rowsB_() + ROW_S * i, Bv);
             // warm start: force implied by last step's acceleration, f = -D (J qacc_ws - aref), made feasible per row
             const int a0 = tadr[tA], nA = tnum[tA], b0 = tB >= 0 ? tadr[tB] : 0, nB = tB >= 0 ? tnum[tB] : 0;
-            real jw = 0;
+            real jw = 0, jas = 0;      // J . warm start, J . qacc_smooth (the Newton solver's two start candidates)
 #pragma unroll
             for (int k = 0; k < TREE_W; k++) {
-                jw += J[k] * warm[a0 + k < nvm ? a0 + k : nvm];
-                jw += J[TREE_W + k] * warm[b0 + k < nvm ? b0 + k : nvm];   // (b0 = 0 with J = 0 for one-tree rows)
+                const int da = a0 + k < nvm ? a0 + k : nvm, db = b0 + k < nvm ? b0 + k : nvm;   // (b0 = 0 with J = 0 for one-tree rows)
+                jw += J[k] * warm[da];
+                jw += J[TREE_W + k] * warm[db];
+                jas += J[k] * asm_[da];
+                jas += J[TREE_W + k] * asm_[db];
             }
             const real big = real(1e30);
             real lo = -big, hi = big, muinv = 0;
@@ -1583,8 +1587,9 @@ struct Env {
             real f = -(jw - aref) / R;
             f = tmin(tmax(f, lo), hi);
             real* S = rowS + RS_S * i;
-            S[0] = aref; S[1] = R; S[2] = real(1) / (dg + R); S[3] = ns ? real(1) / tmax(dg, real(1e-15)) : real(0);
-            S[4] = lo; S[5] = hi; S[6] = f; S[7] = muinv;
+            // word 2: PGS 1 / (A_rr + R); Newton: residual of the warm start, with that of qacc_smooth in word 8
+            S[0] = aref; S[1] = R; S[2] = newton ? jw - aref : real(1) / (dg + R); S[3] = ns ? real(1) / tmax(dg, real(1e-15)) : real(0);
+            S[4] = lo; S[5] = hi; S[6] = f; S[7] = muinv; S[8] = jas - aref;
             rowI[i] = a0 | (nA << 6) | (tA << 10) | ((b0 | (nB << 6) | ((tB >= 0 ? tB : 0) << 10)) << 13);
             rmeta[i] = (meta & 0xfffff) | ((tA + 1) << 20) | ((tB + 1) << 24);
         }
