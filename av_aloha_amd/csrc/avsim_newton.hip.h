@@ -216,9 +216,27 @@ AVS_DEV void nblock4(const NewtonArgs<real>& A, int lane, int r0, int dim, bool 
     real Jt[6];
 #pragma unroll
     for (int p = 0; p < 6; p++) Jt[p] = (on && p < dim) ? J[ROW_S * p + t] : real(0);
-    const int smax = __any(on && ((ra >> 19) & 15) > 0) ? 16 : 8;       // rows of the second window only if some contact has one
+    const bool two = __any(on && ((ra >> 19) & 15) > 0);               // does some contact of this pass have a second window?
+    const int smax = two ? 16 : 8;
     if (!__any(full)) {
         // top / bottom zone only: C = diag(w)
+        if (!two) {
+            // one-tree contacts: the block is 8 x 8, so the two halves of the 16-lane group share the rows (lane t and lane
+            // t + 8 both hold column t & 7; the upper half takes rows 4..7)
+            const int tc = lane & 7, s0 = (lane & 8) >> 1, gqc = on ? nslot_dof(ra, tc) : -1;
+            real Jc[6];
+#pragma unroll
+            for (int p = 0; p < 6; p++) Jc[p] = __shfl(Jt[p], (lane & 48) | tc, 64);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int s = s0 + u, gp = nslot_dof(ra, s);
+                real acc = 0;
+#pragma unroll
+                for (int p = 0; p < 6; p++) acc += w[p] * __shfl(Jt[p], (lane & 48) | s, 64) * Jc[p];
+                if (on && gp >= 0 && gqc >= 0 && gqc <= gp) __hip_atomic_fetch_add(A.H + gp * (gp + 1) / 2 + gqc, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            return;
+        }
         for (int s = 0; s < smax; s++) {
             const int gp = nslot_dof(ra, s);
             real acc = 0;
