@@ -207,7 +207,7 @@ struct MOff {
 struct Layout {
     int qpos, qvel, ctrl, warm, xpos, xmat, xipos, cdof, gcen, M, L, Minv, bias, fsm, asm_, qacc, fcon, nH, ng, ndl, njv, U, nreal;
     // scratch union U, phase A
-    int cinert, cvel, cacc, cfrc;
+    int cinert, cvel, cacc, cfrc, binert;   // binert: the bodies' own spatial inertias (cinert becomes the composites)
     // phase B
     int cdist, cpos, cnrm, rowS, scr;   // scr: narrow-phase scratch (overlays rowS: 64 result slots of 20 words + 9 box work areas)
     // ints
@@ -962,10 +962,10 @@ struct Env {
             SInert<real> s;
             if (body_tree_()[b] >= 0) body_inertia(ka, xmat, xipos, b, s);
             else { s.m = 0; for (int k = 0; k < 3; k++) s.h[k] = 0; for (int k = 0; k < 6; k++) s.I[k] = 0; }
-            real* o = ci + 10 * b;
-            o[0] = s.m;
-            for (int k = 0; k < 3; k++) o[1 + k] = s.h[k];
-            for (int k = 0; k < 6; k++) o[4 + k] = s.I[k];
+            real *o = ci + 10 * b, *ob = r + ka->lay.binert + 10 * b;    // the second copy survives the composite sums (rne_bias reads it)
+            o[0] = ob[0] = s.m;
+            for (int k = 0; k < 3; k++) o[1 + k] = ob[1 + k] = s.h[k];
+            for (int k = 0; k < 6; k++) o[4 + k] = ob[4 + k] = s.I[k];
         }
         for (int i = lane; i < ka->m.msize; i += G) M[i] = 0;
         GSYNC();
@@ -1093,9 +1093,8 @@ struct Env {
                     for (int q = 0; q < 6; q++) { const real c = cdd[6 * d + q]; a[q] += on ? c : real(0); }
                 }
                 for (int q = 0; q < 6; q++) v[q] = cvel[6 * b + q];
-                SInert<real> si;
-                body_inertia(ka, xmat, xipos, b, si);
-                const real sv[10] = {si.m, si.h[0], si.h[1], si.h[2], si.I[0], si.I[1], si.I[2], si.I[3], si.I[4], si.I[5]};
+                real sv[10];      // the body's spatial inertia about the world origin, left by crb
+                for (int q = 0; q < 10; q++) sv[q] = (r + ka->lay.binert)[10 * b + q];
                 real Ia[6], Iv[6], vIv[6];
                 inert_mul(sv, a, Ia);
                 inert_mul(sv, v, Iv);
@@ -2154,7 +2153,7 @@ struct PhysHost {
         }
         L.U = o;
         int a = o;
-        L.cinert = a; a += 10 * nb; L.cvel = a; a += 6 * nb; L.cacc = a; a += 6 * nb; L.cfrc = a; a += 6 * nb;
+        L.cinert = a; a += 10 * nb; L.binert = a; a += 10 * nb; L.cvel = a; a += 6 * nb; L.cacc = a; a += 6 * nb; L.cfrc = a; a += 6 * nb;
         int bq = o;
         L.cdist = bq; bq += maxcon; L.cpos = bq; bq += 3 * maxcon; L.cnrm = bq; bq += 3 * maxcon;
         bq = (bq + 3) & ~3; L.rowS = bq; L.scr = bq; bq += RS_S * maxefc;
