@@ -1614,11 +1614,25 @@ struct Env {
         if (lane == 0) misc[5] = ngrp;
         GSYNC();
         // couplings A_rs = J_r . B_s (r > s) inside each group, one pair per lane
-        for (int w = lane; w < ngrp * 15; w += G) {
-            int g = w / 15, e = w - 15 * g;
-            int rr = 1;
-            while ((rr + 1) * rr / 2 <= e) rr++;          // e = rr*(rr-1)/2 + ss
-            int ss = e - rr * (rr - 1) / 2;
+        // Under the Newton solver only the noslip sweeps use them, and those never move a contact's normal row: a contact group
+        // then needs the 10 pairs among its friction rows (the 5 pairs with the normal row are stored as zeros)
+        const int nlg = (nlead + GRP_MAX - 1) / GRP_MAX;                  // the groups of leading rows come first
+        const int per_c = newton ? 10 : 15, nitem = ngrp <= nlg ? ngrp * 15 : nlg * 15 + (ngrp - nlg) * per_c;
+        for (int w = lane; w < nitem; w += G) {
+            int g, e, rr = 1, ss;
+            if (w < nlg * 15 || !newton) {
+                g = w / 15; e = w - 15 * g;
+                while ((rr + 1) * rr / 2 <= e) rr++;          // e = rr*(rr-1)/2 + ss
+                ss = e - rr * (rr - 1) / 2;
+            } else {
+                const int wc = w - nlg * 15, e2 = wc % 10;
+                g = nlg + wc / 10;
+                while ((rr + 1) * rr / 2 <= e2) rr++;         // pair (rr, ss) among rows 1..5, shifted down by one
+                ss = e2 - rr * (rr - 1) / 2 + 1;
+                rr += 1;
+                e = rr * (rr - 1) / 2 + ss;
+                if (e2 < 5) gA[16 * g + (e2 + 1) * e2 / 2] = 0;   // (row e2 + 1, normal row)
+            }
             int gi = gI[g], start = gi & 0xffff, cnt = (gi >> 16) & 15;
             real v = 0;
             if (rr < cnt) {
