@@ -132,3 +132,25 @@ def test_rgb_objects_have_their_colours():
     assert red.sum() > 20 and green.sum() > 20
     assert np.all(np.abs(r[red] - 2 * g[red]) <= 2) and np.all(np.abs(g[green] - 2 * r[green]) <= 2)
     sim.close()
+
+
+@pytest.mark.parametrize("task", ["hook_package", "tube_transfer", "insert_peg"])
+def test_rgb_and_depth_other_tasks(task):
+    """Cylinders (hook), spheres (ball of TubeTransfer) and the other box sets through both passes, at the reset pose."""
+    from av_aloha_amd.sim import BatchedSim
+    from test_gpu_configs import poses_for
+    H, W = 60, 80
+    poses = poses_for(task, np.arange(1), 4000)
+    sim = BatchedSim(task, 3, 1, f64=True)
+    e = OrcEnv(task, 3)
+    sim.reset(poses)
+    e.reset(poses[0])
+    cams = ["overhead_cam", "wrist_cam_left", "zed_cam_left"]
+    img = sim.render_rgb(cams, H, W)
+    dep = sim.render_depth(cams, H, W)
+    for ci, cam in enumerate(cams):
+        ref, rdep = e.render_rgb(cam, H, W)
+        compare_rgb(img[0, ci], ref)
+        compare(dep[0, ci], rdep)
+    sim.close()
+    e.close()
