@@ -30,6 +30,19 @@ static thread_local std::string g_create_error;
         }                                                                                            \
     } while (0)
 
+// Every entry point runs on the handle's device and puts the caller's current device back on return (a torch process keeps
+// its own current device; one process per GPU is the intended deployment, several handles per process still work).
+struct DevGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DevGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
 struct avsim {
     int device = 0;
     uint32_t flags = 0;
@@ -289,6 +302,7 @@ int avsim_create(const void* blob, size_t nbytes, int num_envs, int device, uint
     h->N = num_envs;
     h->io_device = flags & AVSIM_IO_DEVICE;
     h->f64 = flags & AVSIM_F64_PHYSICS;
+    DevGuard dev_guard_(device);
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return AVSIM_EHIP; }
     try {
@@ -344,7 +358,7 @@ int avsim_create(const void* blob, size_t nbytes, int num_envs, int device, uint
 
 void avsim_destroy(avsim_t* h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DevGuard dev_guard_(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->phys.destroy();
     h->render.destroy();
@@ -373,20 +387,24 @@ int avsim_set_option(avsim_t* h, const char* name, double value) {
     if (!std::strcmp(name, "kernel_timing")) { h->ktiming = value != 0; return AVSIM_OK; }
     if (!std::strcmp(name, "diffik_iters")) { h->ik.diff_iters = (int)value; return AVSIM_OK; }
     if (!std::strcmp(name, "gradik_iters")) { h->ik.grad_iters = (int)value; return AVSIM_OK; }
-    if (h->phys.set_option(name, value)) return AVSIM_OK;
+    if (h->phys.set_option(name, value)) {
+        if (!std::strcmp(name, "num_joints")) h->nj = (int)value;
+        return AVSIM_OK;
+    }
     h->set_error("avsim_set_option: unknown option '%s'", name);
     return AVSIM_EINVAL;
 }
 
 int avsim_sync(avsim_t* h) {
     if (!h) return AVSIM_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return AVSIM_OK;
 }
 
 int avsim_set_stream(avsim_t* h, void* s) {
     if (!h) return AVSIM_EINVAL;
+    DevGuard dev_guard_(h->device);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     h->stream = (hipStream_t)s;
@@ -396,12 +414,14 @@ int avsim_set_stream(avsim_t* h, void* s) {
 
 int avsim_event_record(avsim_t* h, int slot) {
     if (!h || slot < 0 || slot >= 16) return AVSIM_EINVAL;
+    DevGuard dev_guard_(h->device);
     HIPCHK(h, hipEventRecord(h->ev[slot], h->stream));
     return AVSIM_OK;
 }
 
 int avsim_event_elapsed_ms(avsim_t* h, int a, int b, float* ms) {
     if (!h || !ms || a < 0 || a >= 16 || b < 0 || b >= 16) return AVSIM_EINVAL;
+    DevGuard dev_guard_(h->device);
     HIPCHK(h, hipEventSynchronize(h->ev[b]));
     HIPCHK(h, hipEventElapsedTime(ms, h->ev[a], h->ev[b]));
     return AVSIM_OK;
@@ -409,7 +429,7 @@ int avsim_event_elapsed_ms(avsim_t* h, int a, int b, float* ms) {
 
 int avsim_kernel_time(avsim_t* h, int reset, double* total_ms, int64_t* launches) {
     if (!h) return AVSIM_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     double tot = 0;
     for (size_t i = 0; i + 1 < h->kev_used; i += 2) {
         float ms = 0;
@@ -425,7 +445,7 @@ int avsim_kernel_time(avsim_t* h, int reset, double* total_ms, int64_t* launches
 
 int avsim_observe(avsim_t* h, double* agent_pos, int32_t* reward, uint8_t* success) {
     if (!h) return AVSIM_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     int rc;
     void *dap = nullptr, *drw = nullptr, *dsu = nullptr;
     size_t N = h->N;
@@ -445,7 +465,7 @@ int avsim_observe(avsim_t* h, double* agent_pos, int32_t* reward, uint8_t* succe
 
 int avsim_fk_jac(avsim_t* h, int arm, int n, const double* q, double* T, double* J) {
     if (!h || arm < 0 || arm > 2 || n <= 0 || !q) { if (h) h->set_error("avsim_fk_jac: bad arguments"); return AVSIM_EINVAL; }
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     int nj = h->ik.arm[arm].n, rc;
     const void* dq;
     void *dT = nullptr, *dJ = nullptr;
@@ -468,7 +488,7 @@ int avsim_ik(avsim_t* h, int arm, int controller, int max_iters, int n, const do
         return AVSIM_EINVAL;
     }
     if (controller == 1 && arm == 2) { h->set_error("avsim_ik: GradIK is defined for the 6-DoF manipulators only"); return AVSIM_EINVAL; }
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     int nj = h->ik.arm[arm].n, rc;
     int iters = max_iters > 0 ? max_iters : (controller == 0 ? h->ik.diff_iters : h->ik.grad_iters);
     const void *dq, *dp, *dqt;
@@ -512,7 +532,7 @@ extern "C" {
 
 int avsim_reset(avsim_t* h, const uint8_t* mask, const double* obj_qpos) {
     if (!h || !obj_qpos) { if (h) h->set_error("avsim_reset: obj_qpos is required"); return AVSIM_EINVAL; }
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     return h->f64 ? reset_impl<double>(h, mask, obj_qpos) : reset_impl<float>(h, mask, obj_qpos);
 }
 
@@ -542,7 +562,7 @@ static int step_common(avsim_t* h, const float* d_action, int nsub, double* agen
 
 int avsim_step(avsim_t* h, const float* action, int nsub, double* agent_pos, int32_t* reward, uint8_t* success) {
     if (!h || !action || nsub < 0) { if (h) h->set_error("avsim_step: bad arguments"); return AVSIM_EINVAL; }
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     const void* da;
     int rc;
     if ((rc = h->in(0, action, sizeof(float) * h->N * h->nj, &da))) return rc;
@@ -556,7 +576,7 @@ int avsim_step_cartesian(avsim_t* h, const double* action23, int ik_mode, int ns
         return AVSIM_EINVAL;
     }
     if (h->num_arms != 3) { h->set_error("avsim_step_cartesian: the 23-D Cartesian action drives three arms (sim_env.py:277-282)"); return AVSIM_EINVAL; }
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     const void* da;
     int rc;
     if ((rc = h->in(0, action23, sizeof(double) * h->N * 23, &da))) return rc;
@@ -595,7 +615,7 @@ static int get(avsim_t* h, int slot, double* dst, const void* src, size_t n) {
 
 int avsim_get_state(avsim_t* h, double* qpos, double* qvel, double* ctrl, double* warm) {
     if (!h) return AVSIM_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     size_t N = h->N;
     int rc;
     if ((rc = get(h, 0, qpos, h->d_qpos, N * h->nq))) return rc;
@@ -608,7 +628,7 @@ int avsim_get_state(avsim_t* h, double* qpos, double* qvel, double* ctrl, double
 
 int avsim_set_state(avsim_t* h, const double* qpos, const double* qvel, const double* ctrl, const double* warm) {
     if (!h) return AVSIM_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     size_t N = h->N;
     int rc;
     if ((rc = put(h, 0, qpos, h->d_qpos, N * h->nq))) return rc;
@@ -629,7 +649,7 @@ int avsim_set_qpos(avsim_t* h, const double* qpos) {
 
 int avsim_get_contacts(avsim_t* h, int32_t* ncon, int32_t* pairs, double* dist) {
     if (!h) return AVSIM_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     size_t N = h->N, cap = h->phys.maxcon;
     if (h->io_device) {
         if (ncon) HIPCHK(h, hipMemcpyAsync(ncon, h->phys.d_ncon, N * 4, hipMemcpyDeviceToDevice, h->stream));
@@ -647,7 +667,7 @@ int avsim_get_contacts(avsim_t* h, int32_t* ncon, int32_t* pairs, double* dist) 
 /* debug: per-env cycle counters of the 8 physics phases of the last launch (option "profile_phases"); int64[N][10] */
 int avsim_get_phase_cycles(avsim_t* h, int64_t* out) {
     if (!h || !out || !h->phys.d_prof) return AVSIM_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, h->phys.d_prof, (size_t)h->N * 18 * 8, h->io_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return AVSIM_OK;
@@ -655,7 +675,7 @@ int avsim_get_phase_cycles(avsim_t* h, int64_t* out) {
 
 int avsim_get_diag(avsim_t* h, int32_t* diag) {
     if (!h || !diag) return AVSIM_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     size_t N = h->N;
     if (h->io_device) {
         HIPCHK(h, hipMemcpyAsync(diag, h->phys.d_diag, N * 16, hipMemcpyDeviceToDevice, h->stream));
@@ -675,7 +695,7 @@ extern "C" {
 static int render_images(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, void* out, bool rgb) {
     const char* who = rgb ? "avsim_render_rgb" : "avsim_render_depth";
     if (!h || !cam_ids || !out) { if (h) h->set_error("%s: bad arguments", who); return AVSIM_EINVAL; }
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     int rc;
     void* dout = nullptr;
     const size_t bytes = (rgb ? 3 : sizeof(float)) * (size_t)h->N * ncam * height * width;
@@ -703,7 +723,7 @@ int avsim_camera_count(const avsim_t* h) { return h ? h->render.m.ncam : 0; }
 int avsim_reward_from_pairs(avsim_t* h, const int32_t* geom_pairs, int nsets, int cap, int32_t* latch, int32_t* reward) {
     if (!h || (!geom_pairs && cap > 0) || !reward || nsets < 0 || cap < 0) { if (h) h->set_error("avsim_reward_from_pairs: bad arguments"); return AVSIM_EINVAL; }
     if (nsets == 0) return AVSIM_OK;
-    HIPCHK(h, hipSetDevice(h->device));
+    DevGuard dev_guard_(h->device);
     int *dp = nullptr, *dl = nullptr, *dr = nullptr;
     const size_t pb = sizeof(int) * (size_t)nsets * (cap ? cap : 1) * 2, nb = sizeof(int) * (size_t)nsets;
     HIPCHK(h, hipMalloc(&dp, pb + 2 * nb));

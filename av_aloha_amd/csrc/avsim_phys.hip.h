@@ -1952,6 +1952,7 @@ struct PhysHost {
     int* d_img_int = nullptr;
     void* d_kargs = nullptr;        // KArgs<float|double> in device memory
     bool kargs_dirty = true;
+    unsigned attr_done = 0;         // kernel instances whose LDS-size attribute this handle has set (bit WPB, bit 0 = f64)
     // device pointer that converts to the plain and to the global-address-space pointer types
     template <typename T>
     struct DevPtr {
@@ -2264,6 +2265,7 @@ struct PhysHost {
         if (n == "newton_iters") { if (v < 1 || v > 100) return false; mf.newton_iters = md.newton_iters = (int)v; return true; }
         if (n == "newton_tol") { if (v < 0) return false; mf.newton_tol = (float)v; md.newton_tol = v; return true; }
         if (n == "export_contacts") { export_contacts = v != 0; return true; }
+        if (n == "num_joints") { if (v != 14 && v != 21) return false; mf.nj = md.nj = (int)v; return true; }
         if (n == "waves_per_block") { int x = (int)v; if (x >= 0 && x <= 8) { wpb_override = x; return true; } return false; }
         if (n == "profile_phases") {
             if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * 18, 0));
@@ -2288,11 +2290,12 @@ struct PhysHost {
         int epb = WPB;
         size_t shmem = (size_t)lay.bytes_per_env * epb + (size_t)moff.nreal * sizeof(real) + (size_t)moff.nint * 4;
         auto kern = k_phys<real, G, WPB>;
-        static bool attr_set = false;
-        if (!attr_set) {
+        // once per handle (= per device) and kernel instance: a second handle on another GPU of the same process sets its own
+        const unsigned attr_bit = 1u << (sizeof(real) == 8 ? 0 : WPB);
+        if (!(attr_done & attr_bit)) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); return -3; }
-            attr_set = true;
+            attr_done |= attr_bit;
         }
         if (shmem > 160 * 1024) { err = "per-block LDS exceeds 160 KiB; lower maxefc/maxcon or raise the group size"; return -1; }
         dim3 grid((N + epb - 1) / epb);

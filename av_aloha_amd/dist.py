@@ -11,17 +11,23 @@ def shard_ids(rank: int, world: int, envs_per_rank: int) -> np.ndarray:
     return np.arange(rank * envs_per_rank, (rank + 1) * envs_per_rank)
 
 
-def gather_episode_stats(ret, success, dist=None):
-    """All-gather (return f32, success i32) of the local envs into rank-ordered [world*N] tensors on every rank.
-    `ret` / `success` are torch tensors on the rank's device; `dist` is torch.distributed (None = single process)."""
+def _all_gather(t, dist):
     import torch
-    pack = torch.stack([ret.to(torch.float32), success.to(torch.float32)], dim=1).contiguous()
+    dev = t.device
+    if dist.get_backend() == "gloo" and t.is_cuda:      # gloo moves host memory only (CPU tests, one-GPU debugging)
+        t = t.cpu()
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return torch.cat(out, dim=0).to(dev)
+
+
+def gather_episode_stats(ret, success, dist=None):
+    """All-gather of the local envs' (return f32, success i32) into rank-ordered [world*N] tensors on every rank: one
+    collective per dtype, sendcount N words each.  `ret` / `success` are torch tensors on the rank's
+    device; `dist` is torch.distributed (None = single process)."""
+    import torch
+    ret = ret.to(torch.float32).contiguous()
+    success = success.to(torch.int32).contiguous()
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return pack[:, 0].clone(), pack[:, 1].to(torch.int32)
-    dev = pack.device
-    if dist.get_backend() == "gloo" and pack.is_cuda:      # gloo moves host memory only (CPU tests, one-GPU debugging)
-        pack = pack.cpu()
-    out = [torch.empty_like(pack) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, pack)
-    allp = torch.cat(out, dim=0).to(dev)
-    return allp[:, 0].contiguous(), allp[:, 1].to(torch.int32)
+        return ret.clone(), success.clone()
+    return _all_gather(ret, dist), _all_gather(success, dist)

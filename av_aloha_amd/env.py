@@ -30,6 +30,12 @@ except Exception:  # pragma: no cover - gymnasium is absent in the build image
     _EnvBase = object
 
 
+class PhysicsError(RuntimeError):
+    """The simulation state of an env became NaN / Inf / larger than 1e6 during a step: the counterpart of
+    dm_control.rl.control.PhysicsError, which the reference's physics.step (env.py:218) raises on MuJoCo's bad-state
+    warnings.  Raised by single-env facades; batches report per-env flags instead (info["diverged"], truncated)."""
+
+
 class _Box:
     """Minimal stand-in for gymnasium.spaces.Box when gymnasium is not installed."""
 
@@ -107,6 +113,7 @@ class GuidedVisionEnv(_EnvBase):
         self.observation_height = observation_height
         self.observation_width = observation_width
         self.num_joints = 14 if num_arms == 2 else 21
+        self._device, self._f64, self._options, self._model_arms = device, f64, options, num_arms
         self.sim = BatchedSim(self.task, num_arms, self.num_envs, device=device, f64=f64, options=options)
         self.max_reward = self.sim.max_reward
         box = spaces.Box if spaces is not None else _Box
@@ -136,6 +143,15 @@ class GuidedVisionEnv(_EnvBase):
     def _obs(self):
         return {"pixels": self._pixels(), "agent_pos": self._squeeze(self._agent_pos).copy()}
 
+    def _check_diverged(self):
+        """Divergence flag of the last step (bit 0 of diag[3], include/avsim.h): the library has put such an env back to the home
+        pose with the model's default object poses, so its rewards from here on belong to a different episode."""
+        div = (self.sim.diag()[:, 3] & 1).astype(bool)
+        if self.num_envs == 1 and div[0]:
+            raise PhysicsError("the simulation state diverged (NaN / Inf / > 1e6) during the step; the env was put back to the "
+                               "home pose -- call reset()")
+        return div
+
     def _refresh_agent_pos(self):
         ap = np.empty((self.num_envs, self.num_joints))
         h = self.sim.h
@@ -155,16 +171,18 @@ class GuidedVisionEnv(_EnvBase):
     def step(self, action):
         a = np.asarray(action, dtype=np.float32).reshape(self.num_envs, self.num_joints)
         self._agent_pos, self._reward, success = self.sim.step(a, SIM_PHYSICS_ENV_STEP_RATIO)
+        diverged = self._check_diverged()
         reward = self._squeeze(self._reward)
         if self.num_envs == 1:
-            reward = int(reward)
-        info = {"is_success": self._squeeze(success) if self.num_envs > 1 else bool(success[0])}
-        return self._obs(), reward, False, False, info
+            return self._obs(), int(reward), False, False, {"is_success": bool(success[0])}
+        # batch: a diverged env is truncated (its episode cannot continue) and flagged; the others are unaffected
+        return self._obs(), reward, np.zeros(self.num_envs, dtype=bool), diverged, {"is_success": success, "diverged": diverged}
 
     def step_action(self, action):
         """env.py:255-269: apply the action and advance the physics without computing obs / reward."""
         a = np.asarray(action, dtype=np.float32).reshape(self.num_envs, self.num_joints)
         self._agent_pos, _, _ = self.sim.step(a, SIM_PHYSICS_ENV_STEP_RATIO, want_reward=False)
+        self._check_diverged()
 
     def get_obs(self):
         return self._obs()
@@ -198,10 +216,29 @@ class GuidedVisionEnv(_EnvBase):
         img = self.sim.render_depth(list(cameras), h, w)
         return {c: self._squeeze(img[:, i]) for i, c in enumerate(cameras)}
 
-    def hide_middle_arm(self):
-        raise NotImplementedError("choose num_arms at construction (2-arm models carry the hidden middle arm, env.py:394-395)")
+    def _swap_model(self, arms):
+        """The base position of the camera arm is a constant of the compiled model, so moving it (env.py:394-398) means
+        continuing on the other blob of the same task: identical state layout, the arm parked at (0, -2.4, -0.4) or in place.
+        The state carries over; action / agent_pos keep this env's width."""
+        if self._model_arms == arms:
+            return
+        q, v, c, w = self.sim.get_state()
+        old = self.sim
+        self.sim = BatchedSim(self.task, arms, self.num_envs, device=self._device, f64=self._f64, options=self._options)
+        self.sim.set_option("num_joints", self.num_joints)
+        self.sim.nj = self.sim.h.nj = self.num_joints
+        self.sim.set_state(q, v, c, w)
+        old.close()
+        self._model_arms = arms
+        self._refresh_agent_pos()
 
-    show_middle_arm = hide_middle_arm
+    def hide_middle_arm(self):
+        """env.py:394-395: park the camera arm's base at (0, -2.4, -0.4)."""
+        self._swap_model(2)
+
+    def show_middle_arm(self):
+        """env.py:397-398: back to its place."""
+        self._swap_model(3)
 
     def close(self):
         if getattr(self, "sim", None) is not None:

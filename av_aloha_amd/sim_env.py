@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _ffi
 from .constants import SIM_PHYSICS_ENV_STEP_RATIO
-from .env import _TASK_OF_SUBSTRING, sample_object_poses
+from .env import _TASK_OF_SUBSTRING, PhysicsError, sample_object_poses
 from .sim import BatchedSim
 
 
@@ -63,7 +63,6 @@ class GuidedVisionEnv:
         self._dadr = md["obs_dofadr"].astype(np.int64)
         lo, hi = md["grip_range"]
         self._grip_lo, self._grip_span = float(lo), float(hi - lo)
-        self._home_obj = md["qpos_home"][md["objects_qposadr"][0]:].reshape(-1, 7).copy()
 
     # ---- helpers -----------------------------------------------------------------------------------
     def _sq(self, a):
@@ -109,8 +108,8 @@ class GuidedVisionEnv:
 
     # ---- gym-style surface (sim_env.py:220-312) ------------------------------------------------------
     def reset(self, seed=None):
-        if seed is not None:
-            np.random.seed(seed)
+        # sim_env.py:220-250: `seed` only reaches gym's np_random, which nothing reads; the object poses come from the GLOBAL
+        # numpy RNG (env.py:482 ...) and therefore do not depend on it -- kept that way
         poses = np.stack([sample_object_poses(self.task) for _ in range(self.num_envs)])
         self.sim.reset(poses)
         return self.get_obs(), "Resetting arms..."
@@ -118,15 +117,30 @@ class GuidedVisionEnv:
     def set_qpos(self, qpos):
         self.sim.set_qpos(np.asarray(qpos, dtype=np.float64).reshape(self.num_envs, self.sim.nq))
 
+    def _truncated(self):
+        """Divergence flags of the last step: a single env raises (dm_control's PhysicsError in the reference), a batch returns
+        them as its `truncated` array."""
+        div = (self.sim.diag()[:, 3] & 1).astype(bool)
+        if self.num_envs == 1:
+            if div[0]:
+                raise PhysicsError("the simulation state diverged during the step; the env was put back to the home pose")
+            return False
+        return div
+
     def step_joints(self, action):
         a = np.asarray(action, dtype=np.float32).reshape(self.num_envs, 21)
         self.sim.step(a, SIM_PHYSICS_ENV_STEP_RATIO, want_reward=False)
-        return self.get_obs(), 0, False, False, ""
+        return self.get_obs(), 0, False, self._truncated(), ""
 
     def step(self, action):
         a = np.asarray(action, dtype=np.float64).reshape(self.num_envs, 23)
         self.sim.step_cartesian(a, _ffi.IK_REFERENCE, SIM_PHYSICS_ENV_STEP_RATIO)
-        return self.get_obs(), 0, False, False, ""
+        return self.get_obs(), 0, False, self._truncated(), ""
+
+    def hide_middle_arm(self):
+        """replay_sim_episode.py:59 calls this on the Cartesian env; the reference class does not define it there either (the gym
+        flavour does, env.py:394-395).  This env always simulates three arms."""
+        raise NotImplementedError("the Cartesian-action env drives three arms; use the gym flavour with num_arms=2 for a parked camera arm")
 
     def close(self):
         if getattr(self, "sim", None) is not None:

@@ -64,6 +64,8 @@ int avsim_dims(const avsim_t* h, int32_t dims[AVSIM_NDIMS]);
  *   "solver"            0 PGS (BASELINE north_star), 1 Newton (MuJoCo's default, what the reference runs; default)
  *   "pgs_iters"         Gauss-Seidel sweeps of the PGS solver (default 20); "newton_iters" cap (default 30), "newton_tol"
  *   "maxefc", "maxcon"  constraint rows / contacts kept per env (per-task defaults 176-336 / 48-72); re-sizes the records
+ *   "num_joints"        14 | 21: width of the action / agent_pos rows, whatever the blob's arm count (a 3-arm env whose camera
+ *                       arm was parked by hide_middle_arm, env.py:394-395, keeps its 21-D action on the 2-arm model)
  *   "waves_per_block"   envs per workgroup, 0 = as many as fit in 160 KiB of LDS (<= 8)
  *   "export_contacts"   0 skips the per-step contact export (avsim_get_contacts); "kernel_timing" 1 brackets every physics
  *                       launch with HIP events (avsim_kernel_time); "profile_phases" 1 enables avsim_get_phase_cycles */

@@ -4,7 +4,7 @@ than four vertices), the device's contact list after a forward pass must equal t
 order, distances to 1e-12 (f64 mode: same expressions, same tie-breaks).  When a clipped polygon has more than four vertices
 the four kept points are chosen by comparisons (farthest point, largest cross product) that are ties up to rounding for
 symmetric polygons; the device contracts a*b+c into FMAs and gcc does not, so a few percent of such poses keep a different
-vertex: same count, same pairs, one distance differs (tests/dbg_boxbox.py lists them)."""
+vertex: same count, same pairs, one distance differs (tools/dbg_boxbox.py lists them)."""
 import ctypes as C
 
 import numpy as np

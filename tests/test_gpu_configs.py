@@ -25,21 +25,9 @@ def poses_for(task, gids, seed0):
 
 
 def walk_actions(md, gids, T, nj, seed0, close_grippers=False):
-    """Config 4's smooth random walk: default_rng(seed0 + global env id), sigma 0.02 rad per step, clipped to ctrlrange."""
-    h = md["qpos_home"]
-    home = np.concatenate([h[:6], [1.0], h[8:14], [1.0], h[16:23]])[:nj]
-    lo, hi = md["act_ctrlrange"].reshape(-1, 2)[:nj].T.copy()
-    lo[[6, 13]], hi[[6, 13]] = 0.0, 1.0
-    acts = np.empty((T, len(gids), nj), dtype=np.float32)
-    for k, g in enumerate(gids):
-        rng = np.random.default_rng(seed0 + int(g))
-        a = home.copy()
-        for t in range(T):
-            a = np.clip(a + rng.normal(scale=0.02, size=nj), lo, hi)
-            if close_grippers:
-                a[6] = a[13] = 0.0 if t >= 2 else 1.0
-            acts[t, k] = a
-    return acts
+    """Config 4's smooth random walk (av_aloha_amd/workloads.py, the generator bench.py --config 4 uploads)."""
+    from av_aloha_amd.workloads import walk_actions as w
+    return w(md["qpos_home"], md["act_ctrlrange"], gids, T, nj, seed0, close_grippers)
 
 
 def rollout(task, na, gids, T, seed_pose, seed_act, **kw):

@@ -45,7 +45,7 @@ def test_cartesian_step_and_obs_layout_match_the_oracle():
         a[9] -= 0.008 * (t + 1)
         a[18] += 0.005 * (t + 1)
         obs, rew, term, trunc, info = env.step(np.repeat(a[None], 2, 0))
-        assert rew == 0 and term is False and trunc is False and info == ""
+        assert rew == 0 and term is False and not np.any(trunc) and info == ""
         # the oracle runs its own IK on its own measured joints ...
         e.L.orc_cart_to_ctrl(e.dptr, dp(np.ascontiguousarray(a)), 0, dp(a21))
         dev21 = obs["control"][0].copy()                 # the device's command in action-21 form (grippers normalised)

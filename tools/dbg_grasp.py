@@ -1,6 +1,7 @@
 """Debug: scripted top-down grasp-and-lift of the needle by the right arm (BASELINE config 3 flavour)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from av_aloha_amd.sim_env import make_sim_env
 

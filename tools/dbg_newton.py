@@ -2,6 +2,7 @@
 import sys, time
 import numpy as np
 sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from orc_env import OrcEnv
 from test_oracle_physics import OBJ, home_action, model_dict
 from test_gpu_physics import actions_wiggle, make

@@ -1,4 +1,4 @@
-"""Debug helper: writes colour images of one env's cameras as PNG files (tests/dbg_render_png.py out_dir [task])."""
+"""Debug helper: writes colour images of one env's cameras as PNG files (tools/dbg_render_png.py out_dir [task])."""
 import struct
 import sys
 import zlib
@@ -18,6 +18,7 @@ def write_png(path, img):
 
 if __name__ == "__main__":
     sys.path.insert(0, ".")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
     from av_aloha_amd.env import make
     out = sys.argv[1]
     task = sys.argv[2] if len(sys.argv) > 2 else "SlotInsertion"

@@ -1,6 +1,7 @@
 """Soak run (debug aid, GPU box): every task x arm count, random-walk actions with gripper toggles, diagnostics per task."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from av_aloha_amd.sim import BatchedSim
 from test_gpu_configs import poses_for, walk_actions

@@ -1,6 +1,7 @@
 """Experiment: throughput vs waves (envs) per block when the LDS record is made small enough (home-pose scene)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from av_aloha_amd.sim import BatchedSim
 from test_oracle_physics import OBJ, home_action, model_dict

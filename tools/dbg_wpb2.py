@@ -1,6 +1,7 @@
 """Experiment: time of ONE round (one block per CU) vs waves per block."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from av_aloha_amd.sim import BatchedSim
 from test_oracle_physics import OBJ, home_action, model_dict

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tests/prof_counters.sh <outdir> [bench args]; PMC passes kept separate from --kernel-trace/--stats runs
+# usage: tools/prof_counters.sh <outdir> [bench args]; PMC passes kept separate from --kernel-trace/--stats runs
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT

@@ -1,6 +1,7 @@
 """Per-phase cycle breakdown of the physics kernel (debug aid; run on the GPU box)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from av_aloha_amd.sim import BatchedSim
 from test_oracle_physics import OBJ, home_action, model_dict

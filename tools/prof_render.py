@@ -1,6 +1,7 @@
 """Timing of the depth renderer at BASELINE config 5 sizes (debug aid; run on the GPU box)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import torch
 from av_aloha_amd import _ffi

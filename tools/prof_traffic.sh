@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM-side traffic of k_phys per launch: FETCH_SIZE and WRITE_SIZE in separate PMC passes (usage: tests/prof_traffic.sh <tag>)
+# HBM-side traffic of k_phys per launch: FETCH_SIZE and WRITE_SIZE in separate PMC passes (usage: tools/prof_traffic.sh <tag>)
 tag=${1:-x}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
