@@ -17,18 +17,32 @@ def _stale(target, sources):
 
 
 def build_hip(force=False, verbose=False):
-    srcs = [os.path.join(SRC, f) for f in sorted(os.listdir(SRC))] + [os.path.join(ROOT, "include", "avsim.h")]
+    """hipcc --offload-arch=gfx950: avsim_api.hip (C-ABI, f32 product kernels, IK, render) and avsim_phys_f64.hip (the f64 parity
+    kernel, -ffp-contract=off so that it rounds like the oracle) compiled side by side, linked into libavsim.so."""
+    srcs = [os.path.join(SRC, f) for f in sorted(os.listdir(SRC)) if not f.endswith(".o")] + [os.path.join(ROOT, "include", "avsim.h")]
     if not force and not _stale(LIB, srcs):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
-           # f32 divide / sqrt through v_rcp / v_rsq (~1 ulp) instead of the correctly rounded 10-instruction sequences; the f64
-           # parity mode is unaffected and the f32 tolerances of tests/test_gpu_physics.py are stated against the f64 oracle
-           "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-           "-o", LIB, os.path.join(SRC, "avsim_api.hip")]
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-c"]
+    units = [
+        # f32 divide / sqrt through v_rcp / v_rsq (~1 ulp) instead of the correctly rounded 10-instruction sequences; the f64
+        # parity mode is unaffected and the f32 tolerances of tests/test_gpu_physics.py are stated against the f64 oracle
+        ("avsim_api", ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]),
+        ("avsim_phys_f64", ["-ffp-contract=off"]),
+    ]
+    procs = []
+    for name, extra in units:
+        cmd = common + extra + ["-o", os.path.join(SRC, name + ".o"), os.path.join(SRC, name + ".hip")]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB] + [os.path.join(SRC, n + ".o") for n, _ in units]
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link)
     return LIB
 
 

@@ -23,10 +23,21 @@ struct Shape {
     T lc[3], lh[3]; // local bounding box: centre and half extents in the geom frame
 };
 
+// Margins of the discrete choices among candidates that are equal in exact arithmetic (support vertices of a face, the vertices of a
+// clipped polygon on an edge parallel to the base line, ...): a later candidate replaces the incumbent only when it is better by
+// more than rounding noise, so both sides of a parity comparison (f64 device, f64 oracle, and mostly the f32 product kernel too)
+// make the same choice although their inputs differ in the last bits (kinematic chains are multiplied out in different orders).
+template <typename T> struct TieTol;
+template <> struct TieTol<double> { static constexpr double rel = 1e-9, len = 1e-12; };
+template <> struct TieTol<float> { static constexpr float rel = 1e-5f, len = 1e-7f; };
+
 template <typename T>
 AVS_DEV void support(const Shape<T>& s, const T* d, T* out) {
     T l[3], p[3] = {0, 0, 0};
     mulmatT(s.mat, d, l);
+    // a direction component that is zero up to rounding (the direction is normal to a box face / a cylinder cap: every point of
+    // that face supports it) resolves to the + corner / the cap centre instead of following the sign of the noise
+    const T lz = TieTol<T>::rel * (fabs(l[0]) + fabs(l[1]) + fabs(l[2]));
     switch (s.type) {
         case G_SPHERE: {
             T n = sqrt(dot3(l, l));
@@ -34,22 +45,26 @@ AVS_DEV void support(const Shape<T>& s, const T* d, T* out) {
             break;
         }
         case G_BOX:
-            p[0] = l[0] >= 0 ? s.size[0] : -s.size[0];
-            p[1] = l[1] >= 0 ? s.size[1] : -s.size[1];
-            p[2] = l[2] >= 0 ? s.size[2] : -s.size[2];
+            p[0] = l[0] >= -lz ? s.size[0] : -s.size[0];
+            p[1] = l[1] >= -lz ? s.size[1] : -s.size[1];
+            p[2] = l[2] >= -lz ? s.size[2] : -s.size[2];
             break;
         case G_CYLINDER: {
             T n = sqrt(l[0] * l[0] + l[1] * l[1]);
-            if (n > T(0)) { T k = s.size[0] / n; p[0] = k * l[0]; p[1] = k * l[1]; }
-            p[2] = l[2] >= 0 ? s.size[1] : -s.size[1];
+            if (n > lz) { T k = s.size[0] / n; p[0] = k * l[0]; p[1] = k * l[1]; }
+            p[2] = l[2] >= -lz ? s.size[1] : -s.size[1];
             break;
         }
         default: {
+            // the vertex with the largest projection; a later vertex must beat the best so far by a margin (TieTol: a rounding-level
+            // fraction of |l| x 0.1 m), so that the vertices of a face the direction is normal to -- equal projections up to
+            // rounding -- always resolve to the lowest index, on the device and in the oracle alike
             int best = 0;
             T bd = T(-1e30);
+            const T tie = TieTol<T>::rel * T(0.1) * (fabs(l[0]) + fabs(l[1]) + fabs(l[2]));
             for (int i = 0; i < s.nh; i++) {
                 T v = s.hull[3 * i] * l[0] + s.hull[3 * i + 1] * l[1] + s.hull[3 * i + 2] * l[2];
-                if (v > bd) { bd = v; best = i; }
+                if (v > bd + tie) { bd = v; best = i; }
             }
             p[0] = s.hull[3 * best]; p[1] = s.hull[3 * best + 1]; p[2] = s.hull[3 * best + 2];
         }
@@ -254,7 +269,9 @@ AVS_DEV int sphere_box(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T*
     return 1;
 }
 
+#ifndef AVS_LDS
 #define AVS_LDS(T) __attribute__((address_space(3))) T*
+#endif
 
 // select component k of a 3-vector / column k of a row-major 3x3 without dynamic indexing (keeps data in registers)
 template <typename T> AVS_DEV T sel3(const T* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
@@ -429,21 +446,23 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, AVS
     int keep[4], nk = 0;
     if (m <= 4) { for (int q = 0; q < m; q++) keep[nk++] = q; }
     else {
+        // ties are structural here (equal depths on a flat contact; two vertices of an edge parallel to the base line have equal
+        // cross products): a later vertex wins only by more than the TieTol margins
         int i0 = 0;
-        for (int q = 1; q < m; q++) if (dep[q] > dep[i0]) i0 = q;
+        for (int q = 1; q < m; q++) if (dep[q] > dep[i0] + TieTol<T>::len) i0 = q;
         int i1 = i0;
         T bd = -1;
         for (int q = 0; q < m; q++) {
             T dx = tmp[3 * q + a1] - tmp[3 * i0 + a1], dy = tmp[3 * q + a2] - tmp[3 * i0 + a2], dd = dx * dx + dy * dy;
-            if (dd > bd) { bd = dd; i1 = q; }
+            if (dd > bd + TieTol<T>::rel * fabs(bd)) { bd = dd; i1 = q; }
         }
         T ex = tmp[3 * i1 + a1] - tmp[3 * i0 + a1], ey = tmp[3 * i1 + a2] - tmp[3 * i0 + a2];
         int i2 = -1, i3 = -1;
         T mx = T(1e-18), mn = T(-1e-18);
         for (int q = 0; q < m; q++) {
             T cr = ex * (tmp[3 * q + a2] - tmp[3 * i0 + a2]) - ey * (tmp[3 * q + a1] - tmp[3 * i0 + a1]);
-            if (cr > mx) { mx = cr; i2 = q; }
-            if (cr < mn) { mn = cr; i3 = q; }
+            if (cr > mx + TieTol<T>::rel * fabs(mx)) { mx = cr; i2 = q; }
+            if (cr < mn - TieTol<T>::rel * fabs(mn)) { mn = cr; i3 = q; }
         }
         keep[nk++] = i0; keep[nk++] = i1;
         if (i2 >= 0) keep[nk++] = i2;
@@ -665,21 +684,23 @@ __device__ int box_box16(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, A
     if (m <= 4) { for (int q = 0; q < m; q++) keep[nk++] = q; }
     else {
         // rare (more than four polygon vertices): every lane replays the serial selection on the LDS copy
+        // ties are structural here (equal depths on a flat contact; two vertices of an edge parallel to the base line have equal
+        // cross products): a later vertex wins only by more than the TieTol margins
         int i0 = 0;
-        for (int q = 1; q < m; q++) if (dep[q] > dep[i0]) i0 = q;
+        for (int q = 1; q < m; q++) if (dep[q] > dep[i0] + TieTol<T>::len) i0 = q;
         int i1 = i0;
         T bd = -1;
         for (int q = 0; q < m; q++) {
             T dx = tmp[3 * q + a1] - tmp[3 * i0 + a1], dy = tmp[3 * q + a2] - tmp[3 * i0 + a2], dd = dx * dx + dy * dy;
-            if (dd > bd) { bd = dd; i1 = q; }
+            if (dd > bd + TieTol<T>::rel * fabs(bd)) { bd = dd; i1 = q; }
         }
         T ex = tmp[3 * i1 + a1] - tmp[3 * i0 + a1], ey = tmp[3 * i1 + a2] - tmp[3 * i0 + a2];
         int i2 = -1, i3 = -1;
         T mx = T(1e-18), mn = T(-1e-18);
         for (int q = 0; q < m; q++) {
             T cr = ex * (tmp[3 * q + a2] - tmp[3 * i0 + a2]) - ey * (tmp[3 * q + a1] - tmp[3 * i0 + a1]);
-            if (cr > mx) { mx = cr; i2 = q; }
-            if (cr < mn) { mn = cr; i3 = q; }
+            if (cr > mx + TieTol<T>::rel * fabs(mx)) { mx = cr; i2 = q; }
+            if (cr < mn - TieTol<T>::rel * fabs(mn)) { mn = cr; i3 = q; }
         }
         keep[nk++] = i0; keep[nk++] = i1;
         if (i2 >= 0) keep[nk++] = i2;

@@ -5,7 +5,9 @@
 namespace avs {
 
 #define AVS_DEV __device__ __forceinline__
+#ifndef GLB_PTR
 #define GLB_PTR(T) __attribute__((address_space(1))) T*   // global memory, so that loads are global_load, not flat_load
+#endif
 
 template <typename T> AVS_DEV T dot3(const T* a, const T* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 template <typename T> AVS_DEV void cross3(const T* a, const T* b, T* c) {

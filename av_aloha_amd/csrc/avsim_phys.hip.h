@@ -658,6 +658,7 @@ AVS_DEV int reward_from_flags(int f, int t, int* latch) {
     return rw;
 }
 // get_reward on explicit contact lists (one thread per list): geom id pairs int[n][cap][2], -1 = unused slot
+#ifndef AVSIM_TU_F64
 __global__ void k_reward_pairs(GLB_PTR(const int) geom_class, int ngeom, int task_id, const int* __restrict__ pairs, int n, int cap, int* __restrict__ latch, int* __restrict__ reward) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -671,6 +672,7 @@ __global__ void k_reward_pairs(GLB_PTR(const int) geom_class, int ngeom, int tas
     reward[i] = reward_from_flags(f, task_id, &l);
     if (latch) latch[i] = l;
 }
+#endif
 
 
 template <typename real, int G>
@@ -1930,6 +1932,13 @@ __global__ void __launch_bounds__(64 * WPB) k_phys(KPtr<real> ka, const real* __
 // ------------------------------------------------------------------------------------------------
 // host side: device model image, LDS layout, launch
 // ------------------------------------------------------------------------------------------------
+struct PhysHost;
+// k_phys<double> (AVSIM_F64_PHYSICS, the parity mode): defined in avsim_phys_f64.hip, which is compiled with -ffp-contract=off so
+// that the device evaluates every expression with the roundings of the oracle (oracle/Makefile: -ffp-contract=off) -- the
+// narrow phase's support-vertex and clipping tie-breaks then fall the same way on both sides
+int phys_launch_f64(PhysHost& ph, hipStream_t st, int nsub, const float* action, void* qpos, void* qvel, void* ctrl, void* warm, int* latch,
+                    double* agent, int32_t* reward, uint8_t* success, std::string& err);
+
 struct PhysHost {
     int maxcon = 48, maxefc = 144, pgs_iters = 20, group = 64, export_contacts = 1, force_reward = 0, wpb_override = 0;
     bool f64 = false;
@@ -2314,13 +2323,12 @@ struct PhysHost {
         return 0;
     }
 
+#ifndef AVSIM_TU_F64
     int launch(hipStream_t st, int N_, int nsub, const float* action, int nj, void* qpos, void* qvel, void* ctrl, void* warm, int* latch,
                double* agent, int32_t* reward, uint8_t* success, std::string& err) {
         (void)N_; (void)nj;
-        if (f64) {
-            // double precision doubles the LDS record; one env per wave only
-            return launch_t<double, 64, 1>(st, md, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
-        }
+        // the double-precision kernel lives in its own translation unit (avsim_phys_f64.hip), compiled without FMA contraction
+        if (f64) return phys_launch_f64(*this, st, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
         // as many envs (wavefronts) per block as fit next to one copy of the tables in 160 KiB, at most 4 (one per SIMD)
         size_t tables = (size_t)moff.nreal * 4 + (size_t)moff.nint * 4;
         int wpb = (int)((160 * 1024 - tables) / (size_t)lay.bytes_per_env);
@@ -2334,6 +2342,7 @@ struct PhysHost {
         if (wpb >= 2) return launch_t<float, 64, 2>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
         return launch_t<float, 64, 1>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
     }
+#endif
 };
 
 }  // namespace avs

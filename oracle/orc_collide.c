@@ -32,9 +32,15 @@ static void cross3(const double* a, const double* b, double* c) {
 static void sub3(const double* a, const double* b, double* c) { c[0] = a[0] - b[0]; c[1] = a[1] - b[1]; c[2] = a[2] - b[2]; }
 static double normalize3(double* a) {
     double n = sqrt(dot3(a, a));
-    if (n > 0) { a[0] /= n; a[1] /= n; a[2] /= n; }
+    if (n > 0) { double i = 1.0 / n; a[0] *= i; a[1] *= i; a[2] *= i; } /* one reciprocal, as the device kernel does */
     return n;
 }
+/* Margins of the discrete choices among candidates that are equal in exact arithmetic (support vertices of a face the direction
+ * is normal to, vertices of a clipped polygon on an edge parallel to the base line, equal depths of a flat contact): a later
+ * candidate replaces the incumbent only when it is better by more than rounding noise.  Same rule and constants as the device
+ * (avsim_collide.hip.h TieTol<double>), so that both sides choose alike although their inputs differ in the last bits. */
+#define TIE_REL 1e-9
+#define TIE_LEN 1e-12
 static void mulmatT(const double* R, const double* v, double* o) { /* o = R^T v */
     double t0 = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], t1 = R[1] * v[0] + R[4] * v[1] + R[7] * v[2],
            t2 = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
@@ -50,27 +56,31 @@ static void mulmat(const double* R, const double* v, double* o) { /* o = R v */
 static void support(const shape* s, const double* d, double* out) {
     double l[3], p[3] = {0, 0, 0};
     mulmatT(s->mat, d, l);
+    /* a component that is zero up to rounding (direction normal to a box face / a cylinder cap: every point of that face is a
+       support point) resolves to the + corner / the cap centre instead of following the sign of the noise */
+    const double lz = TIE_REL * (fabs(l[0]) + fabs(l[1]) + fabs(l[2]));
     switch (s->type) {
         case ORC_SPHERE: {
             double n = sqrt(dot3(l, l));
-            if (n > 0) for (int i = 0; i < 3; i++) p[i] = s->size[0] * l[i] / n;
+            if (n > 0) { double k = s->size[0] / n; p[0] = k * l[0]; p[1] = k * l[1]; p[2] = k * l[2]; }
             break;
         }
         case ORC_BOX:
-            for (int i = 0; i < 3; i++) p[i] = l[i] >= 0 ? s->size[i] : -s->size[i];
+            for (int i = 0; i < 3; i++) p[i] = l[i] >= -lz ? s->size[i] : -s->size[i];
             break;
         case ORC_CYLINDER: {
             double n = sqrt(l[0] * l[0] + l[1] * l[1]);
-            if (n > 0) { p[0] = s->size[0] * l[0] / n; p[1] = s->size[0] * l[1] / n; }
-            p[2] = l[2] >= 0 ? s->size[1] : -s->size[1];
+            if (n > lz) { double k = s->size[0] / n; p[0] = k * l[0]; p[1] = k * l[1]; }
+            p[2] = l[2] >= -lz ? s->size[1] : -s->size[1];
             break;
         }
         case ORC_MESH: {
             int best = 0;
-            double bd = -1e300;
+            double bd = -1e30;
+            const double tie = TIE_REL * 0.1 * (fabs(l[0]) + fabs(l[1]) + fabs(l[2]));
             for (int i = 0; i < s->nh; i++) {
                 double v = dot3(s->hull + 3 * i, l);
-                if (v > bd) { bd = v; best = i; }
+                if (v > bd + tie) { bd = v; best = i; }
             }
             memcpy(p, s->hull + 3 * best, sizeof p);
             break;
@@ -428,18 +438,18 @@ static int box_box(const shape* a, const shape* b, double* dist, double* pos, do
     if (m <= 4) { for (int q = 0; q < m; q++) keep[nk++] = q; }
     else {
         int i0 = 0;
-        for (int q = 1; q < m; q++) if (dep[q] > dep[i0]) i0 = q;
+        for (int q = 1; q < m; q++) if (dep[q] > dep[i0] + TIE_LEN) i0 = q;
         int i1 = i0; double bd = -1;
         for (int q = 0; q < m; q++) {
             double dx = tmp[q][a1] - tmp[i0][a1], dy = tmp[q][a2] - tmp[i0][a2], dd = dx * dx + dy * dy;
-            if (dd > bd) { bd = dd; i1 = q; }
+            if (dd > bd + TIE_REL * fabs(bd)) { bd = dd; i1 = q; }
         }
         double ex = tmp[i1][a1] - tmp[i0][a1], ey = tmp[i1][a2] - tmp[i0][a2];
         int i2 = -1, i3 = -1; double mx = 1e-18, mn = -1e-18;
         for (int q = 0; q < m; q++) {
             double cr = ex * (tmp[q][a2] - tmp[i0][a2]) - ey * (tmp[q][a1] - tmp[i0][a1]);
-            if (cr > mx) { mx = cr; i2 = q; }
-            if (cr < mn) { mn = cr; i3 = q; }
+            if (cr > mx + TIE_REL * fabs(mx)) { mx = cr; i2 = q; }
+            if (cr < mn - TIE_REL * fabs(mn)) { mn = cr; i3 = q; }
         }
         keep[nk++] = i0; keep[nk++] = i1;
         if (i2 >= 0) keep[nk++] = i2;

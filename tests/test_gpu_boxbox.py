@@ -1,10 +1,9 @@
 """The 16-lane box-box routine against the oracle's serial one on random poses: the two task objects of SlotInsertion are thrown
 into / onto each other and the table in random orientations (face, edge and corner configurations, clipped polygons with more
 than four vertices), the device's contact list after a forward pass must equal the oracle's: same geom pairs in the same
-order, distances to 1e-12 (f64 mode: same expressions, same tie-breaks).  When a clipped polygon has more than four vertices
-the four kept points are chosen by comparisons (farthest point, largest cross product) that are ties up to rounding for
-symmetric polygons; the device contracts a*b+c into FMAs and gcc does not, so a few percent of such poses keep a different
-vertex: same count, same pairs, one distance differs (tools/dbg_boxbox.py lists them)."""
+order, every distance to 1e-12.  The f64 kernel is compiled without FMA contraction (avsim_phys_f64.hip), as the oracle is: the
+same expressions round the same way, so the tie-breaks of the clipping (which four vertices of a larger polygon are kept:
+farthest point, largest cross product -- ties up to rounding for symmetric polygons) fall the same way on both sides."""
 import ctypes as C
 
 import numpy as np
@@ -48,20 +47,15 @@ def test_box_box_contacts_match_the_oracle_on_random_poses():
     e.L.orc_set_qpos.argtypes = [C.c_void_p, C.c_void_p]
     kinds = set()
     total = 0
-    other_vertex = 0
     for i in range(n):
         e.L.orc_set_qpos(e.dptr, q[i].ctypes.data)
         cs = list(e.d.contact)[: e.d.ncon]
         assert ncon[i] == e.d.ncon, (i, ncon[i], e.d.ncon)
-        differ = 0
         for k, c in enumerate(cs):
             assert (pairs[i, k, 0], pairs[i, k, 1]) == (c.geom1, c.geom2), (i, k)
-            differ += abs(dist[i, k] - c.dist) >= 1e-12
-        assert differ <= 4, (i, differ)              # one pair, its kept points in index order
-        other_vertex += differ > 0
+            assert abs(dist[i, k] - c.dist) < 1e-12, (i, k, dist[i, k], c.dist)
         total += e.d.ncon
         kinds.add(min(e.d.ncon, 12))
-    assert other_vertex <= 0.04 * n, other_vertex
     assert total > 4 * n and len(kinds) >= 5          # plenty of contacts, and many different contact counts
     sim.close()
     e.close()
@@ -69,11 +63,9 @@ def test_box_box_contacts_match_the_oracle_on_random_poses():
 
 def test_hull_contacts_match_the_oracle_near_the_grippers():
     """The same comparison for the convex-hull pairs (MPR, one contact per pair): the objects are dropped around the open
-    grippers of randomly perturbed arms.  MPR stops at its own tolerance (1e-6 m portal distance) and its portal walk branches on
-    signs of small dot products: with FMA contraction on the device and none in the oracle a deep, ambiguous penetration can end
-    on a different portal (observed: depths up to 13 % apart on a few deep contacts).  Pairs and counts are exact; about 95 % of the
-    distances agree to 1e-6; the others are deep overlaps (centimetres) whose final portal triangle differs - the depth is the
-    distance to that triangle, not to the face plane - and stay within 25 % of the depth."""
+    grippers of randomly perturbed arms.  MPR's portal walk branches on signs of small dot products and its support function picks
+    the hull vertex with the largest projection (ties up to rounding whenever the search direction is a face normal); without FMA
+    contraction on either side every such decision agrees: pairs, counts and every distance to 1e-12."""
     from av_aloha_amd.sim import BatchedSim
     md = model_dict()
     n = 256
@@ -96,19 +88,17 @@ def test_hull_contacts_match_the_oracle_near_the_grippers():
     e = OrcEnv()
     e.L.orc_set_qpos.argtypes = [C.c_void_p, C.c_void_p]
     names = e.man["geom_names"]
-    hull_contacts = off = seen = 0
+    hull_contacts = seen = 0
     for i in range(n):
         e.L.orc_set_qpos(e.dptr, q[i].ctypes.data)
         cs = list(e.d.contact)[: e.d.ncon]
         assert ncon[i] == e.d.ncon, (i, ncon[i], e.d.ncon)
         for k, c in enumerate(cs):
             assert (pairs[i, k, 0], pairs[i, k, 1]) == (c.geom1, c.geom2), (i, k)
-            assert abs(dist[i, k] - c.dist) < 1e-6 + 0.25 * abs(c.dist), (i, k, names[c.geom1], names[c.geom2], dist[i, k], c.dist)
-            off += abs(dist[i, k] - c.dist) >= 1e-6
+            assert abs(dist[i, k] - c.dist) < 1e-12, (i, k, names[c.geom1], names[c.geom2], dist[i, k], c.dist)
             seen += 1
             hull_contacts += names[c.geom1] not in ("table",) and not names[c.geom1].startswith(("slot", "pin", "stick"))
     assert hull_contacts > 50, hull_contacts
-    print(f"MPR contacts off by more than 1e-6: {off} of {seen}")
-    assert off <= 0.08 * seen, (off, seen)
+    assert seen > 500
     sim.close()
     e.close()
