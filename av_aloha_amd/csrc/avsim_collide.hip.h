@@ -10,6 +10,8 @@
 namespace avs {
 
 enum { G_SPHERE = 2, G_CYLINDER = 5, G_BOX = 6, G_MESH = 7 };
+// narrow-phase result slot of one candidate pair: up to 5 contacts (box-box keeps <= 4, multiccd <= 1 + 4) that share a normal
+constexpr int SLOT_W = 24, SLOT_P = 5, SLOT_N = 20, SLOT_MAXC = 5;
 
 template <typename T>
 struct Shape {
@@ -121,6 +123,7 @@ AVS_DEV T point_tri_dist2(const T* p0, const T* p1, const T* p2, T* w) {
     return dot3(w, w);
 }
 
+template <typename T> AVS_DEV void make_frame(const T* n, T* t1, T* t2);
 template <typename T> struct MprTol;
 template <> struct MprTol<double> { static constexpr double tol = 1e-6, tiny2 = 1e-24, eps = 1e-14; };
 template <> struct MprTol<float> { static constexpr float tol = 1e-6f, tiny2 = 1e-16f, eps = 1e-9f; };
@@ -221,6 +224,86 @@ __device__ int mpr_penetration(const Shape<T>& A, const Shape<T>& B, T* depth, T
     }
 }
 
+// ---- multiccd (aloha_sim.xml:5 <flag multiccd="enable"/>) -----------------------------------------------------------------
+// MuJoCo 3.2's mjc_Convex [EXT] looks for further contacts of a convex pair that its penetration routine found in contact (not for
+// spheres / ellipsoids): both geoms are turned by a small angle in opposite senses about the first contact point, about each of
+// the two tangent axes of the contact frame and in both directions, the penetration routine runs again in each of the four
+// perturbed configurations, and a contact found there is kept if it lies farther than 1e-3 x the smaller bounding radius from
+// every contact kept so far (at most 1 + 4).  A flat finger pad on a flat face thus gets the corners of the touching patch
+// instead of one point somewhere inside it.  The kept contacts share the first contact's frame.
+template <typename T> struct MultiCcd {
+    static constexpr T cs = T(0.9999995000000417), sn = T(0.0009999998333333417);   // cos / sin of the 1e-3 rad perturbation
+    static constexpr T reltol = T(1e-3);
+};
+
+// turn the shape by the angle with cosine c / sine s about the unit axis through the point o
+template <typename T>
+AVS_DEV void rotate_shape(Shape<T>& sh, const T* ax, T c, T s, const T* o) {
+    const T oc = 1 - c;
+    const T R[9] = {c + ax[0] * ax[0] * oc, ax[0] * ax[1] * oc - ax[2] * s, ax[0] * ax[2] * oc + ax[1] * s,
+                    ax[1] * ax[0] * oc + ax[2] * s, c + ax[1] * ax[1] * oc, ax[1] * ax[2] * oc - ax[0] * s,
+                    ax[2] * ax[0] * oc - ax[1] * s, ax[2] * ax[1] * oc + ax[0] * s, c + ax[2] * ax[2] * oc};
+    T M[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) M[3 * i + j] = R[3 * i] * sh.mat[j] + R[3 * i + 1] * sh.mat[3 + j] + R[3 * i + 2] * sh.mat[6 + j];
+#pragma unroll
+    for (int k = 0; k < 9; k++) sh.mat[k] = M[k];
+    T d[3], t[3];
+    sub3(sh.pos, o, d);
+    mulmat(R, d, t);
+    for (int k = 0; k < 3; k++) sh.pos[k] = o[k] + t[k];
+    sub3(sh.center, o, d);
+    mulmat(R, d, t);
+    for (int k = 0; k < 3; k++) sh.center[k] = o[k] + t[k];
+}
+
+// perturbation `pert` (0..3: tangent 1 +, tangent 1 -, tangent 2 +, tangent 2 -) of the pair about the contact point p0 with
+// normal n0: 1 with the contact's distance and position, or 0
+template <typename T>
+__device__ int mpr_perturbed(Shape<T> A, Shape<T> B, const T* p0, const T* n0, int pert, T* dist, T* pos) {
+    T t1[3], t2[3];
+    make_frame(n0, t1, t2);
+    T ax[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) ax[k] = pert < 2 ? t1[k] : t2[k];
+    const T s = (pert & 1) ? -MultiCcd<T>::sn : MultiCcd<T>::sn;
+    rotate_shape(A, ax, MultiCcd<T>::cs, s, p0);
+    rotate_shape(B, ax, MultiCcd<T>::cs, -s, p0);
+    T depth, dir[3];
+    if (!mpr_penetration(A, B, &depth, dir, pos)) return 0;
+    *dist = -depth;
+    return 1;
+}
+
+// is the point p farther than tol from the first n kept positions?
+template <typename T, typename P>
+AVS_DEV bool multiccd_distinct(const T* p, const P kept, int n, T tol) {
+    bool ok = true;
+    for (int k = 0; k < n; k++) {
+        const T d[3] = {p[0] - kept[3 * k], p[1] - kept[3 * k + 1], p[2] - kept[3 * k + 2]};
+        ok = ok && dot3(d, d) > tol * tol;
+    }
+    return ok;
+}
+
+// the four perturbations one after the other (host builds and tests; the kernel spreads them over lanes, same order of
+// acceptance): dist[0], pos[0..2] hold the first contact, nrm its normal; returns the number of contacts kept (1..5)
+template <typename T>
+__device__ int multiccd_serial(const Shape<T>& a, const Shape<T>& b, T tol, T* dist, T* pos, const T* nrm) {
+    int n = 1;
+    for (int pert = 0; pert < 4; pert++) {
+        T d, p[3];
+        if (mpr_perturbed(a, b, pos, nrm, pert, &d, p) && multiccd_distinct(p, pos, n, tol)) {
+            dist[n] = d;
+            pos[3 * n] = p[0]; pos[3 * n + 1] = p[1]; pos[3 * n + 2] = p[2];
+            n++;
+        }
+    }
+    return n;
+}
+
 template <typename T>
 AVS_DEV int sphere_sphere(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T* nrm) {
     T d[3];
@@ -279,7 +362,7 @@ template <typename T> AVS_DEV void col3(const T* M, int k, T* o) { o[0] = sel3(M
 
 // box-box: 15-axis SAT then reference-face clipping (face contact, <=4 points) or closest edge points.
 // `work` = 56 words of LDS scratch for the clipped polygon (dynamic indexing would otherwise spill it to scratch memory),
-// `scr` = the lane's 20-word result slot: dist [0,4), pos [4,16), common normal [16,19).
+// `scr` = the lane's result slot (SLOT_W words): dist [0,5), pos [SLOT_P, SLOT_P + 15), common normal [SLOT_N, SLOT_N + 3).
 template <typename T>
 __device__ int box_box(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, AVS_LDS(T) work) {
     const T *Ra = a.mat, *Rb = b.mat;
@@ -363,8 +446,8 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, AVS
         for (int k = 0; k < 3; k++) {
             pA[k] += ua[k] * alpha;
             pB[k] += ub[k] * beta;
-            scr[4 + k] = T(0.5) * (pA[k] + pB[k]);
-            scr[16 + k] = n[k];
+            scr[SLOT_P + k] = T(0.5) * (pA[k] + pB[k]);
+            scr[SLOT_N + k] = n[k];
         }
         scr[0] = -depth;
         return 1;
@@ -479,10 +562,10 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, AVS
         T wv[3];
         mulmat(rmat, l, wv);
         T dq_ = dep[q];
-        for (int c = 0; c < 3; c++) scr[4 + 3 * x + c] = wv[c] + rpos[c];
+        for (int c = 0; c < 3; c++) scr[SLOT_P + 3 * x + c] = wv[c] + rpos[c];
         scr[x] = -dq_;
     }
-    for (int c = 0; c < 3; c++) scr[16 + c] = n[c];
+    for (int c = 0; c < 3; c++) scr[SLOT_N + c] = n[c];
     return nk;
 }
 
@@ -591,8 +674,8 @@ __device__ int box_box16(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, A
             for (int k = 0; k < 3; k++) {
                 pA[k] += ua[k] * alpha;
                 pB[k] += ub[k] * beta;
-                scr[4 + k] = T(0.5) * (pA[k] + pB[k]);
-                scr[16 + k] = n[k];
+                scr[SLOT_P + k] = T(0.5) * (pA[k] + pB[k]);
+                scr[SLOT_N + k] = n[k];
             }
             scr[0] = -depth;
         }
@@ -717,10 +800,10 @@ __device__ int box_box16(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, A
         for (int j = 0; j < 3; j++) l[j] += (j == ax) ? T(0.5) * dq_ * face : T(0);
         T wv[3];
         mulmat(rmat, l, wv);
-        for (int c = 0; c < 3; c++) scr[4 + 3 * t + c] = wv[c] + rpos[c];
+        for (int c = 0; c < 3; c++) scr[SLOT_P + 3 * t + c] = wv[c] + rpos[c];
         scr[t] = -dq_;
     }
-    if (on && t == 0) { for (int c = 0; c < 3; c++) scr[16 + c] = n[c]; }
+    if (on && t == 0) { for (int c = 0; c < 3; c++) scr[SLOT_N + c] = n[c]; }
     (void)rowmask_sh;
     return nk;
 }
@@ -747,7 +830,7 @@ AVS_DEV bool boxes_separated(const Shape<T>& a, const Shape<T>& b) {
 }
 
 // dispatch for every pair that is not box-box (those go through box_box with their own work area); at most one contact,
-// written to the lane's result slot: dist [0], pos [4,7), normal [16,19)
+// written to the lane's result slot: dist [0], pos [SLOT_P, +3), normal [SLOT_N, +3)
 template <typename T>
 __device__ int narrow(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr) {
     int ta = a.type, tb = b.type;
@@ -766,7 +849,7 @@ __device__ int narrow(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr) {
     }
     if (n) {
         scr[0] = dist[0];
-        for (int k = 0; k < 3; k++) { scr[4 + k] = pos[k]; scr[16 + k] = nrm[k]; }
+        for (int k = 0; k < 3; k++) { scr[SLOT_P + k] = pos[k]; scr[SLOT_N + k] = nrm[k]; }
     }
     return n;
 }

@@ -321,6 +321,11 @@ AVS_DEV double lane_get(double x, int l) {   // l is wave-uniform at every call 
 }
 
 constexpr int GRP_MAX = 6;   // rows per Gauss-Seidel group (a condim-6 contact is one group)
+// convergence thresholds of the multiplier iteration in the noslip QCQP: MuJoCo's absolute 1e-10 in double; in float a relative
+// part on top, since v.v - r^2 and the multiplier carry 1e-7 relative rounding
+template <typename T> struct QTol;
+template <> struct QTol<double> { static constexpr double abs = 1e-10, rel = 0.0; };
+template <> struct QTol<float> { static constexpr float abs = 1e-10f, rel = 2e-6f; };
 
 // ------------------------------------------------------------------------------------------------
 // P8 inner loop, one env per wavefront: projected Gauss-Seidel over GROUPS of up to 6 consecutive rows.
@@ -368,7 +373,7 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
     for (int s = 0; s < GRP_MAX - 1; s++) ac[s] = gA[tri + s];
     const int total = (iters + noslip_iters) * ngrp;
     int g = 0, it = 0;
-    real imp = 0;      // improvement of the dual cost over the current noslip sweep
+    real imp = 0, imp_c = 0;      // improvement of the dual cost over the current noslip sweep (per-lane parts, uniform part)
     for (int step = 0; step < total; step++) {
         const bool noslip = it >= iters;
         const int start = gi & 0xffff, cnt = (gi >> 16) & 15;
@@ -394,18 +399,155 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         // ---- row residuals J_r . qacc: every row is summed over its 8 lanes, lane r then fetches row r's sum ----
         const real x = oct_sum(JA * qA + JB * qB);
         const real dot = __shfl(x, 8 * lr, 64);
+        real f = f0;
+        if (noslip && contact) {
+            // ---- mj_solNoSlip [EXT], friction block of an elliptic contact: the exact minimiser of 1/2 x'Ax + x'b over the cone
+            // section sum (x_j / mu_j)^2 <= fn^2 (mju_QCQP2 / mju_QCQP), fn = the normal force held fixed.  Lane r owns row r
+            // (row 0 = normal); the block (A lower triangle from the couplings, diagonal 1 / invn), b and mu are gathered from
+            // the owner lanes and the small Newton iteration on the multiplier runs redundantly on every lane ----
+            const int n = cnt - 1;
+            if (n >= 1) {
+                const real fn = lane_get(f0, 0);
+                real Aq[5][5], bq[5], dq[5], oldf[5], resq[5], v[5];
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const bool in = j < n;
+                    resq[j] = in ? lane_get(dot - aref, j + 1) : real(0);
+                    oldf[j] = in ? lane_get(f0, j + 1) : real(0);
+                    const real mi = lane_get(muinv, j + 1);
+                    dq[j] = in ? real(1) / mi : real(1);
+                    const real di = lane_get(inv3, j + 1);
+                    Aq[j][j] = in ? real(1) / di : real(1);
+#pragma unroll
+                    for (int k = 0; k < j; k++) { const real c = in ? lane_get(ac[k + 1], j + 1) : real(0); Aq[j][k] = c; Aq[k][j] = c; }
+                }
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    real t = resq[j];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) t -= (j < n && k < n) ? Aq[j][k] * oldf[k] : real(0);
+                    bq[j] = t;
+                    v[j] = 0;
+                }
+                if (!(fn < real(1e-15))) {
+                    const real r2 = fn * fn, vtol = QTol<real>::abs + QTol<real>::rel * r2;
+                    real la = 0;
+                    bool active;
+                    if (n == 2) {
+                        const real b1 = bq[0] * dq[0], b2 = bq[1] * dq[1];
+                        const real A11 = Aq[0][0] * dq[0] * dq[0], A22 = Aq[1][1] * dq[1] * dq[1], A12 = Aq[1][0] * dq[0] * dq[1];
+                        real v1 = 0, v2 = 0;
+                        bool singular = false;
+                        for (int iter = 0; iter < 20; iter++) {
+                            const real det = (A11 + la) * (A22 + la) - A12 * A12;
+                            if (det < real(1e-10)) { singular = true; break; }
+                            const real detinv = real(1) / det, P11 = (A22 + la) * detinv, P22 = (A11 + la) * detinv, P12 = -A12 * detinv;
+                            v1 = -P11 * b1 - P12 * b2;
+                            v2 = -P12 * b1 - P22 * b2;
+                            const real val = v1 * v1 + v2 * v2 - r2;
+                            if (val < vtol) break;
+                            const real deriv = -2 * (P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2);
+                            const real delta = -val / deriv;
+                            if (delta < QTol<real>::abs + QTol<real>::rel * la) break;
+                            la += delta;
+                        }
+                        v[0] = singular ? real(0) : v1 * dq[0];
+                        v[1] = singular ? real(0) : v2 * dq[1];
+                        active = !singular && la != 0;
+                    } else {
+                        real As[5][5], bs[5], L[5][5], y[5], w[5];
+#pragma unroll
+                        for (int j = 0; j < 5; j++) {
+                            bs[j] = j < n ? bq[j] * dq[j] : real(0);
+                            y[j] = 0;
+#pragma unroll
+                            for (int k = 0; k < 5; k++) As[j][k] = (j < n && k < n) ? Aq[j][k] * dq[j] * dq[k] : (j == k ? real(1) : real(0));
+                        }
+                        bool singular = false;
+                        for (int iter = 0; iter < 20; iter++) {
+#pragma unroll
+                            for (int j = 0; j < 5; j++) {
+                                real dd = As[j][j] + (j < n ? la : real(0));
+#pragma unroll
+                                for (int k = 0; k < j; k++) dd -= L[j][k] * L[j][k];
+                                if (j < n && dd < real(1e-10)) singular = true;
+                                dd = sqrt(tmax(dd, real(1e-30)));
+                                L[j][j] = dd;
+#pragma unroll
+                                for (int i = j + 1; i < 5; i++) {
+                                    real t = As[i][j];
+#pragma unroll
+                                    for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+                                    L[i][j] = t / dd;
+                                }
+                            }
+                            if (singular) break;
+#pragma unroll
+                            for (int i = 0; i < 5; i++) { real t = -bs[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t / L[i][i]; }
+#pragma unroll
+                            for (int i = 4; i >= 0; i--) { real t = y[i]; for (int k = i + 1; k < 5; k++) t -= L[k][i] * y[k]; y[i] = t / L[i][i]; }
+                            real val = -r2;
+#pragma unroll
+                            for (int i = 0; i < 5; i++) val += y[i] * y[i];
+                            if (val < vtol) break;
+#pragma unroll
+                            for (int i = 0; i < 5; i++) { real t = y[i]; for (int k = 0; k < i; k++) t -= L[i][k] * w[k]; w[i] = t / L[i][i]; }
+#pragma unroll
+                            for (int i = 4; i >= 0; i--) { real t = w[i]; for (int k = i + 1; k < 5; k++) t -= L[k][i] * w[k]; w[i] = t / L[i][i]; }
+                            real deriv = 0;
+#pragma unroll
+                            for (int i = 0; i < 5; i++) deriv += y[i] * w[i];
+                            deriv *= -2;
+                            const real delta = -val / deriv;
+                            if (delta < QTol<real>::abs + QTol<real>::rel * la) break;
+                            la += delta;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 5; j++) v[j] = (singular || !(j < n)) ? real(0) : y[j] * dq[j];
+                        active = !singular && la != 0;
+                    }
+                    if (active) {       // exactly onto the ellipsoid
+                        real sq = 0;
+#pragma unroll
+                        for (int j = 0; j < 5; j++) sq += j < n ? v[j] * v[j] / (dq[j] * dq[j]) : real(0);
+                        const real sc = sqrt(r2 / tmax(real(1e-15), sq));
+#pragma unroll
+                        for (int j = 0; j < 5; j++) v[j] *= sc;
+                    }
+                }
+                // change of the cost [EXT: costChange]; an update that would raise it by more than 1e-10 is not made
+                real change = 0;
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    real t = 0;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) t += (j < n && k < n) ? Aq[j][k] * (v[k] - oldf[k]) : real(0);
+                    change += j < n ? (v[j] - oldf[j]) * (real(0.5) * t + resq[j]) : real(0);
+                }
+                if (!(change > real(1e-10))) {
+                    imp_c -= change;
+#pragma unroll
+                    for (int j = 0; j < 5; j++) if (lane == j + 1 && j < n) f = v[j];
+                }
+            }
+        } else {
         // ---- sequential relaxation on lanes 0..cnt-1 (lane r = row start + r) ----
         const real inv = noslip ? inv3 : inv2;
         real res = dot - aref + (noslip ? real(0) : R * f0);
-        real f = f0;
 #pragma unroll
         for (int s = 0; s < GRP_MAX; s++) {
-            const real fs = tmin(tmax(f0 - res * inv, lo), hi);
+            real fs = tmin(tmax(f0 - res * inv, lo), hi);
+            if (noslip) {
+                // dry-friction rows of mj_solNoSlip [EXT]: clamped scalar update, undone when it would raise the cost (costChange)
+                const real dl_ = fs - f0, ch = inv != 0 ? dl_ * (real(0.5) * dl_ / inv + res) : real(0);
+                if (ch > real(1e-10)) fs = f0;
+                else if (lane == s && s < cnt) imp -= ch;
+            }
             const real ds = s < cnt ? lane_get(fs - f0, s) : real(0);
             if (lane == s && s < cnt) f = fs;
             if (s < GRP_MAX - 1) res += a[s < GRP_MAX - 1 ? s : 0] * ds;
         }
-        // ---- elliptic cone: scale the friction block back when sliding ----
+        // ---- elliptic cone: scale the friction block back when sliding (PGS sweeps) ----
         if (contact && cnt > 1) {
             const real fn = lane_get(f, 0);
             const real t = (mine && lane >= 1) ? f * muinv : real(0);
@@ -415,17 +557,9 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
                 if (mine && lane >= 1) f *= sc;
             }
         }
+        }
         if (mine) S[6] = f;
         const real delta = mine ? f - f0 : real(0);
-        if (noslip) {
-            // decrease of the dual cost by this group [EXT: costChange in mj_solNoSlip]: -(delta . res0 + 1/2 delta^T A delta),
-            // res0 the residuals before the group moved, A its coupling block (diagonal 1 / inv)
-            real cross = 0;
-#pragma unroll
-            for (int s = 0; s < GRP_MAX - 1; s++) cross += a[s] * lane_get(delta, s);
-            const real mine_c = delta * (dot - aref) + (inv3 != 0 ? real(0.5) * delta * delta / inv3 : real(0)) + delta * cross;
-            imp -= lane_get(oct_sum(mine ? mine_c : real(0)), 0);
-        }
         // ---- qacc += B_r^T delta_r ----
         const real dd = __shfl(delta, d, 64);
         if (inA) __hip_atomic_fetch_add(q + adrA, BA * dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -445,8 +579,14 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         g = g1;
         if (g1 == 0) {
             // end of a sweep; a noslip sweep that improved the cost by less than noslip_tolerance ends the pass [EXT]
-            if (noslip && imp < noslip_tol_scaled) break;
+            if (noslip) {
+                // contact blocks add their (wave-uniform) change on every lane, dry-friction rows on their own lane only: lane 0's
+                // share of the former plus the lanes' own parts
+                const real uni = lane_get(imp_c, 0);
+                if (uni + lane_get(oct_sum(lane < GRP_MAX ? imp : real(0)), 0) < noslip_tol_scaled) break;
+            }
             imp = 0;
+            imp_c = 0;
             it++;
         }
     }
@@ -1267,17 +1407,20 @@ struct Env {
         real *cdist = r + ka->lay.cdist, *cpos = r + ka->lay.cpos, *cnrm = r + ka->lay.cnrm;
         int* cpair = ii + ka->lay.cpair;
         int ncon = 0, ovf = 0;
-        // 64 candidate pairs per pass, one per lane, each with a 20-word result slot in LDS (the solver records, not live
-        // during collision).  Box-box pairs go first, NBOX at a time through the polygon work areas behind the slots, then
-        // everything else: the wave executes the clipping code and the MPR code once each instead of both in every pass.
+        // 64 candidate pairs per pass, one per lane, each with a result slot in LDS (the solver records, not live during
+        // collision).  Box-box pairs go first, four at a time through the polygon work areas behind the slots, then everything
+        // else, then the multiccd perturbations of the convex pairs found in contact: the wave executes the clipping code and the
+        // MPR code once each instead of both in every pass.
+        int* mlist = ii + ka->lay.cand;      // lanes of the pairs that get the multiccd treatment (the kinematics' table is idle here)
         for (int base = 0; base < ncand; base += G) {
             const int ci = base + lane;
             int n = 0, p = 0, nn = 0;
-            LDS_PTR(real) scr = (LDS_PTR(real))(r + ka->lay.scr + 20 * lane);
+            LDS_PTR(real) scr = (LDS_PTR(real))(r + ka->lay.scr + SLOT_W * lane);
             const bool valid = ci < ncand;
             if (valid) p = cand[ci];
             const int ga = ka->m.pair_geom[2 * p], gb = ka->m.pair_geom[2 * p + 1];
-            const bool isbox = valid && geom_type_()[ga] == G_BOX && geom_type_()[gb] == G_BOX;
+            const int tya = geom_type_()[ga], tyb = geom_type_()[gb];
+            const bool isbox = valid && tya == G_BOX && tyb == G_BOX;
             {
                 // box-box pairs, four at a time: every 16-lane row of the wave works on one pair (box_box16), the results land in
                 // the result slot of the lane that owns the pair
@@ -1297,7 +1440,7 @@ struct Env {
                     load_shape(pgb, b);
                     int n16 = 0;
                     if (!boxes_separated(a, b))
-                        n16 = box_box16(a, b, (LDS_PTR(real))(r + ka->lay.scr + 20 * src), (LDS_PTR(real))(r + ka->lay.scr + 20 * G + 56 * row), lane, on);
+                        n16 = box_box16(a, b, (LDS_PTR(real))(r + ka->lay.scr + SLOT_W * src), (LDS_PTR(real))(r + ka->lay.scr + SLOT_W * G + 56 * row), lane, on);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     const int got = __shfl(on ? n16 : 0, 16 * ((rk - b0) & 3), 64);
@@ -1310,6 +1453,50 @@ struct Env {
                 load_shape(gb, b);
                 nn = narrow(a, b, scr);
             }
+            {
+                // multiccd [EXT: mjc_Convex]: the convex (MPR) pairs found in contact, spheres excluded.  Lane 4 q + k runs perturbation
+                // k of the q-th such pair (16 pairs per round) and leaves its contact in entry 1 + k of the owner's slot (distance
+                // 1e30: none); the owner then keeps, in the order k = 0..3, those that are distinct from the ones kept before.
+                const bool multi = valid && !isbox && nn == 1 && tya != G_SPHERE && tyb != G_SPHERE;
+                int nm, mrk = group_rank<G>(multi, grp, lane, &nm);
+                if (nm > 0) {
+                    if (multi) mlist[mrk] = lane;
+                    GSYNC();
+                    for (int m0 = 0; m0 < nm; m0 += 16) {
+                        const int q = m0 + (lane >> 2), pert = lane & 3;
+                        const bool on = q < nm;
+                        const int src = on ? mlist[q] : 0;
+                        const int pga = __shfl(ga, src, 64), pgb = __shfl(gb, src, 64);
+                        if (on) {
+                            LDS_PTR(real) os = (LDS_PTR(real))(r + ka->lay.scr + SLOT_W * src);
+                            const real p0[3] = {os[SLOT_P], os[SLOT_P + 1], os[SLOT_P + 2]}, n0[3] = {os[SLOT_N], os[SLOT_N + 1], os[SLOT_N + 2]};
+                            Shape<real> a, b;
+                            load_shape(pga, a);
+                            load_shape(pgb, b);
+                            real dk = real(1e30), pk[3] = {0, 0, 0};
+                            if (!mpr_perturbed(a, b, p0, n0, pert, &dk, pk)) dk = real(1e30);
+                            os[1 + pert] = dk;
+                            for (int c = 0; c < 3; c++) os[SLOT_P + 3 * (1 + pert) + c] = pk[c];
+                        }
+                    }
+                    GSYNC();
+                    if (multi) {
+                        const real rb1 = geom_rbound_()[ga], rb2 = geom_rbound_()[gb];
+                        const real tol = MultiCcd<real>::reltol * (rb1 < rb2 ? rb1 : rb2);
+                        int kept = 1;
+                        for (int k = 1; k <= 4; k++) {
+                            const real dk = scr[k];
+                            const real pk[3] = {scr[SLOT_P + 3 * k], scr[SLOT_P + 3 * k + 1], scr[SLOT_P + 3 * k + 2]};
+                            if (dk < real(1e29) && multiccd_distinct(pk, scr + SLOT_P, kept, tol)) {
+                                scr[kept] = dk;
+                                for (int c = 0; c < 3; c++) scr[SLOT_P + 3 * kept + c] = pk[c];
+                                kept++;
+                            }
+                        }
+                        nn = kept;
+                    }
+                }
+            }
             int keepmask = 0;
             if (valid) {
                 // drop separated points (margin = 0 here) while keeping order
@@ -1318,20 +1505,20 @@ struct Env {
                     if (scr[k] < mg) { keepmask |= 1 << k; n++; }
             }
             int off = 0, tot = 0;
-            for (int j = 1; j <= 4; j++) {
+            for (int j = 1; j <= SLOT_MAXC; j++) {
                 int tj, rj = group_rank<G>(n >= j, grp, lane, &tj);
                 off += rj;
                 tot += tj;
             }
             int w = 0;
-            for (int k = 0; k < 4; k++)
+            for (int k = 0; k < SLOT_MAXC; k++)
                 if ((keepmask >> k) & 1) {
                     int c = ncon + off + w;
                     w++;
                     if (c < ka->lay.maxcon) {
                         cdist[c] = scr[k];
                         cpair[c] = p;
-                        for (int q = 0; q < 3; q++) { cpos[3 * c + q] = scr[4 + 3 * k + q]; cnrm[3 * c + q] = scr[16 + q]; }
+                        for (int q = 0; q < 3; q++) { cpos[3 * c + q] = scr[SLOT_P + 3 * k + q]; cnrm[3 * c + q] = scr[SLOT_N + q]; }
                     }
                 }
             if (ncon + tot > ka->lay.maxcon) ovf = 1;
@@ -1819,7 +2006,10 @@ struct Env {
 
 // WPB wavefronts per block, one env per wavefront; the block shares one LDS copy of the hot model tables
 template <typename real, int G, int WPB>
-__global__ void __launch_bounds__(64 * WPB) k_phys(KPtr<real> ka, const real* __restrict__ img_real, const int* __restrict__ img_int, int N, int nsub, int pgs_iters, const float* __restrict__ action,
+#ifndef AVSIM_PHYS_ATTR
+#define AVSIM_PHYS_ATTR
+#endif
+__global__ void __launch_bounds__(64 * WPB) AVSIM_PHYS_ATTR k_phys(KPtr<real> ka, const real* __restrict__ img_real, const int* __restrict__ img_int, int N, int nsub, int pgs_iters, const float* __restrict__ action,
                                              int want_reward, real* __restrict__ g_qpos, real* __restrict__ g_qvel, real* __restrict__ g_ctrl,
                                              real* __restrict__ g_warm, int* __restrict__ g_latch, double* __restrict__ o_agent,
                                              int* __restrict__ o_reward, unsigned char* __restrict__ o_success, int* __restrict__ o_ncon,
@@ -2182,7 +2372,7 @@ struct PhysHost {
         L.cdist = bq; bq += maxcon; L.cpos = bq; bq += 3 * maxcon; L.cnrm = bq; bq += 3 * maxcon;
         bq = (bq + 3) & ~3; L.rowS = bq; L.scr = bq; bq += RS_S * maxefc;
         L.maxgrp = maxefc / 3 + 8;
-        if (bq < L.scr + 64 * 20 + 9 * 56) bq = L.scr + 64 * 20 + 9 * 56;     // narrow phase: 64 result slots + 9 box work areas
+        if (bq < L.scr + 64 * SLOT_W + 4 * 56) bq = L.scr + 64 * SLOT_W + 4 * 56;     // narrow phase: 64 result slots + 4 box work areas
         o = a > bq ? a : bq;
         L.nreal = (o + 3) & ~3;
         int io = 0;
@@ -2300,7 +2490,7 @@ struct PhysHost {
         size_t shmem = (size_t)lay.bytes_per_env * epb + (size_t)moff.nreal * sizeof(real) + (size_t)moff.nint * 4;
         auto kern = k_phys<real, G, WPB>;
         // once per handle (= per device) and kernel instance: a second handle on another GPU of the same process sets its own
-        const unsigned attr_bit = 1u << (sizeof(real) == 8 ? 0 : WPB);
+        const unsigned attr_bit = 1u << (sizeof(real) == 8 ? 0 : WPB);     // WPB <= 16
         if (!(attr_done & attr_bit)) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); return -3; }

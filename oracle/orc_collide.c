@@ -22,6 +22,7 @@ typedef struct {
     const double* hull; /* hull vertices, geom frame */
     int nh;
     double center[3]; /* an interior point, world */
+    double rbound;    /* bounding radius about the interior point (tolerance of the multiccd distinctness test) */
 } shape;
 
 static double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -471,6 +472,74 @@ static int box_box(const shape* a, const shape* b, double* dist, double* pos, do
     return nk;
 }
 
+static void make_frame(double* f);
+
+/* ---- multiccd (aloha_sim.xml:5 <flag multiccd="enable"/>) ----
+ * MuJoCo 3.2's mjc_Convex [EXT] looks for further contacts of a convex pair that its penetration routine found in contact (not
+ * for spheres / ellipsoids): both geoms are turned by a small angle in opposite senses about the first contact point, about each
+ * of the two tangent axes of the contact frame and in both directions; the penetration routine runs again in each of the four
+ * perturbed configurations and a contact found there is kept if it lies farther than 1e-3 x the smaller bounding radius from
+ * every contact kept so far (at most 1 + 4).  The kept contacts share the first contact's frame.  Same constants and expression
+ * order as the device (avsim_collide.hip.h MultiCcd, rotate_shape, mpr_perturbed). */
+#define MCCD_COS 0.9999995000000417
+#define MCCD_SIN 0.0009999998333333417
+#define MCCD_RELTOL 1e-3
+
+typedef struct { shape s; double pos[3], mat[9]; } rshape; /* a shape with its own (turned) pose */
+
+static void rotate_shape(rshape* r, const shape* src, const double* ax, double c, double s, const double* o) {
+    const double oc = 1 - c;
+    const double R[9] = {c + ax[0] * ax[0] * oc, ax[0] * ax[1] * oc - ax[2] * s, ax[0] * ax[2] * oc + ax[1] * s,
+                         ax[1] * ax[0] * oc + ax[2] * s, c + ax[1] * ax[1] * oc, ax[1] * ax[2] * oc - ax[0] * s,
+                         ax[2] * ax[0] * oc - ax[1] * s, ax[2] * ax[1] * oc + ax[0] * s, c + ax[2] * ax[2] * oc};
+    r->s = *src;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) r->mat[3 * i + j] = R[3 * i] * src->mat[j] + R[3 * i + 1] * src->mat[3 + j] + R[3 * i + 2] * src->mat[6 + j];
+    double d[3], t[3];
+    sub3(src->pos, o, d);
+    mulmat(R, d, t);
+    for (int k = 0; k < 3; k++) r->pos[k] = o[k] + t[k];
+    sub3(src->center, o, d);
+    mulmat(R, d, t);
+    for (int k = 0; k < 3; k++) r->s.center[k] = o[k] + t[k];
+    r->s.pos = r->pos;
+    r->s.mat = r->mat;
+}
+
+static int mpr_perturbed(const shape* A, const shape* B, const double* p0, const double* n0, int pert, double* dist, double* pos) {
+    double f[9] = {n0[0], n0[1], n0[2], 0, 0, 0, 0, 0, 0};
+    make_frame(f);
+    const double* ax = pert < 2 ? f + 3 : f + 6;
+    const double s = (pert & 1) ? -MCCD_SIN : MCCD_SIN;
+    rshape ra, rb;
+    rotate_shape(&ra, A, ax, MCCD_COS, s, p0);
+    rotate_shape(&rb, B, ax, MCCD_COS, -s, p0);
+    double depth, dir[3];
+    if (!mpr_penetration(&ra.s, &rb.s, &depth, dir, pos)) return 0;
+    *dist = -depth;
+    return 1;
+}
+
+static int multiccd(const shape* a, const shape* b, double* dist, double* pos, double* nrm) {
+    const double tol = MCCD_RELTOL * (a->rbound < b->rbound ? a->rbound : b->rbound);
+    int n = 1;
+    for (int pert = 0; pert < 4; pert++) {
+        double d, p[3];
+        if (!mpr_perturbed(a, b, pos, nrm, pert, &d, p)) continue;
+        int ok = 1;
+        for (int k = 0; k < n; k++) {
+            const double e[3] = {p[0] - pos[3 * k], p[1] - pos[3 * k + 1], p[2] - pos[3 * k + 2]};
+            ok = ok && dot3(e, e) > tol * tol;
+        }
+        if (!ok) continue;
+        dist[n] = d;
+        memcpy(pos + 3 * n, p, 24);
+        memcpy(nrm + 3 * n, nrm, 24);
+        n++;
+    }
+    return n;
+}
+
 static int narrow(const shape* a, const shape* b, double* dist, double* pos, double* nrm) {
     int ta = a->type, tb = b->type;
     if (ta == ORC_SPHERE && tb == ORC_SPHERE) return sphere_sphere(a, b, dist, pos, nrm);
@@ -484,7 +553,8 @@ static int narrow(const shape* a, const shape* b, double* dist, double* pos, dou
     double depth;
     if (!mpr_penetration(a, b, &depth, nrm, pos)) return 0;
     dist[0] = -depth;
-    return 1;
+    if (ta == ORC_SPHERE || tb == ORC_SPHERE) return 1;
+    return multiccd(a, b, dist, pos, nrm);
 }
 
 static void shape_center(shape* s, const double* bcenter) {
@@ -496,7 +566,7 @@ static void shape_center(shape* s, const double* bcenter) {
 int orc_narrow(int t1, const double* size1, const double* pos1, const double* mat1, const double* hull1, int nh1,
                int t2, const double* size2, const double* pos2, const double* mat2, const double* hull2, int nh2,
                double* dist, double* pos, double* normal) {
-    shape a = {t1, size1, pos1, mat1, hull1, nh1, {0, 0, 0}}, b = {t2, size2, pos2, mat2, hull2, nh2, {0, 0, 0}};
+    shape a = {t1, size1, pos1, mat1, hull1, nh1, {0, 0, 0}, 0.05}, b = {t2, size2, pos2, mat2, hull2, nh2, {0, 0, 0}, 0.05};
     double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
     for (int i = 0; i < nh1; i++) for (int k = 0; k < 3; k++) ca[k] += hull1[3 * i + k] / nh1;
     for (int i = 0; i < nh2; i++) for (int k = 0; k < 3; k++) cb[k] += hull2[3 * i + k] / nh2;
@@ -522,9 +592,9 @@ void orc_collide(orc_data* d) {
     for (int p = 0; p < m->npair; p++) {
         int g1 = m->pair_geom[2 * p], g2 = m->pair_geom[2 * p + 1];
         shape a = {m->geom_type[g1], m->geom_size + 3 * g1, d->geom_xpos + 3 * g1, d->geom_xmat + 9 * g1,
-                   m->hull_vert + 3 * m->geom_hull[2 * g1], m->geom_hull[2 * g1 + 1], {0, 0, 0}};
+                   m->hull_vert + 3 * m->geom_hull[2 * g1], m->geom_hull[2 * g1 + 1], {0, 0, 0}, m->geom_rbound[g1]};
         shape b = {m->geom_type[g2], m->geom_size + 3 * g2, d->geom_xpos + 3 * g2, d->geom_xmat + 9 * g2,
-                   m->hull_vert + 3 * m->geom_hull[2 * g2], m->geom_hull[2 * g2 + 1], {0, 0, 0}};
+                   m->hull_vert + 3 * m->geom_hull[2 * g2], m->geom_hull[2 * g2 + 1], {0, 0, 0}, m->geom_rbound[g2]};
         shape_center(&a, m->geom_bcenter + 3 * g1);
         shape_center(&b, m->geom_bcenter + 3 * g2);
         /* broad phase: bounding spheres about the interior points */

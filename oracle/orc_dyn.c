@@ -603,27 +603,134 @@ void orc_solve(orc_data* d) {
     orc_noslip(d);
 }
 
+/* mju_QCQP2 [EXT]: minimise 1/2 x'Ax + x'b subject to sum (x_i / d_i)^2 <= r^2, two unknowns.  The problem is scaled so that the
+ * constraint becomes |y| <= r, then Newton's method on the multiplier la of the constraint: y(la) = -(A + la I)^-1 b, root of
+ * |y|^2 - r^2.  Returns 1 when the constraint is active (la != 0). */
+static int qcqp2(double* res, const double* Ain, const double* bin, const double* d, double r) {
+    double b1 = bin[0] * d[0], b2 = bin[1] * d[1];
+    double A11 = Ain[0] * d[0] * d[0], A22 = Ain[3] * d[1] * d[1], A12 = Ain[1] * d[0] * d[1];
+    double la = 0, v1 = 0, v2 = 0;
+    for (int iter = 0; iter < 20; iter++) {
+        double det = (A11 + la) * (A22 + la) - A12 * A12;
+        if (det < 1e-10) { res[0] = res[1] = 0; return 0; }
+        double detinv = 1 / det, P11 = (A22 + la) * detinv, P22 = (A11 + la) * detinv, P12 = -A12 * detinv;
+        v1 = -P11 * b1 - P12 * b2;
+        v2 = -P12 * b1 - P22 * b2;
+        double val = v1 * v1 + v2 * v2 - r * r;
+        if (val < 1e-10) break;
+        double deriv = -2 * (P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2);
+        double delta = -val / deriv;
+        if (delta < 1e-10) break;
+        la += delta;
+    }
+    res[0] = v1 * d[0];
+    res[1] = v2 * d[1];
+    return la != 0;
+}
+
+/* mju_QCQP [EXT]: the same for n <= 5 unknowns, (A + la I) by Cholesky (pivots below 1e-10: singular, result 0) */
+static int qcqpn(double* res, const double* Ain, const double* bin, const double* d, double r, int n) {
+    double A[25], b[5], L[25], v[5], w[5], la = 0;
+    for (int i = 0; i < n; i++) {
+        b[i] = bin[i] * d[i];
+        for (int j = 0; j < n; j++) A[n * i + j] = Ain[n * i + j] * d[i] * d[j];
+    }
+    for (int i = 0; i < n; i++) v[i] = 0;
+    for (int iter = 0; iter < 20; iter++) {
+        /* L L' = A + la I */
+        for (int j = 0; j < n; j++) {
+            double dd = A[n * j + j] + la;
+            for (int k = 0; k < j; k++) dd -= L[n * j + k] * L[n * j + k];
+            if (dd < 1e-10) { for (int i = 0; i < n; i++) res[i] = 0; return 0; }
+            dd = sqrt(dd);
+            L[n * j + j] = dd;
+            for (int i = j + 1; i < n; i++) {
+                double t = A[n * i + j];
+                for (int k = 0; k < j; k++) t -= L[n * i + k] * L[n * j + k];
+                L[n * i + j] = t / dd;
+            }
+        }
+        /* v = -(A + la I)^-1 b */
+        for (int i = 0; i < n; i++) { double t = -b[i]; for (int k = 0; k < i; k++) t -= L[n * i + k] * v[k]; v[i] = t / L[n * i + i]; }
+        for (int i = n - 1; i >= 0; i--) { double t = v[i]; for (int k = i + 1; k < n; k++) t -= L[n * k + i] * v[k]; v[i] = t / L[n * i + i]; }
+        double val = -r * r;
+        for (int i = 0; i < n; i++) val += v[i] * v[i];
+        if (val < 1e-10) break;
+        /* deriv = -2 v' (A + la I)^-1 v */
+        for (int i = 0; i < n; i++) { double t = v[i]; for (int k = 0; k < i; k++) t -= L[n * i + k] * w[k]; w[i] = t / L[n * i + i]; }
+        for (int i = n - 1; i >= 0; i--) { double t = w[i]; for (int k = i + 1; k < n; k++) t -= L[n * k + i] * w[k]; w[i] = t / L[n * i + i]; }
+        double deriv = 0;
+        for (int i = 0; i < n; i++) deriv += v[i] * w[i];
+        deriv *= -2;
+        double delta = -val / deriv;
+        if (delta < 1e-10) break;
+        la += delta;
+    }
+    for (int i = 0; i < n; i++) res[i] = v[i] * d[i];
+    return la != 0;
+}
+
 void orc_noslip(orc_data* d) {
     const orc_model* m = d->m;
     int nv = m->nv, ne = d->nefc;
-    /* noslip post-pass (aloha_sim.xml:4 noslip_iterations=3): PGS sweeps over dry-friction and contact friction rows with
-     * the regulariser R removed; normal forces are held fixed.  As in mj_solNoSlip [EXT] a sweep whose scaled improvement of
-     * the dual cost falls below noslip_tolerance (MuJoCo default 1e-6, not set by the reference's XML) ends the pass. */
+    /* mj_solNoSlip [EXT] (aloha_sim.xml:4 noslip_iterations=3): Gauss-Seidel sweeps over the dry-friction rows and the friction
+     * blocks of the contacts with the regulariser R removed, normal forces held fixed.  A dry-friction row is a clamped scalar
+     * update; the friction block of an elliptic contact (2 or 5 rows) is the exact minimiser of its quadratic over the cone
+     * section sum (f_j / mu_j)^2 <= f_normal^2 (mju_QCQP2 / mju_QCQP), put exactly on the ellipsoid when the constraint is active.
+     * An update that would increase the cost by more than 1e-10 is undone (costChange); a sweep whose scaled improvement falls
+     * below noslip_tolerance (MuJoCo default 1e-6, not set by the reference's XML) ends the pass. */
     const double noslip_tolerance = 1e-6;
     for (int it = 0; it < m->noslip_iterations; it++) {
         double imp = 0;
         for (int i = 0; i < ne; i++) {
             int t = d->efc_type[i];
             if (t == ORC_FLOSS) {
-                double f = d->efc_force[i] - row_res(d, i, 0) / fmax(MINVAL, d->efc_diag[i]);
+                double res = row_res(d, i, 0), A = d->efc_diag[i];
+                double f = d->efc_force[i] - res / fmax(MINVAL, A);
                 if (f > d->efc_floss[i]) f = d->efc_floss[i];
                 if (f < -d->efc_floss[i]) f = -d->efc_floss[i];
-                noslip_set(d, i, f, &imp);
+                double dl = f - d->efc_force[i], change = 0.5 * A * dl * dl + dl * res;
+                if (change > 1e-10 || dl == 0) continue;
+                apply_delta(d, i, dl);
+                d->efc_force[i] = f;
+                imp -= change;
             } else if (t == ORC_CONTACT) {
                 const orc_contact* c = &d->contact[d->efc_id[i]];
-                if (i == c->efc_adr) continue;
-                noslip_set(d, i, d->efc_force[i] - row_res(d, i, 0) / fmax(MINVAL, d->efc_diag[i]), &imp);
-                if (i == c->efc_adr + c->dim - 1) cone_project(d, c, c->efc_adr, &imp);
+                if (i != c->efc_adr || c->dim < 2) continue;
+                const int n = c->dim - 1, i1 = i + 1;
+                double res[5], old[5], Ac[25], bc[5], v[5], dl[5];
+                for (int j = 0; j < n; j++) { res[j] = row_res(d, i1 + j, 0); old[j] = d->efc_force[i1 + j]; }
+                for (int j = 0; j < n; j++)
+                    for (int k = 0; k < n; k++) {
+                        const double *Jr = d->efc_J + (size_t)(i1 + j) * nv, *Bk = d->efc_B + (size_t)(i1 + k) * nv;
+                        double a = 0;
+                        for (int q = 0; q < nv; q++) a += Jr[q] * Bk[q];
+                        Ac[n * j + k] = a;
+                    }
+                for (int j = 0; j < n; j++)
+                    for (int k = 0; k < j; k++) Ac[n * k + j] = Ac[n * j + k];      /* exactly symmetric: lower triangle rules */
+                for (int j = 0; j < n; j++) { double a = 0; for (int k = 0; k < n; k++) a += Ac[n * j + k] * old[k]; bc[j] = res[j] - a; }
+                const double fn = d->efc_force[i];
+                if (fn < MINVAL) { for (int j = 0; j < n; j++) v[j] = 0; }
+                else {
+                    int active = n == 2 ? qcqp2(v, Ac, bc, c->friction, fn) : qcqpn(v, Ac, bc, c->friction, fn, n);
+                    if (active) {
+                        double s = 0;
+                        for (int j = 0; j < n; j++) s += v[j] * v[j] / (c->friction[j] * c->friction[j]);
+                        s = sqrt(fn * fn / fmax(MINVAL, s));
+                        for (int j = 0; j < n; j++) v[j] *= s;
+                    }
+                }
+                double change = 0;
+                for (int j = 0; j < n; j++) {
+                    dl[j] = v[j] - old[j];
+                    double a = 0;
+                    for (int k = 0; k < n; k++) a += Ac[n * j + k] * (v[k] - old[k]);
+                    change += dl[j] * (0.5 * a + res[j]);
+                }
+                if (change > 1e-10) continue;
+                for (int j = 0; j < n; j++) { apply_delta(d, i1 + j, dl[j]); d->efc_force[i1 + j] = v[j]; }
+                imp -= change;
             }
         }
         d->stat_noslip = it + 1;

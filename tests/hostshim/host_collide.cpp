@@ -17,7 +17,7 @@ static void fill(Shape<T>& s, int type, const double* size, const double* pos, c
 template <typename T>
 static int run(int t1, const double* size1, const double* pos1, const double* mat1, const double* hull1, int nh1, const double* c1,
                int t2, const double* size2, const double* pos2, const double* mat2, const double* hull2, int nh2, const double* c2,
-               double* dist, double* pos, double* normal) {
+               double rb1, double rb2, double* dist, double* pos, double* normal) {
     T h1[3 * 64], h2[3 * 64];
     for (int i = 0; i < 3 * nh1 && i < 192; i++) h1[i] = (T)hull1[i];
     for (int i = 0; i < 3 * nh2 && i < 192; i++) h2[i] = (T)hull2[i];
@@ -26,25 +26,30 @@ static int run(int t1, const double* size1, const double* pos1, const double* ma
     fill(b, t2, size2, pos2, mat2, h2, nh2);
     if (c1) for (int k = 0; k < 3; k++) a.center[k] = (T)c1[k];
     if (c2) for (int k = 0; k < 3; k++) b.center[k] = (T)c2[k];
-    T scr[20], work[56];
+    T scr[SLOT_W], work[56];
     int n;
     if (t1 == G_BOX && t2 == G_BOX) n = box_box(a, b, scr, work);
-    else n = narrow(a, b, scr);
+    else {
+        n = narrow(a, b, scr);
+        // multiccd for the convex (MPR) pairs, spheres excluded -- the kernel's rule (Env::collide_i)
+        if (n == 1 && t1 != G_SPHERE && t2 != G_SPHERE)
+            n = multiccd_serial(a, b, MultiCcd<T>::reltol * (T)(rb1 < rb2 ? rb1 : rb2), scr, scr + SLOT_P, scr + SLOT_N);
+    }
     for (int k = 0; k < n; k++) {
         dist[k] = scr[k];
-        for (int c = 0; c < 3; c++) pos[3 * k + c] = scr[4 + 3 * k + c];
+        for (int c = 0; c < 3; c++) pos[3 * k + c] = scr[SLOT_P + 3 * k + c];
     }
-    for (int c = 0; c < 3; c++) normal[c] = n ? scr[16 + c] : 0;
+    for (int c = 0; c < 3; c++) normal[c] = n ? scr[SLOT_N + c] : 0;
     return n;
 }
 
 extern "C" int dev_narrow_f64(int t1, const double* size1, const double* pos1, const double* mat1, const double* hull1, int nh1, const double* c1,
                               int t2, const double* size2, const double* pos2, const double* mat2, const double* hull2, int nh2, const double* c2,
-                              double* dist, double* pos, double* normal) {
-    return run<double>(t1, size1, pos1, mat1, hull1, nh1, c1, t2, size2, pos2, mat2, hull2, nh2, c2, dist, pos, normal);
+                              double rb1, double rb2, double* dist, double* pos, double* normal) {
+    return run<double>(t1, size1, pos1, mat1, hull1, nh1, c1, t2, size2, pos2, mat2, hull2, nh2, c2, rb1, rb2, dist, pos, normal);
 }
 extern "C" int dev_narrow_f32(int t1, const double* size1, const double* pos1, const double* mat1, const double* hull1, int nh1, const double* c1,
                               int t2, const double* size2, const double* pos2, const double* mat2, const double* hull2, int nh2, const double* c2,
-                              double* dist, double* pos, double* normal) {
-    return run<float>(t1, size1, pos1, mat1, hull1, nh1, c1, t2, size2, pos2, mat2, hull2, nh2, c2, dist, pos, normal);
+                              double rb1, double rb2, double* dist, double* pos, double* normal) {
+    return run<float>(t1, size1, pos1, mat1, hull1, nh1, c1, t2, size2, pos2, mat2, hull2, nh2, c2, rb1, rb2, dist, pos, normal);
 }

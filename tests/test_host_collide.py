@@ -1,5 +1,5 @@
 """The device's narrow-phase source (av_aloha_amd/csrc/avsim_collide.hip.h: box_box clipping, sphere / cylinder / hull pairs
-through MPR) compiled for the HOST by g++ with the oracle's floating-point rules (tests/hostshim/) and run against the oracle's
+through MPR, the multiccd perturbation contacts) compiled for the HOST by g++ with the oracle's floating-point rules (tests/hostshim/) and run against the oracle's
 orc_collide on the poses of tests/test_gpu_boxbox.py -- no GPU needed:
 
 * identical inputs -> identical contacts, bit for bit (same expressions in the same order);
@@ -79,6 +79,7 @@ def compare(host, q, fn, pert, tol, only_boxes):
     rng = np.random.default_rng(1)
     f = getattr(host, fn)
     tot = bad = 0
+    multi = np.zeros(6, dtype=np.int64)          # histogram of contacts per pair
     for i in range(q.shape[0]):
         e.L.orc_set_qpos(e.dptr, q[i].ctypes.data)
         gx = np.ctypeslib.as_array(e.d.geom_xpos, shape=(ng, 3)).copy()
@@ -105,10 +106,12 @@ def compare(host, q, fn, pert, tol, only_boxes):
             a, b = shape(g1), shape(g2)
             dist, pos, nrm = np.zeros(8), np.zeros(24), np.zeros(3)
             nn = f(t1, dp(a[0]), dp(a[1]), dp(a[2]), dp(a[3]), a[4], dp(a[5]), t2, dp(b[0]), dp(b[1]), dp(b[2]), dp(b[3]), b[4], dp(b[5]),
-                   dp(dist), dp(pos), dp(nrm))
+                   C.c_double(float(md["geom_rbound"][g1])), C.c_double(float(md["geom_rbound"][g2])), dp(dist), dp(pos), dp(nrm))
+            multi[min(nn, 5)] += 1
             tot += 1
             bad += nn != len(ref) or np.abs(dist[:nn] - ref).max() > tol
     e.close()
+    compare.multi = multi
     return tot, bad
 
 
@@ -127,7 +130,39 @@ def test_device_mpr_source_equals_the_oracle_and_ignores_rounding_noise(host):
     q = hull_poses(160)
     tot, bad = compare(host, q, "dev_narrow_f64", 0.0, 0.0, False)
     assert tot > 900 and bad == 0, (tot, bad)
+    # (these are deep corner-first overlaps: a unique deepest point, so the multiccd perturbations rarely find a second contact)
     tot, bad = compare(host, q, "dev_narrow_f64", 2e-16, 1e-9, False)
     assert bad == 0, (tot, bad)
     tot, bad = compare(host, q, "dev_narrow_f32", 0.0, 1e-4, False)
     assert bad <= 0.05 * tot, (tot, bad)
+
+
+def test_multiccd_gives_a_flat_contact_its_rim(host):
+    """aloha_sim.xml:5 multiccd: a cylinder standing on a box (flat cap on flat face, 0.1 mm deep) gets the first contact plus the
+    four perturbation contacts on the rim of the cap, about +-x and +-y of the contact frame; tilting the cylinder by 0.01 rad
+    leaves the contacts of the low side only.  Device source == oracle."""
+    from orc_ffi import lib
+    L = lib()
+    z, I = np.zeros(3), np.eye(3).reshape(-1).copy()
+    cyl, box = np.array([0.02, 0.03, 0.0]), np.array([0.1, 0.1, 0.02])
+    seen = {}
+    for tilt in (0.0, 0.01):
+        c, s = np.cos(tilt), np.sin(tilt)
+        Rc = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]]).reshape(-1).copy()
+        cp, bp = np.array([0.01, 0.02, 0.02 + 0.03 - 1e-4]), np.zeros(3)
+        dist, pos, nrm = np.zeros(8), np.zeros(24), np.zeros(3)
+        n = host.dev_narrow_f64(5, dp(cyl), dp(cp), dp(Rc), dp(z), 0, dp(cp.copy()), 6, dp(box), dp(bp), dp(I), dp(z), 0, dp(bp.copy()),
+                                C.c_double(0.05), C.c_double(0.05), dp(dist), dp(pos), dp(nrm))
+        do, po, no = np.zeros(8), np.zeros(24), np.zeros(24)
+        m = L.orc_narrow(5, dp(cyl), dp(cp), dp(Rc), dp(z), 0, 6, dp(box), dp(bp), dp(I), dp(z), 0, dp(do), dp(po), dp(no))
+        assert n == m and np.array_equal(dist[:n], do[:n]) and np.array_equal(pos[:3 * n], po[:3 * n])
+        seen[tilt] = (n, dist[:n].copy(), pos[:3 * n].reshape(-1, 3).copy())
+        assert abs(nrm[2] + 1) < 1e-6                      # normal from the cylinder (geom 1) down into the box
+    n, dist, pos = seen[0.0]
+    assert n == 5 and abs(dist[0] + 1e-4) < 1e-9 and (dist[1:] < -1e-4).all() and (dist[1:] > -2e-4).all()
+    rad = np.linalg.norm(pos[1:, :2] - [0.01, 0.02], axis=1)
+    assert np.abs(rad - 0.02).max() < 3e-4                 # the four extra contacts sit on the rim
+    dirs = (pos[1:, :2] - [0.01, 0.02]) / rad[:, None]
+    assert np.abs(dirs @ dirs.T).round(2).tolist().count([1.0, 1.0, 0.0, 0.0]) >= 1 or len({tuple(np.sign(d.round(1))) for d in dirs}) == 4
+    n, dist, pos = seen[0.01]
+    assert 1 <= n <= 4 and (pos[:, 0] > 0.025).all()          # only the low side (+x) of the tilted cap touches
