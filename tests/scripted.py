@@ -8,12 +8,12 @@ from av_aloha_amd.workloads import GRASP_HEIGHT, grasp_lift_targets, qmul  # noq
 
 class SlotInsertionScript:
     """One manipulator grasps the stick top-down at its centre, lifts it, carries it over the slot, lowers it until its
-    underside is inside the slot walls' height and lets go (the arm nearer to the stick does it) (task_slot_insertion.xml:5-16; clearance 4 mm a side): the pins
+    underside is 1.5 cm above the slot walls (4 cm high: lower, and the opening fingers press on the walls and keep the stick pinched) and lets go (the arm nearer to the stick does it) (task_slot_insertion.xml:5-16; clearance 4 mm a side): the pins
     touch when the stick has dropped in (env.py:584-587, reward 4).  Closed loop on the measured stick and slot poses
     (qpos[23:30] slot, [30:37] stick): the carry / lower phases add the integrated xy error to the hand target."""
     T = (60, 40, 25, 40, 90, 50, 10, 15, 20)
 
-    def __init__(self, home, qpos, drop=0.04, clip=0.05, gain=0.15):
+    def __init__(self, home, qpos, drop=0.055, clip=0.05, gain=0.15, yaw_gain=0.15, yaw_clip=1.2):
         n = qpos.shape[0]
         self.n = n
         self.home = home
@@ -24,6 +24,10 @@ class SlotInsertionScript:
         self.stick0 = qpos[:, 30:33].copy()
         self.use_left = self.stick0[:, 0] < 0.0          # the nearer arm carries (top-down reach ends near the far side)
         self.corr = np.zeros((n, 2))
+        # the pinched stick follows the hand's rotation about the vertical, and the IK trades some of the commanded orientation
+        # for its joint-centring terms on the way to the slot: the commanded hand yaw integrates the measured stick / slot yaw error
+        self.yaw_gain, self.yaw_clip = yaw_gain, yaw_clip
+        self.yaw = np.zeros(n)
         self.t = 0
 
     def phase(self):
@@ -57,6 +61,11 @@ class SlotInsertionScript:
             g = min(1.0, f / 0.7) if k == 4 else 1.0
             if (k == 4 and f > 0.7) or k in (5, 6):
                 self.corr = np.clip(self.corr + self.gain * (slot[:, :2] - stick[:, :2]), -self.clip, self.clip)
+            if k in (4, 5, 6):
+                yaw_of = lambda qq: 2.0 * np.arctan2(qq[:, 3], qq[:, 0])
+                err = yaw_of(qpos[:, 26:30]) - yaw_of(qpos[:, 33:37])
+                err = (err + np.pi / 2) % np.pi - np.pi / 2                  # the stick fits either way round
+                self.yaw = np.clip(self.yaw + self.yaw_gain * err, -self.yaw_clip, self.yaw_clip)
             base = self.stick0[:, :2] + g * (slot[:, :2] - self.stick0[:, :2]) + self.corr
             zr = zc + self.drop
             z = hi if k == 4 else (hi + (zr - hi) * min(1.0, f / 0.8) if k == 5 else zr)
@@ -65,8 +74,11 @@ class SlotInsertionScript:
         a[:, 0:7] = self.home["left"]
         a[:, 8:15] = self.home["right"]
         L, R = self.use_left, ~self.use_left
-        a[L, 0:2] = base[L]; a[L, 2] = z; a[L, 3:7] = self.down_l[L]; a[L, 7] = grip
-        a[R, 8:10] = base[R]; a[R, 10] = z; a[R, 11:15] = self.down_r[R]; a[R, 15] = grip
+        qz = np.stack([np.cos(self.yaw / 2), np.zeros(n), np.zeros(n), np.sin(self.yaw / 2)], axis=1)
+        dl = np.stack([qmul(qz[i], self.down_l[i]) for i in range(n)])
+        dr = np.stack([qmul(qz[i], self.down_r[i]) for i in range(n)])
+        a[L, 0:2] = base[L]; a[L, 2] = z; a[L, 3:7] = dl[L]; a[L, 7] = grip
+        a[R, 8:10] = base[R]; a[R, 10] = z; a[R, 11:15] = dr[R]; a[R, 15] = grip
         a[:, 16:23] = self.home["middle"]
         self.t += 1
         return a

@@ -117,15 +117,14 @@ def test_config3_scripted_grasp_and_lift():
         worst = max(worst, int(d[:, 2].max()))
         flagged |= (d[:, 3] & 1) != 0
     assert worst == 0, "row / contact caps overflowed"
-    # a needle that is pinched at its edge can be squeezed out of the closing fingers and fly off spinning; the Euler
-    # integrator lets such a free spinning bar run away (as MuJoCo's does [EXT]) until the divergence check resets the env
-    assert flagged.mean() <= 0.10, f"{flagged.sum()} envs were reset by the divergence check"
+    # the finger pads hold the needle with several contact points each (multiccd) and MuJoCo's noslip pass: nothing is squeezed out
+    assert flagged.mean() <= 0.01, f"{flagged.sum()} envs were reset by the divergence check"
     q, v = env.sim.get_state()[:2]
     assert np.isfinite(q).all() and np.isfinite(v).all()
     lifted = q[:, 32] - needle0[:, 2] > 0.08
     assert (rich >= 100).mean() >= 0.5, f"contact-rich envs: {(rich >= 100).mean():.2f}"
-    assert lifted.mean() >= 0.7, f"needle lifted in {lifted.mean():.2f} of the envs"
-    assert (rw[lifted] >= 2).all() and (rw >= 2).mean() >= 0.7
+    assert lifted.mean() >= 0.95, f"needle lifted in {lifted.mean():.2f} of the envs"
+    assert (rw[lifted] >= 2).all() and (rw >= 2).mean() >= 0.95
     env.close()
 
 
