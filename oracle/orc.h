@@ -24,6 +24,15 @@
 extern "C" {
 #endif
 
+/* flop-counting build (tools/count_flops.py, oracle/count/cdouble.h): the phase the counted operations are booked under */
+enum { ORC_PH_OTHER = 0, ORC_PH_KINEMATICS, ORC_PH_CRB, ORC_PH_COLLIDE, ORC_PH_RNE, ORC_PH_SMOOTH, ORC_PH_ROWS, ORC_PH_NEWTON, ORC_PH_NOSLIP,
+       ORC_PH_EULER, ORC_PH_IK, ORC_PH_COUNT };
+#ifdef ORC_COUNT_FLOPS
+#define ORC_PHASE(k) (orc_phase = (k))
+#else
+#define ORC_PHASE(k) ((void)0)
+#endif
+
 #define ORC_MAXCON 64
 #define ORC_MAXEFC 400
 #define ORC_MAXNV 48

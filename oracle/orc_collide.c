@@ -426,7 +426,8 @@ static int box_box(const shape* a, const shape* b, double* dist, double* pos, do
         if (np == 0) return 0;
     }
     /* keep points below the reference face */
-    double face = (dot3(nr, (double[3]){ref->mat[ax], ref->mat[3 + ax], ref->mat[6 + ax]}) > 0 ? 1.0 : -1.0);
+    const double refax[3] = {ref->mat[ax], ref->mat[3 + ax], ref->mat[6 + ax]};
+    double face = (dot3(nr, refax) > 0 ? 1.0 : -1.0);
     double dep[16];
     int m = 0;
     for (int q = 0; q < np; q++) {

@@ -745,18 +745,19 @@ void orc_noslip(orc_data* d) {
 
 /* mj_forward [EXT] */
 void orc_forward(orc_data* d) {
-    orc_kinematics(d);
-    orc_crb(d);
-    orc_collide(d);
-    orc_rne_bias(d);
-    smooth_forces(d);
-    orc_make_constraints(d);
+    ORC_PHASE(ORC_PH_KINEMATICS); orc_kinematics(d);
+    ORC_PHASE(ORC_PH_CRB); orc_crb(d);
+    ORC_PHASE(ORC_PH_COLLIDE); orc_collide(d);
+    ORC_PHASE(ORC_PH_RNE); orc_rne_bias(d);
+    ORC_PHASE(ORC_PH_SMOOTH); smooth_forces(d);
+    ORC_PHASE(ORC_PH_ROWS); orc_make_constraints(d);
     if (d->solver == 1) {
-        orc_solve_newton(d);
-        orc_noslip(d);   /* noslip runs on the dual after the main solve [EXT]; qacc and forces stay consistent */
+        ORC_PHASE(ORC_PH_NEWTON); orc_solve_newton(d);
+        ORC_PHASE(ORC_PH_NOSLIP); orc_noslip(d);   /* noslip runs on the dual after the main solve [EXT]; qacc and forces stay consistent */
     } else {
-        orc_solve(d);
+        ORC_PHASE(ORC_PH_NEWTON); orc_solve(d);
     }
+    ORC_PHASE(ORC_PH_OTHER);
 }
 
 /* P9: mj_Euler with implicit joint damping [EXT]: (M + h diag(b)) qacc_d = qfrc_smooth + qfrc_constraint */
@@ -801,12 +802,13 @@ static void euler(orc_data* d) {
 void orc_step(orc_data* d, int nsub) {
     for (int s = 0; s < nsub; s++) {
         orc_forward(d);
-        euler(d);
+        ORC_PHASE(ORC_PH_EULER); euler(d);
     }
     /* refresh position-dependent quantities of the final state (dm_control Physics.step's trailing
      * mj_step1): the contact list read by get_reward is that of the new state */
-    orc_kinematics(d);
-    orc_collide(d);
+    ORC_PHASE(ORC_PH_KINEMATICS); orc_kinematics(d);
+    ORC_PHASE(ORC_PH_COLLIDE); orc_collide(d);
+    ORC_PHASE(ORC_PH_OTHER);
 }
 
 void orc_reset(orc_data* d, const double* obj_qpos) {
@@ -859,6 +861,7 @@ void orc_env_step(orc_data* d, const double* action, int nsub, double* agent_pos
 /* sim_env.py:277-301 */
 void orc_cart_to_ctrl(const orc_data* d, const double* a, int mode, double* out21) {
     const orc_model* m = d->m;
+    ORC_PHASE(ORC_PH_IK);
     const double kn[7] = {10.0, 10.0, 10.0, 10.0, 5.0, 5.0, 5.0};
     double lo = m->grip_range[0], hi = m->grip_range[1];
     for (int arm = 0; arm < 3; arm++) {
@@ -873,4 +876,5 @@ void orc_cart_to_ctrl(const orc_data* d, const double* a, int mode, double* out2
         if (arm < 2) out21[base + 6] = 1.0 - t[7];
     }
     (void)lo; (void)hi;
+    ORC_PHASE(ORC_PH_OTHER);
 }
