@@ -27,7 +27,7 @@ def build_hip(force=False, verbose=False):
     units = [
         # f32 divide / sqrt through v_rcp / v_rsq (~1 ulp) instead of the correctly rounded 10-instruction sequences; the f64
         # parity mode is unaffected and the f32 tolerances of tests/test_gpu_physics.py are stated against the f64 oracle
-        ("avsim_api", ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]),
+        ("avsim_api", ["-fno-hip-fp32-correctly-rounded-divide-sqrt"] + (["-DAVSIM_RENDER_STATS"] if os.environ.get("AVSIM_RENDER_STATS") else []) + os.environ.get("AVSIM_EXTRA_FLAGS", "").split()),
         ("avsim_phys_f64", ["-ffp-contract=off"]),
     ]
     procs = []

@@ -28,9 +28,22 @@
 namespace avs {
 
 
-constexpr int REC_W = 28;   // floats per geom record: o_l[3], A[9] (camera dir -> geom frame), c[3], r, size[3], type, plane adr, plane count,
-                            // geom id, pad, screen box xl xr yb yt (units of tan), nearest depth
+constexpr int REC_W = 32;   // floats per geom record: o_l[3], A[9] (camera dir -> geom frame), c[3], r, size[3], type, plane adr, plane count,
+                            // geom id, nearest depth, screen box xl xr yb yt (units of tan), and the extents of x + y and x - y over
+                            // the projected vertices [28..31]: with the box an octagon, tight for the long thin frame bars that cross the
+                            // image at an angle
 constexpr int TILE_W = 32, TILE_H = 8;
+#ifndef AVSIM_BIN_TX
+#define AVSIM_BIN_TX 2
+#define AVSIM_BIN_TY 4
+#endif
+constexpr int BIN_TX = AVSIM_BIN_TX, BIN_TY = AVSIM_BIN_TY;           // a block's bin: 2 x 4 tiles = 64 x 32 pixels (measured best of 4x8, 2x4, 2x2, 1x4)
+#ifdef AVSIM_RENDER_STATS
+__device__ unsigned long long g_rstat[8];   // debug build: tiles, bin-list entries seen, box hits, records cast, entry faces, veto faces, primitives, -
+#define RSTAT(i, n) do { if (lane == 0) atomicAdd(&g_rstat[i], (unsigned long long)(n)); } while (0)
+#else
+#define RSTAT(i, n) ((void)0)
+#endif
 
 struct RenderModel {
     int ngeom, ncam, nbody, nplane;   // nplane: faces summed over the visible mesh geoms
@@ -106,7 +119,7 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
             rec[20] = __int_as_float(m.geom_hplane[2 * g]); rec[21] = __int_as_float(m.geom_hplane[2 * g + 1]);
             rec[22] = __int_as_float(g); rec[23] = 0;
             // screen box of the geom's vertices (hull vertices, box corners, bounding box of spheres / cylinders)
-            float bx0 = 1e30f, bx1 = -1e30f, by0 = 1e30f, by1 = -1e30f, zmin = 1e30f;
+            float bx0 = 1e30f, bx1 = -1e30f, by0 = 1e30f, by1 = -1e30f, zmin = 1e30f, bu0 = 1e30f, bu1 = -1e30f, bv0 = 1e30f, bv1 = -1e30f;
             bool crossing = false;
             const int type = m.geom_type[g];
             const int nvert = type == 7 ? m.geom_hull[2 * g + 1] : 8;
@@ -122,12 +135,18 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
                 const float depth = -zc;
                 if (depth < 0.5f * m.znear) { crossing = true; continue; }
                 const float iz = 1.0f / depth;
-                bx0 = fminf(bx0, xc * iz); bx1 = fmaxf(bx1, xc * iz); by0 = fminf(by0, yc * iz); by1 = fmaxf(by1, yc * iz);
+                const float sxp = xc * iz, syp = yc * iz;
+                bx0 = fminf(bx0, sxp); bx1 = fmaxf(bx1, sxp); by0 = fminf(by0, syp); by1 = fmaxf(by1, syp);
+                bu0 = fminf(bu0, sxp + syp); bu1 = fmaxf(bu1, sxp + syp); bv0 = fminf(bv0, sxp - syp); bv1 = fmaxf(bv1, sxp - syp);
                 zmin = fminf(zmin, depth);
             }
-            if (crossing) { bx0 = by0 = -1e30f; bx1 = by1 = 1e30f; zmin = 0; }
+            if (type != 7 && type != 6) {   // spheres / cylinders: the corners of their bounding box are not on the surface; box only
+                bu0 = bv0 = -1e30f; bu1 = bv1 = 1e30f;
+            }
+            if (crossing) { bx0 = by0 = bu0 = bv0 = -1e30f; bx1 = by1 = bu1 = bv1 = 1e30f; zmin = 0; }
             const float pad = 1e-4f;
             rec[24] = bx0 - pad; rec[25] = bx1 + pad; rec[26] = by0 - pad; rec[27] = by1 + pad; rec[23] = zmin * 0.9999f - 1e-5f;
+            rec[28] = bu0 - 2 * pad; rec[29] = bu1 + 2 * pad; rec[30] = bv0 - 2 * pad; rec[31] = bv1 + 2 * pad;
             keep = (c[2] - r < -m.znear) && rec[24] <= tx && rec[25] >= -tx && rec[26] <= ty && rec[27] >= -ty;
         }
         const unsigned long long bal = __ballot(keep);
@@ -224,22 +243,16 @@ __device__ inline bool ray_prim(int type, const float* sz, const float* o, const
     return true;
 }
 
-// grid (tiles_x * tiles_y, ncam_sel, N), block 64: lane -> 4 pixels (x0 .. x0+3, y).  RGB: the cast also remembers which record
-// (and hull face) each pixel sees, and an epilogue shades it (flat material colour, Lambert terms of the headlight along
-// the ray and of the scene's directional light, sky gradient where nothing is hit) into u8[H][W][3]
+// One 32 x 8 pixel tile by one wavefront: lane -> 4 pixels (x0 .. x0+3, y).  `blist` / `cnt` = the records of the tile's bin in
+// front-to-back order (LDS, built by k_render_depth).  RGB: the cast also remembers which record (and hull face) each pixel sees,
+// and an epilogue shades it (flat material colour, Lambert terms of the headlight along the ray and of the scene's directional
+// light, sky gradient where nothing is hit) into u8[H][W][3]
 template <bool RGB>
-__global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ recs, const int* __restrict__ counts, const int* __restrict__ order,
-                                                     const float4* __restrict__ tplanes, int nplane,
-                                                     const float* __restrict__ cam_fovy, const int* __restrict__ cam_ids, int ncam_sel, int ngeom, int H,
-                                                     int W, float znear, float zfar, float* __restrict__ out, const float* __restrict__ geom_rgba, const float* __restrict__ light,
-                                                     const float* __restrict__ camaux, unsigned char* __restrict__ out_rgb) {
-    const int lane = threadIdx.x, cs = blockIdx.y, env = blockIdx.z;
-    const int tiles_x = (W + TILE_W - 1) / TILE_W, tx0 = (blockIdx.x % tiles_x) * TILE_W, ty0 = (blockIdx.x / tiles_x) * TILE_H;
+__device__ __forceinline__ void render_tile(const int lane, const int tx0, const int ty0, const int cs, const int env, const unsigned short* blist, const int cnt,
+                                            const float* __restrict__ R, const float4* __restrict__ tplanes, int nplane, const float scale, int ncam_sel, int H,
+                                            int W, float znear, float zfar, float* __restrict__ out, const float* __restrict__ geom_rgba, const float* __restrict__ light,
+                                            const float* __restrict__ camaux, unsigned char* __restrict__ out_rgb) {
     const int px = tx0 + 4 * (lane & 7), py = ty0 + (lane >> 3);
-    const float scale = 2.0f * cam_fovy[cam_ids[cs]] / (float)H;     // cam_fovy holds tan(fovy / 2)
-    const float* R = recs + ((size_t)env * ncam_sel + cs) * ngeom * REC_W;
-    const int cnt = counts[(size_t)env * ncam_sel + cs];
-    const int* ord = order + ((size_t)env * ncam_sel + cs) * ngeom;
     // tile pyramid: x in [xl, xr], y in [yb, yt] at z = -1
     const int x1 = tx0 + TILE_W < W ? tx0 + TILE_W : W, y1 = ty0 + TILE_H < H ? ty0 + TILE_H : H;
     const float xl = (tx0 - 0.5f * W) * scale, xr = (x1 - 0.5f * W) * scale, yt = -(ty0 - 0.5f * H) * scale, yb = -(y1 - 0.5f * H) * scale;
@@ -249,15 +262,17 @@ __global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ r
 #pragma unroll
     for (int q = 0; q < 4; q++) { dx[q] = (px + q + 0.5f - 0.5f * W) * scale; best[q] = (px + q < W && py < H) ? zfar : 0.0f; win[q] = -1; }
     float far = zfar;    // farthest current depth over the tile's pixels (off-image pixels count as 0)
+    RSTAT(0, 1); RSTAT(1, cnt);
     for (int k0 = 0; k0 < cnt; k0 += 64) {
         bool hit = false;
         int mine = 0;
         if (k0 + lane < cnt) {
-            mine = ord[k0 + lane];
+            mine = blist[k0 + lane];
             const float* bb = R + (size_t)mine * REC_W + 24;
-            hit = bb[0] <= xr && bb[1] >= xl && bb[2] <= yt && bb[3] >= yb;
+            hit = bb[0] <= xr && bb[1] >= xl && bb[2] <= yt && bb[3] >= yb && bb[4] <= xr + yt && bb[5] >= xl + yb && bb[6] <= xr - yb && bb[7] >= xl - yt;
         }
         unsigned long long mask = __ballot(hit);
+        RSTAT(2, __popcll(mask));
         while (mask) {
             const int pos = __builtin_ctzll(mask);
             mask &= mask - 1;
@@ -268,40 +283,97 @@ __global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ r
             const float o[3] = {rec[0], rec[1], rec[2]};
             const int type = __float_as_int(rec[19]);
             if (type == 7) {
-                // separating face: one hull plane per lane; the tile's pyramid misses the hull if the camera and all four
-                // corner rays are on the outer side of some face (tight for the long frame bars that cross the camera plane)
+                // Faces of the hull in camera-ray form, one per lane, evaluated on the four corner rays of the tile.  A face's
+                // crossing t = no / (a x + b y - c) is a ratio of affine functions, so over the tile it takes its extremes at the
+                // corners (as long as the denominator keeps its sign).  That sorts the faces once per tile:
+                //  * a face seen from outside (no < 0) that no corner ray approaches separates the tile from the hull;
+                //  * the entry of a ray is the LARGEST crossing over those faces, so a face whose largest crossing over the tile is
+                //    below L = the largest of the faces' smallest crossings can never be the entry face of a ray of this tile;
+                //  * the other faces only veto entries that lie behind them: a face whose nearest crossing over the tile is beyond
+                //    the farthest possible entry U never does.
+                // Interior tiles of a hull keep one or two entry faces and no vetoing face instead of all ~40.
                 const float4* P = tplanes + ((size_t)env * ncam_sel + cs) * nplane + __float_as_int(rec[20]);
                 const int np = __float_as_int(rec[21]);
+                unsigned long long mF = 0, mB = 0;     // np <= 64 (hulls are decimated to <= 32 vertices); larger hulls keep every face
+                float L = -1e30f, U = 1e30f;
                 bool sep = false;
-                for (int p = lane; p < np; p += 64) {
-                    const float4 f = P[p];
-                    sep = sep || (f.w < 0 && f.x * xl + f.y * yt - f.z >= 0 && f.x * xr + f.y * yt - f.z >= 0 && f.x * xl + f.y * yb - f.z >= 0 &&
-                                  f.x * xr + f.y * yb - f.z >= 0);
+                float4 fl = make_float4(0.f, 0.f, 0.f, 0.f);      // this lane's face: the casting loops fetch the kept faces from here (v_readlane)
+                if (np <= 64) {
+                    const bool on = lane < np;
+                    const float4 f = P[on ? lane : 0];
+                    fl = f;
+                    const float n00 = f.x * xl + f.y * yb - f.z, n10 = f.x * xr + f.y * yb - f.z, n01 = f.x * xl + f.y * yt - f.z, n11 = f.x * xr + f.y * yt - f.z;
+                    const bool front = on && f.w < 0;
+                    const bool allneg = n00 < 0 && n10 < 0 && n01 < 0 && n11 < 0, allpos = n00 >= 0 && n10 >= 0 && n01 >= 0 && n11 >= 0;
+                    sep = front && allpos;
+                    const float t00 = f.w * __builtin_amdgcn_rcpf(n00), t10 = f.w * __builtin_amdgcn_rcpf(n10), t01 = f.w * __builtin_amdgcn_rcpf(n01), t11 = f.w * __builtin_amdgcn_rcpf(n11);
+                    float tmn = -1e30f, tmx = 1e30f;
+                    if (front && allneg) { tmn = fminf(fminf(t00, t10), fminf(t01, t11)); tmx = fmaxf(fmaxf(t00, t10), fmaxf(t01, t11)); }
+                    L = wave_max(front ? tmn : -1e30f);
+                    U = wave_max(front ? tmx : -1e30f);
+                    const bool keepF = front && tmx >= L - (1e-5f * fabsf(L) + 1e-6f);
+                    // the other faces (camera inside their half space) bound the EXIT of a ray, the smallest crossing over the faces it
+                    // leaves through; an entry is valid iff it is not beyond the exit.  Mirror image of the entry faces: a face whose
+                    // smallest crossing over the tile is above X = the smallest of the faces' largest crossings is never the exit face
+                    // (nor is one that no corner ray leaves through); and none matters when even X is beyond the farthest entry U
+                    float bmin = 1e30f, bmax = 1e30f;
+                    const bool back = on && !front;
+                    const bool allpos_s = n00 > 0 && n10 > 0 && n01 > 0 && n11 > 0, allneg_b = n00 <= 0 && n10 <= 0 && n01 <= 0 && n11 <= 0;
+                    if (back && allpos_s) { bmin = fminf(fminf(t00, t10), fminf(t01, t11)); bmax = fmaxf(fmaxf(t00, t10), fmaxf(t01, t11)); }
+                    else if (back && !allneg_b) bmin = -1e30f;     // sign change inside the tile: keep, no bound from it
+                    const float X = -wave_max(back ? -bmax : -1e30f);
+                    const bool keepB = back && !allneg_b && bmin <= X + (1e-5f * fabsf(X) + 1e-6f) && bmin <= U + (1e-5f * fabsf(U) + 1e-6f);
+                    mF = __ballot(keepF);
+                    mB = __ballot(keepB);
+                } else {
+                    for (int p = lane; p < np; p += 64) {
+                        const float4 f = P[p];
+                        sep = sep || (f.w < 0 && f.x * xl + f.y * yt - f.z >= 0 && f.x * xr + f.y * yt - f.z >= 0 && f.x * xl + f.y * yb - f.z >= 0 &&
+                                      f.x * xr + f.y * yb - f.z >= 0);
+                    }
                 }
                 if (__any(sep)) continue;
-            }
-            if (type == 7) {
-                const float4* P = tplanes + ((size_t)env * ncam_sel + cs) * nplane + __float_as_int(rec[20]);
-                const int np = __float_as_int(rec[21]);
-                // the camera is outside a face iff no < 0 (wave-uniform).  Pass 1, faces seen from outside: the entry is the
-                // largest crossing, a ray that does not approach such a face misses.  Pass 2, the other faces: the entry
-                // point must lie behind them (lo * n.v <= no; no division).
+                if (np <= 64 && L >= far) continue;
+                RSTAT(3, 1); RSTAT(4, __popcll(mF)); RSTAT(5, __popcll(mB));        // nothing of this hull in the tile is nearer than what the tile already shows
+                // Pass 1, candidate entry faces: the entry is the largest crossing, a ray that does not approach such a face misses.
+                // Pass 2, vetoing faces: the entry point must lie behind them (lo * n.v <= no; no division).
                 float lo[4];
                 bool ok[4];
                 int face[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) { lo[q] = -1e30f; ok[q] = true; face[q] = 0; }
-                for (int p = 0; p < np; p++) {
-                    const float4 f = P[p];
-                    if (!(f.w < 0)) continue;
-                    const float nb = f.y * dy - f.z;
+                if (np <= 64) {
+                    while (mF) {
+                        const int p = __builtin_ctzll(mF);
+                        mF &= mF - 1;
+                        float4 f;
+                        f.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.x), p));
+                        f.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.y), p));
+                        f.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.z), p));
+                        f.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.w), p));
+                        const float nb = f.y * dy - f.z;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float nv = nb + f.x * dx[q];
-                        const float t = f.w * __builtin_amdgcn_rcpf(nv);
-                        ok[q] = ok[q] && nv < 0;
-                        if (RGB) { if (t > lo[q]) face[q] = p; }
-                        lo[q] = fmaxf(lo[q], t);
+                        for (int q = 0; q < 4; q++) {
+                            const float nv = nb + f.x * dx[q];
+                            const float t = f.w * __builtin_amdgcn_rcpf(nv);
+                            ok[q] = ok[q] && nv < 0;
+                            if (RGB) { if (t > lo[q]) face[q] = p; }
+                            lo[q] = fmaxf(lo[q], t);
+                        }
+                    }
+                } else {
+                    for (int p = 0; p < np; p++) {
+                        const float4 f = P[p];
+                        if (!(f.w < 0)) continue;
+                        const float nb = f.y * dy - f.z;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const float nv = nb + f.x * dx[q];
+                            const float t = f.w * __builtin_amdgcn_rcpf(nv);
+                            ok[q] = ok[q] && nv < 0;
+                            if (RGB) { if (t > lo[q]) face[q] = p; }
+                            lo[q] = fmaxf(lo[q], t);
+                        }
                     }
                 }
                 // no ray of the tile can still improve on what it already sees: skip the validity pass
@@ -311,12 +383,27 @@ __global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ r
                     for (int q = 0; q < 4; q++) need = need || (ok[q] && lo[q] >= znear && lo[q] < best[q]);
                     if (!__any(need)) continue;
                 }
-                for (int p = 0; p < np; p++) {
-                    const float4 f = P[p];
-                    if (f.w < 0) continue;
-                    const float nb = f.y * dy - f.z;
+                if (np <= 64) {
+                    while (mB) {
+                        const int p = __builtin_ctzll(mB);
+                        mB &= mB - 1;
+                        float4 f;
+                        f.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.x), p));
+                        f.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.y), p));
+                        f.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.z), p));
+                        f.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.w), p));
+                        const float nb = f.y * dy - f.z;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) ok[q] = ok[q] && lo[q] * (nb + f.x * dx[q]) <= f.w;
+                        for (int q = 0; q < 4; q++) ok[q] = ok[q] && lo[q] * (nb + f.x * dx[q]) <= f.w;
+                    }
+                } else {
+                    for (int p = 0; p < np; p++) {
+                        const float4 f = P[p];
+                        if (f.w < 0) continue;
+                        const float nb = f.y * dy - f.z;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) ok[q] = ok[q] && lo[q] * (nb + f.x * dx[q]) <= f.w;
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++)
@@ -324,6 +411,7 @@ __global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ r
                 far = wave_max(fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3])));
             } else {
                 // direction in the geom frame: A (dx, dy, -1)
+                RSTAT(6, 1);
                 float vb[3], va[3];
 #pragma unroll
                 for (int i = 0; i < 3; i++) { va[i] = rec[3 + 3 * i]; vb[i] = rec[3 + 3 * i + 1] * dy - rec[3 + 3 * i + 2]; }
@@ -408,6 +496,69 @@ __global__ void __launch_bounds__(64) k_render_depth(const float* __restrict__ r
 #pragma unroll
         for (int q = 0; q < 4; q++)
             if (px + q < W) { dst[3 * q] = col[3 * q]; dst[3 * q + 1] = col[3 * q + 1]; dst[3 * q + 2] = col[3 * q + 2]; }
+    }
+}
+
+// grid (bins_x * bins_y, ncam_sel, N), block 256 = 4 wavefronts.  A block owns a bin of BIN_TX x BIN_TY tiles (64 x 32 pixels).
+// Wave 0 first makes the bin's record list: one record per lane in front-to-back order, kept if its screen octagon (box + the
+// extents of x + y and x - y) meets the bin's rectangle and -- hulls -- no face seen from outside has all four corner rays of the
+// bin on its outer side; ordered ballot compaction into LDS.  The four waves then cast the bin's
+// 32 tiles, each against this short list instead of every record of the camera.
+
+template <bool RGB>
+__global__ void __launch_bounds__(256) k_render_depth(const float* __restrict__ recs, const int* __restrict__ counts, const int* __restrict__ order,
+                                                      const float4* __restrict__ tplanes, int nplane,
+                                                      const float* __restrict__ cam_fovy, const int* __restrict__ cam_ids, int ncam_sel, int ngeom, int H,
+                                                      int W, float znear, float zfar, float* __restrict__ out, const float* __restrict__ geom_rgba, const float* __restrict__ light,
+                                                      const float* __restrict__ camaux, unsigned char* __restrict__ out_rgb) {
+    __shared__ unsigned short blist[512];
+    __shared__ int bcount;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cs = blockIdx.y, env = blockIdx.z;
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H, bins_x = (tiles_x + BIN_TX - 1) / BIN_TX;
+    const int btx = (blockIdx.x % bins_x) * BIN_TX, bty = (blockIdx.x / bins_x) * BIN_TY;
+    const float scale = 2.0f * cam_fovy[cam_ids[cs]] / (float)H;     // cam_fovy holds tan(fovy / 2)
+    const float* R = recs + ((size_t)env * ncam_sel + cs) * ngeom * REC_W;
+    if (wave == 0) {
+        const int cnt = counts[(size_t)env * ncam_sel + cs];
+        const int* ord = order + ((size_t)env * ncam_sel + cs) * ngeom;
+        const int px0 = btx * TILE_W, py0 = bty * TILE_H;
+        const int px1 = px0 + BIN_TX * TILE_W < W ? px0 + BIN_TX * TILE_W : W, py1 = py0 + BIN_TY * TILE_H < H ? py0 + BIN_TY * TILE_H : H;
+        const float xl = (px0 - 0.5f * W) * scale, xr = (px1 - 0.5f * W) * scale, yt = -(py0 - 0.5f * H) * scale, yb = -(py1 - 0.5f * H) * scale;
+        const float4* TP = tplanes + ((size_t)env * ncam_sel + cs) * nplane;
+        int n = 0;
+        for (int k0 = 0; k0 < cnt; k0 += 64) {
+            bool keep = false;
+            int mine = 0;
+            if (k0 + lane < cnt) {
+                mine = ord[k0 + lane];
+                const float* rec = R + (size_t)mine * REC_W;
+                keep = rec[24] <= xr && rec[25] >= xl && rec[26] <= yt && rec[27] >= yb && rec[28] <= xr + yt && rec[29] >= xl + yb && rec[30] <= xr - yb && rec[31] >= xl - yt;
+                if (keep && __float_as_int(rec[19]) == 7) {
+                    // hulls: no face seen from outside may have all four corner rays of the bin on its outer side
+                    const float4* P = TP + __float_as_int(rec[20]);
+                    const int np = __float_as_int(rec[21]);
+                    for (int p = 0; p < np; p++) {
+                        const float4 f = P[p];
+                        if (f.w < 0 && f.x * xl + f.y * yt - f.z >= 0 && f.x * xr + f.y * yt - f.z >= 0 && f.x * xl + f.y * yb - f.z >= 0 && f.x * xr + f.y * yb - f.z >= 0) {
+                            keep = false;
+                            break;
+                        }
+                    }
+                }
+            }
+            const unsigned long long bal = __ballot(keep);
+            if (keep) { const int at = n + __popcll(bal & ((1ull << lane) - 1ull)); if (at < 512) blist[at] = (unsigned short)mine; }
+            n += __popcll(bal);
+        }
+        if (lane == 0) bcount = n < 512 ? n : 512;
+    }
+    __syncthreads();
+    const int cnt = bcount;
+    for (int t = wave; t < BIN_TX * BIN_TY; t += 4) {
+        const int tix = btx + (t % BIN_TX), tiy = bty + (t / BIN_TX);
+        if (tix >= tiles_x || tiy >= tiles_y) continue;
+        render_tile<RGB>(lane, tix * TILE_W, tiy * TILE_H, cs, env, blist, cnt, R, tplanes, nplane, scale, ncam_sel, H, W, znear, zfar, out, geom_rgba, light, camaux, out_rgb);
     }
 }
 
@@ -504,15 +655,26 @@ struct RenderHost {
         if (!d_cam_ids && hipMalloc((void**)&d_cam_ids, 16 * sizeof(int)) != hipSuccess) { err = "hipMalloc(camera ids) failed"; return -3; }
         if (hipMemcpyAsync(d_cam_ids, cam_ids_host, ncam_sel * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { err = "camera id copy failed"; return -3; }
         hipLaunchKernelGGL(k_render_geoms, dim3(ncam_sel, N), dim3(64), 0, st, m, (const float*)d_xpose, (const int*)d_cam_ids, ncam_sel, H, W, d_recs, d_counts, d_order, d_tplanes, d_camaux);
-        const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
+        const int tiles = (((W + TILE_W - 1) / TILE_W + BIN_TX - 1) / BIN_TX) * (((H + TILE_H - 1) / TILE_H + BIN_TY - 1) / BIN_TY);     // bins
         if (rgb)
-            hipLaunchKernelGGL(k_render_depth<true>, dim3(tiles, ncam_sel, N), dim3(64), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, m.nplane,
+            hipLaunchKernelGGL(k_render_depth<true>, dim3(tiles, ncam_sel, N), dim3(256), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, m.nplane,
                                m.cam_fovy, (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, (float*)nullptr, m.geom_rgba, m.light, (const float*)d_camaux, (unsigned char*)d_out);
         else
-            hipLaunchKernelGGL(k_render_depth<false>, dim3(tiles, ncam_sel, N), dim3(64), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, m.nplane,
+            hipLaunchKernelGGL(k_render_depth<false>, dim3(tiles, ncam_sel, N), dim3(256), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, m.nplane,
                                m.cam_fovy, (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, (float*)d_out, m.geom_rgba, m.light, (const float*)d_camaux, (unsigned char*)nullptr);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("render kernel launch: ") + hipGetErrorString(e); return -3; }
+#ifdef AVSIM_RENDER_STATS
+        {
+            unsigned long long hst[8];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpyFromSymbol(hst, HIP_SYMBOL(g_rstat), sizeof hst);
+            fprintf(stderr, "render stats per tile: list %.1f, box hits %.2f, hulls cast %.2f (entry faces %.2f, veto faces %.2f), primitives %.2f; tiles %llu\n",
+                    (double)hst[1] / hst[0], (double)hst[2] / hst[0], (double)hst[3] / hst[0], (double)hst[4] / hst[0], (double)hst[5] / hst[0], (double)hst[6] / hst[0], hst[0]);
+            memset(hst, 0, sizeof hst);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rstat), hst, sizeof hst);
+        }
+#endif
         return 0;
     }
 };
