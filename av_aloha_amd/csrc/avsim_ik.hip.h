@@ -24,17 +24,23 @@ __device__ __forceinline__ void mat3mul(const T* A, const T* B, T* C) {
     for (int i = 0; i < 9; i++) C[i] = t[i];
 }
 
-// transform_utils.py:52-79 incl. the float32 cast at :66
+// transform_utils.py:52-79 incl. the float32 cast at :66, op for op as NumPy evaluates it (oracle/orc_ik.c orc_quat2mat): float32
+// products accumulated in double for the norm (OpenBLAS sdot), a correctly rounded float32 division, sqrt in double, float32 outer
+// products and entries, nothing fused -- bit-identical to the reference's matrices (tests/golden/so3_helpers.npz)
 template <typename T>
 __device__ __forceinline__ void quat2mat_xyzw(const T qx[4], T R[9]) {
+#pragma clang fp contract(off)
     float q[4] = {(float)qx[3], (float)qx[0], (float)qx[1], (float)qx[2]};
-    float n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    double acc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const float p = q[i] * q[i]; acc += (double)p; }
+    const float n = (float)acc;
     if (n < 8.8817841970012523e-16f) {
 #pragma unroll
         for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? T(1) : T(0);
         return;
     }
-    float s = (float)sqrt((double)(2.0f / n));
+    float s = (float)sqrt((double)__fdiv_rn(2.0f, n));
 #pragma unroll
     for (int i = 0; i < 4; i++) q[i] *= s;
     float q2[4][4];
@@ -229,33 +235,73 @@ __device__ void diffik(const IkParams& P, int arm, const T* qin, const T pos[3],
     }
 }
 
-// closed-form rotation angle+axis (replaces mat2quat(eigh)+quat2axisangle inside limit_pose,
-// transform_utils.py:276-278: only the rotation vector of the relative rotation is needed)
+// transform_utils.py:9-49 mat2quat followed by :82-106 quat2axisangle, as limit_pose uses them (:276-278): the quaternion is the
+// eigenvector of the 4 x 4 matrix K for its largest eigenvalue (numpy.linalg.eigh in the reference, cyclic Jacobi here as in
+// oracle/orc_ik.c).  The relative rotation is the product of a float32-rounded target matrix and a transpose, i.e. orthonormal
+// only to 1e-7, and the eigenvector is the least-squares quaternion of such a matrix: a closed-form extraction from single
+// entries differs from it by 1e-8, which the float32 quat2mat of the clamped target then turns into a different matrix.
 template <typename T>
-__device__ __forceinline__ void rotvec_from_mat(const T* R, T aa[3]) {
-    // quaternion via Shepperd's branch on the largest diagonal term, w >= 0 as mat2quat returns
-    T tr = R[0] + R[4] + R[8], qw, qx, qy, qz;
-    if (tr > 0) {
-        T s = sqrt(tr + 1) * 2;
-        qw = T(0.25) * s; qx = (R[7] - R[5]) / s; qy = (R[2] - R[6]) / s; qz = (R[3] - R[1]) / s;
-    } else if (R[0] > R[4] && R[0] > R[8]) {
-        T s = sqrt(1 + R[0] - R[4] - R[8]) * 2;
-        qw = (R[7] - R[5]) / s; qx = T(0.25) * s; qy = (R[1] + R[3]) / s; qz = (R[2] + R[6]) / s;
-    } else if (R[4] > R[8]) {
-        T s = sqrt(1 + R[4] - R[0] - R[8]) * 2;
-        qw = (R[2] - R[6]) / s; qx = (R[1] + R[3]) / s; qy = T(0.25) * s; qz = (R[5] + R[7]) / s;
-    } else {
-        T s = sqrt(1 + R[8] - R[0] - R[4]) * 2;
-        qw = (R[3] - R[1]) / s; qx = (R[2] + R[6]) / s; qy = (R[5] + R[7]) / s; qz = T(0.25) * s;
+__device__ void rotvec_from_mat(const T* M, T aa[3]) {
+    T A[16], V[16];
+    {
+        const T m00 = M[0], m01 = M[1], m02 = M[2], m10 = M[3], m11 = M[4], m12 = M[5], m20 = M[6], m21 = M[7], m22 = M[8];
+        const T K[16] = {m00 - m11 - m22, 0, 0, 0, m01 + m10, m11 - m00 - m22, 0, 0, m02 + m20, m12 + m21, m22 - m00 - m11, 0,
+                         m21 - m12, m02 - m20, m10 - m01, m00 + m11 + m22};
+#pragma unroll
+        for (int i = 0; i < 16; i++) A[i] = K[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = i + 1; j < 4; j++) A[i * 4 + j] = A[j * 4 + i];
+#pragma unroll
+        for (int i = 0; i < 16; i++) { A[i] /= T(3); V[i] = (i % 5 == 0) ? T(1) : T(0); }
     }
-    T n = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
-    qw /= n; qx /= n; qy /= n; qz /= n;
-    if (qw < 0) { qw = -qw; qx = -qx; qy = -qy; qz = -qz; }
-    qw = qw > 1 ? T(1) : qw;
-    T den = sqrt(1 - qw * qw);
-    if (den <= T(1e-8)) { aa[0] = aa[1] = aa[2] = 0; return; }
-    T s = 2 * acos(qw) / den;
-    aa[0] = qx * s; aa[1] = qy * s; aa[2] = qz * s;
+    for (int sweep = 0; sweep < 64; sweep++) {
+        T off = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = i + 1; j < 4; j++) off += A[i * 4 + j] * A[i * 4 + j];
+        if (off < T(1e-300)) break;
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int q = p + 1; q < 4; q++) {
+                const T apq = A[p * 4 + q];
+                if (fabs(apq) < T(1e-300)) continue;
+                const T theta = (A[q * 4 + q] - A[p * 4 + p]) / (2 * apq);
+                const T t = (theta >= 0 ? T(1) : T(-1)) / (fabs(theta) + sqrt(theta * theta + 1));
+                const T c = 1 / sqrt(t * t + 1), s = t * c;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const T akp = A[k * 4 + p], akq = A[k * 4 + q];
+                    A[k * 4 + p] = c * akp - s * akq;
+                    A[k * 4 + q] = s * akp + c * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const T apk = A[p * 4 + k], aqk = A[q * 4 + k];
+                    A[p * 4 + k] = c * apk - s * aqk;
+                    A[q * 4 + k] = s * apk + c * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const T vkp = V[k * 4 + p], vkq = V[k * 4 + q];
+                    V[k * 4 + p] = c * vkp - s * vkq;
+                    V[k * 4 + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    T wb = A[0], qv[4] = {V[0], V[4], V[8], V[12]};     // (x, y, z, w) of eigenvector 0
+#pragma unroll
+    for (int b = 1; b < 4; b++)
+        if (A[b * 5] > wb) { wb = A[b * 5]; qv[0] = V[b]; qv[1] = V[4 + b]; qv[2] = V[8 + b]; qv[3] = V[12 + b]; }
+    if (qv[3] < 0) { qv[0] = -qv[0]; qv[1] = -qv[1]; qv[2] = -qv[2]; qv[3] = -qv[3]; }
+    T w = qv[3] > 1 ? T(1) : qv[3];
+    const T den = sqrt(1 - w * w);
+    if (fabs(den) <= T(1e-8)) { aa[0] = aa[1] = aa[2] = 0; return; }
+    const T s = 2 * acos(w) / den;
+    aa[0] = qv[0] * s; aa[1] = qv[1] * s; aa[2] = qv[2] * s;
 }
 
 // transform_utils.py:263-287
@@ -275,8 +321,10 @@ __device__ __forceinline__ void limit_pose(const T cp[3], const T cR[9], const T
     rotvec_from_mat(rel, aa);
     T ang = sqrt(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]);
     if (ang > maxr) {
-        T h = maxr * T(0.5), sc = sin(h) / ang;  // axisangle2quat of aa*(maxr/ang)
-        T q[4] = {aa[0] * sc, aa[1] * sc, aa[2] * sc, cos(h)}, lim[9];
+        // axisangle2quat (transform_utils.py:108-133) of aa * (maxr / ang), same expressions as oracle/orc_ik.c
+        const T k = maxr / ang, v[3] = {aa[0] * k, aa[1] * k, aa[2] * k};
+        const T a = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), sn = sin(a / 2);
+        T q[4] = {v[0] / a * sn, v[1] / a * sn, v[2] / a * sn, cos(a / 2)}, lim[9];
         quat2mat_xyzw(q, lim);
         mat3mul(lim, cR, oR);
     } else {

@@ -19,11 +19,16 @@ static void cross3(const double* a, const double* b, double* c) {
 }
 static double norm3(const double* a) { return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
 
-/* transform_utils.py:52-79.  The reference rounds the quaternion to float32 (:66); run as plain
- * NumPy (the way the golden vectors were produced) every product below stays float32. */
+/* transform_utils.py:52-79.  The reference rounds the quaternion to float32 (:66); run as plain NumPy (the way the golden vectors
+ * were produced) every product below stays float32.  Op for op: np.dot of two float32 vectors is OpenBLAS sdot, which rounds each
+ * product to float and accumulates in double (kernel/x86_64/sdot.c tail loop); 2.0 / n is a float32 division, math.sqrt works in
+ * double on that value and the scale goes back to float32 for the in-place multiply; outer products and the nine entries float32.
+ * Reproduces tests/golden/so3_helpers.npz bit for bit. */
 void orc_quat2mat(const double qx[4], double R[9]) {
     float q[4] = {(float)qx[3], (float)qx[0], (float)qx[1], (float)qx[2]}; /* w x y z */
-    float n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    double acc = 0;
+    for (int i = 0; i < 4; i++) { float p = q[i] * q[i]; acc += (double)p; }
+    float n = (float)acc;
     if (n < (float)EPS4) {
         for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0);
         return;
