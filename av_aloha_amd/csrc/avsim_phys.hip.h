@@ -321,6 +321,9 @@ AVS_DEV double lane_get(double x, int l) {   // l is wave-uniform at every call 
 }
 
 constexpr int GRP_MAX = 6;   // rows per Gauss-Seidel group (a condim-6 contact is one group)
+// per-group record in global scratch: [0, 15) couplings (packed lower triangle), then for a contact with >= 3 friction rows the rows
+// of its friction block for the noslip QCQP, 12 words per friction row r: A[r][0..4], (D A D)^-1[r][0..4], mu_r, singular flag
+constexpr int GA_W = 80, GA_Q = 16, GA_QW = 12;
 // convergence thresholds of the multiplier iteration in the noslip QCQP: MuJoCo's absolute 1e-10 in double; in float a relative
 // part on top, since v.v - r^2 and the multiplier carry 1e-7 relative rounding
 template <typename T> struct QTol;
@@ -371,6 +374,11 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
     real ac[GRP_MAX - 1];
 #pragma unroll
     for (int s = 0; s < GRP_MAX - 1; s++) ac[s] = gA[tri + s];
+    // noslip QCQP rows of the group (lanes 1..5 = friction rows), prefetched with the couplings
+    const int qr = (lane >= 1 && lane <= 5) ? lane - 1 : 0;
+    real qc[GA_QW], qn[GA_QW];
+#pragma unroll
+    for (int s = 0; s < GA_QW; s++) qc[s] = gA[GA_Q + GA_QW * qr + s];
     const int total = (iters + noslip_iters) * ngrp;
     int g = 0, it = 0;
     real imp = 0, imp_c = 0;      // improvement of the dual cost over the current noslip sweep (per-lane parts, uniform part)
@@ -393,7 +401,11 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         const real aref = S[0], R = S[1], inv2 = S[2], inv3 = S[3], lo = S[4], hi = S[5], f0 = S[6], muinv = S[7];
         real a[GRP_MAX - 1], an[GRP_MAX - 1];
 #pragma unroll
-        for (int s = 0; s < GRP_MAX - 1; s++) an[s] = gA[16 * g1 + tri + s];      // next group's couplings (global memory)
+        for (int s = 0; s < GRP_MAX - 1; s++) an[s] = gA[GA_W * g1 + tri + s];      // next group's couplings (global memory)
+        if (noslip_iters > 0) {
+#pragma unroll
+            for (int s = 0; s < GA_QW; s++) qn[s] = gA[GA_W * g1 + GA_Q + GA_QW * qr + s];
+        }
 #pragma unroll
         for (int s = 0; s < GRP_MAX - 1; s++) a[s] = (mine && s < lane) ? ac[s] : real(0);
         // ---- row residuals J_r . qacc: every row is summed over its 8 lanes, lane r then fetches row r's sum ----
@@ -406,7 +418,42 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
             // (row 0 = normal); the block (A lower triangle from the couplings, diagonal 1 / invn), b and mu are gathered from
             // the owner lanes and the small Newton iteration on the multiplier runs redundantly on every lane ----
             const int n = cnt - 1;
-            if (n >= 1) {
+            bool done = false;
+            if (n >= 3) {
+                // multiplier 0 first, through the inverse of the scaled block made with the rows (make_constraints): lane r = 1..n holds
+                // row r - 1 of A and of (D A D)^-1; the 5-vectors travel by v_readlane.  Inside the cone section this is the answer.
+                const real fn = lane_get(f0, 0), r2 = fn * fn;
+                const bool row = lane >= 1 && lane <= n;
+                const real res_r = dot - aref;
+                if (!(fn < real(1e-15)) && lane_get(qc[11], 1) == real(0)) {
+                    real t = 0;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) t += k < n ? qc[k] * lane_get(f0, k + 1) : real(0);
+                    const real bs = (res_r - t) * qc[10];
+                    t = 0;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) t += k < n ? qc[5 + k] * lane_get(bs, k + 1) : real(0);
+                    const real y = -t;
+                    real val = -r2;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) { const real yk = lane_get(y, k + 1); val += k < n ? yk * yk : real(0); }
+                    if (val < QTol<real>::abs + QTol<real>::rel * r2) {
+                        const real vr = y * qc[10], dl_ = row ? vr - f0 : real(0);
+                        t = 0;
+#pragma unroll
+                        for (int k = 0; k < 5; k++) t += k < n ? qc[k] * lane_get(dl_, k + 1) : real(0);
+                        real change = 0;
+#pragma unroll
+                        for (int k = 0; k < 5; k++) change += k < n ? lane_get(dl_ * (real(0.5) * t + res_r), k + 1) : real(0);
+                        if (!(change > real(1e-10))) {
+                            imp_c -= change;
+                            if (row) f = vr;
+                        }
+                        done = true;
+                    }
+                }
+            }
+            if (n >= 1 && !done) {
                 const real fn = lane_get(f0, 0);
                 real Aq[5][5], bq[5], dq[5], oldf[5], resq[5], v[5];
 #pragma unroll
@@ -576,6 +623,8 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         JA = JAn; JB = JBn; BA = BAn; BB = BBn;
 #pragma unroll
         for (int s = 0; s < GRP_MAX - 1; s++) ac[s] = an[s];
+#pragma unroll
+        for (int s = 0; s < GA_QW; s++) qc[s] = qn[s];
         g = g1;
         if (g1 == 0) {
             // end of a sweep; a noslip sweep that improved the cost by less than noslip_tolerance ends the pass [EXT]
@@ -835,7 +884,7 @@ struct Env {
     AVS_DEV const real* LR() const { const real* p = lr; AVS_ASSUME_LDS(p); return p; }
     AVS_DEV GLB_PTR(real) rows_() const { return (GLB_PTR(real))ka->m.rJ_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
     AVS_DEV GLB_PTR(real) rowsB_() const { return (GLB_PTR(real))ka->m.rB_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
-    AVS_DEV GLB_PTR(real) coup_() const { return (GLB_PTR(real))ka->m.gA_glob + (size_t)env * ka->lay.maxgrp * 16; }
+    AVS_DEV GLB_PTR(real) coup_() const { return (GLB_PTR(real))ka->m.gA_glob + (size_t)env * ka->lay.maxgrp * GA_W; }
     AVS_DEV GLB_PTR(int) near_() const { return (GLB_PTR(int))ka->m.near_glob + (size_t)env * NEAR_MAX; }
     AVS_DEV GLB_PTR(int) cand_() const { return (GLB_PTR(int))ka->m.cand_glob + (size_t)env * CAND_MAX; }
     AVS_DEV GLB_PTR(real) gref_() const { return (GLB_PTR(real))ka->m.gref_glob + (size_t)env * ka->m.ngeom * 3; }
@@ -1820,7 +1869,7 @@ struct Env {
                 ss = e2 - rr * (rr - 1) / 2 + 1;
                 rr += 1;
                 e = rr * (rr - 1) / 2 + ss;
-                if (e2 < 5) gA[16 * g + (e2 + 1) * e2 / 2] = 0;   // (row e2 + 1, normal row)
+                if (e2 < 5) gA[GA_W * g + (e2 + 1) * e2 / 2] = 0;   // (row e2 + 1, normal row)
             }
             int gi = gI[g], start = gi & 0xffff, cnt = (gi >> 16) & 15;
             real v = 0;
@@ -1844,7 +1893,65 @@ struct Env {
                     }
                 }
             }
-            gA[16 * g + e] = v;
+            gA[GA_W * g + e] = v;
+        }
+        GSYNC();
+        // noslip QCQP rows (mj_solNoSlip [EXT], see pgs_groups): one contact per lane builds the friction block A of its group from the
+        // couplings just written and the rows' diagonals, scales it by the friction coefficients, inverts it through its Cholesky
+        // factor (qc_inverse of oracle/orc_dyn.c, same loops) and leaves, per friction row, A's row, the inverse's row and mu
+        if (ka->m.noslip_iters > 0)
+        for (int g = nlg + lane; g < ngrp; g += G) {
+            const int gi = gI[g], start = gi & 0xffff, n = ((gi >> 16) & 15) - 1;
+            if (n < 3) continue;
+            real A[5][5], As[5][5], L[5][5], Inv[5][5], mu[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const bool in = j < n;
+                const real* S = rowS + RS_S * (start + 1 + (in ? j : 0));
+                mu[j] = in ? real(1) / S[7] : real(1);
+                A[j][j] = in ? real(1) / S[3] : real(1);
+#pragma unroll
+                for (int k = 0; k < j; k++) { const real c = in ? gA[GA_W * g + (j + 1) * j / 2 + (k + 1)] : real(0); A[j][k] = c; A[k][j] = c; }
+            }
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+#pragma unroll
+                for (int j = 0; j < 5; j++) As[i][j] = (i < n && j < n) ? A[i][j] * mu[i] * mu[j] : (i == j ? real(1) : real(0));
+            bool singular = false;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                real dd = As[j][j];
+#pragma unroll
+                for (int k = 0; k < j; k++) dd -= L[j][k] * L[j][k];
+                if (j < n && dd < real(1e-10)) singular = true;
+                dd = sqrt(tmax(dd, real(1e-30)));
+                L[j][j] = dd;
+#pragma unroll
+                for (int i = j + 1; i < 5; i++) {
+                    real t = As[i][j];
+#pragma unroll
+                    for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+                    L[i][j] = t / dd;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                real x[5];
+#pragma unroll
+                for (int i = 0; i < 5; i++) { real t = (i == c) ? real(1) : real(0); for (int k = 0; k < i; k++) t -= L[i][k] * x[k]; x[i] = t / L[i][i]; }
+#pragma unroll
+                for (int i = 4; i >= 0; i--) { real t = x[i]; for (int k = i + 1; k < 5; k++) t -= L[k][i] * x[k]; x[i] = t / L[i][i]; }
+#pragma unroll
+                for (int i = 0; i < 5; i++) Inv[i][c] = x[i];
+            }
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                GLB_PTR(real) o = gA + GA_W * g + GA_Q + GA_QW * j;
+#pragma unroll
+                for (int k = 0; k < 5; k++) { o[k] = A[j][k]; o[5 + k] = Inv[j][k]; }
+                o[10] = mu[j];
+                o[11] = singular ? real(1) : real(0);
+            }
         }
         GSYNC();
     }
@@ -2406,7 +2513,7 @@ struct PhysHost {
         d_coup = nullptr; d_near = nullptr; d_gref = nullptr;
         if (hipMalloc(&d_gref, (size_t)N * dims[4] * 3 * (f64 ? 8 : 4)) != hipSuccess) throw std::runtime_error("hipMalloc of the Verlet reference buffer failed");
         mf.gref_glob = (float*)d_gref; md.gref_glob = (double*)d_gref;
-        if (hipMalloc(&d_coup, (size_t)N * lay.maxgrp * 16 * (f64 ? 8 : 4)) != hipSuccess || hipMalloc((void**)&d_near, (size_t)N * (NEAR_MAX + CAND_MAX) * 4) != hipSuccess)
+        if (hipMalloc(&d_coup, (size_t)N * lay.maxgrp * GA_W * (f64 ? 8 : 4)) != hipSuccess || hipMalloc((void**)&d_near, (size_t)N * (NEAR_MAX + CAND_MAX) * 4) != hipSuccess)
             throw std::runtime_error("hipMalloc of the coupling / neighbour buffers failed");
         mf.gA_glob = (float*)d_coup; md.gA_glob = (double*)d_coup; mf.near_glob = d_near; md.near_glob = d_near; mf.cand_glob = md.cand_glob = d_near + (size_t)N * NEAR_MAX;
         kargs_dirty = true;

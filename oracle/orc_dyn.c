@@ -670,6 +670,34 @@ static int qcqpn(double* res, const double* Ain, const double* bin, const double
     return la != 0;
 }
 
+/* Inverse of the scaled friction block As = D A D (n x n, n <= 5) through its Cholesky factor; 0 when a pivot falls below 1e-10
+ * (the singularity rule of mju_QCQP).  Computed once per contact and substep: at the multiplier 0 the QCQP's candidate is
+ * y = -As^-1 (D b), and most resting contacts end there (inside the cone).  Same loops as the device (qc_inverse5). */
+static int qc_inverse(const double* Ac, const double* dsc, int n, double* Inv) {
+    double A[25], L[25];
+    for (int i = 0; i < 5; i++)
+        for (int j = 0; j < 5; j++) A[5 * i + j] = (i < n && j < n) ? Ac[n * i + j] * dsc[i] * dsc[j] : (i == j ? 1.0 : 0.0);
+    for (int j = 0; j < 5; j++) {
+        double dd = A[5 * j + j];
+        for (int k = 0; k < j; k++) dd -= L[5 * j + k] * L[5 * j + k];
+        if (j < n && dd < 1e-10) return 0;
+        dd = sqrt(dd);
+        L[5 * j + j] = dd;
+        for (int i = j + 1; i < 5; i++) {
+            double t = A[5 * i + j];
+            for (int k = 0; k < j; k++) t -= L[5 * i + k] * L[5 * j + k];
+            L[5 * i + j] = t / dd;
+        }
+    }
+    for (int c = 0; c < 5; c++) {
+        double x[5];
+        for (int i = 0; i < 5; i++) { double t = (i == c) ? 1.0 : 0.0; for (int k = 0; k < i; k++) t -= L[5 * i + k] * x[k]; x[i] = t / L[5 * i + i]; }
+        for (int i = 4; i >= 0; i--) { double t = x[i]; for (int k = i + 1; k < 5; k++) t -= L[5 * k + i] * x[k]; x[i] = t / L[5 * i + i]; }
+        for (int i = 0; i < 5; i++) Inv[5 * i + c] = x[i];
+    }
+    return 1;
+}
+
 void orc_noslip(orc_data* d) {
     const orc_model* m = d->m;
     int nv = m->nv, ne = d->nefc;
@@ -713,7 +741,19 @@ void orc_noslip(orc_data* d) {
                 const double fn = d->efc_force[i];
                 if (fn < MINVAL) { for (int j = 0; j < n; j++) v[j] = 0; }
                 else {
-                    int active = n == 2 ? qcqp2(v, Ac, bc, c->friction, fn) : qcqpn(v, Ac, bc, c->friction, fn, n);
+                    /* larger blocks first try the multiplier 0 through the block's inverse (the unconstrained minimiser): inside
+                     * the cone section it is the answer; otherwise the multiplier iteration of mju_QCQP runs as it stands */
+                    int active = -1;
+                    if (n >= 3) {
+                        double Inv[25], bs[5], y[5], val = -fn * fn;
+                        if (qc_inverse(Ac, c->friction, n, Inv)) {
+                            for (int j = 0; j < n; j++) bs[j] = bc[j] * c->friction[j];
+                            for (int j = 0; j < n; j++) { double t = 0; for (int k = 0; k < n; k++) t += Inv[5 * j + k] * bs[k]; y[j] = -t; }
+                            for (int j = 0; j < n; j++) val += y[j] * y[j];
+                            if (val < 1e-10) { for (int j = 0; j < n; j++) v[j] = y[j] * c->friction[j]; active = 0; }
+                        }
+                    }
+                    if (active < 0) active = n == 2 ? qcqp2(v, Ac, bc, c->friction, fn) : qcqpn(v, Ac, bc, c->friction, fn, n);
                     if (active) {
                         double s = 0;
                         for (int j = 0; j < n; j++) s += v[j] * v[j] / (c->friction[j] * c->friction[j]);
