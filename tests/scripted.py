@@ -13,7 +13,7 @@ class SlotInsertionScript:
     (qpos[23:30] slot, [30:37] stick): the carry / lower phases add the integrated xy error to the hand target."""
     T = (60, 40, 25, 40, 90, 50, 10, 15, 20)
 
-    def __init__(self, home, qpos, drop=0.055, clip=0.05, gain=0.15, yaw_gain=0.15, yaw_clip=1.2):
+    def __init__(self, home, qpos, drop=0.055, clip=0.05, gain=0.15, yaw_gain=0.15, yaw_clip=1.2, side=0.04):
         n = qpos.shape[0]
         self.n = n
         self.home = home
@@ -23,6 +23,9 @@ class SlotInsertionScript:
         self.down_l = np.stack([qmul(np.array([c, 0.0, s, 0.0]), home["left"][i, 3:]) for i in range(n)])
         self.stick0 = qpos[:, 30:33].copy()
         self.use_left = self.stick0[:, 0] < 0.0          # the nearer arm carries (top-down reach ends near the far side)
+        # grasp `side` metres off the stick's centre, towards the carrying arm (the stick is 34 cm long): that much less reach
+        self.off = np.zeros((n, 2))
+        self.off[:, 0] = np.where(self.use_left, -side, side)
         self.corr = np.zeros((n, 2))
         # the pinched stick follows the hand's rotation about the vertical, and the IK trades some of the commanded orientation
         # for its joint-centring terms on the way to the slot: the commanded hand yaw integrates the measured stick / slot yaw error
@@ -47,7 +50,7 @@ class SlotInsertionScript:
         slot, stick = qpos[:, 23:26], qpos[:, 30:33]
         zc = 0.02 + GRASP_HEIGHT                      # site height that pinches the stick at mid height on the table
         hi = zc + 0.10
-        base = self.stick0[:, :2].copy()
+        base = self.stick0[:, :2] + self.off
         grip = 0.0
         if k == 0:
             z = hi
@@ -66,7 +69,7 @@ class SlotInsertionScript:
                 err = yaw_of(qpos[:, 26:30]) - yaw_of(qpos[:, 33:37])
                 err = (err + np.pi / 2) % np.pi - np.pi / 2                  # the stick fits either way round
                 self.yaw = np.clip(self.yaw + self.yaw_gain * err, -self.yaw_clip, self.yaw_clip)
-            base = self.stick0[:, :2] + g * (slot[:, :2] - self.stick0[:, :2]) + self.corr
+            base = self.stick0[:, :2] + self.off + g * (slot[:, :2] - self.stick0[:, :2]) + self.corr
             zr = zc + self.drop
             z = hi if k == 4 else (hi + (zr - hi) * min(1.0, f / 0.8) if k == 5 else zr)
             grip = 1.0 if k <= 6 else (max(0.0, 1.0 - f / 0.5) if k == 7 else 0.0)

@@ -7,14 +7,24 @@ from av_aloha_amd.sim import BatchedSim
 from test_oracle_physics import OBJ, home_action, model_dict
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 opts = {"pgs_iters": 20, "profile_phases": 1, "export_contacts": 0}
+task, arms = os.environ.get("TASK", "slot_insertion"), int(os.environ.get("ARMS", "3"))
 for a in sys.argv[2:]:
     k, v = a.split("="); opts[k] = float(v)
-sim = BatchedSim("slot_insertion", 3, N, options=opts)
-sim.reset(np.repeat(OBJ[None], N, 0))
-md = model_dict()
-a = np.repeat(home_action(md)[None], N, 0)
-for _ in range(3):
-    sim.step(a)
+sim = BatchedSim(task, arms, N, options=opts)
+md = model_dict(task, arms)
+if task == "slot_insertion":
+    sim.reset(np.repeat(OBJ[None], N, 0))
+    a = np.repeat(home_action(md)[None], N, 0)
+    for _ in range(3):
+        sim.step(a)
+else:       # the random-walk workload of bench.py --config 4 (av_aloha_amd/workloads.py), 30 steps in
+    from av_aloha_amd import workloads as W
+    seed = {"hook_package": 3000, "sew_needle": 2000}.get(task, 1000)
+    sim.reset(W.object_poses(task, np.arange(N), seed))
+    nj = 21 if arms == 3 else 14
+    acts = W.walk_actions(md["qpos_home"], md["act_ctrlrange"], np.arange(N), 30, nj, seed)
+    for t in range(30):
+        sim.step(acts[t])
 out = np.zeros((N, 18), dtype=np.int64)
 sim.h.check(sim.h.L.avsim_get_phase_cycles(sim.h.h, out.ctypes.data))
 names = ["kinematics", "crb", "rne", "smooth", "collide", "rows", "solve", "euler"]
@@ -27,3 +37,8 @@ print(f"  total      {m.sum():10.0f}  -> {m.sum() * 20 / 2.4e6:.2f} ms per env-s
 nn = ["init", "grad", "hess", "chol", "search", "final", "noslip", "backsub"]
 mn = out[:, 10:18].mean(0) / 20
 print("inside solve (Newton):", "  ".join(f"{n} {v:.0f}" for n, v in zip(nn, mn)), f"  iterations/substep {((sim.diag()[:, 3] >> 16) & 0xfff).mean() / 20:.2f}")
+tot = out[:, :8].sum(1) / 20
+print("per-env total cycles/substep percentiles 50/90/99/max:", np.percentile(tot, [50, 90, 99, 100]).round(0), " noslip 50/90/99/max:", np.percentile(out[:, 16] / 20, [50, 90, 99, 100]).round(0),
+      " narrow 50/90/99/max:", np.percentile(out[:, 9] / 21, [50, 90, 99, 100]).round(0))
+d = sim.diag()
+print("ncon percentiles", np.percentile(d[:, 0], [50, 90, 99, 100]), "newton max iters", np.percentile((d[:, 3] >> 28) & 0xf, [50, 90, 99, 100]))
