@@ -293,7 +293,7 @@ AVS_DEV void nlead_rows(const NewtonArgs<real>& A, int lane) {
 
 #define NSYNC()                                              \
     do {                                                     \
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, AVS_SYNC_SCOPE); \
         __builtin_amdgcn_wave_barrier();                     \
     } while (0)
 #define NPROF(k)                                                                           \

@@ -62,7 +62,7 @@ int avsim_dims(const avsim_t* h, int32_t dims[AVSIM_NDIMS]);
 
 /* Solver / capacity / debug knobs (returns AVSIM_EINVAL for an unknown name or a value out of range):
  *   "solver"            0 PGS (BASELINE north_star), 1 Newton (MuJoCo's default, what the reference runs; default)
- *   "pgs_iters"         Gauss-Seidel sweeps of the PGS solver (default 20); "newton_iters" cap (default 30), "newton_tol"
+ *   "pgs_iters"         Gauss-Seidel sweeps of the PGS solver (default 20); "newton_iters" cap (default 100 = MuJoCo), "newton_tol" (1e-8 in f64 = MuJoCo, 1e-6 in f32)
  *   "maxefc", "maxcon"  constraint rows / contacts kept per env (per-task defaults 176-336 / 48-72); re-sizes the records
  *   "num_joints"        14 | 21: width of the action / agent_pos rows, whatever the blob's arm count (a 3-arm env whose camera
  *                       arm was parked by hide_middle_arm, env.py:394-395, keeps its 21-D action on the 2-arm model)

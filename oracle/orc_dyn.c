@@ -66,7 +66,7 @@ orc_data* orc_data_new(const orc_model* m) {
     d->pgs_iters = 50;
     d->pgs_tol = 0;
     d->solver = 0;
-    d->newton_iters = 30;
+    d->newton_iters = 100; /* MuJoCo default opt.iterations */
     d->newton_tol = 1e-8;
     d->pgs_scale = 1.0 / (m->meaninertia * (m->nv > 1 ? m->nv : 1));
     memcpy(d->qpos, m->qpos0, sizeof(double) * m->nq);

@@ -85,7 +85,7 @@ def test_config3_sew_needle_contact_rich_vs_oracle():
     d = sim.diag()
     assert (d[:, 2] == 0).all(), "row / contact caps overflowed"
     assert ((d[:, 3] & 1) == 0).all(), "NaN state"
-    assert (((d[:, 3] >> 28) & 0xf) < 15).all()          # far from the 30-iteration cap
+    assert (((d[:, 3] >> 28) & 0xf) < 15).all()          # far from the 100-iteration cap
     assert d[:, 0].mean() >= 8, "config 3 is meant to be contact-rich"
     for e in orcs:
         e.close()
