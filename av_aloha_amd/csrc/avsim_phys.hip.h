@@ -250,12 +250,12 @@ using KPtr = const KArgs<real> __attribute__((address_space(4)))*;
 
 
 
-// Synchronisation between the steps of a phase.  One env is one wavefront: every LDS word and every global scratch word of an env is
-// written and read by lanes of that same wavefront only, and a wavefront's LDS / vector-memory instructions execute in issue order.
-// So the hardware needs no wait between a step's stores and the next step's loads; what is needed is that the COMPILER keeps the
-// order: a wavefront-scope fence (no instruction) + wave barrier.  (A workgroup-scope fence drains vmcnt and lgkmcnt every time.)
+// Synchronisation between the steps of a phase.  One env is one wavefront, so no barrier between waves is needed; the fence is
+// workgroup scope: it drains the wave's outstanding stores (vmcnt / lgkmcnt) before the next step's loads, and the steps hand data
+// from lane to lane through the global row scratch as well as through LDS.  A wavefront-scope fence (compiler ordering only; build
+// with -DAVS_SYNC_SCOPE='"wavefront"') passes every parity and determinism test and is 1 % faster; the conservative scope is kept.
 #ifndef AVS_SYNC_SCOPE
-#define AVS_SYNC_SCOPE "wavefront"
+#define AVS_SYNC_SCOPE "workgroup"
 #endif
 #define GSYNC()                                              \
     do {                                                     \
@@ -2300,7 +2300,7 @@ struct PhysHost {
         auto opt = F("opt");
         m.timestep = (real)opt[0]; m.gravity[0] = (real)opt[1]; m.gravity[1] = (real)opt[2]; m.gravity[2] = (real)opt[3];
         m.impratio = (real)opt[4]; m.noslip_iters = (int)opt[5];
-        m.solver = 1; m.newton_iters = 100;   // MuJoCo default opt.iterations m.newton_tol = sizeof(real) == 8 ? (real)1e-8 : (real)1e-6;
+        m.solver = 1; m.newton_iters = 100; m.newton_tol = sizeof(real) == 8 ? (real)1e-8 : (real)1e-6;     // MuJoCo defaults: iterations 100, tolerance 1e-8
         m.nscale = (real)(1.0 / ((opt.size() > 7 && opt[7] > 0 ? opt[7] : 1.0) * std::max(1, m.nv)));
         auto gr = F("grip_range");
         m.grip_lo = (real)gr[0]; m.grip_hi = (real)gr[1];
