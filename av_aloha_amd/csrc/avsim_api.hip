@@ -163,20 +163,25 @@ template <int NJ>
 __global__ void __launch_bounds__(64) k_ik(IkParams P, int arm, int controller, int iters, int n, const double* __restrict__ q,
                                            const double* __restrict__ pos, const double* __restrict__ quat,
                                            double* __restrict__ qout) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    // DiffIK: one problem per lane.  GradIK: one problem per 16-lane row (gradik spreads its cost evaluations over the row)
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = controller == 1 ? gt >> 4 : gt;
+    const bool live = i < n;
+    const int ii = live ? i : n - 1;          // idle rows of the last block shadow the last problem (wave-wide shuffles inside gradik)
     double th[NJ], out[NJ], tp[3], qx[4], Rt[9];
 #pragma unroll
-    for (int k = 0; k < NJ; k++) th[k] = q[(size_t)i * NJ + k];
+    for (int k = 0; k < NJ; k++) th[k] = q[(size_t)ii * NJ + k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) tp[k] = pos[(size_t)i * 3 + k];
-    qx[0] = quat[(size_t)i * 4 + 1]; qx[1] = quat[(size_t)i * 4 + 2]; qx[2] = quat[(size_t)i * 4 + 3];
-    qx[3] = quat[(size_t)i * 4 + 0];  // wxyz_to_xyzw (diff_ik.py:59)
+    for (int k = 0; k < 3; k++) tp[k] = pos[(size_t)ii * 3 + k];
+    qx[0] = quat[(size_t)ii * 4 + 1]; qx[1] = quat[(size_t)ii * 4 + 2]; qx[2] = quat[(size_t)ii * 4 + 3];
+    qx[3] = quat[(size_t)ii * 4 + 0];  // wxyz_to_xyzw (diff_ik.py:59)
     quat2mat_xyzw(qx, Rt);
     if (controller == 0) {
+        if (!live) return;
         diffik<double, NJ>(P, arm, th, tp, Rt, iters, out);
     } else {
         if constexpr (NJ == 6) gradik<double>(P, arm, th, tp, Rt, iters, out);
+        if (!live || (threadIdx.x & 15) != 0) return;
     }
 #pragma unroll
     for (int k = 0; k < NJ; k++) qout[(size_t)i * NJ + k] = out[k];
@@ -184,11 +189,16 @@ __global__ void __launch_bounds__(64) k_ik(IkParams P, int arm, int controller, 
 
 // sim_env.py:277-301: Cartesian action -> ctrl, IK seeded with the MEASURED qpos
 template <typename real>
-__global__ void __launch_bounds__(64) k_cart_ctrl(IkParams P, int mode, int N, int nq, int nu, const double* __restrict__ act,
+__global__ void __launch_bounds__(64) k_cart_ctrl(IkParams P, int mode, int arm0, int N, int nq, int nu, const double* __restrict__ act,
                                                   const real* __restrict__ qpos, real* __restrict__ ctrl) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int arm = blockIdx.y;
-    if (i >= N) return;
+    // blockIdx.y + arm0 = arm.  One env per lane, except the GradIK arms of the reference mode: one env per 16-lane row
+    const int arm = blockIdx.y + arm0;
+    const bool rowwise = arm < 2 && mode != AVSIM_IK_DLS;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i0 = rowwise ? gt >> 4 : gt;
+    const bool live = i0 < N;
+    if (!live && !rowwise) return;
+    const int i = live ? i0 : N - 1;
     const double* a = act + (size_t)i * 23 + (arm == 0 ? 0 : (arm == 1 ? 8 : 16));
     double tp[3] = {a[0], a[1], a[2]}, qx[4] = {a[4], a[5], a[6], a[3]}, Rt[9];
     quat2mat_xyzw(qx, Rt);
@@ -207,7 +217,10 @@ __global__ void __launch_bounds__(64) k_cart_ctrl(IkParams P, int mode, int N, i
 #pragma unroll
         for (int k = 0; k < 6; k++) th[k] = (double)qp[A.qadr[k]];
         if (mode == AVSIM_IK_DLS) diffik<double, 6>(P, arm, th, tp, Rt, P.diff_iters, out);
-        else gradik<double>(P, arm, th, tp, Rt, P.grad_iters, out);
+        else {
+            gradik<double>(P, arm, th, tp, Rt, P.grad_iters, out);
+            if (!live || (threadIdx.x & 15) != 0) return;
+        }
 #pragma unroll
         for (int k = 0; k < 6; k++) c[k] = (real)out[k];
         double trig = a[7];  // sim_env.py:300-301: unnorm(1 - trigger)
@@ -497,7 +510,7 @@ int avsim_ik(avsim_t* h, int arm, int controller, int max_iters, int n, const do
     if ((rc = h->in(1, pos, sizeof(double) * n * 3, &dp))) return rc;
     if ((rc = h->in(2, quat, sizeof(double) * n * 4, &dqt))) return rc;
     if ((rc = h->out_begin(3, qout, sizeof(double) * n * nj, &dout))) return rc;
-    dim3 grid((n + 63) / 64);
+    dim3 grid(controller == 1 ? (n + 3) / 4 : (n + 63) / 64);
     if (nj == 6)
         hipLaunchKernelGGL(k_ik<6>, grid, dim3(64), 0, h->stream, h->ik, arm, controller, iters, n, (const double*)dq, (const double*)dp,
                            (const double*)dqt, (double*)dout);
@@ -580,13 +593,19 @@ int avsim_step_cartesian(avsim_t* h, const double* action23, int ik_mode, int ns
     const void* da;
     int rc;
     if ((rc = h->in(0, action23, sizeof(double) * h->N * 23, &da))) return rc;
-    dim3 grid((h->N + 63) / 64, 3);
-    if (h->f64)
-        hipLaunchKernelGGL(k_cart_ctrl<double>, grid, dim3(64), 0, h->stream, h->ik, ik_mode, h->N, h->nq, h->nu, (const double*)da,
-                           (const double*)h->d_qpos, (double*)h->d_ctrl);
-    else
-        hipLaunchKernelGGL(k_cart_ctrl<float>, grid, dim3(64), 0, h->stream, h->ik, ik_mode, h->N, h->nq, h->nu, (const double*)da,
-                           (const float*)h->d_qpos, (float*)h->d_ctrl);
+    auto launch = [&](dim3 grid, int arm0) {
+        if (h->f64)
+            hipLaunchKernelGGL(k_cart_ctrl<double>, grid, dim3(64), 0, h->stream, h->ik, ik_mode, arm0, h->N, h->nq, h->nu, (const double*)da,
+                               (const double*)h->d_qpos, (double*)h->d_ctrl);
+        else
+            hipLaunchKernelGGL(k_cart_ctrl<float>, grid, dim3(64), 0, h->stream, h->ik, ik_mode, arm0, h->N, h->nq, h->nu, (const double*)da,
+                               (const float*)h->d_qpos, (float*)h->d_ctrl);
+    };
+    if (ik_mode == AVSIM_IK_DLS) launch(dim3((h->N + 63) / 64, 3), 0);
+    else {
+        launch(dim3((h->N + 3) / 4, 2), 0);       // GradIK on the two manipulators: 16 lanes per env
+        launch(dim3((h->N + 63) / 64, 1), 2);     // DiffIK on the camera arm: one env per lane
+    }
     HIPCHK(h, hipGetLastError());
     return step_common(h, nullptr, nsub, agent_pos, reward, success);
 }

@@ -333,15 +333,18 @@ __device__ __forceinline__ void limit_pose(const T cp[3], const T cR[9], const T
     }
 }
 
+// cost of grad_ik.py:168-198 at q; also hands back the position / rotation error norms of the pose (solution_fn, :200-220)
 template <typename T>
-__device__ __forceinline__ T gik_cost(const IkParams& P, const IkArm& A, const T* q, const T* qs, const T* tp, const T* tR) {
+__device__ __forceinline__ T gik_cost(const IkParams& P, const IkArm& A, const T* q, const T* qs, const T* tp, const T* tR, T* perr, T* rerr) {
     T Rc[9], pc[3], e[3];
     fk<T, 6>(A, q, Rc, pc);
     T d0 = tp[0] - pc[0], d1 = tp[1] - pc[1], d2 = tp[2] - pc[2];
-    T t = (T)P.g_pw * sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    const T pn = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    T t = (T)P.g_pw * pn;
     T c = t * t;
     angular_error(tR, Rc, e);
-    t = (T)P.g_rw * sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    const T rn = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    t = (T)P.g_rw * rn;
     c += t * t;
     T s = 0;
 #pragma unroll
@@ -357,64 +360,75 @@ __device__ __forceinline__ T gik_cost(const IkParams& P, const IkArm& A, const T
         t = (T)P.g_jdw[i] * (q[i] - qs[i]);
         s += t * t;
     }
+    *perr = pn;
+    *rerr = rn;
     return c + s;
 }
 
-// grad_ik.py:8-99 (6-DoF manipulators)
+// grad_ik.py:8-99 (6-DoF manipulators), one problem per 16-lane row: the reference's loop evaluates its cost function 15 times per
+// iteration one after the other -- 12 central-difference points, the two secant points, the new iterate (+ a forward kinematics for
+// the solution test, which the last evaluation already contains).  The 12 difference points are independent: lane t < 12 of the row
+// takes joint t / 2, sign t & 1; the secant points go to the even / odd lanes; so an iteration is three evaluations deep instead of
+// sixteen.  Every evaluation is the same arithmetic as in the one-lane form and the gradient is gathered in joint order, so the result
+// is bit-identical to it.  All 16 lanes of a row must call this with the same arguments; every lane returns the answer.
 template <typename T>
 __device__ void gradik(const IkParams& P, int arm, const T* qs, const T pos[3], const T tR0[9], int max_it, T* qout) {
     const IkArm& A = P.arm[arm];
+    const int lane = threadIdx.x & 63, t = lane & 15, row0 = lane & ~15;
     const T step = (T)P.g_step;
-    T cR[9], cp[3], tp[3], tR[9];
+    T cR[9], cp[3], tp[3], tR[9], pe, re;
     fk<T, 6>(A, qs, cR, cp);
     limit_pose(cp, cR, pos, tR0, (T)P.g_maxp, (T)P.g_maxr, tp, tR);
-    T init = gik_cost(P, A, qs, qs, tp, tR);
+    const T init = gik_cost(P, A, qs, qs, tp, tR, &pe, &re);
     T grad[6], work[6], local[6], best[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) { work[i] = local[i] = best[i] = qs[i]; grad[i] = 0; }
     T best_cost = init, prev = 0;
+    bool done = false;
+    const int gi = t >> 1;                              // joint of this lane's difference point (t < 12)
+    const T gs = (t & 1) ? step : -step;                // odd lanes +step (p3), even lanes -step (p1)
     for (int it = 0; it < max_it; it++) {
+        if (!__any(!done)) break;
+        // ---- 12 difference points ----
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            work[i] = local[i] - step;
-            T p1 = gik_cost(P, A, work, qs, tp, tR);
-            work[i] = local[i] + step;
-            T p3 = gik_cost(P, A, work, qs, tp, tR);
-            work[i] = local[i];
-            grad[i] = p3 - p1;
-        }
+        for (int i = 0; i < 6; i++) work[i] = local[i] + ((t < 12 && i == gi) ? gs : T(0));
+        // (local[i] - step and local[i] + step exactly as the reference forms them: x + (-step) == x - step)
+        const T cd1 = gik_cost(P, A, work, qs, tp, tR, &pe, &re);
+#pragma unroll
+        for (int i = 0; i < 6; i++) grad[i] = __shfl(cd1, row0 + 2 * i + 1, 64) - __shfl(cd1, row0 + 2 * i, 64);
         T sum = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++) sum += fabs(grad[i]);
         sum += step;
-        T f = step / sum;
+        const T f = step / sum;
+        // ---- secant points: even lanes local - g, odd lanes local + g ----
 #pragma unroll
-        for (int i = 0; i < 6; i++) { grad[i] *= f; work[i] = local[i] - grad[i]; }
-        T p1 = gik_cost(P, A, work, qs, tp, tR);
-#pragma unroll
-        for (int i = 0; i < 6; i++) work[i] = local[i] + grad[i];
-        T p3 = gik_cost(P, A, work, qs, tp, tR);
-        T p2 = T(0.5) * (p1 + p3), cd = T(0.5) * (p3 - p1);
-        T jd = (isfinite(cd) && cd != T(0)) ? p2 / cd : T(0);
+        for (int i = 0; i < 6; i++) { grad[i] *= f; work[i] = (t & 1) ? local[i] + grad[i] : local[i] - grad[i]; }
+        const T cd2 = gik_cost(P, A, work, qs, tp, tR, &pe, &re);
+        const T p1 = __shfl(cd2, row0, 64), p3 = __shfl(cd2, row0 + 1, 64);
+        const T p2 = T(0.5) * (p1 + p3), cd = T(0.5) * (p3 - p1);
+        const T jd = (isfinite(cd) && cd != T(0)) ? p2 / cd : T(0);
+        T nl[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             T x = local[i] - grad[i] * jd;
             x = x < (T)A.lo[i] ? (T)A.lo[i] : (x > (T)A.hi[i] ? (T)A.hi[i] : x);
-            local[i] = work[i] = x;
+            nl[i] = x;
         }
-        T lc = gik_cost(P, A, local, qs, tp, tR);
-        if (lc < best_cost) {
+        // ---- the new iterate: cost and pose errors in one evaluation ----
+        const T lc = gik_cost(P, A, nl, qs, tp, tR, &pe, &re);
+        if (!done) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) best[i] = local[i];
-            best_cost = lc;
+            for (int i = 0; i < 6; i++) local[i] = nl[i];
+            if (lc < best_cost) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) best[i] = local[i];
+                best_cost = lc;
+            }
+            if (pe < (T)P.g_pthr && re < (T)P.g_rthr) done = true;
+            else if (fabs(lc - prev) <= (T)P.g_min_delta) done = true;
+            prev = lc;
         }
-        T Rl[9], pl[3], e[3];
-        fk<T, 6>(A, local, Rl, pl);
-        T d0 = tp[0] - pl[0], d1 = tp[1] - pl[1], d2 = tp[2] - pl[2];
-        angular_error(tR, Rl, e);
-        if (sqrt(d0 * d0 + d1 * d1 + d2 * d2) < (T)P.g_pthr && sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) < (T)P.g_rthr) break;
-        if (fabs(lc - prev) <= (T)P.g_min_delta) break;
-        prev = lc;
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) qout[i] = qs[i] + (T)P.g_joint_p * (best[i] - qs[i]);
