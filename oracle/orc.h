@@ -12,8 +12,12 @@
  *  - The physics (env.py:218 -> MuJoCo mj_step, un-vendored third-party C library, mujoco ^3.2.2
  *    per gym_guided_vision/pyproject.toml:11) restates MuJoCo's *documented* pipeline with the
  *    Newton solver the reference runs (MuJoCo default) and the PGS solver BASELINE.json's
- *    north_star names (orc_data.solver).  MuJoCo cannot be imported or built here,
- *    the reference ships no golden trajectories: PARITY UNPINNED at the MuJoCo boundary.
+ *    north_star names (orc_data.solver), the options the reference's XML sets (aloha_sim.xml:4-5:
+ *    elliptic cones, impratio 100, noslip_iterations 3 as mj_solNoSlip's per-contact QCQP,
+ *    multiccd perturbation contacts) and MuJoCo's defaults for the rest.  MuJoCo cannot be
+ *    imported or built here, the reference ships no golden trajectories: PARITY UNPINNED at the
+ *    MuJoCo boundary.  tests/golden/gen_mujoco_traj.py records such trajectories where MuJoCo is
+ *    installed; tests/test_mujoco_pin.py compares this oracle and the device with them.
  */
 #ifndef ORC_H
 #define ORC_H
