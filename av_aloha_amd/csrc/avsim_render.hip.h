@@ -32,7 +32,11 @@ constexpr int REC_W = 32;   // floats per geom record: o_l[3], A[9] (camera dir 
                             // geom id, nearest depth, screen box xl xr yb yt (units of tan), and the extents of x + y and x - y over
                             // the projected vertices [28..31]: with the box an octagon, tight for the long thin frame bars that cross the
                             // image at an angle
-constexpr int TILE_W = 32, TILE_H = 8;
+#ifndef AVSIM_TILE_R
+#define AVSIM_TILE_R 1
+#endif
+constexpr int TILE_R = AVSIM_TILE_R, NPX = 4 * TILE_R;      // rows of 4 pixels per lane (2 rows = 32 x 16 tiles measured slower: 71-74 ms against 67)
+constexpr int TILE_W = 32, TILE_H = 8 * TILE_R;
 #ifndef AVSIM_BIN_TX
 #define AVSIM_BIN_TX 2
 #define AVSIM_BIN_TY 4
@@ -252,15 +256,19 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                                             const float* __restrict__ R, const float4* __restrict__ tplanes, int nplane, const float scale, int ncam_sel, int H,
                                             int W, float znear, float zfar, float* __restrict__ out, const float* __restrict__ geom_rgba, const float* __restrict__ light,
                                             const float* __restrict__ camaux, unsigned char* __restrict__ out_rgb) {
-    const int px = tx0 + 4 * (lane & 7), py = ty0 + (lane >> 3);
+    // lane -> 4 adjacent pixels in each of TILE_R rows (rows 8 apart, so that a row of the tile is still written by 8 lanes)
+    const int px = tx0 + 4 * (lane & 7), py0 = ty0 + (lane >> 3);
     // tile pyramid: x in [xl, xr], y in [yb, yt] at z = -1
     const int x1 = tx0 + TILE_W < W ? tx0 + TILE_W : W, y1 = ty0 + TILE_H < H ? ty0 + TILE_H : H;
     const float xl = (tx0 - 0.5f * W) * scale, xr = (x1 - 0.5f * W) * scale, yt = -(ty0 - 0.5f * H) * scale, yb = -(y1 - 0.5f * H) * scale;
-    const float dy = -(py + 0.5f - 0.5f * H) * scale;
-    float dx[4], best[4];
-    int win[4];     // RGB: record index | entry face << 8 of what the pixel sees
+    float dyr[TILE_R], dx[4], best[NPX];
+    int win[NPX];     // RGB: record index | entry face << 8 of what the pixel sees; pixel q = 4 * row + column
 #pragma unroll
-    for (int q = 0; q < 4; q++) { dx[q] = (px + q + 0.5f - 0.5f * W) * scale; best[q] = (px + q < W && py < H) ? zfar : 0.0f; win[q] = -1; }
+    for (int r = 0; r < TILE_R; r++) dyr[r] = -(py0 + 8 * r + 0.5f - 0.5f * H) * scale;
+#pragma unroll
+    for (int q = 0; q < 4; q++) dx[q] = (px + q + 0.5f - 0.5f * W) * scale;
+#pragma unroll
+    for (int q = 0; q < NPX; q++) { best[q] = (px + (q & 3) < W && py0 + 8 * (q >> 2) < H) ? zfar : 0.0f; win[q] = -1; }
     float far = zfar;    // farthest current depth over the tile's pixels (off-image pixels count as 0)
     RSTAT(0, 1); RSTAT(1, cnt);
     for (int k0 = 0; k0 < cnt; k0 += 64) {
@@ -337,11 +345,11 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                 RSTAT(3, 1); RSTAT(4, __popcll(mF)); RSTAT(5, __popcll(mB));        // nothing of this hull in the tile is nearer than what the tile already shows
                 // Pass 1, candidate entry faces: the entry is the largest crossing, a ray that does not approach such a face misses.
                 // Pass 2, vetoing faces: the entry point must lie behind them (lo * n.v <= no; no division).
-                float lo[4];
-                bool ok[4];
-                int face[4];
+                float lo[NPX];
+                bool ok[NPX];
+                int face[NPX];
 #pragma unroll
-                for (int q = 0; q < 4; q++) { lo[q] = -1e30f; ok[q] = true; face[q] = 0; }
+                for (int q = 0; q < NPX; q++) { lo[q] = -1e30f; ok[q] = true; face[q] = 0; }
                 if (np <= 64) {
                     while (mF) {
                         const int p = __builtin_ctzll(mF);
@@ -351,10 +359,12 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                         f.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.y), p));
                         f.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.z), p));
                         f.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.w), p));
-                        const float nb = f.y * dy - f.z;
+                        float nb[TILE_R];
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const float nv = nb + f.x * dx[q];
+                        for (int r = 0; r < TILE_R; r++) nb[r] = f.y * dyr[r] - f.z;
+#pragma unroll
+                        for (int q = 0; q < NPX; q++) {
+                            const float nv = nb[q >> 2] + f.x * dx[q & 3];
                             const float t = f.w * __builtin_amdgcn_rcpf(nv);
                             ok[q] = ok[q] && nv < 0;
                             if (RGB) { if (t > lo[q]) face[q] = p; }
@@ -365,10 +375,12 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                     for (int p = 0; p < np; p++) {
                         const float4 f = P[p];
                         if (!(f.w < 0)) continue;
-                        const float nb = f.y * dy - f.z;
+                        float nb[TILE_R];
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const float nv = nb + f.x * dx[q];
+                        for (int r = 0; r < TILE_R; r++) nb[r] = f.y * dyr[r] - f.z;
+#pragma unroll
+                        for (int q = 0; q < NPX; q++) {
+                            const float nv = nb[q >> 2] + f.x * dx[q & 3];
                             const float t = f.w * __builtin_amdgcn_rcpf(nv);
                             ok[q] = ok[q] && nv < 0;
                             if (RGB) { if (t > lo[q]) face[q] = p; }
@@ -380,7 +392,7 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                 {
                     bool need = false;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) need = need || (ok[q] && lo[q] >= znear && lo[q] < best[q]);
+                    for (int q = 0; q < NPX; q++) need = need || (ok[q] && lo[q] >= znear && lo[q] < best[q]);
                     if (!__any(need)) continue;
                 }
                 if (np <= 64) {
@@ -392,72 +404,95 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                         f.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.y), p));
                         f.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.z), p));
                         f.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.w), p));
-                        const float nb = f.y * dy - f.z;
+                        float nb[TILE_R];
 #pragma unroll
-                        for (int q = 0; q < 4; q++) ok[q] = ok[q] && lo[q] * (nb + f.x * dx[q]) <= f.w;
+                        for (int r = 0; r < TILE_R; r++) nb[r] = f.y * dyr[r] - f.z;
+#pragma unroll
+                        for (int q = 0; q < NPX; q++) ok[q] = ok[q] && lo[q] * (nb[q >> 2] + f.x * dx[q & 3]) <= f.w;
                     }
                 } else {
                     for (int p = 0; p < np; p++) {
                         const float4 f = P[p];
                         if (f.w < 0) continue;
-                        const float nb = f.y * dy - f.z;
+                        float nb[TILE_R];
 #pragma unroll
-                        for (int q = 0; q < 4; q++) ok[q] = ok[q] && lo[q] * (nb + f.x * dx[q]) <= f.w;
+                        for (int r = 0; r < TILE_R; r++) nb[r] = f.y * dyr[r] - f.z;
+#pragma unroll
+                        for (int q = 0; q < NPX; q++) ok[q] = ok[q] && lo[q] * (nb[q >> 2] + f.x * dx[q & 3]) <= f.w;
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++)
+                for (int q = 0; q < NPX; q++)
                     if (ok[q] && lo[q] >= znear && lo[q] < best[q]) { best[q] = lo[q]; if (RGB) win[q] = k | (face[q] << 8); }
-                far = wave_max(fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3])));
+                {
+                    float bm = best[0];
+#pragma unroll
+                    for (int q = 1; q < NPX; q++) bm = fmaxf(bm, best[q]);
+                    far = wave_max(bm);
+                }
             } else {
                 // direction in the geom frame: A (dx, dy, -1)
                 RSTAT(6, 1);
-                float vb[3], va[3];
+                float va[3];
 #pragma unroll
-                for (int i = 0; i < 3; i++) { va[i] = rec[3 + 3 * i]; vb[i] = rec[3 + 3 * i + 1] * dy - rec[3 + 3 * i + 2]; }
+                for (int i = 0; i < 3; i++) va[i] = rec[3 + 3 * i];
                 const float sz[3] = {rec[16], rec[17], rec[18]};
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float v[3] = {vb[0] + va[0] * dx[q], vb[1] + va[1] * dx[q], vb[2] + va[2] * dx[q]};
+                for (int q = 0; q < NPX; q++) {
+                    const float dyq = dyr[q >> 2], dxq = dx[q & 3];
+                    const float v[3] = {rec[4] * dyq - rec[5] + va[0] * dxq, rec[7] * dyq - rec[8] + va[1] * dxq, rec[10] * dyq - rec[11] + va[2] * dxq};
                     float t0;
                     if (ray_prim(type, sz, o, v, &t0) && t0 >= znear && t0 < best[q]) { best[q] = t0; if (RGB) win[q] = k; }
                 }
-                far = wave_max(fmaxf(fmaxf(best[0], best[1]), fmaxf(best[2], best[3])));
+                {
+                    float bm = best[0];
+#pragma unroll
+                    for (int q = 1; q < NPX; q++) bm = fmaxf(bm, best[q]);
+                    far = wave_max(bm);
+                }
             }
         }
     }
     if (!RGB) {
-        if (py < H) {
-            float* dst = out + (((size_t)env * ncam_sel + cs) * H + py) * W + px;
-            if (px + 3 < W && (W & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(best[0], best[1], best[2], best[3]);
-            else {
 #pragma unroll
-                for (int q = 0; q < 4; q++) if (px + q < W) dst[q] = best[q];
+        for (int r = 0; r < TILE_R; r++) {
+            const int py = py0 + 8 * r;
+            if (py < H) {
+                float* dst = out + (((size_t)env * ncam_sel + cs) * H + py) * W + px;
+                if (px + 3 < W && (W & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(best[4 * r], best[4 * r + 1], best[4 * r + 2], best[4 * r + 3]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) if (px + q < W) dst[q] = best[4 * r + q];
+                }
             }
         }
         return;
     }
-    if (py >= H) return;
     const float* aux = camaux + ((size_t)env * ncam_sel + cs) * 8;
     const float amb = light[0], hd = light[1], ld = light[2];
+#pragma unroll
+    for (int r = 0; r < TILE_R; r++) {
+        const int py = py0 + 8 * r;
+        const float dy_ = dyr[r];
+        if (py >= H) continue;
     unsigned char col[12];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const float idn = rsqrtf(dx[q] * dx[q] + dy * dy + 1.0f);
+        const float idn = rsqrtf(dx[q] * dx[q] + dy_ * dy_ + 1.0f);
         float rgb[3];
-        if (win[q] >= 0) {
-            const int k = win[q] & 255;
+        if (win[4 * r + q] >= 0) {
+            const int k = win[4 * r + q] & 255;
             const float* rec = R + (size_t)k * REC_W;
             const int type = __float_as_int(rec[19]);
             float n[3];    // outward normal in the camera frame
             if (type == 7) {
-                const float4 f = tplanes[((size_t)env * ncam_sel + cs) * nplane + __float_as_int(rec[20]) + (win[q] >> 8)];
+                const float4 f = tplanes[((size_t)env * ncam_sel + cs) * nplane + __float_as_int(rec[20]) + (win[4 * r + q] >> 8)];
                 n[0] = f.x; n[1] = f.y; n[2] = f.z;
             } else {
                 float p[3], ng[3] = {0, 0, 0};
-                const float t = best[q];
+                const float t = best[4 * r + q];
 #pragma unroll
-                for (int i = 0; i < 3; i++) p[i] = rec[i] + t * (rec[3 + 3 * i] * dx[q] + rec[3 + 3 * i + 1] * dy - rec[3 + 3 * i + 2]);
+                for (int i = 0; i < 3; i++) p[i] = rec[i] + t * (rec[3 + 3 * i] * dx[q] + rec[3 + 3 * i + 1] * dy_ - rec[3 + 3 * i + 2]);
                 if (type == 2) {
                     const float ir = rsqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
                     ng[0] = p[0] * ir; ng[1] = p[1] * ir; ng[2] = p[2] * ir;
@@ -473,12 +508,12 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
 #pragma unroll
                 for (int j = 0; j < 3; j++) n[j] = rec[3 + j] * ng[0] + rec[6 + j] * ng[1] + rec[9 + j] * ng[2];   // A^T
             }
-            const float ch = -(n[0] * dx[q] + n[1] * dy - n[2]) * idn, cl = -(n[0] * aux[0] + n[1] * aux[1] + n[2] * aux[2]);
+            const float ch = -(n[0] * dx[q] + n[1] * dy_ - n[2]) * idn, cl = -(n[0] * aux[0] + n[1] * aux[1] + n[2] * aux[2]);
             const float lum = fminf(1.0f, amb + hd * fmaxf(ch, 0.0f) + ld * fmaxf(cl, 0.0f));
             const float* c = geom_rgba + 4 * __float_as_int(rec[22]);
             rgb[0] = c[0] * lum; rgb[1] = c[1] * lum; rgb[2] = c[2] * lum;
         } else {
-            const float w = 0.5f + 0.5f * (aux[4] * dx[q] + aux[5] * dy - aux[6]) * idn;
+            const float w = 0.5f + 0.5f * (aux[4] * dx[q] + aux[5] * dy_ - aux[6]) * idn;
 #pragma unroll
             for (int j = 0; j < 3; j++) rgb[j] = light[12 + j] + (light[8 + j] - light[12 + j]) * w;
         }
@@ -496,6 +531,7 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
 #pragma unroll
         for (int q = 0; q < 4; q++)
             if (px + q < W) { dst[3 * q] = col[3 * q]; dst[3 * q + 1] = col[3 * q + 1]; dst[3 * q + 2] = col[3 * q + 2]; }
+    }
     }
 }
 
