@@ -2542,7 +2542,7 @@ struct PhysHost {
             int ms = f64 ? md.msize : mf.msize;
             // row / contact capacities per task: every box of a compound object resting on the condim-6 table
             // contributes 4 contacts x 6 rows (SewNeedle 24 contacts / 128 rows, TubeTransfer 40 / 248 at rest)
-            static const int cap_efc[5] = {176, 176, 240, 336, 192}, cap_con[5] = {48, 48, 56, 72, 48};
+            static const int cap_efc[5] = {176, 176, 240, 336, 176}, cap_con[5] = {48, 48, 56, 72, 48};
             maxefc = cap_efc[b.scalar("task_id")];
             maxcon = cap_con[b.scalar("task_id")];
             dims[0] = b.scalar("nq"); dims[1] = b.scalar("nv"); dims[2] = b.scalar("nu"); dims[3] = b.scalar("nbody"); dims[4] = b.scalar("ngeom"); dims[5] = ms; dims[6] = b.scalar("ntree");

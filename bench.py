@@ -170,7 +170,11 @@ def main():
     from av_aloha_amd.build import build_hip
     from av_aloha_amd.dist import gather_episode_stats, shard_ids
     from av_aloha_amd.sim import load_blob
-    build_hip()
+    # the library travels prebuilt; should its sources look newer on this box, ONE rank rebuilds it and the others wait
+    if rank == 0:
+        build_hip()
+    if dist is not None:
+        dist.barrier()
     cfg = W.CONFIGS[args.config]
     if args.config == 5 and not args.render:
         args.render = RENDER_DEFAULT
