@@ -688,7 +688,7 @@ int avsim_get_phase_cycles(avsim_t* h, int64_t* out) {
     if (!h || !out || !h->phys.d_prof) return AVSIM_EINVAL;
     DevGuard dev_guard_(h->device);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out, h->phys.d_prof, (size_t)h->N * 18 * 8, h->io_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out, h->phys.d_prof, (size_t)h->N * avs::PROF_W * 8, h->io_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return AVSIM_OK;
 }
 

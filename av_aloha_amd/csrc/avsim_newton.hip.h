@@ -349,7 +349,7 @@ AVS_DEV void nblock_chol(const NewtonArgs<real>& A, int lane) {
     }
 #pragma unroll
     for (int j = 0; j < TREE_W; j++) {
-        const real piv = tmax(__shfl(row[j], gb | j, 64), real(1e-30));
+        const real piv = tmax(oct_bcast_n(row[j], j), real(1e-30));
         real d, rinv;
         if (sizeof(real) == 4) { rinv = (real)__builtin_amdgcn_rsqf((float)piv); d = piv * rinv; }
         else { d = sqrt(piv); rinv = real(1) / d; }
@@ -357,7 +357,7 @@ AVS_DEV void nblock_chol(const NewtonArgs<real>& A, int lane) {
         row[j] = lij;
         const real mul = i > j ? lij : real(0);
 #pragma unroll
-        for (int k = j + 1; k < TREE_W; k++) row[k] -= mul * __shfl(lij, gb | k, 64);
+        for (int k = j + 1; k < TREE_W; k++) row[k] -= mul * oct_bcast_n(lij, k);
     }
     if (i < n) {
 #pragma unroll
@@ -386,12 +386,12 @@ AVS_DEV void nblock_solve(const NewtonArgs<real>& A, int lane) {
     real x = mine ? -A.g[a0 + i] : real(0);
 #pragma unroll
     for (int j = 0; j < TREE_W; j++) {
-        const real yj = __shfl(x * dinv, gb | j, 64);
+        const real yj = oct_bcast_n(x * dinv, j);
         x = i == j ? yj : x - row[j] * yj;
     }
 #pragma unroll
     for (int j = TREE_W - 1; j >= 0; j--) {
-        const real xj = __shfl(x * dinv, gb | j, 64);
+        const real xj = oct_bcast_n(x * dinv, j);
         x = i == j ? xj : x - col[j] * xj;
     }
     if (mine) A.dl[a0 + i] = x;

@@ -33,6 +33,7 @@ constexpr int ROW_W = 2 * TREE_W;
 constexpr int ROW_S = ROW_W;       // Jacobian rows live in global memory (L2-resident scratch): 64-byte rows, no banks to dodge
 constexpr int RS_S = 9;            // solver record: 8 words used
 constexpr int CAND_MAX = 256;  // exact broad-phase survivors per substep (narrow-phase work list, global scratch)
+constexpr int PROF_W = 26;   // words per env of the phase profile: 8 phases, broad / narrow, 16 solver / probe slots
 constexpr int ANC_MAX = 64;    // LDS ints of the kinematics' pointer-jumping table (one per body)
 constexpr int NEAR_MAX = 512;  // Verlet neighbour list: pairs within reach + skin, rebuilt when a geom moved > skin/2
 
@@ -320,6 +321,30 @@ AVS_DEV double oct_sum(double x) {
     x += __shfl_xor(x, 4, 8);
     return x;
 }
+// value of lane J (0..7) of every aligned group of 8 lanes, to all 8 lanes of the group: a quad broadcast, then the other quad's
+// copy through the half-row mirror -- two DPP moves and a select instead of a ds_bpermute round trip through the LDS crossbar
+template <int J>
+AVS_DEV int oct_bcast_i(int x) {
+    constexpr int q = J & 3, ctrl = q | (q << 2) | (q << 4) | (q << 6);
+    const int a = __builtin_amdgcn_update_dpp(0, x, ctrl, 0xf, 0xf, false);      // quad_perm:[q,q,q,q]
+    const int b = __builtin_amdgcn_update_dpp(0, a, 0x141, 0xf, 0xf, false);     // row_half_mirror: lane i <- lane 7 - i of its 8
+    const bool hi = (threadIdx.x & 4) != 0;
+    return hi == (J >= 4) ? a : b;
+}
+template <int J> AVS_DEV float oct_bcast(float x) { return __builtin_bit_cast(float, oct_bcast_i<J>(__builtin_bit_cast(int, x))); }
+template <int J> AVS_DEV double oct_bcast(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const unsigned lo = (unsigned)oct_bcast_i<J>((int)(unsigned)b), hi = (unsigned)oct_bcast_i<J>((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+// the same with the source lane in a loop counter of an unrolled loop
+template <typename T>
+AVS_DEV T oct_bcast_n(T x, int j) {
+    switch (j & 7) {
+        case 0: return oct_bcast<0>(x); case 1: return oct_bcast<1>(x); case 2: return oct_bcast<2>(x); case 3: return oct_bcast<3>(x);
+        case 4: return oct_bcast<4>(x); case 5: return oct_bcast<5>(x); case 6: return oct_bcast<6>(x); default: return oct_bcast<7>(x);
+    }
+}
 AVS_DEV float lane_get(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
 AVS_DEV double lane_get(double x, int l) {   // l is wave-uniform at every call site
     const long long b = __builtin_bit_cast(long long, x);
@@ -330,7 +355,7 @@ AVS_DEV double lane_get(double x, int l) {   // l is wave-uniform at every call 
 constexpr int GRP_MAX = 6;   // rows per Gauss-Seidel group (a condim-6 contact is one group)
 // per-group record in global scratch: [0, 15) couplings (packed lower triangle), then for a contact with >= 3 friction rows the rows
 // of its friction block for the noslip QCQP, 12 words per friction row r: A[r][0..4], (D A D)^-1[r][0..4], mu_r, singular flag
-constexpr int GA_W = 80, GA_Q = 16, GA_QW = 12;
+constexpr int GA_W = 64, GA_Q = 16, GA_QW = 6;   // group record: 15 couplings, then the noslip block transposed: word 8 k + r = entry k of row r
 // convergence thresholds of the multiplier iteration in the noslip QCQP: MuJoCo's absolute 1e-10 in double; in float a relative
 // part on top, since v.v - r^2 and the multiplier carry 1e-7 relative rounding
 template <typename T> struct QTol;
@@ -351,15 +376,107 @@ template <> struct QTol<float> { static constexpr float abs = 1e-10f, rel = 2e-6
 // rowI[i] = two 13-bit dof windows of row i: first dof (6) | count (4) | kinematic tree (3).
 // B = J M^-1 is read from the global row scratch next to J (written by the row's lane in make_constraints).
 // ------------------------------------------------------------------------------------------------
+// The dry-friction rows of a noslip sweep, all kinematic trees at once (see pgs_groups)
+template <typename real>
+struct NoslipLead {
+    LDS_PTR(const real) Minv;        // 8 x 8 inverse inertia block per tree
+    LDS_PTR(const int) tadr;         // tree -> first dof, dof count
+    LDS_PTR(const int) tnum;
+    LDS_PTR(const int) floss_dof;    // dry-friction row -> dof (increasing)
+    LDS_PTR(int) dmap;               // nv ints of dead LDS: dof -> row
+    LDS_PTR(int) prof;               // probe slots (8 ints) or null
+    int ntree, nv, neq, nfloss, nlg; // nlg = groups of leading (non-contact) rows; -1: no per-tree pass (more than 8 trees)
+};
+
+// arguments of a non-kernel function arrive in VGPRs: the wave-uniform ones go back to SGPRs (scalar branches, scalar addressing)
+template <typename T> AVS_DEV LDS_PTR(T) uni_lds(LDS_PTR(T) p) {
+    return (LDS_PTR(T))(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)p);
+}
+template <typename T> AVS_DEV GLB_PTR(T) uni_glb(GLB_PTR(T) p) {
+    const unsigned long long v = (unsigned long long)p;
+    return (GLB_PTR(T))(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v));
+}
+
 template <typename real>
 __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
                                                      LDS_PTR(real) q, LDS_PTR(const int) gI, GLB_PTR(const real) gA, int ngrp, int iters,
-                                                     int noslip_iters, real noslip_tol_scaled) {
+                                                     int noslip_iters, real noslip_tol_scaled, NoslipLead<real> nl) {
+    const long long tent = __builtin_readcyclecounter();
+    rowS = uni_lds(rowS); rowI = uni_lds(rowI); q = uni_lds(q); gI = uni_lds(gI);
+    rJ = uni_glb(rJ); rB = uni_glb(rB); gA = uni_glb(gA);
+    ngrp = __builtin_amdgcn_readfirstlane(ngrp); iters = __builtin_amdgcn_readfirstlane(iters); noslip_iters = __builtin_amdgcn_readfirstlane(noslip_iters);
+    noslip_tol_scaled = lane_get(noslip_tol_scaled, 0);
+    nl.Minv = uni_lds(nl.Minv); nl.tadr = uni_lds(nl.tadr); nl.tnum = uni_lds(nl.tnum); nl.floss_dof = uni_lds(nl.floss_dof); nl.dmap = uni_lds(nl.dmap); nl.prof = uni_lds(nl.prof);
+    nl.ntree = __builtin_amdgcn_readfirstlane(nl.ntree); nl.nv = __builtin_amdgcn_readfirstlane(nl.nv); nl.neq = __builtin_amdgcn_readfirstlane(nl.neq);
+    nl.nfloss = __builtin_amdgcn_readfirstlane(nl.nfloss); nl.nlg = __builtin_amdgcn_readfirstlane(nl.nlg);
     // lane 8 d + k serves row d of the group (d < 6) and dof slot k of BOTH of the row's tree windows
     const int lane = threadIdx.x & 63, d = lane >> 3, k8 = lane & 7, dr = d < GRP_MAX ? d : 0;
     const int lr = lane < GRP_MAX ? lane : 0;          // row slot owned in the sequential phase
     const int tri = lr * (lr - 1) / 2;                 // offset of that row in the packed lower triangle
     if (ngrp <= 0) return;
+    // ---- dry-friction rows in the noslip sweeps ----
+    // A dry-friction row is a unit row (J = e_dof), so its residual is qacc[dof] - aref, its J M^-1 is a row of the tree's inverse
+    // inertia block, and rows of different trees do not interact: instead of walking them six at a time through the group
+    // machinery, lane 8 t + i takes dof i of tree t and every tree relaxes its rows in row order at the same time (eight
+    // steps for all of them; x follows qacc[dof] through the updates of its tree, which is all a later row's residual sees).
+    // Contact blocks couple trees and come after all dry-friction rows in mj_solNoSlip's sweep [EXT], so the order of the
+    // updates that can see each other is the reference's.
+    const bool fl = noslip_iters > 0 && nl.nlg >= 0;
+    const int ft = lane >> 3, fi = lane & 7, fgb = lane & ~7;
+    bool fm = false;
+    int fdof = 0, frow = -1;
+    real mrow[TREE_W], faref = 0, finv = 0, fdiag = 0, flo = 0, fhi = 0;
+#pragma unroll
+    for (int s = 0; s < TREE_W; s++) mrow[s] = 0;
+    if (fl) {
+        for (int k = lane; k < nl.nv; k += 64) nl.dmap[k] = -1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int r = lane; r < nl.nfloss; r += 64) nl.dmap[nl.floss_dof[r]] = nl.neq + r;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        fm = ft < nl.ntree && fi < nl.tnum[ft < nl.ntree ? ft : 0];
+        fdof = fm ? nl.tadr[ft] + fi : 0;
+        frow = fm ? nl.dmap[fdof] : -1;
+        if (fm) {
+#pragma unroll
+            for (int s = 0; s < TREE_W; s++) mrow[s] = nl.Minv[64 * ft + 8 * fi + s];
+        }
+        LDS_PTR(const real) FS = rowS + RS_S * (frow >= 0 ? frow : 0);
+        faref = FS[0]; finv = frow >= 0 ? FS[3] : real(0); flo = FS[4]; fhi = FS[5];
+        fdiag = finv != 0 ? real(1) / finv : real(0);
+    }
+    real imp = 0, imp_c = 0;      // improvement of the dual cost over the current noslip sweep (per-lane parts, uniform part)
+    LDS_PTR(int) prof = nl.prof;
+    const long long tq0 = prof ? __builtin_readcyclecounter() : 0;
+    int nstep = 0, nsweep = 0;
+    auto floss_sweep = [&]() {
+        const long long tf0 = prof ? __builtin_readcyclecounter() : 0;
+        real x = fm ? q[fdof] : real(0);
+        LDS_PTR(real) FS = rowS + RS_S * (frow >= 0 ? frow : 0);
+        real f = frow >= 0 ? FS[6] : real(0);
+#pragma unroll
+        for (int s = 0; s < TREE_W; s++) {
+            // dry-friction rows of mj_solNoSlip [EXT]: clamped scalar update, undone when it would raise the cost (costChange)
+            const real res = x - faref;
+            const real fs = tmin(tmax(f - res * finv, flo), fhi);
+            const real dl_ = fs - f, ch = dl_ * (real(0.5) * dl_ * fdiag + res);      // (lanes without a row never take the update)
+            const bool take = frow >= 0 && fi == s && !(ch > real(1e-10));
+            if (take) { imp -= ch; f = fs; }
+            const real ds = oct_bcast_n(take ? dl_ : real(0), s);
+            x += mrow[s] * ds;
+        }
+        if (fm) q[fdof] = x;
+        if (frow >= 0) FS[6] = f;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        nsweep++;
+        if (prof && lane == 0) prof[2] += (int)(__builtin_readcyclecounter() - tf0);
+    };
+    const int first_ns = fl ? nl.nlg : 0;               // first group of a noslip sweep
+    const int per_ns = ngrp - first_ns;                 // (contact groups only when the dry-friction rows go per tree)
+    const int noslip_only = (fl && per_ns <= 0) ? noslip_iters : 0;
+    if (noslip_only) noslip_iters = 0;   // no contact: the noslip sweeps are the dry-friction rows alone, after the PGS sweeps (if any)
     // software pipeline: group headers three groups ahead, row windows two ahead, the J / J M^-1 entries (global memory, L2
     // latency) one group ahead, so that a step only waits for LDS
     auto jb_load = [&](int hdr, int win, real& ja, real& jb, real& ba, real& bb) {
@@ -369,31 +486,38 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         const bool a = in && k8 < ((win >> 6) & 15), b = in && k8 < ((win >> 19) & 15);
         GLB_PTR(const real) Jr = rJ + ROW_S * rw + k8;
         GLB_PTR(const real) Br = rB + ROW_S * rw + k8;
-        ja = a ? Jr[0] : real(0); jb = b ? Jr[TREE_W] : real(0);
-        ba = a ? Br[0] : real(0); bb = b ? Br[TREE_W] : real(0);
+        // unconditional loads (every row record is 16 words, zero padded; a lane outside the group reads the group's first row): no
+        // exec-mask detours, and nothing touches the values before the step that uses them, which masks them (inA / inB)
+        (void)a; (void)b;
+        ja = Jr[0]; jb = Jr[TREE_W]; ba = Br[0]; bb = Br[TREE_W];
     };
-    int gi = __builtin_amdgcn_readfirstlane(gI[0]);
-    int gin = __builtin_amdgcn_readfirstlane(gI[ngrp > 1 ? 1 : 0]);
-    int ginn = __builtin_amdgcn_readfirstlane(gI[ngrp > 2 ? 2 : (ngrp > 1 ? 0 : 0)]);
+    // wrap-around of the group index at the end of a sweep: a noslip sweep starts at first_ns
+    auto nextg = [&](int gq, int itq) { return gq + 1 < ngrp ? gq + 1 : (itq + 1 >= iters ? first_ns : 0); };
+    int g = iters > 0 ? 0 : first_ns, it = 0;
+    if (g >= ngrp) g = 0;      // (no step will run)
+    int gi = __builtin_amdgcn_readfirstlane(gI[g]);
+    int gin = __builtin_amdgcn_readfirstlane(gI[nextg(g, it)]);
+    int ginn = __builtin_amdgcn_readfirstlane(gI[nextg(nextg(g, it), it)]);
     int ra = rowI[(gi & 0xffff) + dr], ran = rowI[(gin & 0xffff) + dr];
     real JA, JB, BA, BB;
     jb_load(gi, ra, JA, JB, BA, BB);
     real ac[GRP_MAX - 1];
 #pragma unroll
-    for (int s = 0; s < GRP_MAX - 1; s++) ac[s] = gA[tri + s];
+    for (int s = 0; s < GRP_MAX - 1; s++) ac[s] = gA[GA_W * g + tri + s];
     // noslip QCQP rows of the group (lanes 1..5 = friction rows), prefetched with the couplings
     const int qr = (lane >= 1 && lane <= 5) ? lane - 1 : 0;
     real qc[GA_QW], qn[GA_QW];
 #pragma unroll
-    for (int s = 0; s < GA_QW; s++) qc[s] = gA[GA_Q + GA_QW * qr + s];
-    const int total = (iters + noslip_iters) * ngrp;
-    int g = 0, it = 0;
-    real imp = 0, imp_c = 0;      // improvement of the dual cost over the current noslip sweep (per-lane parts, uniform part)
+    for (int s = 0; s < GA_QW; s++) qc[s] = gA[GA_W * g + GA_Q + 8 * s + qr];
+    const int total = iters * ngrp + noslip_iters * per_ns;
+    if (prof && lane == 0) prof[3] += (int)(__builtin_readcyclecounter() - tq0);
+    if (fl && iters == 0 && noslip_iters > 0) floss_sweep();
     for (int step = 0; step < total; step++) {
+        nstep++;
         const bool noslip = it >= iters;
         const int start = gi & 0xffff, cnt = (gi >> 16) & 15;
         const bool contact = (gi >> 24) & 1;
-        const int g1 = g + 1 < ngrp ? g + 1 : 0, g2 = g1 + 1 < ngrp ? g1 + 1 : 0, g3 = g2 + 1 < ngrp ? g2 + 1 : 0;
+        const int g1 = nextg(g, it), g2 = nextg(g1, it), g3 = nextg(g2, it);
         // ---- issue the look-ahead reads and this group's LDS reads in one batch ----
         const int ginnn_v = gI[g3];
         const int rann = rowI[(ginn & 0xffff) + dr];
@@ -411,12 +535,12 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         for (int s = 0; s < GRP_MAX - 1; s++) an[s] = gA[GA_W * g1 + tri + s];      // next group's couplings (global memory)
         if (noslip_iters > 0) {
 #pragma unroll
-            for (int s = 0; s < GA_QW; s++) qn[s] = gA[GA_W * g1 + GA_Q + GA_QW * qr + s];
+            for (int s = 0; s < GA_QW; s++) qn[s] = gA[GA_W * g1 + GA_Q + 8 * s + qr];
         }
 #pragma unroll
         for (int s = 0; s < GRP_MAX - 1; s++) a[s] = (mine && s < lane) ? ac[s] : real(0);
         // ---- row residuals J_r . qacc: every row is summed over its 8 lanes, lane r then fetches row r's sum ----
-        const real x = oct_sum(JA * qA + JB * qB);
+        const real x = oct_sum((inA ? JA * qA : real(0)) + (inB ? JB * qB : real(0)));
         const real dot = __shfl(x, 8 * lr, 64);
         real f = f0;
         if (noslip && contact) {
@@ -427,31 +551,21 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
             const int n = cnt - 1;
             bool done = false;
             if (n >= 3) {
-                // multiplier 0 first, through the inverse of the scaled block made with the rows (make_constraints): lane r = 1..n holds
-                // row r - 1 of A and of (D A D)^-1; the 5-vectors travel by v_readlane.  Inside the cone section this is the answer.
+                // multiplier 0 first: the unconstrained minimiser f - A^-1 res, through the inverse of the friction block made with the
+                // rows (make_constraints: lane r = 1..n holds row r - 1 of A^-1).  Inside the cone section this is mju_QCQP's answer,
+                // and its cost change is dl . (A dl / 2 + res) = dl . res / 2 because A dl = -res.
                 const real fn = lane_get(f0, 0), r2 = fn * fn;
                 const bool row = lane >= 1 && lane <= n;
-                const real res_r = dot - aref;
-                if (!(fn < real(1e-15)) && lane_get(qc[11], 1) == real(0)) {
+                const real res_r = row ? dot - aref : real(0);
+                if (!(fn < real(1e-15)) && lane_get(qc[5], 1) == real(0)) {
                     real t = 0;
 #pragma unroll
-                    for (int k = 0; k < 5; k++) t += k < n ? qc[k] * lane_get(f0, k + 1) : real(0);
-                    const real bs = (res_r - t) * qc[10];
-                    t = 0;
-#pragma unroll
-                    for (int k = 0; k < 5; k++) t += k < n ? qc[5 + k] * lane_get(bs, k + 1) : real(0);
-                    const real y = -t;
-                    real val = -r2;
-#pragma unroll
-                    for (int k = 0; k < 5; k++) { const real yk = lane_get(y, k + 1); val += k < n ? yk * yk : real(0); }
+                    for (int k = 0; k < 5; k++) t += qc[k] * lane_get(res_r, k + 1);
+                    const real dl_ = row ? -t : real(0), vr = f0 + dl_;
+                    const real w = row ? vr * muinv : real(0);
+                    const real val = lane_get(oct_sum(w * w), 0) - r2;
                     if (val < QTol<real>::abs + QTol<real>::rel * r2) {
-                        const real vr = y * qc[10], dl_ = row ? vr - f0 : real(0);
-                        t = 0;
-#pragma unroll
-                        for (int k = 0; k < 5; k++) t += k < n ? qc[k] * lane_get(dl_, k + 1) : real(0);
-                        real change = 0;
-#pragma unroll
-                        for (int k = 0; k < 5; k++) change += k < n ? lane_get(dl_ * (real(0.5) * t + res_r), k + 1) : real(0);
+                        const real change = real(0.5) * lane_get(oct_sum(dl_ * res_r), 0);
                         if (!(change > real(1e-10))) {
                             imp_c -= change;
                             if (row) f = vr;
@@ -632,18 +746,28 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         for (int s = 0; s < GRP_MAX - 1; s++) ac[s] = an[s];
 #pragma unroll
         for (int s = 0; s < GA_QW; s++) qc[s] = qn[s];
+        const bool sweep_end = g + 1 >= ngrp;
         g = g1;
-        if (g1 == 0) {
+        if (sweep_end) {
             // end of a sweep; a noslip sweep that improved the cost by less than noslip_tolerance ends the pass [EXT]
             if (noslip) {
                 // contact blocks add their (wave-uniform) change on every lane, dry-friction rows on their own lane only: lane 0's
                 // share of the former plus the lanes' own parts
                 const real uni = lane_get(imp_c, 0);
-                if (uni + lane_get(oct_sum(lane < GRP_MAX ? imp : real(0)), 0) < noslip_tol_scaled) break;
+                if (uni + lane_get(wave_sum(imp), 0) < noslip_tol_scaled) break;
             }
             imp = 0;
             imp_c = 0;
             it++;
+            if (fl && it >= iters && step + 1 < total) floss_sweep();
+        }
+    }
+    if (prof && lane == 0) { prof[0] += nstep; prof[1] += nsweep; prof[4] += (int)(tq0 - tent); prof[5] += (int)(__builtin_readcyclecounter() - tent); }
+    if (fl && per_ns <= 0) {
+        for (int sw = 0; sw < noslip_only; sw++) {
+            imp = 0;
+            floss_sweep();
+            if (lane_get(wave_sum(imp), 0) < noslip_tol_scaled) break;
         }
     }
 }
@@ -966,12 +1090,12 @@ struct Env {
         }
 #pragma unroll
         for (int j = 0; j < TREE_W; j++) {
-            const real d = sqrt(tmax(__shfl(row[j], gb | j, 64), real(1e-30)));
+            const real d = sqrt(tmax(oct_bcast_n(row[j], j), real(1e-30)));
             const real lij = i == j ? d : row[j] / d;
             row[j] = lij;
             const real mul = i > j ? lij : real(0);
 #pragma unroll
-            for (int k = j + 1; k < TREE_W; k++) row[k] -= mul * __shfl(lij, gb | k, 64);
+            for (int k = j + 1; k < TREE_W; k++) row[k] -= mul * oct_bcast_n(lij, k);
         }
         if (i < n) {
 #pragma unroll
@@ -993,12 +1117,12 @@ struct Env {
         if (!(i < n)) x = 0;
 #pragma unroll
         for (int j = 0; j < TREE_W; j++) {
-            const real yj = __shfl(x * dinv, gb | j, 64);
+            const real yj = oct_bcast_n(x * dinv, j);
             x = i == j ? yj : x - row[j] * yj;
         }
 #pragma unroll
         for (int j = TREE_W - 1; j >= 0; j--) {
-            const real xj = __shfl(x * dinv, gb | j, 64);
+            const real xj = oct_bcast_n(x * dinv, j);
             x = i == j ? xj : x - col[j] * xj;
         }
         return x;
@@ -1657,6 +1781,9 @@ struct Env {
         GLB_PTR(real) rJ = rows_();
         real *rowS = r + ka->lay.rowS, *warm = r + ka->lay.warm, *Minv = r + ka->lay.Minv, *asm_ = r + ka->lay.asm_;
         const bool newton = ka->m.solver == 1;
+        // Newton + noslip with the dry-friction rows relaxed per tree (pgs_groups): nothing reads the J M^-1 rows or the
+        // couplings of the leading rows
+        const bool lead_slim = newton && lead_per_tree();
         int* rowI = ii + ka->lay.rowI;
         real* Lm = r + ka->lay.L;
         const int *bmask = body_dofmask_(), *tadr = tree_dofadr_(), *tnum = tree_dofnum_();
@@ -1807,7 +1934,7 @@ struct Env {
                 }
             }
             store_row16(rJ + ROW_S * i, J);
-            store_row16(rowsB_() + ROW_S * i, Bv);
+            if (type == R_CONTACT || !lead_slim) store_row16(rowsB_() + ROW_S * i, Bv);
             // warm start: force implied by last step's acceleration, f = -D (J qacc_ws - aref), made feasible per row
             const int a0 = tadr[tA], nA = tnum[tA], b0 = tB >= 0 ? tadr[tB] : 0, nB = tB >= 0 ? tnum[tB] : 0;
             real jw = 0, jas = 0;      // J . warm start, J . qacc_smooth (the Newton solver's two start candidates)
@@ -1862,15 +1989,15 @@ struct Env {
         // Under the Newton solver only the noslip sweeps use them, and those never move a contact's normal row: a contact group
         // then needs the 10 pairs among its friction rows (the 5 pairs with the normal row are stored as zeros)
         const int nlg = (nlead + GRP_MAX - 1) / GRP_MAX;                  // the groups of leading rows come first
-        const int per_c = newton ? 10 : 15, nitem = ngrp <= nlg ? ngrp * 15 : nlg * 15 + (ngrp - nlg) * per_c;
+        const int per_c = newton ? 10 : 15, nl15 = lead_slim ? 0 : nlg * 15, nitem = ngrp <= nlg ? (lead_slim ? 0 : ngrp * 15) : nl15 + (ngrp - nlg) * per_c;
         for (int w = lane; w < nitem; w += G) {
             int g, e, rr = 1, ss;
-            if (w < nlg * 15 || !newton) {
+            if (w < nl15 || !newton) {
                 g = w / 15; e = w - 15 * g;
                 while ((rr + 1) * rr / 2 <= e) rr++;          // e = rr*(rr-1)/2 + ss
                 ss = e - rr * (rr - 1) / 2;
             } else {
-                const int wc = w - nlg * 15, e2 = wc % 10;
+                const int wc = w - nl15, e2 = wc % 10;
                 g = nlg + wc / 10;
                 while ((rr + 1) * rr / 2 <= e2) rr++;         // pair (rr, ss) among rows 1..5, shifted down by one
                 ss = e2 - rr * (rr - 1) / 2 + 1;
@@ -1953,11 +2080,12 @@ struct Env {
             }
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                GLB_PTR(real) o = gA + GA_W * g + GA_Q + GA_QW * j;
+                // row j of A^-1 = D (D A D)^-1 D and the singular flag, entry k at word 8 k + j: the row's lane fetches six separate
+                // words (a 16-byte load here gets a register copy, and with it a wait for the look-ahead load, in every step)
+                GLB_PTR(real) o = gA + GA_W * g + GA_Q + j;
 #pragma unroll
-                for (int k = 0; k < 5; k++) { o[k] = A[j][k]; o[5 + k] = Inv[j][k]; }
-                o[10] = mu[j];
-                o[11] = singular ? real(1) : real(0);
+                for (int k = 0; k < 5; k++) o[8 * k] = mu[j] * Inv[j][k] * mu[k];
+                o[40] = singular ? real(1) : real(0);
             }
         }
         GSYNC();
@@ -1991,7 +2119,7 @@ struct Env {
             GSYNC();
             long long tn0 = profiling ? __builtin_readcyclecounter() : 0;
             pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (GLB_PTR(const real))rJ, (GLB_PTR(const real))rowsB_(), (LDS_PTR(real))qacc,
-                             (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], 0, ka->m.noslip_iters, real(1e-6) / ka->m.nscale);
+                             (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], 0, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
             if (profiling && lane == 0) (ii + ka->lay.nprof)[6] += (int)(__builtin_readcyclecounter() - tn0);
         } else {
         // warm-start forces of friction blocks back onto their cones (one contact per lane)
@@ -2017,11 +2145,24 @@ struct Env {
         // Gauss-Seidel sweeps (+ noslip sweeps) in the register-resident wave kernel
         static_assert(G == 64, "the solver maps one env to one wavefront");
         pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (GLB_PTR(const real))rJ, (GLB_PTR(const real))rowsB_(), (LDS_PTR(real))qacc,
-                         (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], pgs_iters, ka->m.noslip_iters, real(1e-6) / ka->m.nscale);
+                         (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], pgs_iters, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
         }
         GSYNC();
         // qfrc_constraint = J^T f
         jt_force(fcon, nefc);
+    }
+
+    // what pgs_groups needs to relax the dry-friction rows of a noslip sweep per tree (lane 8 t + i: at most 8 trees)
+    AVS_DEV bool lead_per_tree() const { return ka->m.ntree <= 8 && ka->m.noslip_iters > 0; }
+    AVS_DEV NoslipLead<real> noslip_lead() const {
+        NoslipLead<real> nl;
+        nl.Minv = (LDS_PTR(const real))(r + ka->lay.Minv);
+        nl.tadr = (LDS_PTR(const int))tree_dofadr_(); nl.tnum = (LDS_PTR(const int))tree_dofnum_(); nl.floss_dof = (LDS_PTR(const int))floss_dof_();
+        nl.dmap = (LDS_PTR(int))(r + ka->lay.ng);       // the Newton gradient's words: dead once the primal solve has returned
+        nl.ntree = ka->m.ntree; nl.nv = ka->m.nv; nl.neq = ka->m.neq; nl.nfloss = ka->m.nfloss;
+        nl.prof = profiling ? (LDS_PTR(int))(ii + ka->lay.nprof + 8) : (LDS_PTR(int))nullptr;
+        nl.nlg = lead_per_tree() ? ((ii + ka->lay.misc)[4] + GRP_MAX - 1) / GRP_MAX : -1;
+        return nl;
     }
 
     // MuJoCo's mj_checkPos / mj_checkVel [EXT]: a state with NaN / Inf / huge entries is unusable; MuJoCo warns and resets
@@ -2148,7 +2289,7 @@ __global__ void __launch_bounds__(64 * WPB) AVSIM_PHYS_ATTR k_phys(KPtr<real> ka
     for (int i = lane; i < ka->m.nq; i += G) r[ka->lay.qpos + i] = g_qpos[(size_t)env * ka->m.nq + i];
     for (int i = lane; i < ka->m.nv; i += G) { r[ka->lay.qvel + i] = g_qvel[(size_t)env * ka->m.nv + i]; r[ka->lay.warm + i] = g_warm[(size_t)env * ka->m.nv + i]; }
     for (int i = lane; i < ka->m.nu; i += G) r[ka->lay.ctrl + i] = g_ctrl[(size_t)env * ka->m.nu + i];
-    if (lane == 0) for (int k = 0; k < 8; k++) { ii[ka->lay.misc + k] = 0; ii[ka->lay.nprof + k] = 0; }
+    if (lane == 0) for (int k = 0; k < 8; k++) { ii[ka->lay.misc + k] = 0; ii[ka->lay.nprof + k] = 0; ii[ka->lay.nprof + 8 + k] = 0; }
     E.profiling = o_prof != nullptr;
     GSYNC();
     if (action) {
@@ -2184,9 +2325,9 @@ __global__ void __launch_bounds__(64 * WPB) AVSIM_PHYS_ATTR k_phys(KPtr<real> ka
         }
     }
     if (o_prof && lane == 0) {
-        for (int k = 0; k < 8; k++) o_prof[(size_t)env * 18 + k] = tp[k];
-        o_prof[(size_t)env * 18 + 8] = E.t_broad; o_prof[(size_t)env * 18 + 9] = E.t_narrow;
-        for (int k = 0; k < 8; k++) o_prof[(size_t)env * 18 + 10 + k] = ii[ka->lay.nprof + k];   // Newton: init, grad, hess, chol, search, final, noslip
+        for (int k = 0; k < 8; k++) o_prof[(size_t)env * PROF_W + k] = tp[k];
+        o_prof[(size_t)env * PROF_W + 8] = E.t_broad; o_prof[(size_t)env * PROF_W + 9] = E.t_narrow;
+        for (int k = 0; k < 16; k++) o_prof[(size_t)env * PROF_W + 10 + k] = ii[ka->lay.nprof + k];   // Newton: init, grad, hess, chol, search, final, noslip
     }
     // trailing refresh of the position-dependent quantities of the final state
     int nefc_last = ii[ka->lay.misc + 1];
@@ -2491,7 +2632,7 @@ struct PhysHost {
         L.nreal = (o + 3) & ~3;
         int io = 0;
         auto Iq = [&](int n) { int x = io; io += n; return x; };
-        L.cand = Iq(ANC_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.misc = Iq(8); L.nprof = Iq(8);
+        L.cand = Iq(ANC_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.misc = Iq(8); L.nprof = Iq(16);
         L.nint = (io + 3) & ~3;
         L.maxcon = maxcon;
         L.maxefc = maxefc;
@@ -2581,7 +2722,7 @@ struct PhysHost {
         if (n == "num_joints") { if (v != 14 && v != 21) return false; mf.nj = md.nj = (int)v; return true; }
         if (n == "waves_per_block") { int x = (int)v; if (x >= 0 && x <= 8) { wpb_override = x; return true; } return false; }
         if (n == "profile_phases") {
-            if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * 18, 0));
+            if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * PROF_W, 0));
             if (v == 0) d_prof = nullptr;
             return true;
         }

@@ -111,8 +111,9 @@ int avsim_get_diag(avsim_t* h, int32_t* diag);
 
 /* debug: shader-clock cycles each env's wave spent in the 8 phases (kinematics, CRB, RNE, smooth, collide, rows,
  * solve, integrate, + broad / narrow phase incl. the trailing refresh) during the last launch; needs
- * avsim_set_option("profile_phases", 1); int64[N][18]: 8 phases, broad, narrow, then the Newton solver's
- * init / gradient / Hessian / factorisation / line search / final forces / noslip cycles, one spare */
+ * avsim_set_option("profile_phases", 1); int64[N][26]: 8 phases, broad, narrow, then the Newton solver's
+ * init / gradient / Hessian / factorisation / line search / final forces / noslip / back-substitution cycles and 8 probe slots
+ * (noslip: group steps, dry-friction passes, their cycles, look-ahead set-up, entry set-up, whole call; two free) */
 int avsim_get_phase_cycles(avsim_t* h, int64_t* out);
 
 /* Replaces the camera part of get_obs / render (gym_guided_vision/gym_guided_vision/env.py:180-188, :195-200; MuJoCo OpenGL

@@ -25,7 +25,7 @@ else:       # the random-walk workload of bench.py --config 4 (av_aloha_amd/work
     acts = W.walk_actions(md["qpos_home"], md["act_ctrlrange"], np.arange(N), 30, nj, seed)
     for t in range(30):
         sim.step(acts[t])
-out = np.zeros((N, 18), dtype=np.int64)
+out = np.zeros((N, 26), dtype=np.int64)
 sim.h.check(sim.h.L.avsim_get_phase_cycles(sim.h.h, out.ctypes.data))
 names = ["kinematics", "crb", "rne", "smooth", "collide", "rows", "solve", "euler"]
 print("broad/narrow per collide call:", out[:, 8].mean() / 21, out[:, 9].mean() / 21)
@@ -40,5 +40,6 @@ print("inside solve (Newton):", "  ".join(f"{n} {v:.0f}" for n, v in zip(nn, mn)
 tot = out[:, :8].sum(1) / 20
 print("per-env total cycles/substep percentiles 50/90/99/max:", np.percentile(tot, [50, 90, 99, 100]).round(0), " noslip 50/90/99/max:", np.percentile(out[:, 16] / 20, [50, 90, 99, 100]).round(0),
       " narrow 50/90/99/max:", np.percentile(out[:, 9] / 21, [50, 90, 99, 100]).round(0))
+print("probe slots per substep:", (out[:, 18:26].mean(0) / 20).round(1))
 d = sim.diag()
 print("ncon percentiles", np.percentile(d[:, 0], [50, 90, 99, 100]), "newton max iters", np.percentile((d[:, 3] >> 28) & 0xf, [50, 90, 99, 100]))
