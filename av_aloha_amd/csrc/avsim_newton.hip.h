@@ -93,6 +93,15 @@ AVS_DEV real nrow_dot(const NewtonArgs<real>& A, int i, LDS_PTR(const real) v) {
     return s;
 }
 
+// the same for a leading row (see lead_d1 below): two products, no global memory
+template <typename real>
+AVS_DEV real nrow_dot_lead(const NewtonArgs<real>& A, int i, LDS_PTR(const real) v) {
+    const int ra = A.rowI[i];
+    const int d1 = (ra & 63) + ((ra >> 26) & 7), d2 = (ra & 63) + ((ra >> 29) & 7);
+    const real v1 = ((ra >> 13) & 1) ? real(-1) : real(1), v2 = A.rowS[RS_S * i + 7];
+    return v1 * v[d1] + v2 * v[d2];
+}
+
 // scalar rows: force and curvature at constraint-space residual z
 template <typename real>
 AVS_DEV void nrow_scalar(int type, real z, real R, real eta, real* f, real* h) {
@@ -204,6 +213,47 @@ AVS_DEV int nslot_dof(int ra, int s) {
     return k < ((ra >> (sh + 6)) & 15) ? ((ra >> sh) & 63) + k : -1;
 }
 
+// A leading (non-contact) row has at most two non-zero entries, both in its first dof window: the row word carries their slots
+// (bits 26-28, 29-31; equal when there is one entry) and the sign of the first (bit 13; the value is +-1), word 7 of the row record
+// the second value (0: none).  Nothing that walks these rows needs the 16-word record in global memory.
+AVS_DEV int lead_d1(int ra) { return (ra & 63) + ((ra >> 26) & 7); }
+AVS_DEV int lead_d2(int ra) { return (ra & 63) + ((ra >> 29) & 7); }
+template <typename real> AVS_DEV real lead_v1(int ra) { return ((ra >> 13) & 1) ? real(-1) : real(1); }
+
+// out[dof] += sgn * sum_rows J[row][dof] f[row] (f = word 6 of the row records).  Leading rows: one row per lane, one or two LDS
+// atomics.  Contacts: four at a time, 16-lane group q takes a contact and lane t of the group column t of its 16-slot dof window,
+// sums the contact's <= 6 rows in registers (coalesced 64-byte row reads) and adds once: an atomic instruction then carries 16
+// distinct addresses per contact instead of one address per tree from every row (the rows of a tree all share their slots).
+template <typename real>
+AVS_DEV void rows_jt_force(LDS_PTR(const real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const int) cefc, GLB_PTR(const real) rJ, LDS_PTR(real) out,
+                           int nlead, int ncon, int lane, real sgn) {
+    for (int i = lane; i < nlead; i += 64) {
+        const real f = rowS[RS_S * i + 6];
+        if (f == 0) continue;
+        const int ra = rowI[i];
+        const real v2 = rowS[RS_S * i + 7];
+        __hip_atomic_fetch_add(out + lead_d1(ra), sgn * lead_v1<real>(ra) * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v2 != 0) __hip_atomic_fetch_add(out + lead_d2(ra), sgn * v2 * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    const int t = lane & 15;
+    for (int c0 = 0; c0 < ncon; c0 += 4) {
+        const int c = c0 + (lane >> 4);
+        const int ce = c < ncon ? cefc[c] : -1;
+        const bool on = ce >= 0;
+        const int head = on ? (ce & 0xffff) : 0, dim = on ? (ce >> 16) : 0;
+        const int ra = rowI[head];
+        real acc = 0;
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+            const int row = head + (p < dim ? p : 0);          // (a row of this contact in any case: always inside the env's rows)
+            const real Jp = rJ[ROW_S * row + t], fp = rowS[RS_S * row + 6];
+            acc += p < dim ? Jp * fp : real(0);
+        }
+        const int dof = on ? nslot_dof(ra, t) : -1;
+        if (dof >= 0 && acc != 0) __hip_atomic_fetch_add(out + dof, sgn * acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
 // H += J_b^T C_b J_b for the block of rows r0 .. r0+dim-1 of a contact: C_b = diag(w) + s1 c1 c1^T - s2 c2 c2^T in the cone's
 // middle zone (`full`), diag(w) otherwise.  Lane t of a 16-lane group owns column t of the block's 16 x 16 dof window (two
 // tree windows of 8) and walks the rows s; lower-triangle entries only, added to the packed H by LDS atomics.
@@ -274,19 +324,14 @@ AVS_DEV void nlead_rows(const NewtonArgs<real>& A, int lane) {
     for (int i = lane; i < A.nlead; i += 64) {
         const real w = A.jv[i];
         if (w == 0) continue;
-        const int ra = A.rowI[i], a0 = ra & 63, nA = (ra >> 6) & 15;
-        GLB_PTR(const real) J = A.rJ + ROW_S * i;
-        real Jr[TREE_W];
-#pragma unroll
-        for (int k = 0; k < TREE_W; k++) Jr[k] = J[k];
-#pragma unroll
-        for (int k = 0; k < TREE_W; k++) {
-            if (!(k < nA) || Jr[k] == 0) continue;
-#pragma unroll
-            for (int m = 0; m <= k; m++) {
-                if (Jr[m] == 0) continue;
-                __hip_atomic_fetch_add(A.H + (a0 + k) * (a0 + k + 1) / 2 + a0 + m, w * Jr[k] * Jr[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+        const int ra = A.rowI[i], d1 = lead_d1(ra), d2 = lead_d2(ra);
+        const real v1 = lead_v1<real>(ra), v2 = A.rowS[RS_S * i + 7];
+        __hip_atomic_fetch_add(A.H + d1 * (d1 + 1) / 2 + d1, w * v1 * v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v2 != 0) {
+            const int hi = d1 > d2 ? d1 : d2, lo = d1 > d2 ? d2 : d1;
+            const real vh = d1 > d2 ? v1 : v2, vl = d1 > d2 ? v2 : v1;
+            __hip_atomic_fetch_add(A.H + d2 * (d2 + 1) / 2 + d2, w * v2 * v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(A.H + hi * (hi + 1) / 2 + lo, w * vh * vl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
@@ -567,18 +612,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
             A.g[k] = s;
         }
         NSYNC();
-        for (int i = lane; i < ne; i += 64) {
-            const real f = A.rowS[RS_S * i + 6];
-            if (f == 0) continue;
-            const int ra = A.rowI[i];
-            real J[ROW_W];
-            load_row16(A.rJ + ROW_S * i, J);
-#pragma unroll
-            for (int s = 0; s < ROW_W; s++) {
-                const int dof = nslot_dof(ra, s);
-                if (dof >= 0) __hip_atomic_fetch_add(A.g + dof, -J[s] * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
+        rows_jt_force<real>((LDS_PTR(const real))A.rowS, A.rowI, A.cefc, A.rJ, A.g, A.nlead, A.ncon, lane, real(-1));
         NSYNC();
         real gn2 = 0;
         for (int k = lane; k < nv; k += 64) { const real s = A.g[k]; gn2 += s * s; }
@@ -680,7 +714,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         }
         q1 = wave_sum(q1);
         q2 = wave_sum(q2);
-        for (int i = lane; i < ne; i += 64) A.jv[i] = nrow_dot(A, i, (LDS_PTR(const real))A.dl);
+        for (int i = lane; i < ne; i += 64) A.jv[i] = i < A.nlead ? nrow_dot_lead(A, i, (LDS_PTR(const real))A.dl) : nrow_dot(A, i, (LDS_PTR(const real))A.dl);
         NSYNC();
         real cj0[NCH][6], cjv[NCH][6];
 #pragma unroll
@@ -741,7 +775,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
     }
     // ---- forces at the solution (already there when the loop ended on the gradient test) ----
     if (!forces_current) {
-        for (int i = lane; i < ne; i += 64) A.rowS[RS_S * i + 2] = nrow_dot(A, i, (LDS_PTR(const real))A.a) - A.rowS[RS_S * i];
+        for (int i = lane; i < ne; i += 64) A.rowS[RS_S * i + 2] = (i < A.nlead ? nrow_dot_lead(A, i, (LDS_PTR(const real))A.a) : nrow_dot(A, i, (LDS_PTR(const real))A.a)) - A.rowS[RS_S * i];
         NSYNC();
         for (int i = lane; i < A.nlead; i += 64) {
             real f, h;

@@ -510,6 +510,9 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
 #pragma unroll
     for (int s = 0; s < GA_QW; s++) qc[s] = gA[GA_W * g + GA_Q + 8 * s + qr];
     const int total = iters * ngrp + noslip_iters * per_ns;
+    // the first group's look-ahead loads land here: with one of them still pending at the loop entry, the compiler's wait for it
+    // inside the loop body (in-order counter, sized for the first pass) would also drain the loads every later step has just issued
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
     if (prof && lane == 0) prof[3] += (int)(__builtin_readcyclecounter() - tq0);
     if (fl && iters == 0 && noslip_iters > 0) floss_sweep();
     for (int step = 0; step < total; step++) {
@@ -1601,6 +1604,7 @@ struct Env {
             const int ga = ka->m.pair_geom[2 * p], gb = ka->m.pair_geom[2 * p + 1];
             const int tya = geom_type_()[ga], tyb = geom_type_()[gb];
             const bool isbox = valid && tya == G_BOX && tyb == G_BOX;
+            const long long tn0_ = profiling ? __builtin_readcyclecounter() : 0;
             {
                 // box-box pairs, four at a time: every 16-lane row of the wave works on one pair (box_box16), the results land in
                 // the result slot of the lane that owns the pair
@@ -1627,11 +1631,16 @@ struct Env {
                     if (isbox && rk >= b0 && rk < b0 + 4) nn = got;
                 }
             }
+            const long long tn1 = profiling ? __builtin_readcyclecounter() : 0;
             if (valid && !isbox) {
                 Shape<real> a, b;
                 load_shape(ga, a);
                 load_shape(gb, b);
                 nn = narrow(a, b, scr);
+            }
+            if (profiling) {
+                const long long tn2 = __builtin_readcyclecounter();
+                if (lane == 0) { (ii + ka->lay.nprof)[14] += (int)(tn1 - tn0_); (ii + ka->lay.nprof)[15] += (int)(tn2 - tn1); }
             }
             {
                 // multiccd [EXT: mjc_Convex]: the convex (MPR) pairs found in contact, spheres excluded.  Lane 4 q + k runs perturbation
@@ -1961,7 +1970,11 @@ struct Env {
             // word 2: PGS 1 / (A_rr + R); Newton: residual of the warm start, with that of qacc_smooth in word 8
             S[0] = aref; S[1] = R; S[2] = newton ? jw - aref : real(1) / (dg + R); S[3] = ns ? real(1) / tmax(dg, real(1e-15)) : real(0);
             S[4] = lo; S[5] = hi; S[6] = f; S[7] = muinv; S[8] = jas - aref;
-            rowI[i] = a0 | (nA << 6) | (tA << 10) | ((b0 | (nB << 6) | ((tB >= 0 ? tB : 0) << 10)) << 13);
+            // leading rows: slots of the (at most two) entries and the sign of the first in the row word, the second value in word 7
+            // (lead_d1 / lead_d2 / lead_v1 of avsim_newton.hip.h)
+            const int lead_bits = type == R_CONTACT ? 0 : ((v1 < 0 ? 1 : 0) << 13) | (j1 << 26) | ((j2 >= 0 ? j2 : j1) << 29);
+            if (type != R_CONTACT) S[7] = j2 >= 0 ? v2 : real(0);
+            rowI[i] = a0 | (nA << 6) | (tA << 10) | ((b0 | (nB << 6) | ((tB >= 0 ? tB : 0) << 10)) << 13) | lead_bits;
             rmeta[i] = (meta & 0xfffff) | ((tA + 1) << 20) | ((tB + 1) << 24);
         }
         GSYNC();
@@ -2186,23 +2199,12 @@ struct Env {
     __device__ __attribute__((always_inline)) void jt_force(real* out, int nefc) {
         LDS_BASES();
         AVS_ASSUME_LDS(out);
-        int* rowI = ii + ka->lay.rowI;
-        real* rowS = r + ka->lay.rowS;
-        GLB_PTR(real) rJ = rows_();
+        (void)nefc;
+        int* misc = ii + ka->lay.misc;
         for (int k = lane; k < ka->m.nv; k += G) out[k] = 0;
         GSYNC();
-        for (int i = lane; i < nefc; i += G) {
-            const real f = rowS[RS_S * i + 6];
-            if (f == 0) continue;
-            const int ra = rowI[i];
-            real Jr[ROW_W];
-            load_row16((GLB_PTR(const real))rJ + ROW_S * i, Jr);
-#pragma unroll
-            for (int s = 0; s < ROW_W; s++) {
-                const int dof = nslot_dof(ra, s);
-                if (dof >= 0) __hip_atomic_fetch_add(out + dof, Jr[s] * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
+        rows_jt_force<real>((LDS_PTR(const real))(r + ka->lay.rowS), (LDS_PTR(const int))(ii + ka->lay.rowI), (LDS_PTR(const int))(ii + ka->lay.cefc),
+                            (GLB_PTR(const real))rows_(), (LDS_PTR(real))out, misc[4], misc[0], lane, real(1));
         GSYNC();
     }
 
