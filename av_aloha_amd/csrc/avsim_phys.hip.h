@@ -376,6 +376,8 @@ template <> struct QTol<float> { static constexpr float abs = 1e-10f, rel = 2e-6
 // rowI[i] = two 13-bit dof windows of row i: first dof (6) | count (4) | kinematic tree (3).
 // B = J M^-1 is read from the global row scratch next to J (written by the row's lane in make_constraints).
 // ------------------------------------------------------------------------------------------------
+template <bool B> struct BoolTag { static constexpr bool value = B; };
+
 // The dry-friction rows of a noslip sweep, all kinematic trees at once (see pgs_groups)
 template <typename real>
 struct NoslipLead {
@@ -1754,6 +1756,7 @@ struct Env {
         int ovf = 0;
         if (nefc > ka->lay.maxefc) { nefc = ka->lay.maxefc; ovf = 1; }
         if (lane == 0) misc[4] = nefc;   // rows before the contacts
+        const int nlead0 = nefc;
         int cend = nefc;   // end of the last contact block that fits under the row cap (row offsets are monotonic)
         for (int base = 0; base < ncon; base += G) {
             int c = base + lane, dim = 0;
@@ -1798,7 +1801,11 @@ struct Env {
         const int *bmask = body_dofmask_(), *tadr = tree_dofadr_(), *tnum = tree_dofnum_();
         const real* cdofp = r + ka->lay.cdof;
         const int nvm = ka->m.nv - 1;
-        for (int i = lane; i < nefc; i += G) {
+        // Two passes of one body: the leading rows (equality, dry friction, limits: at most two entries, everything they need comes
+        // from a handful of LDS words) and the contact rows (dense over the two dof windows).  One loop over all rows would run the
+        // dense code for every 64 rows, leading or not.
+        auto fill = [&](int i, auto lead_tag) {
+            constexpr bool LEAD = decltype(lead_tag)::value;
             int meta = rmeta[i], type = meta & 3, id = (meta >> 2) & 1023, sub = (meta >> 12) & 255, dim = meta >> 20;
             real J[ROW_W];   // kept in registers: every index below is a compile-time constant after unrolling
 #pragma unroll
@@ -1809,7 +1816,7 @@ struct Env {
             real pos = 0, margin = 0, diag0 = 0, floss = 0;
             real solref[2], solimp[5];
             bool valid = true;
-            if (type == R_EQ) {
+            if (LEAD && type == R_EQ) {
                 GLB_PTR(const real) c = ka->m.eq_polycoef + 5 * id;
                 real q1 = qpos[ka->m.eq_qpos1[id]] - ka->m.qpos0[ka->m.eq_qpos1[id]], q2 = qpos[ka->m.eq_qpos2[id]] - ka->m.qpos0[ka->m.eq_qpos2[id]];
                 real poly = c[0] + q2 * (c[1] + q2 * (c[2] + q2 * (c[3] + q2 * c[4])));
@@ -1822,7 +1829,7 @@ struct Env {
                 j2 = d2 - tree_dofadr_()[tA]; v2 = -dpoly;   // both joints of a gripper live in the same tree
                 for (int k = 0; k < 2; k++) solref[k] = ka->m.eq_solref[2 * id + k];
                 for (int k = 0; k < 5; k++) solimp[k] = ka->m.eq_solimp[5 * id + k];
-            } else if (type == R_FLOSS) {
+            } else if (LEAD && type == R_FLOSS) {
                 int d = floss_dof_()[id];
                 tA = dof_tree_()[d];
                 diag0 = dof_invweight0_()[d];
@@ -1830,7 +1837,7 @@ struct Env {
                 j1 = d - tree_dofadr_()[tA]; v1 = 1;
                 for (int k = 0; k < 2; k++) solref[k] = ka->m.dof_solref[2 * d + k];
                 for (int k = 0; k < 5; k++) solimp[k] = ka->m.dof_solimp[5 * d + k];
-            } else if (type == R_LIMIT) {
+            } else if (LEAD && type == R_LIMIT) {
                 int j = id, d = jnt_dofadr_()[j];
                 real q = qpos[jnt_qposadr_()[j]];
                 tA = dof_tree_()[d];
@@ -1840,7 +1847,7 @@ struct Env {
                 j1 = d - tree_dofadr_()[tA]; v1 = sub == 0 ? real(1) : real(-1);
                 for (int k = 0; k < 2; k++) solref[k] = ka->m.jnt_solref[2 * j + k];
                 for (int k = 0; k < 5; k++) solimp[k] = ka->m.jnt_solimp[5 * j + k];
-            } else {
+            } else if (!LEAD) {
                 int c = id, p = cpair[c];
                 int g1 = ka->m.pair_geom[2 * p], g2 = ka->m.pair_geom[2 * p + 1], b1 = geom_body_()[g1], b2 = geom_body_()[g2];
                 int t1 = body_tree_()[b1], t2 = body_tree_()[b2];
@@ -1853,29 +1860,28 @@ struct Env {
 #pragma unroll
                 for (int q = 0; q < 3; q++) ax[q] = sm == 0 ? n[q] : (sm == 1 ? t1v[q] : t2v[q]);
                 const bool rot = sub >= 3;
-                // entry of dof slot k: the axis' component of the dof's motion at the contact point, signed by which of the
-                // two bodies the dof moves (branch-free: every slot reads its cdof, the body masks select)
+                // entry of dof slot k: the axis' component of the dof's motion at the contact point, signed by which of the two bodies
+                // the dof moves.  ax . (lin + ang x cp) = ax . lin + (cp x ax) . ang, so the row is one 6-vector W = (cp x ax, ax) --
+                // (ax, 0) for a rotational row -- against every slot's cdof: six FMAs per slot, no branch, the body masks as factors
+                real cx[3], Wa[3], Wl[3];
+                cross3(cp, ax, cx);
+#pragma unroll
+                for (int q = 0; q < 3; q++) { Wa[q] = rot ? ax[q] : cx[q]; Wl[q] = rot ? real(0) : ax[q]; }
                 const int mA = (t1 == tA ? bmask[b1] : 0), pA = (t2 == tA ? bmask[b2] : 0);
                 const int mB = (tB >= 0 && t1 == tB ? bmask[b1] : 0), pB = (tB >= 0 ? bmask[b2] : 0);
                 const int aA = tadr[tA], aB = tadr[tB >= 0 ? tB : tA];
 #pragma unroll
                 for (int k = 0; k < TREE_W; k++) {
                     const real* ca = cdofp + 6 * (aA + k < nvm ? aA + k : nvm);
-                    real xa[3];
-                    cross3(ca, cp, xa);
-                    const real ea = rot ? ax[0] * ca[0] + ax[1] * ca[1] + ax[2] * ca[2] : ax[0] * (ca[3] + xa[0]) + ax[1] * (ca[4] + xa[1]) + ax[2] * (ca[5] + xa[2]);
-                    const int sa = ((pA >> k) & 1) - ((mA >> k) & 1);
-                    J[k] = sa > 0 ? ea : (sa < 0 ? -ea : real(0));
+                    const real ea = Wa[0] * ca[0] + Wa[1] * ca[1] + Wa[2] * ca[2] + Wl[0] * ca[3] + Wl[1] * ca[4] + Wl[2] * ca[5];
+                    J[k] = real(((pA >> k) & 1) - ((mA >> k) & 1)) * ea;
                 }
                 if (tB >= 0) {       // second window: contacts between two kinematic trees only
 #pragma unroll
                     for (int k = 0; k < TREE_W; k++) {
                         const real* cb = cdofp + 6 * (aB + k < nvm ? aB + k : nvm);
-                        real xb[3];
-                        cross3(cb, cp, xb);
-                        const real eb = rot ? ax[0] * cb[0] + ax[1] * cb[1] + ax[2] * cb[2] : ax[0] * (cb[3] + xb[0]) + ax[1] * (cb[4] + xb[1]) + ax[2] * (cb[5] + xb[2]);
-                        const int sb = ((pB >> k) & 1) - ((mB >> k) & 1);
-                        J[TREE_W + k] = sb > 0 ? eb : (sb < 0 ? -eb : real(0));
+                        const real eb = Wa[0] * cb[0] + Wa[1] * cb[1] + Wa[2] * cb[2] + Wl[0] * cb[3] + Wl[1] * cb[4] + Wl[2] * cb[5];
+                        J[TREE_W + k] = real(((pB >> k) & 1) - ((mB >> k) & 1)) * eb;
                     }
                 }
                 pos = sub == 0 ? cdist[c] : real(0);
@@ -1885,14 +1891,18 @@ struct Env {
                 for (int k = 0; k < 5; k++) solimp[k] = ka->m.pair_solimp[5 * p + k];
             }
             (void)valid;
+            const int j2c = j2 >= 0 ? j2 : (j1 >= 0 ? j1 : 0), j1c = j1 >= 0 ? j1 : 0;      // leading rows: the two entries (the second
+            const real v2c = j2 >= 0 ? v2 : real(0);                                       // one repeated with value 0 when absent)
+            if (LEAD) {
 #pragma unroll
-            for (int k = 0; k < TREE_W; k++) J[k] += (k == j1 ? v1 : real(0)) + (k == j2 ? v2 : real(0));
+                for (int k = 0; k < TREE_W; k++) J[k] += (k == j1 ? v1 : real(0)) + (k == j2 ? v2 : real(0));
+            }
             // K, B, impedance, R [EXT: mj_makeImpedance]
             real dmax = tclamp(solimp[1], real(0.0001), real(0.9999));
             real tc = tmax(solref[0], 2 * ka->m.timestep), dr = solref[1];
             real K = real(1) / tmax(real(1e-15), dmax * dmax * tc * tc * dr * dr), Bd = real(2) / tmax(real(1e-15), dmax * tc);
             real imp, R;
-            if (type == R_CONTACT && sub > 0) {
+            if (!LEAD && sub > 0) {
                 int c = id, p = cpair[c];
                 real imp0 = impedance(solimp, cdist[c], margin);
                 real R0 = tmax(real(1e-15), (1 - imp0) * diag0 / imp0);
@@ -1908,7 +1918,10 @@ struct Env {
             }
             // velocity along the row, reference acceleration
             real vel = 0;
-            {
+            if (LEAD) {
+                const int a0 = tadr[tA];
+                vel = v1 * qvel[a0 + j1c] + v2c * qvel[a0 + j2c];
+            } else {
                 // J is zero beyond a tree's dofs: clamped reads instead of per-slot branches
                 const int a0 = tadr[tA], b0 = tadr[tB >= 0 ? tB : tA];
 #pragma unroll
@@ -1921,6 +1934,17 @@ struct Env {
             // B = J M^-1 per tree (dense 8x8 inverse), diag = J B^T
             real dg = 0;
             real Bv[ROW_W];
+            if (LEAD) {
+                // J M^-1 = v1 (row j1 of the tree's inverse) + v2 (row j2): the diagonal needs four of its entries, the whole row is
+                // made only where something reads it (PGS sweeps)
+                const real* Mi = Minv + 64 * tA;
+                const real s1 = Mi[8 * j1c + j1c] * v1 + Mi[8 * j1c + j2c] * v2c, s2 = Mi[8 * j2c + j1c] * v1 + Mi[8 * j2c + j2c] * v2c;
+                dg = v1 * s1 + v2c * s2;
+                if (!lead_slim) {
+#pragma unroll
+                    for (int k = 0; k < TREE_W; k++) { Bv[k] = Mi[8 * k + j1c] * v1 + Mi[8 * k + j2c] * v2c; Bv[TREE_W + k] = 0; }
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < TREE_W; k++) {
                 real mr[TREE_W], sa = 0;
@@ -1942,11 +1966,18 @@ struct Env {
                     Bv[TREE_W + k] = sb;
                 }
             }
-            store_row16(rJ + ROW_S * i, J);
-            if (type == R_CONTACT || !lead_slim) store_row16(rowsB_() + ROW_S * i, Bv);
+            }
+            if (!LEAD || !lead_slim) {       // (the Newton solver and the per-tree noslip pass read the leading rows' descriptors)
+                store_row16(rJ + ROW_S * i, J);
+                store_row16(rowsB_() + ROW_S * i, Bv);
+            }
             // warm start: force implied by last step's acceleration, f = -D (J qacc_ws - aref), made feasible per row
             const int a0 = tadr[tA], nA = tnum[tA], b0 = tB >= 0 ? tadr[tB] : 0, nB = tB >= 0 ? tnum[tB] : 0;
             real jw = 0, jas = 0;      // J . warm start, J . qacc_smooth (the Newton solver's two start candidates)
+            if (LEAD) {
+                jw = v1 * warm[a0 + j1c] + v2c * warm[a0 + j2c];
+                jas = v1 * asm_[a0 + j1c] + v2c * asm_[a0 + j2c];
+            } else {
 #pragma unroll
             for (int k = 0; k < TREE_W; k++) {
                 const int da = a0 + k < nvm ? a0 + k : nvm, db = b0 + k < nvm ? b0 + k : nvm;   // (b0 = 0 with J = 0 for one-tree rows)
@@ -1955,12 +1986,13 @@ struct Env {
                 jas += J[k] * asm_[da];
                 jas += J[TREE_W + k] * asm_[db];
             }
+            }
             const real big = real(1e30);
             real lo = -big, hi = big, muinv = 0;
             bool ns = false;   // takes part in the noslip sweeps (dry friction and contact friction rows)
-            if (type == R_FLOSS) { lo = -floss; hi = floss; ns = true; }
-            else if (type == R_LIMIT) lo = 0;
-            else if (type == R_CONTACT) {
+            if (LEAD && type == R_FLOSS) { lo = -floss; hi = floss; ns = true; }
+            else if (LEAD && type == R_LIMIT) lo = 0;
+            else if (!LEAD) {
                 if (sub == 0) lo = 0;
                 else { ns = true; muinv = real(1) / tmax(real(1e-15), floss); }
             }
@@ -1972,11 +2004,13 @@ struct Env {
             S[4] = lo; S[5] = hi; S[6] = f; S[7] = muinv; S[8] = jas - aref;
             // leading rows: slots of the (at most two) entries and the sign of the first in the row word, the second value in word 7
             // (lead_d1 / lead_d2 / lead_v1 of avsim_newton.hip.h)
-            const int lead_bits = type == R_CONTACT ? 0 : ((v1 < 0 ? 1 : 0) << 13) | (j1 << 26) | ((j2 >= 0 ? j2 : j1) << 29);
-            if (type != R_CONTACT) S[7] = j2 >= 0 ? v2 : real(0);
+            const int lead_bits = !LEAD ? 0 : ((v1 < 0 ? 1 : 0) << 13) | (j1c << 26) | (j2c << 29);
+            if (LEAD) S[7] = v2c;
             rowI[i] = a0 | (nA << 6) | (tA << 10) | ((b0 | (nB << 6) | ((tB >= 0 ? tB : 0) << 10)) << 13) | lead_bits;
             rmeta[i] = (meta & 0xfffff) | ((tA + 1) << 20) | ((tB + 1) << 24);
-        }
+        };
+        for (int i = lane; i < nlead0; i += G) fill(i, BoolTag<true>{});
+        for (int i = nlead0 + lane; i < nefc; i += G) fill(i, BoolTag<false>{});
         GSYNC();
         // --- Gauss-Seidel groups: the leading non-contact rows in packs of GRP_MAX, then one group per contact ---
         int* gI = ii + ka->lay.gI;
