@@ -2304,11 +2304,15 @@ __global__ void __launch_bounds__(64 * WPB) AVSIM_PHYS_ATTR k_phys(KPtr<real> ka
                                              int want_reward, real* __restrict__ g_qpos, real* __restrict__ g_qvel, real* __restrict__ g_ctrl,
                                              real* __restrict__ g_warm, int* __restrict__ g_latch, double* __restrict__ o_agent,
                                              int* __restrict__ o_reward, unsigned char* __restrict__ o_success, int* __restrict__ o_ncon,
-                                             int* __restrict__ o_cpairs, double* __restrict__ o_cdist, int* __restrict__ o_diag, int max_reward, int export_contacts, long long* __restrict__ o_prof, float* __restrict__ o_xpose) {
+                                             int* __restrict__ o_cpairs, double* __restrict__ o_cdist, int* __restrict__ o_diag, int max_reward, int export_contacts, long long* __restrict__ o_prof, float* __restrict__ o_xpose,
+                                             const int* __restrict__ env_order, int* __restrict__ o_cost) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(G == 64, "one env per wavefront");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = 0;
-    const int env = blockIdx.x * WPB + wave;
+    // wave -> env: in the order of the previous launch's cost, most expensive first (k_env_order), or the identity
+    const int slot = blockIdx.x * WPB + wave;
+    const int env = (env_order && slot < N) ? env_order[slot] : slot;
+    const long long t_launch = __builtin_readcyclecounter();
     // hot model tables -> LDS, once per block
     real* lr = reinterpret_cast<real*>(smem + (size_t)WPB * ka->lay.bytes_per_env);
     int* li = reinterpret_cast<int*>(lr + ka->mo.nreal);
@@ -2402,12 +2406,37 @@ __global__ void __launch_bounds__(64 * WPB) AVSIM_PHYS_ATTR k_phys(KPtr<real> ka
         o_cpairs[((size_t)env * ka->lay.maxcon + c) * 2 + 1] = p >= 0 ? ka->m.pair_geom[2 * p + 1] : -1;
         o_cdist[(size_t)env * ka->lay.maxcon + c] = c < ncon ? (double)r[ka->lay.cdist + c] : 0.0;
     }
+    if (lane == 0 && o_cost && nsub > 0) o_cost[env] = (int)((__builtin_readcyclecounter() - t_launch) >> 6);    // this env's cost, for the next launch's order
     if (lane == 0 && !o_xpose) {   // the render path's pose-export pass leaves the step diagnostics alone
         o_ncon[env] = ncon;
         bool bad = E.diverged != 0;
         for (int i = 0; i < ka->m.nq; i++) bad |= !(fabs(r[ka->lay.qpos + i]) < real(1e6));
         o_diag[4 * env] = ncon; o_diag[4 * env + 1] = nefc_last; o_diag[4 * env + 2] = ii[ka->lay.misc + 2]; o_diag[4 * env + 3] = (bad ? 1 : 0) | ((ii[ka->lay.misc + 3] & 0xff) << 8) | ((E.nit_sum & 0xfff) << 16) | ((E.nit_max < 15 ? E.nit_max : 15) << 28);
     }
+}
+
+// Launch order of the envs: by the cost (shader-clock cycles) of their last step, most expensive first.  A block holds its LDS
+// until its slowest env is done and the blocks of a launch are dispatched in index order as CUs free up, so (a) envs of similar
+// cost share a block and (b) the long blocks start first, the short ones fill in behind them (longest-processing-time-first).
+// The state arrays stay indexed by env: only the wave -> env map changes, results do not depend on it (nor on the order inside a
+// bucket, which the atomics leave open).  One block: counting sort into 256 cost buckets between the launch's minimum and maximum.
+static __global__ void __launch_bounds__(1024) k_env_order(const int* __restrict__ cost, int* __restrict__ order, int N) {
+    __shared__ int lo, hi, cnt[256], off[256];
+    if (threadIdx.x == 0) { lo = 0x7fffffff; hi = 0; }
+    if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int mn = 0x7fffffff, mx = 0;
+    for (int i = threadIdx.x; i < N; i += 1024) { const int c = cost[i]; mn = c < mn ? c : mn; mx = c > mx ? c : mx; }
+    atomicMin(&lo, mn);
+    atomicMax(&hi, mx);
+    __syncthreads();
+    const int base = lo;
+    const float scale = 255.0f / (float)(hi - lo + 1);
+    for (int i = threadIdx.x; i < N; i += 1024) atomicAdd(&cnt[255 - (int)((float)(cost[i] - base) * scale)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) { int a = 0; for (int b = 0; b < 256; b++) { off[b] = a; a += cnt[b]; } }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += 1024) order[atomicAdd(&off[255 - (int)((float)(cost[i] - base) * scale)], 1)] = i;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2431,6 +2460,9 @@ struct PhysHost {
     double *d_qpos_home = nullptr, *d_ctrl_home = nullptr;
     int* d_obj_qadr = nullptr;
     int *d_ncon = nullptr, *d_cpairs = nullptr, *d_diag = nullptr;
+    int *d_cost = nullptr, *d_order = nullptr;     // per-env cost of the last step and the launch order made from it (k_env_order)
+    int order_envs = 1;                            // option "order_envs"
+    bool have_cost = false;
     long long* d_prof = nullptr;   // optional per-env phase cycle counters (option "profile_phases")
     float* d_xpose = nullptr;      // when set, the launch also exports body poses float[N][nbody][12] (render path)
     double* d_cdist = nullptr;
@@ -2729,6 +2761,8 @@ struct PhysHost {
             d_obj_qadr = up(b.i("objects_qposadr"));
             d_ncon = up(std::vector<int>((size_t)N, 0));
             d_diag = up(std::vector<int>((size_t)N * 4, 0));
+            d_cost = up(std::vector<int>((size_t)N, 0));
+            d_order = up(std::vector<int>((size_t)N, 0));
             alloc_contacts();
         } catch (const std::exception& e) {
             err = std::string("physics init: ") + e.what();
@@ -2756,6 +2790,7 @@ struct PhysHost {
         if (n == "newton_tol") { if (v < 0) return false; mf.newton_tol = (float)v; md.newton_tol = v; return true; }
         if (n == "export_contacts") { export_contacts = v != 0; return true; }
         if (n == "num_joints") { if (v != 14 && v != 21) return false; mf.nj = md.nj = (int)v; return true; }
+        if (n == "order_envs") { order_envs = v != 0; return true; }
         if (n == "waves_per_block") { int x = (int)v; if (x >= 0 && x <= 8) { wpb_override = x; return true; } return false; }
         if (n == "profile_phases") {
             if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * PROF_W, 0));
@@ -2796,9 +2831,16 @@ struct PhysHost {
             if (hipMemcpy(d_kargs, &ka, sizeof(ka), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy(kernel arguments) failed"; return -3; }
             kargs_dirty = false;
         }
+        // launch order from the previous step's per-env cost
+        const int* order = nullptr;
+        if (order_envs && have_cost && nsub > 0 && N > WPB) {
+            hipLaunchKernelGGL(k_env_order, dim3(1), dim3(1024), 0, st, (const int*)d_cost, d_order, N);
+            order = d_order;
+        }
         hipLaunchKernelGGL(kern, grid, dim3(64 * WPB), shmem, st, (KPtr<real>)d_kargs, (const real*)d_img_real, (const int*)d_img_int, N, nsub, pgs_iters, action, (reward || success) && (nsub > 0 || force_reward) ? 1 : 0,
                            (real*)qpos, (real*)qvel, (real*)ctrl, (real*)warm, latch, agent, (int*)reward, (unsigned char*)success, d_ncon,
-                           d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof, d_xpose);
+                           d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof, d_xpose, order, order_envs ? d_cost : (int*)nullptr);
+        if (nsub > 0) have_cost = true;
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("physics kernel launch: ") + hipGetErrorString(e); return -3; }
         return 0;

@@ -67,6 +67,8 @@ int avsim_dims(const avsim_t* h, int32_t dims[AVSIM_NDIMS]);
  *   "num_joints"        14 | 21: width of the action / agent_pos rows, whatever the blob's arm count (a 3-arm env whose camera
  *                       arm was parked by hide_middle_arm, env.py:394-395, keeps its 21-D action on the 2-arm model)
  *   "waves_per_block"   envs per workgroup, 0 = as many as fit in 160 KiB of LDS (<= 8)
+ *   "order_envs"        1 (default): workgroups take the envs in the order of their cost in the previous step, most expensive
+ *                       first (results do not depend on it); 0 = in index order
  *   "export_contacts"   0 skips the per-step contact export (avsim_get_contacts); "kernel_timing" 1 brackets every physics
  *                       launch with HIP events (avsim_kernel_time); "profile_phases" 1 enables avsim_get_phase_cycles */
 int avsim_set_option(avsim_t* h, const char* name, double value);
