@@ -2298,7 +2298,12 @@ struct Env {
 // WPB wavefronts per block, one env per wavefront; the block shares one LDS copy of the hot model tables
 template <typename real, int G, int WPB>
 #ifndef AVSIM_PHYS_ATTR
+#ifdef AVSIM_TU_F64
 #define AVSIM_PHYS_ATTR
+#else
+// two waves per SIMD for every block size (<= 256 VGPRs): two small blocks per CU then hold as many envs as one large block
+#define AVSIM_PHYS_ATTR __attribute__((amdgpu_waves_per_eu(2)))
+#endif
 #endif
 __global__ void __launch_bounds__(64 * WPB) AVSIM_PHYS_ATTR k_phys(KPtr<real> ka, const real* __restrict__ img_real, const int* __restrict__ img_int, int N, int nsub, int pgs_iters, const float* __restrict__ action,
                                              int want_reward, real* __restrict__ g_qpos, real* __restrict__ g_qvel, real* __restrict__ g_ctrl,
@@ -2855,6 +2860,10 @@ struct PhysHost {
         // as many envs (wavefronts) per block as fit next to one copy of the tables in 160 KiB, at most 4 (one per SIMD)
         size_t tables = (size_t)moff.nreal * 4 + (size_t)moff.nint * 4;
         int wpb = (int)((160 * 1024 - tables) / (size_t)lay.bytes_per_env);
+        if (wpb > 8) wpb = 8;
+        // two blocks of half the size per CU when they fit (each with its own copy of the tables): the same number of envs in flight,
+        // but a block waits for the slowest of fewer envs
+        if (wpb >= 4 && wpb % 2 == 0 && 2 * (tables + (size_t)(wpb / 2) * lay.bytes_per_env) <= 160 * 1024) wpb /= 2;
         if (wpb_override > 0) wpb = wpb_override;
         if (wpb >= 8) return launch_t<float, 64, 8>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
         if (wpb >= 7) return launch_t<float, 64, 7>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
