@@ -259,13 +259,21 @@ AVS_DEV void rows_jt_force(LDS_PTR(const real) rowS, LDS_PTR(const int) rowI, LD
 // tree windows of 8) and walks the rows s; lower-triangle entries only, added to the packed H by LDS atomics.
 // Four contacts at once: 16-lane group q of the wave takes the contact whose arguments its lanes carry (group-uniform
 // values); the groups' row loads are in flight together, one memory round trip per four contacts.
+// column t of the block's rows: issued one pass ahead of nblock4 (rows past the block re-read its first row and are masked at the use)
 template <typename real>
-AVS_DEV void nblock4(const NewtonArgs<real>& A, int lane, int r0, int dim, bool on, bool full, const real* w, int c, const real* cc1, const real* cc2, real cs1, real cs2) {
-    const int ra = A.rowI[on ? r0 : 0], t = lane & 15, gq = on ? nslot_dof(ra, t) : -1;
+AVS_DEV void nblock4_load(const NewtonArgs<real>& A, int lane, int r0, int dim, bool on, real* Jraw) {
+    const int t = lane & 15;
     GLB_PTR(const real) J = A.rJ + ROW_S * (on ? r0 : 0);
+#pragma unroll
+    for (int p = 0; p < 6; p++) Jraw[p] = J[ROW_S * (p < dim ? p : 0) + t];
+}
+template <typename real>
+AVS_DEV void nblock4(const NewtonArgs<real>& A, int lane, int r0, int dim, bool on, bool full, const real* w, int c, const real* cc1, const real* cc2, real cs1, real cs2,
+                     const real* Jraw) {
+    const int ra = A.rowI[on ? r0 : 0], t = lane & 15, gq = on ? nslot_dof(ra, t) : -1;
     real Jt[6];
 #pragma unroll
-    for (int p = 0; p < 6; p++) Jt[p] = (on && p < dim) ? J[ROW_S * p + t] : real(0);
+    for (int p = 0; p < 6; p++) Jt[p] = (on && p < dim) ? Jraw[p] : real(0);
     const bool two = __any(on && ((ra >> 19) & 15) > 0);               // does some contact of this pass have a second window?
     const int smax = two ? 16 : 8;
     if (!__any(full)) {
@@ -273,16 +281,24 @@ AVS_DEV void nblock4(const NewtonArgs<real>& A, int lane, int r0, int dim, bool 
         if (!two) {
             // one-tree contacts: the block is 8 x 8, so the two halves of the 16-lane group share the rows (lane t and lane
             // t + 8 both hold column t & 7; the upper half takes rows 4..7)
+            // The entries of the other columns come straight from the rows in memory (the look-ahead read has just brought the
+            // lines in): 30 four-byte reads in flight together instead of 30 ds_bpermute round trips of 50 - 75 cycles each.
             const int tc = lane & 7, s0 = (lane & 8) >> 1, gqc = on ? nslot_dof(ra, tc) : -1;
-            real Jc[6];
+            GLB_PTR(const real) J = A.rJ + ROW_S * (on ? r0 : 0);
+            real Jc[6], Js[4][6];
 #pragma unroll
-            for (int p = 0; p < 6; p++) Jc[p] = __shfl(Jt[p], (lane & 48) | tc, 64);
+            for (int p = 0; p < 6; p++) {
+                GLB_PTR(const real) Jp = J + ROW_S * (p < dim ? p : 0);
+                Jc[p] = Jp[tc];
+#pragma unroll
+                for (int u = 0; u < 4; u++) Js[u][p] = Jp[s0 + u];
+            }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int s = s0 + u, gp = nslot_dof(ra, s);
                 real acc = 0;
 #pragma unroll
-                for (int p = 0; p < 6; p++) acc += w[p] * __shfl(Jt[p], (lane & 48) | s, 64) * Jc[p];
+                for (int p = 0; p < 6; p++) acc += (on && p < dim) ? w[p] * Js[u][p] * Jc[p] : real(0);
                 if (on && gp >= 0 && gqc >= 0 && gqc <= gp) __hip_atomic_fetch_add(A.H + gp * (gp + 1) / 2 + gqc, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             return;
@@ -632,8 +648,11 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         }
         if (!(same && !middle)) {
             // ---- Hessian: packed lower triangle ----
-            for (int e = lane; e < nv * (nv + 1) / 2; e += 64) A.H[e] = 0;
-            NSYNC();
+            // (block-diagonal case: only entries inside the tree blocks are read, and the M blocks below overwrite all of them)
+            if (coupled) {
+                for (int e = lane; e < nv * (nv + 1) / 2; e += 64) A.H[e] = 0;
+                NSYNC();
+            }
             for (int e = lane; e < nv * TREE_W; e += 64) {           // M blocks
                 const int k = e >> 3, j8 = e & 7, t = A.dof_tree[k], a0 = A.tree_dofadr[t], n = A.tree_dofnum[t], kk = k - a0;
                 if (j8 < n && j8 <= kk) A.H[k * (k + 1) / 2 + a0 + j8] = A.M[A.tree_madr[t] + kk * n + j8];
@@ -644,16 +663,28 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
             for (int ch = 0; ch < NCH; ch++) {
                 if (ch * 64 >= A.ncon) break;
                 const int nc = A.ncon - ch * 64 < 64 ? A.ncon - ch * 64 : 64;
+                // one pass = four contacts (one per 16-lane group); the next pass's rows are requested before this pass is worked on
+                int c = lane >> 4;                                 // this 16-lane group's contact
+                int zn = c < nc ? __shfl(zone[ch], c & 63, 64) : 0; // (every lane takes part in the shuffles: any lane can be a source)
+                int head = __shfl(con[ch].head, c & 63, 64), dim = __shfl(con[ch].dim, c & 63, 64);
+                real Jraw[6];
+                nblock4_load<real>(A, lane, head, dim, zn != 0, Jraw);
                 for (int c0 = 0; c0 < nc; c0 += 4) {
-                    const int c = c0 + (lane >> 4);                // this 16-lane group's contact
-                    const int zs = __shfl(zone[ch], c & 63, 64);  // every lane takes part: a lane outside the condition could be a source
-                    const int zn = c < nc ? zs : 0;
-                    if (!__any(zn != 0)) continue;
-                    const int head = __shfl(con[ch].head, c & 63, 64), dim = __shfl(con[ch].dim, c & 63, 64);
-                    real w[6];
+                    const int cn = c0 + 4 + (lane >> 4);
+                    const int zsn = __shfl(zone[ch], cn & 63, 64);
+                    const int znn = (c0 + 4 < nc && cn < nc) ? zsn : 0;
+                    const int headn = __shfl(con[ch].head, cn & 63, 64), dimn = __shfl(con[ch].dim, cn & 63, 64);
+                    real Jnext[6];
+                    nblock4_load<real>(A, lane, headn, dimn, znn != 0, Jnext);
+                    if (__any(zn != 0)) {
+                        real w[6];
     #pragma unroll
-                    for (int p = 0; p < 6; p++) w[p] = __shfl(cw[ch][p], c & 63, 64);
-                    nblock4<real>(A, lane, head, dim, zn != 0, zn == 2, w, c, cc1[ch], cc2[ch], cs1[ch], cs2[ch]);
+                        for (int p = 0; p < 6; p++) w[p] = __shfl(cw[ch][p], c & 63, 64);
+                        nblock4<real>(A, lane, head, dim, zn != 0, zn == 2, w, c, cc1[ch], cc2[ch], cs1[ch], cs2[ch], Jraw);
+                    }
+                    c = cn; zn = znn; head = headn; dim = dimn;
+    #pragma unroll
+                    for (int p = 0; p < 6; p++) Jraw[p] = Jnext[p];
                 }
             }
             NSYNC();
