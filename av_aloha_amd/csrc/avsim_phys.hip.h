@@ -537,7 +537,14 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         const real aref = S[0], R = S[1], inv2 = S[2], inv3 = S[3], lo = S[4], hi = S[5], f0 = S[6], muinv = S[7];
         real a[GRP_MAX - 1], an[GRP_MAX - 1];
 #pragma unroll
-        for (int s = 0; s < GRP_MAX - 1; s++) an[s] = gA[GA_W * g1 + tri + s];      // next group's couplings (global memory)
+        for (int s = 0; s < GRP_MAX - 1; s++) an[s] = 0;
+        // next group's couplings (global memory): the PGS sweeps use them in every step, a noslip step only when its contact slides
+        // (the multiplier iteration below then fetches them itself)
+        const bool next_noslip = (g + 1 >= ngrp ? it + 1 : it) >= iters;
+        if (!next_noslip) {
+#pragma unroll
+            for (int s = 0; s < GRP_MAX - 1; s++) an[s] = gA[GA_W * g1 + tri + s];
+        }
         if (noslip_iters > 0) {
 #pragma unroll
             for (int s = 0; s < GA_QW; s++) qn[s] = gA[GA_W * g1 + GA_Q + 8 * s + qr];
@@ -581,6 +588,9 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
             }
             if (n >= 1 && !done) {
                 const real fn = lane_get(f0, 0);
+                real acs[GRP_MAX - 1];      // this group's couplings, fetched here: the sliding case pays the memory round trip, not every step
+#pragma unroll
+                for (int s = 0; s < GRP_MAX - 1; s++) acs[s] = gA[GA_W * g + tri + s];
                 real Aq[5][5], bq[5], dq[5], oldf[5], resq[5], v[5];
 #pragma unroll
                 for (int j = 0; j < 5; j++) {
@@ -592,7 +602,7 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
                     const real di = lane_get(inv3, j + 1);
                     Aq[j][j] = in ? real(1) / di : real(1);
 #pragma unroll
-                    for (int k = 0; k < j; k++) { const real c = in ? lane_get(ac[k + 1], j + 1) : real(0); Aq[j][k] = c; Aq[k][j] = c; }
+                    for (int k = 0; k < j; k++) { const real c = in ? lane_get(acs[k + 1], j + 1) : real(0); Aq[j][k] = c; Aq[k][j] = c; }
                 }
 #pragma unroll
                 for (int j = 0; j < 5; j++) {
