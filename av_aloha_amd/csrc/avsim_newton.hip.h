@@ -73,6 +73,8 @@ struct NewtonArgs {
     LDS_PTR(int) prof;           // optional cycle counters (8 ints) or null
     int nv, nefc, ncon, nlead, ntree, iters;
     real tol, scale, ls_tol;
+    // this lane's dof (lane < nv <= 64): first dof and size of its tree, offset of its row in the tree's block of M
+    int k_a0, k_n, k_mb;
 };
 
 enum { NR_EQ = 0, NR_FLOSS = 1, NR_LIMIT = 2, NR_CONTACT = 3 };
@@ -365,7 +367,7 @@ AVS_DEV void nlead_rows(const NewtonArgs<real>& A, int lane) {
 // cost of the point v (LDS, dof indexed): rows + contacts + 1/2 (v - a_s)^T M (v - a_s).  The row residuals J v - aref are read
 // from word `slot` of the row records: make_constraints leaves them there for the two start candidates (2: warm start, 8: a_s)
 template <typename real, int NCH>
-AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, LDS_PTR(const real) v, int slot) {
+AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, LDS_PTR(const real) v, int slot, bool inertial = true) {
     real cs = 0;
     for (int i = lane; i < A.nlead; i += 64) cs += nrow_scalar_cost<real>(A.rmeta[i] & 3, A.rowS[RS_S * i + slot], A.rowS[RS_S * i + 1], A.rowS[RS_S * i + 5]);
 #pragma unroll
@@ -380,10 +382,10 @@ AVS_DEV real ncost(const NewtonArgs<real>& A, int lane, const NCon<real>* con, L
             cs += cc;
         }
     }
+    if (inertial)        // (v = a_s: the Gauss term is exactly zero)
     for (int k = lane; k < A.nv; k += 64) {
-        const int t = A.dof_tree[k], a0 = A.tree_dofadr[t], n = A.tree_dofnum[t], kk = k - a0;
+        const int a0 = A.k_a0, n = A.k_n, mb = A.k_mb;
         real sacc = 0;
-        const int mb = A.tree_madr[t] + kk * n;
 #pragma unroll
         for (int j = 0; j < TREE_W; j++) { const int jj = j < n ? j : 0; const real m = A.M[mb + jj], d = v[a0 + jj] - A.as[a0 + jj]; sacc += j < n ? m * d : real(0); }
         cs += real(0.5) * sacc * (v[k] - A.as[k]);
@@ -530,6 +532,10 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         A.tol = tol; A.scale = scale; A.ls_tol = sizeof(real) == 8 ? real(1e-10) : real(1e-4);
     }
     const int nv = A.nv, ne = A.nefc;
+    {   // nv <= 64 (one dof per lane; the register row of the dense factorisation holds 48)
+        const int k = lane < nv ? lane : 0, t = A.dof_tree[k];
+        A.k_a0 = A.tree_dofadr[t]; A.k_n = A.tree_dofnum[t]; A.k_mb = A.tree_madr[t] + (k - A.k_a0) * A.k_n;
+    }
     int used = 0;
     // does any row reach into two kinematic trees?  (second dof window non-empty; wave-uniform)
     bool coupled = false;
@@ -567,7 +573,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
     // (the residuals of both candidates come with the row records; the winner's end up in word 2 for the first iteration)
     const bool jar_ready = true;
     {
-        const real c1 = ncost<real, NCH>(A, lane, con, A.as, 8);
+        const real c1 = ncost<real, NCH>(A, lane, con, A.as, 8, false);
         const real c0 = ncost<real, NCH>(A, lane, con, (LDS_PTR(const real))A.a, 2);
         if (!(c0 < c1)) {
             for (int k = lane; k < nv; k += 64) A.a[k] = A.as[k];
@@ -620,9 +626,8 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         }
         // ---- gradient g = M (a - a_s) - J^T f ----
         for (int k = lane; k < nv; k += 64) {
-            const int t = A.dof_tree[k], a0 = A.tree_dofadr[t], n = A.tree_dofnum[t], kk = k - a0;
+            const int a0 = A.k_a0, n = A.k_n, mb = A.k_mb;
             real s = 0;
-            const int mb = A.tree_madr[t] + kk * n;
 #pragma unroll
             for (int j = 0; j < TREE_W; j++) { const int jj = j < n ? j : 0; const real m = A.M[mb + jj], d = A.a[a0 + jj] - A.as[a0 + jj]; s += j < n ? m * d : real(0); }
             A.g[k] = s;
@@ -735,9 +740,8 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         // ---- exact line search along dl ----
         real q1 = 0, q2 = 0;
         for (int k = lane; k < nv; k += 64) {
-            const int t = A.dof_tree[k], a0 = A.tree_dofadr[t], n = A.tree_dofnum[t], kk = k - a0;
+            const int a0 = A.k_a0, n = A.k_n, mb = A.k_mb;
             real s = 0;
-            const int mb = A.tree_madr[t] + kk * n;
 #pragma unroll
             for (int j = 0; j < TREE_W; j++) { const int jj = j < n ? j : 0; const real m = A.M[mb + jj], d = A.dl[a0 + jj]; s += j < n ? m * d : real(0); }
             q2 += s * A.dl[k];
