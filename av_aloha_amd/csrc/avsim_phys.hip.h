@@ -1912,9 +1912,11 @@ struct Env {
             real tc = tmax(solref[0], 2 * ka->m.timestep), dr = solref[1];
             real K = real(1) / tmax(real(1e-15), dmax * dmax * tc * tc * dr * dr), Bd = real(2) / tmax(real(1e-15), dmax * tc);
             real imp, R;
+            // (a contact's rows all take the impedance at the contact distance: pos is that distance for the normal row)
+            const real imp_row = impedance(solimp, (!LEAD && sub > 0) ? cdist[id] : pos, margin);
             if (!LEAD && sub > 0) {
                 int c = id, p = cpair[c];
-                real imp0 = impedance(solimp, cdist[c], margin);
+                real imp0 = imp_row;
                 real R0 = tmax(real(1e-15), (1 - imp0) * diag0 / imp0);
                 real R1 = R0 / tmax(real(1e-15), ka->m.impratio);
                 real mu0 = ka->m.pair_friction[5 * p], mur = ka->m.pair_friction[5 * p + sub - 1];
@@ -1923,7 +1925,7 @@ struct Env {
                 K = 0;
                 floss = mur;
             } else {
-                imp = impedance(solimp, pos, margin);
+                imp = imp_row;
                 R = tmax(real(1e-15), (1 - imp) * diag0 / imp);
             }
             // velocity along the row, reference acceleration
@@ -1935,9 +1937,10 @@ struct Env {
                 // J is zero beyond a tree's dofs: clamped reads instead of per-slot branches
                 const int a0 = tadr[tA], b0 = tadr[tB >= 0 ? tB : tA];
 #pragma unroll
-                for (int k = 0; k < TREE_W; k++) {
-                    vel += J[k] * qvel[a0 + k < nvm ? a0 + k : nvm];
-                    vel += J[TREE_W + k] * qvel[b0 + k < nvm ? b0 + k : nvm];
+                for (int k = 0; k < TREE_W; k++) vel += J[k] * qvel[a0 + k < nvm ? a0 + k : nvm];
+                if (tB >= 0) {
+#pragma unroll
+                    for (int k = 0; k < TREE_W; k++) vel += J[TREE_W + k] * qvel[b0 + k < nvm ? b0 + k : nvm];
                 }
             }
             const real aref = -Bd * vel - K * imp * (pos - margin);
@@ -1990,11 +1993,17 @@ struct Env {
             } else {
 #pragma unroll
             for (int k = 0; k < TREE_W; k++) {
-                const int da = a0 + k < nvm ? a0 + k : nvm, db = b0 + k < nvm ? b0 + k : nvm;   // (b0 = 0 with J = 0 for one-tree rows)
+                const int da = a0 + k < nvm ? a0 + k : nvm;
                 jw += J[k] * warm[da];
-                jw += J[TREE_W + k] * warm[db];
                 jas += J[k] * asm_[da];
-                jas += J[TREE_W + k] * asm_[db];
+            }
+            if (tB >= 0) {
+#pragma unroll
+                for (int k = 0; k < TREE_W; k++) {
+                    const int db = b0 + k < nvm ? b0 + k : nvm;
+                    jw += J[TREE_W + k] * warm[db];
+                    jas += J[TREE_W + k] * asm_[db];
+                }
             }
             }
             const real big = real(1e30);
