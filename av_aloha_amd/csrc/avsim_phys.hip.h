@@ -1528,7 +1528,7 @@ struct Env {
         GLB_PTR(int) cand = cand_();
         int ncand = 0;
         long long tb0 = __builtin_readcyclecounter();
-        const real skin = real(0.05);
+        const real skin = real(0.03);
         GLB_PTR(real) gref = gref_();
         GLB_PTR(int) nearl = near_();
         // pair test with extra reach `pad` (0 = exact broad phase)
