@@ -1620,27 +1620,34 @@ struct Env {
             {
                 // box-box pairs, four at a time: every 16-lane row of the wave works on one pair (box_box16), the results land in
                 // the result slot of the lane that owns the pair
-                int nbox, rk = group_rank<G>(isbox, grp, lane, &nbox);
+                // the conservative cull first, one pair per lane: only boxes whose local bounding boxes overlap take a 16-lane row of a
+                // pass (resting scenes have more box pairs in reach of each other than in contact: one pass of four instead of two)
+                bool boxlive = false;
+                if (isbox) {
+                    Shape<real> a, b;
+                    load_shape(ga, a);
+                    load_shape(gb, b);
+                    boxlive = !boxes_separated(a, b);
+                }
+                int nbox, rk = group_rank<G>(boxlive, grp, lane, &nbox);
                 const int row = lane >> 4;
                 for (int b0 = 0; b0 < nbox; b0 += 4) {
                     int src = 0;
                     bool on = false;
 #pragma unroll
                     for (int gg = 0; gg < 4; gg++) {
-                        const unsigned long long mm = __ballot(isbox && rk == b0 + gg);
+                        const unsigned long long mm = __ballot(boxlive && rk == b0 + gg);
                         if (row == gg && mm != 0) { src = __builtin_ctzll(mm); on = true; }
                     }
                     const int pga = __shfl(ga, src, 64), pgb = __shfl(gb, src, 64);     // an idle row runs on lane 0's pair, unused
                     Shape<real> a, b;
                     load_shape(pga, a);
                     load_shape(pgb, b);
-                    int n16 = 0;
-                    if (!boxes_separated(a, b))
-                        n16 = box_box16(a, b, (LDS_PTR(real))(r + ka->lay.scr + SLOT_W * src), (LDS_PTR(real))(r + ka->lay.scr + SLOT_W * G + 56 * row), lane, on);
+                    const int n16 = box_box16(a, b, (LDS_PTR(real))(r + ka->lay.scr + SLOT_W * src), (LDS_PTR(real))(r + ka->lay.scr + SLOT_W * G + 56 * row), lane, on);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     const int got = __shfl(on ? n16 : 0, 16 * ((rk - b0) & 3), 64);
-                    if (isbox && rk >= b0 && rk < b0 + 4) nn = got;
+                    if (boxlive && rk >= b0 && rk < b0 + 4) nn = got;
                 }
             }
             const long long tn1 = profiling ? __builtin_readcyclecounter() : 0;
