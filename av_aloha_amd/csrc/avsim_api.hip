@@ -188,17 +188,41 @@ __global__ void __launch_bounds__(64) k_ik(IkParams P, int arm, int controller, 
 }
 
 // sim_env.py:277-301: Cartesian action -> ctrl, IK seeded with the MEASURED qpos
+// The GradIK arms of the reference mode in a kernel of their own, one env per 16-lane row, gradik inlined: as an out-of-line function
+// next to the DiffIK code it spilled 3.3 KB per lane at 512 registers.  (Capped at 256 registers for two waves per SIMD it is no
+// faster: 50 iterations x 3 rounds of f64 forward kinematics are VALU-bound, not latency-bound.)
+template <typename real>
+__global__ void __launch_bounds__(64) k_gradik_ctrl(IkParams P, int N, int nq, int nu, const double* __restrict__ act,
+                                                                                          const real* __restrict__ qpos, real* __restrict__ ctrl) {
+    const int arm = blockIdx.y;
+    const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool live = i0 < N;
+    const int i = live ? i0 : N - 1;
+    const double* a = act + (size_t)i * 23 + (arm == 0 ? 0 : 8);
+    double tp[3] = {a[0], a[1], a[2]}, qx[4] = {a[4], a[5], a[6], a[3]}, Rt[9];
+    quat2mat_xyzw(qx, Rt);
+    const real* qp = qpos + (size_t)i * nq;
+    real* c = ctrl + (size_t)i * nu + (arm == 0 ? 0 : 7);
+    const IkArm& A = P.arm[arm];
+    double th[6], out[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) th[k] = (double)qp[A.qadr[k]];
+    gradik<double>(P, arm, th, tp, Rt, P.grad_iters, out);
+    if (!live || (threadIdx.x & 15) != 0) return;
+#pragma unroll
+    for (int k = 0; k < 6; k++) c[k] = (real)out[k];
+    const double trig = a[7];  // sim_env.py:300-301: unnorm(1 - trigger)
+    c[6] = (real)((1.0 - trig) * (P.grip_hi - P.grip_lo) + P.grip_lo);
+}
+
 template <typename real>
 __global__ void __launch_bounds__(64) k_cart_ctrl(IkParams P, int mode, int arm0, int N, int nq, int nu, const double* __restrict__ act,
                                                   const real* __restrict__ qpos, real* __restrict__ ctrl) {
     // blockIdx.y + arm0 = arm.  One env per lane, except the GradIK arms of the reference mode: one env per 16-lane row
     const int arm = blockIdx.y + arm0;
-    const bool rowwise = arm < 2 && mode != AVSIM_IK_DLS;
-    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i0 = rowwise ? gt >> 4 : gt;
-    const bool live = i0 < N;
-    if (!live && !rowwise) return;
-    const int i = live ? i0 : N - 1;
+    (void)mode;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
     const double* a = act + (size_t)i * 23 + (arm == 0 ? 0 : (arm == 1 ? 8 : 16));
     double tp[3] = {a[0], a[1], a[2]}, qx[4] = {a[4], a[5], a[6], a[3]}, Rt[9];
     quat2mat_xyzw(qx, Rt);
@@ -216,11 +240,7 @@ __global__ void __launch_bounds__(64) k_cart_ctrl(IkParams P, int mode, int arm0
         double th[6], out[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) th[k] = (double)qp[A.qadr[k]];
-        if (mode == AVSIM_IK_DLS) diffik<double, 6>(P, arm, th, tp, Rt, P.diff_iters, out);
-        else {
-            gradik<double>(P, arm, th, tp, Rt, P.grad_iters, out);
-            if (!live || (threadIdx.x & 15) != 0) return;
-        }
+        diffik<double, 6>(P, arm, th, tp, Rt, P.diff_iters, out);       // (the GradIK arms of the reference mode: k_gradik_ctrl)
 #pragma unroll
         for (int k = 0; k < 6; k++) c[k] = (real)out[k];
         double trig = a[7];  // sim_env.py:300-301: unnorm(1 - trigger)
@@ -603,7 +623,9 @@ int avsim_step_cartesian(avsim_t* h, const double* action23, int ik_mode, int ns
     };
     if (ik_mode == AVSIM_IK_DLS) launch(dim3((h->N + 63) / 64, 3), 0);
     else {
-        launch(dim3((h->N + 3) / 4, 2), 0);       // GradIK on the two manipulators: 16 lanes per env
+        // GradIK on the two manipulators: 16 lanes per env
+        if (h->f64) hipLaunchKernelGGL(k_gradik_ctrl<double>, dim3((h->N + 3) / 4, 2), dim3(64), 0, h->stream, h->ik, h->N, h->nq, h->nu, (const double*)da, (const double*)h->d_qpos, (double*)h->d_ctrl);
+        else hipLaunchKernelGGL(k_gradik_ctrl<float>, dim3((h->N + 3) / 4, 2), dim3(64), 0, h->stream, h->ik, h->N, h->nq, h->nu, (const double*)da, (const float*)h->d_qpos, (float*)h->d_ctrl);
         launch(dim3((h->N + 63) / 64, 1), 2);     // DiffIK on the camera arm: one env per lane
     }
     HIPCHK(h, hipGetLastError());

@@ -372,7 +372,9 @@ __device__ __forceinline__ T gik_cost(const IkParams& P, const IkArm& A, const T
 // sixteen.  Every evaluation is the same arithmetic as in the one-lane form and the gradient is gathered in joint order, so the result
 // is bit-identical to it.  All 16 lanes of a row must call this with the same arguments; every lane returns the answer.
 template <typename T>
-__device__ void gradik(const IkParams& P, int arm, const T* qs, const T pos[3], const T tR0[9], int max_it, T* qout) {
+// (inlined into its kernels: an out-of-line device function is compiled for the full 512-register budget, which caps its callers
+// at one wave per SIMD whatever they ask for)
+__device__ __forceinline__ void gradik(const IkParams& P, int arm, const T* qs, const T pos[3], const T tR0[9], int max_it, T* qout) {
     const IkArm& A = P.arm[arm];
     const int lane = threadIdx.x & 63, t = lane & 15, row0 = lane & ~15;
     const T step = (T)P.g_step;
