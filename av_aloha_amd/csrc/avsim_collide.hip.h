@@ -64,19 +64,19 @@ AVS_DEV void support(const Shape<T>& s, const T* d, T* out) {
             int best = 0;
             T bd = T(-1e30);
             const T tie = TieTol<T>::rel * T(0.1) * (fabs(l[0]) + fabs(l[1]) + fabs(l[2]));
-            // four vertices per round trip to memory (indices past the end repeat the last vertex, which cannot beat itself), the
+            // eight vertices per round trip to memory (indices past the end repeat the last vertex, which cannot beat itself), the
             // comparisons in index order as before; the winner's coordinates ride along instead of being fetched again
             T bx = 0, by = 0, bz = 0;
             const int last = s.nh - 1;
-            for (int i = 0; i < s.nh; i += 4) {
-                T vx[4], vy[4], vz[4];
+            for (int i = 0; i < s.nh; i += 8) {
+                T vx[8], vy[8], vz[8];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < 8; u++) {
                     const int iu = i + u < last ? i + u : last;
                     vx[u] = s.hull[3 * iu]; vy[u] = s.hull[3 * iu + 1]; vz[u] = s.hull[3 * iu + 2];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < 8; u++) {
                     const T v = vx[u] * l[0] + vy[u] * l[1] + vz[u] * l[2];
                     if (v > bd + tie) { bd = v; best = i + u; bx = vx[u]; by = vy[u]; bz = vz[u]; }
                 }
