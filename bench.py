@@ -234,7 +234,7 @@ def main():
     reward = torch.empty((N,), dtype=torch.int32, device=dev)
     success = torch.empty((N,), dtype=torch.uint8, device=dev)
     ret = torch.zeros((N,), dtype=torch.float32, device=dev)
-    succ_any = torch.zeros((N,), dtype=torch.int32, device=dev)
+    succ_any = torch.zeros((N,), dtype=torch.uint8, device=dev)
     diverged = torch.zeros((N,), dtype=torch.int32, device=dev)
     diag = torch.empty((N, 4), dtype=torch.int32, device=dev)
     ncon_sum = torch.zeros((N,), dtype=torch.float64, device=dev)
@@ -270,11 +270,12 @@ def main():
         else:
             h.check(L.avsim_step_cartesian(h.h, acts[k % period].data_ptr(), ik_mode, 20, agent.data_ptr(),
                                            reward.data_ptr(), success.data_ptr()))
-        ret.add_(reward.to(torch.float32))
-        torch.maximum(succ_any, success.to(torch.int32), out=succ_any)
+        # one elementwise kernel each (type promotion inside add_ / maximum, no temporaries)
+        ret.add_(reward)
+        torch.maximum(succ_any, success, out=succ_any)
         # per-step diagnostics stay on the device: divergence flags, contact counts (a few tiny elementwise kernels)
         h.check(L.avsim_get_diag(h.h, diag.data_ptr()))
-        diverged.bitwise_or_(diag[:, 3] & 1)
+        diverged.bitwise_or_(diag[:, 3])          # (bit 0 = diverged; masked where it is read)
         if args.config == 3:
             ncon_sum.add_(diag[:, 0].to(torch.float64))
             rich.add_((diag[:, 0] >= 8).to(torch.int32))
@@ -346,7 +347,7 @@ def main():
                        "survey_config": args.config, "envs_per_gpu": N, "envs_total": n_total, "substeps_per_step": 20, "solver": args.solver,
                        "pgs_iters": args.pgs_iters, "noslip_iters": 3, "lanes_per_env": 64, "episode_len": EPISODE_LEN,
                        "physics_substeps_per_s": value * 20,
-                       "overflow_envs": int((dg[:, 2] != 0).sum()), "nan_envs": int(diverged.sum().item()),
+                       "overflow_envs": int((dg[:, 2] != 0).sum()), "nan_envs": int((diverged & 1).sum().item()),
                        "newton_iters_per_substep": float(((dg[:, 3] >> 16) & 0xfff).mean()) / 20.0, "newton_iters_max": int(((dg[:, 3] >> 28) & 0xf).max()),
                        "mean_ncon": float(ncon_sum.mean().item()) / args.steps if args.config == 3 else float(dg[:, 0].mean()),
                        "mean_nefc": float(dg[:, 1].mean()),
