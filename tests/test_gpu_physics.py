@@ -196,3 +196,24 @@ def test_staged_rewards_and_success_match_the_oracle():
     for e in orcs:
         e.close()
     sim.close()
+
+
+@pytest.mark.parametrize("solver", [1, 0])
+def test_contact_free_steps_match_the_oracle(solver):
+    """No contact at all (the objects start 30 cm above the table and fall; the arms move in the air): the noslip pass is then the
+    dry-friction rows alone, which the kernel relaxes per kinematic tree outside its group loop.  f64 device = oracle to 1e-10."""
+    md = model_dict()
+    obj = OBJ.copy()
+    obj[:, 2] += 0.30
+    acts = actions_wiggle(md, 4)
+    ref = oracle_rollout("slot_insertion", 3, obj, acts, 20, solver=solver)
+    assert ref[0][5] == 0 and ref[2][5] == 0                     # contact-free indeed
+    sim = make(f64=True, pgs_iters=20, solver=solver)
+    sim.reset(obj[None])
+    for t, a in enumerate(acts):
+        sim.step(a[None])
+        qpos, qvel, _, _ = sim.get_state()
+        assert int(sim.contacts()[0][0]) == ref[t][5]
+        np.testing.assert_allclose(qpos[0], ref[t][0], atol=1e-10 if solver == 1 else 1e-8, err_msg=f"qpos step {t}")
+        np.testing.assert_allclose(qvel[0], ref[t][1], atol=1e-8 if solver == 1 else 1e-6, err_msg=f"qvel step {t}")
+    sim.close()
