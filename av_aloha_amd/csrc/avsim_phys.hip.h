@@ -42,6 +42,7 @@ struct DevModel {
     int nq, nv, nu, nbody, njnt, ngeom, npair, ntree, neq, nfloss, nlimited, nment, task_id, nj, msize;
     real timestep, gravity[3], impratio, grip_lo, grip_hi;
     int noslip_iters;
+    int noslip_per_tree;          // 1: the dry-friction rows of the noslip pass go per kinematic tree (needs <= 8 trees); option "noslip_per_tree"
     int solver, newton_iters;     // 0 = PGS (dual), 1 = Newton (primal, the reference's default solver)
     real newton_tol, nscale;      // MuJoCo tolerance and 1/(meaninertia*nv) scaling of the termination tests
     // bodies
@@ -538,10 +539,10 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         real a[GRP_MAX - 1], an[GRP_MAX - 1];
 #pragma unroll
         for (int s = 0; s < GRP_MAX - 1; s++) an[s] = 0;
-        // next group's couplings (global memory): the PGS sweeps use them in every step, a noslip step only when its contact slides
-        // (the multiplier iteration below then fetches them itself)
+        // next group's couplings (global memory): the PGS sweeps and the leading rows' groups use them in every step, a noslip step on
+        // a contact only when the contact slides (the multiplier iteration below then fetches them itself)
         const bool next_noslip = (g + 1 >= ngrp ? it + 1 : it) >= iters;
-        if (!next_noslip) {
+        if (!(next_noslip && ((gin >> 24) & 1))) {
 #pragma unroll
             for (int s = 0; s < GRP_MAX - 1; s++) an[s] = gA[GA_W * g1 + tri + s];
         }
@@ -2226,7 +2227,7 @@ struct Env {
     }
 
     // what pgs_groups needs to relax the dry-friction rows of a noslip sweep per tree (lane 8 t + i: at most 8 trees)
-    AVS_DEV bool lead_per_tree() const { return ka->m.ntree <= 8 && ka->m.noslip_iters > 0; }
+    AVS_DEV bool lead_per_tree() const { return ka->m.ntree <= 8 && ka->m.noslip_iters > 0 && ka->m.noslip_per_tree != 0; }
     AVS_DEV NoslipLead<real> noslip_lead() const {
         NoslipLead<real> nl;
         nl.Minv = (LDS_PTR(const real))(r + ka->lay.Minv);
@@ -2539,7 +2540,7 @@ struct PhysHost {
         m.nj = b.scalar("num_arms") == 3 ? 21 : 14;
         auto opt = F("opt");
         m.timestep = (real)opt[0]; m.gravity[0] = (real)opt[1]; m.gravity[1] = (real)opt[2]; m.gravity[2] = (real)opt[3];
-        m.impratio = (real)opt[4]; m.noslip_iters = (int)opt[5];
+        m.impratio = (real)opt[4]; m.noslip_iters = (int)opt[5]; m.noslip_per_tree = 1;
         m.solver = 1; m.newton_iters = 100; m.newton_tol = sizeof(real) == 8 ? (real)1e-8 : (real)1e-6;     // MuJoCo defaults: iterations 100, tolerance 1e-8
         m.nscale = (real)(1.0 / ((opt.size() > 7 && opt[7] > 0 ? opt[7] : 1.0) * std::max(1, m.nv)));
         auto gr = F("grip_range");
@@ -2822,6 +2823,7 @@ struct PhysHost {
         if (n == "export_contacts") { export_contacts = v != 0; return true; }
         if (n == "num_joints") { if (v != 14 && v != 21) return false; mf.nj = md.nj = (int)v; return true; }
         if (n == "order_envs") { order_envs = v != 0; return true; }
+        if (n == "noslip_per_tree") { mf.noslip_per_tree = md.noslip_per_tree = v != 0; return true; }
         if (n == "waves_per_block") { int x = (int)v; if (x >= 0 && x <= 8) { wpb_override = x; return true; } return false; }
         if (n == "profile_phases") {
             if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * PROF_W, 0));

@@ -67,6 +67,9 @@ int avsim_dims(const avsim_t* h, int32_t dims[AVSIM_NDIMS]);
  *   "num_joints"        14 | 21: width of the action / agent_pos rows, whatever the blob's arm count (a 3-arm env whose camera
  *                       arm was parked by hide_middle_arm, env.py:394-395, keeps its 21-D action on the 2-arm model)
  *   "waves_per_block"   envs per workgroup, 0 = as many as fit in 160 KiB of LDS (<= 8)
+ *   "noslip_per_tree"   1 (default): the dry-friction rows of the noslip pass are relaxed per kinematic tree, all trees at once
+ *                       (models with <= 8 trees); 0 = six rows at a time through the Gauss-Seidel groups (what models with more
+ *                       trees get); same results to rounding
  *   "order_envs"        1 (default): workgroups take the envs in the order of their cost in the previous step, most expensive
  *                       first (results do not depend on it); 0 = in index order
  *   "export_contacts"   0 skips the per-step contact export (avsim_get_contacts); "kernel_timing" 1 brackets every physics

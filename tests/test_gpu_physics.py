@@ -217,3 +217,21 @@ def test_contact_free_steps_match_the_oracle(solver):
         np.testing.assert_allclose(qpos[0], ref[t][0], atol=1e-10 if solver == 1 else 1e-8, err_msg=f"qpos step {t}")
         np.testing.assert_allclose(qvel[0], ref[t][1], atol=1e-8 if solver == 1 else 1e-6, err_msg=f"qvel step {t}")
     sim.close()
+
+
+def test_noslip_through_the_row_groups_matches_the_oracle_too():
+    """Option noslip_per_tree = 0: the dry-friction rows of the noslip pass go through the Gauss-Seidel groups (the path of a model
+    with more than 8 kinematic trees; none of the reference's tasks has one), with the leading rows' J M^-1 rows and couplings in the
+    global scratch.  Same oracle, same tolerance as the default path."""
+    md = model_dict()
+    acts = actions_wiggle(md, 8)
+    ref = oracle_rollout("slot_insertion", 3, OBJ, acts, 20, solver=1)
+    sim = make(f64=True, pgs_iters=20, solver=1, noslip_per_tree=0)
+    sim.reset(OBJ[None])
+    for t, a in enumerate(acts):
+        sim.step(a[None])
+        qpos, qvel, _, _ = sim.get_state()
+        assert int(sim.contacts()[0][0]) == ref[t][5]
+        np.testing.assert_allclose(qpos[0], ref[t][0], atol=1e-10, err_msg=f"qpos step {t}")
+        np.testing.assert_allclose(qvel[0], ref[t][1], atol=1e-8, err_msg=f"qvel step {t}")
+    sim.close()
