@@ -658,9 +658,11 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
                 for (int e = lane; e < nv * (nv + 1) / 2; e += 64) A.H[e] = 0;
                 NSYNC();
             }
-            for (int e = lane; e < nv * TREE_W; e += 64) {           // M blocks
-                const int k = e >> 3, j8 = e & 7, t = A.dof_tree[k], a0 = A.tree_dofadr[t], n = A.tree_dofnum[t], kk = k - a0;
-                if (j8 < n && j8 <= kk) A.H[k * (k + 1) / 2 + a0 + j8] = A.M[A.tree_madr[t] + kk * n + j8];
+            if (lane < nv) {                                         // M blocks: lane = dof copies the lower part of its row
+                const int k = lane, a0 = A.k_a0, kk = k - a0, hb = k * (k + 1) / 2 + a0;
+#pragma unroll
+                for (int j8 = 0; j8 < TREE_W; j8++)
+                    if (j8 <= kk) A.H[hb + j8] = A.M[A.k_mb + j8];
             }
             NSYNC();
             nlead_rows<real>(A, lane);
