@@ -733,6 +733,12 @@ __device__ int box_box16(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, A
     int np = 4;
     const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
     AVS_LDS(T) dst = tmp;
+    // The incident face entirely inside the reference face's rectangle (a box resting on a larger one): every clip would keep the
+    // four vertices as they are, in their order (dp <= 0 for all of them, no crossing edge), so the four rounds of neighbour
+    // shuffles, ballots and LDS compaction are skipped -- the result is the same polygon, bit for bit
+    const bool inside = t >= 4 || (fabs(sel3(P, a1)) <= sel3(rsize, a1) && fabs(sel3(P, a2)) <= sel3(rsize, a2));
+    const bool noclip = ((__ballot(inside) >> g16) & 0xffffull) == 0xffffull;
+    if (!noclip)
     for (int side = 0; side < 4; side++) {
         const int axis = side < 2 ? a1 : a2;
         const T s = (side & 1) ? T(-1) : T(1), lim = sel3(rsize, axis);
