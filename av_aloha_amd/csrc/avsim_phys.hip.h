@@ -359,6 +359,12 @@ constexpr int GRP_MAX = 6;   // rows per Gauss-Seidel group (a condim-6 contact 
 constexpr int GA_W = 64, GA_Q = 16, GA_QW = 6;   // group record: 15 couplings, then the noslip block transposed: word 8 k + r = entry k of row r
 // convergence thresholds of the multiplier iteration in the noslip QCQP: MuJoCo's absolute 1e-10 in double; in float a relative
 // part on top, since v.v - r^2 and the multiplier carry 1e-7 relative rounding
+// t / d with 1 / d at hand.  The product kernel (float) multiplies: a division there is ten instructions (range scaling around
+// v_rcp_f32), and the multiplier iteration of the noslip QCQP is thirty divisions per step.  The parity kernel (double) divides, as
+// the oracle does.
+template <typename T> AVS_DEV T qdiv(T t, T d, T dinv) { return sizeof(T) == 4 ? t * dinv : t / d; }
+AVS_DEV float qrsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+AVS_DEV double qrsqrt(double x) { return 1.0 / sqrt(x); }
 template <typename T> struct QTol;
 template <> struct QTol<double> { static constexpr double abs = 1e-10, rel = 0.0; };
 template <> struct QTol<float> { static constexpr float abs = 1e-10f, rel = 2e-6f; };
@@ -639,7 +645,7 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
                         v[1] = singular ? real(0) : v2 * dq[1];
                         active = !singular && la != 0;
                     } else {
-                        real As[5][5], bs[5], L[5][5], y[5], w[5];
+                        real As[5][5], bs[5], L[5][5], y[5], w[5], rd[5];
 #pragma unroll
                         for (int j = 0; j < 5; j++) {
                             bs[j] = j < n ? bq[j] * dq[j] : real(0);
@@ -655,29 +661,31 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
 #pragma unroll
                                 for (int k = 0; k < j; k++) dd -= L[j][k] * L[j][k];
                                 if (j < n && dd < real(1e-10)) singular = true;
-                                dd = sqrt(tmax(dd, real(1e-30)));
+                                dd = tmax(dd, real(1e-30));
+                                if (sizeof(real) == 4) { rd[j] = qrsqrt(dd); dd = dd * rd[j]; }
+                                else { dd = sqrt(dd); rd[j] = real(1) / dd; }
                                 L[j][j] = dd;
 #pragma unroll
                                 for (int i = j + 1; i < 5; i++) {
                                     real t = As[i][j];
 #pragma unroll
                                     for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
-                                    L[i][j] = t / dd;
+                                    L[i][j] = qdiv(t, dd, rd[j]);
                                 }
                             }
                             if (singular) break;
 #pragma unroll
-                            for (int i = 0; i < 5; i++) { real t = -bs[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = t / L[i][i]; }
+                            for (int i = 0; i < 5; i++) { real t = -bs[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = qdiv(t, L[i][i], rd[i]); }
 #pragma unroll
-                            for (int i = 4; i >= 0; i--) { real t = y[i]; for (int k = i + 1; k < 5; k++) t -= L[k][i] * y[k]; y[i] = t / L[i][i]; }
+                            for (int i = 4; i >= 0; i--) { real t = y[i]; for (int k = i + 1; k < 5; k++) t -= L[k][i] * y[k]; y[i] = qdiv(t, L[i][i], rd[i]); }
                             real val = -r2;
 #pragma unroll
                             for (int i = 0; i < 5; i++) val += y[i] * y[i];
                             if (val < vtol) break;
 #pragma unroll
-                            for (int i = 0; i < 5; i++) { real t = y[i]; for (int k = 0; k < i; k++) t -= L[i][k] * w[k]; w[i] = t / L[i][i]; }
+                            for (int i = 0; i < 5; i++) { real t = y[i]; for (int k = 0; k < i; k++) t -= L[i][k] * w[k]; w[i] = qdiv(t, L[i][i], rd[i]); }
 #pragma unroll
-                            for (int i = 4; i >= 0; i--) { real t = w[i]; for (int k = i + 1; k < 5; k++) t -= L[k][i] * w[k]; w[i] = t / L[i][i]; }
+                            for (int i = 4; i >= 0; i--) { real t = w[i]; for (int k = i + 1; k < 5; k++) t -= L[k][i] * w[k]; w[i] = qdiv(t, L[i][i], rd[i]); }
                             real deriv = 0;
 #pragma unroll
                             for (int i = 0; i < 5; i++) deriv += y[i] * w[i];
