@@ -27,7 +27,9 @@ def build_hip(force=False, verbose=False):
     units = [
         # f32 divide / sqrt through v_rcp / v_rsq (~1 ulp) instead of the correctly rounded 10-instruction sequences; the f64
         # parity mode is unaffected and the f32 tolerances of tests/test_gpu_physics.py are stated against the f64 oracle
-        ("avsim_api", ["-fno-hip-fp32-correctly-rounded-divide-sqrt"] + (["-DAVSIM_RENDER_STATS"] if os.environ.get("AVSIM_RENDER_STATS") else []) + os.environ.get("AVSIM_EXTRA_FLAGS", "").split()),
+        # f32 denormals are flushed: with them on, every division and square root carries a range-scaling sequence (ten instructions
+        # instead of v_rcp + multiply); nothing in the physics lives below 1e-38
+        ("avsim_api", ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero"] + (["-DAVSIM_RENDER_STATS"] if os.environ.get("AVSIM_RENDER_STATS") else []) + os.environ.get("AVSIM_EXTRA_FLAGS", "").split()),
         ("avsim_phys_f64", ["-ffp-contract=off"]),
     ]
     procs = []
