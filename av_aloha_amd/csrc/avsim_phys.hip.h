@@ -354,8 +354,9 @@ AVS_DEV double lane_get(double x, int l) {   // l is wave-uniform at every call 
 }
 
 constexpr int GRP_MAX = 6;   // rows per Gauss-Seidel group (a condim-6 contact is one group)
-// per-group record in global scratch: [0, 15) couplings (packed lower triangle), then for a contact with >= 3 friction rows the rows
-// of its friction block for the noslip QCQP, 12 words per friction row r: A[r][0..4], (D A D)^-1[r][0..4], mu_r, singular flag
+// per-group record in global scratch: [0, 15) couplings (packed lower triangle), then for a contact with >= 3 friction rows the
+// inverse of its friction block for the noslip pass, transposed (entry k of row r at word 16 + 8 k + r, so that row r's lane fetches
+// six separate words), and the rows' singular flags at words 56 ..
 constexpr int GA_W = 64, GA_Q = 16, GA_QW = 6;   // group record: 15 couplings, then the noslip block transposed: word 8 k + r = entry k of row r
 // convergence thresholds of the multiplier iteration in the noslip QCQP: MuJoCo's absolute 1e-10 in double; in float a relative
 // part on top, since v.v - r^2 and the multiplier carry 1e-7 relative rounding
