@@ -2473,11 +2473,12 @@ static __global__ void __launch_bounds__(1024) k_env_order(const int* __restrict
     __syncthreads();
     const int base = lo;
     const float scale = 255.0f / (float)(hi - lo + 1);
-    for (int i = threadIdx.x; i < N; i += 1024) atomicAdd(&cnt[255 - (int)((float)(cost[i] - base) * scale)], 1);
+    auto bucket = [&](int c) { const int b = 255 - (int)((float)(c - base) * scale); return b < 0 ? 0 : (b > 255 ? 255 : b); };
+    for (int i = threadIdx.x; i < N; i += 1024) atomicAdd(&cnt[bucket(cost[i])], 1);
     __syncthreads();
     if (threadIdx.x == 0) { int a = 0; for (int b = 0; b < 256; b++) { off[b] = a; a += cnt[b]; } }
     __syncthreads();
-    for (int i = threadIdx.x; i < N; i += 1024) order[atomicAdd(&off[255 - (int)((float)(cost[i] - base) * scale)], 1)] = i;
+    for (int i = threadIdx.x; i < N; i += 1024) order[atomicAdd(&off[bucket(cost[i])], 1)] = i;
 }
 
 // ------------------------------------------------------------------------------------------------
