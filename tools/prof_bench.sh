@@ -14,6 +14,7 @@ python bench.py --config 5 --steps 10 --warmup 2 --no-cpu-baseline > $o/bench_co
 python bench.py --f64 --steps 20 --warmup 3 --no-cpu-baseline > $o/bench_config2_f64.json 2> $o/bench2f64.err
 rocprofv3 --kernel-trace --stats -d $o/trace2 -o t -f csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $o/trace2.log 2>&1
 rocprofv3 --kernel-trace --stats -d $o/trace3 -o t -f csv -- python bench.py --config 3 --steps 60 --warmup 150 --no-cpu-baseline > $o/trace3.log 2>&1
+rocprofv3 --kernel-trace --stats -d $o/trace4 -o t -f csv -- python bench.py --config 4 --steps 20 --warmup 30 --no-cpu-baseline > $o/trace4.log 2>&1
 rocprofv3 --kernel-trace --stats -d $o/trace5 -o t -f csv -- python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline > $o/trace5.log 2>&1
 for c in 2 3; do
   extra=""; [ $c = 3 ] && extra="--config 3 --warmup 150"
@@ -23,7 +24,7 @@ done
 python - <<PY
 import csv, glob, json
 o = "$o"
-for c in (2, 3, 5):
+for c in (2, 3, 4, 5):
     for f in glob.glob(o + "/trace%d/**/*kernel_stats.csv" % c, recursive=True):
         open(o + "/kernel_stats_config%d.csv" % c, "w").write(open(f).read())
 res = {}
@@ -36,4 +37,4 @@ for c in (2, 3):
 json.dump(res, open(o + "/pmc_summary.json", "w"), indent=1)
 print(res)
 PY
-head -c 600 $o/bench_config2.json; echo; for c in 2 3 5; do head -8 $o/kernel_stats_config$c.csv; done
+head -c 600 $o/bench_config2.json; echo; for c in 2 3 4 5; do head -8 $o/kernel_stats_config$c.csv; done
