@@ -41,10 +41,13 @@ def build_hip(force=False, verbose=False):
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB] + [os.path.join(SRC, n + ".o") for n, _ in units]
+    # linked next to the target and renamed over it: a process that has the old library mapped keeps its (old) file
+    tmp = LIB + ".tmp%d" % os.getpid()
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", tmp] + [os.path.join(SRC, n + ".o") for n, _ in units]
     if verbose:
-        print(" ".join(link), file=sys.stderr)
+        print(" ".join(link).replace(tmp, LIB), file=sys.stderr)
     subprocess.check_call(link)
+    os.replace(tmp, LIB)
     return LIB
 
 
