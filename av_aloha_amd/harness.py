@@ -10,8 +10,9 @@
   sequence replaces the VR headset; the episode holds T = len(actions) + 1 time steps with `/observations/qpos` (T, 21),
   `/observations/qvel` (T, 21), `/observations/all_qpos` (T, nq), `/action` (T, 21: the joint-space command with
   normalised grippers, i.e. obs['control']) as float32, `/observations/images/<cam>` uint8 (T, H, W, 3) for the env's cameras
-  and the attribute sim = True.  Written as HDF5 when h5py is
-  importable, otherwise as .npz with the same names (h5py is not installed in this image).
+  and the attribute sim = True.  Written as HDF5 either way: through h5py when it is importable, otherwise through the
+  package's own minimal writer (av_aloha_amd/hdf5min.py: same groups, names, dtypes, image chunking (1, H, W, 3) and attribute, in
+  the structures libhdf5 writes by default); `load_episode` reads both, and the older .npz files.
 * `replay_episode` (gym_guided_vision/scripts/replay_sim_episode.py:221-262): set_qpos through `/observations/all_qpos`.
 """
 from __future__ import annotations
@@ -88,15 +89,23 @@ def record_episode(env, actions23) -> dict:
     return data
 
 
-def save_episode(data: dict, dataset_dir: str, episode_idx: int) -> str:
-    """episode_<idx>.hdf5 with the reference's layout when h5py is available, else episode_<idx>.npz with the same names."""
+def save_episode(data: dict, dataset_dir: str, episode_idx: int, use_h5py: bool | None = None) -> str:
+    """episode_<idx>.hdf5 with the reference's layout (record_sim_episodes.py:186-206): through h5py when it is importable
+    (use_h5py None / True), else through av_aloha_amd.hdf5min."""
     os.makedirs(dataset_dir, exist_ok=True)
     base = os.path.join(dataset_dir, f"episode_{episode_idx}")
-    try:
-        import h5py
-    except ImportError:
-        np.savez(base + ".npz", sim=np.array(True), **{k: v for k, v in data.items()})
-        return base + ".npz"
+    h5py = None
+    if use_h5py is not False:
+        try:
+            import h5py
+        except ImportError:
+            if use_h5py:
+                raise
+    if h5py is None:
+        from . import hdf5min
+        chunks = {k: (1, *v.shape[1:]) for k, v in data.items() if "/images/" in k}
+        hdf5min.write(base + ".hdf5", data, attrs={"sim": np.bool_(True)}, chunks=chunks)
+        return base + ".hdf5"
     with h5py.File(base + ".hdf5", "w", rdcc_nbytes=1024 ** 2 * 2) as root:
         root.attrs["sim"] = True
         for name, array in data.items():
@@ -109,7 +118,11 @@ def load_episode(path: str) -> dict:
     if path.endswith(".npz"):
         with np.load(path) as z:
             return {k: z[k] for k in z.files if k != "sim"}
-    import h5py
+    try:
+        import h5py
+    except ImportError:
+        from . import hdf5min
+        return hdf5min.read(path)[0]
     out = {}
     with h5py.File(path, "r") as root:
         root.visititems(lambda n, o: out.__setitem__("/" + n, o[()]) if hasattr(o, "shape") else None)

@@ -1,0 +1,165 @@
+"""Full-episode runs of the scripted policies on the CPU oracle (test infrastructure): open-loop replay of a recorded ctrl sequence
+and closed-loop runs of the same script on the oracle's own state.  One env per call, so that a process pool spreads the envs of a
+test over the host's cores (an oracle env-step takes 15-30 ms).
+
+The scripted policies: tests/scripted.py SlotInsertionScript (grasp - carry - insert, env.py:546-589 reward stages) and
+av_aloha_amd/workloads.py grasp_lift_targets (BASELINE config 3, SewNeedle reach - grasp - lift, env.py:640-690)."""
+import multiprocessing as mp
+import os
+
+import numpy as np
+
+from av_aloha_amd import workloads as W
+from orc_env import OrcEnv
+from orc_ffi import dp
+
+TASK_SEED = {"slot_insertion": 1000, "sew_needle": 2000}
+GRIP_RANGE = (0.002, 0.037)
+
+
+def oracle_home(task="slot_insertion"):
+    """{'left','right','middle'} -> [7] eef poses (xyz + quat wxyz) at the home ctrl, through the oracle's FK (kinematics.py:17-24)."""
+    e = OrcEnv(task, 3)
+    ch = np.array(e.ctrl, dtype=np.float64)
+    Ts = []
+    for arm, sl in ((0, slice(0, 6)), (1, slice(7, 13)), (2, slice(14, 21))):
+        T = np.zeros(16)
+        q = np.ascontiguousarray(ch[sl])
+        e.L.orc_fk(e.m, arm, dp(q), dp(T))
+        Ts.append(T)
+    e.close()
+    return W.home_poses(Ts)
+
+
+def make_script(task, home, qpos0):
+    """Per-step 23-D action source for n envs: .steps(), .action(qpos [n, nq]) -> [n, 23]."""
+    n = qpos0.shape[0]
+    home = {k: np.broadcast_to(np.asarray(v, dtype=np.float64), (n, 7)).copy() for k, v in home.items()}
+    if task == "slot_insertion":
+        from scripted import SlotInsertionScript
+        return SlotInsertionScript(home, qpos0)
+
+    class Lift:
+        def __init__(self):
+            self.acts = list(W.grasp_lift_targets(home, qpos0[:, 30:33] + np.array([0.0, 0.0, 0.01])))
+            self.t = 0
+
+        def steps(self):
+            return len(self.acts)
+
+        def action(self, qpos):
+            self.t += 1
+            return self.acts[self.t - 1]
+    return Lift()
+
+
+def _new_env(task, pose):
+    e = OrcEnv(task, 3)
+    e.d.solver = 1                  # Newton, the reference's solver (MuJoCo default; aloha_sim.xml:4 does not change it)
+    e.reset(pose)
+    return e
+
+
+def _step_ctrl(e, ctrl, nsub=20):
+    """ctrl is written as it is (actuator units: the gripper entries are not re-normalised), then nsub substeps + the trailing
+    refresh; reward / success as env.py:221-224."""
+    e.ctrl[:] = ctrl
+    e.step(nsub)
+    r = e.L.orc_reward(e.dptr)
+    return r, r == e.L.orc_max_reward(e.m)
+
+
+def replay_worker(args):
+    """Open loop: the oracle steps the recorded ctrl sequence [T, nu] of one env.  -> rewards [T], success [T], qpos [T, nq], ncon [T]"""
+    task, pose, ctrls = args
+    e = _new_env(task, pose)
+    T = ctrls.shape[0]
+    rw, su, qs, nc = np.zeros(T, np.int32), np.zeros(T, bool), np.zeros((T, e.nq)), np.zeros(T, np.int32)
+    for t in range(T):
+        rw[t], su[t] = _step_ctrl(e, ctrls[t])
+        qs[t] = e.qpos
+        nc[t] = e.d.ncon
+    e.close()
+    return rw, su, qs, nc
+
+
+def closed_loop_worker(args):
+    """Closed loop: the script reads the oracle's own qpos, the oracle's GradIK / DiffIK (sim_env.py:277-301) make ctrl.
+    -> rewards [T], success [T], final qpos, ctrl [T, nu]"""
+    task, pose, home = args
+    e = _new_env(task, pose)
+    script = make_script(task, home, np.array(e.qpos)[None])
+    T = script.steps()
+    rw, su, cs = np.zeros(T, np.int32), np.zeros(T, bool), np.zeros((T, e.nu))
+    a21 = np.zeros(21)
+    lo, hi = GRIP_RANGE            # gripper ctrl range (constants.py:31-34 unnormalisation, model "grip_range")
+    for t in range(T):
+        a = np.ascontiguousarray(script.action(np.array(e.qpos)[None])[0])
+        e.L.orc_cart_to_ctrl(e.dptr, dp(a), 0, dp(a21))
+        c = a21.copy()
+        for k in (6, 13):           # orc_cart_to_ctrl hands back the normalised opening 1 - trigger (sim_env.py:300-301)
+            c[k] = a21[k] * (hi - lo) + lo
+        cs[t] = c
+        rw[t], su[t] = _step_ctrl(e, c)
+    q = np.array(e.qpos)
+    e.close()
+    return rw, su, q, cs
+
+
+def pool_map(fn, jobs, procs=None):
+    procs = procs or max(1, min(os.cpu_count() or 1, 64, len(jobs)))
+    if procs == 1:
+        return [fn(j) for j in jobs]
+    with mp.get_context("fork").Pool(procs) as pool:
+        return pool.map(fn, jobs)
+
+
+# ---- device side -------------------------------------------------------------------------------------------------------
+def device_episode(task, n, f64, seed0=None, record_qpos=True):
+    """The scripted policy closed loop on the device (23-D action -> GradIK x2 + DiffIK on the measured joints -> 20 substeps,
+    sim_env.py:277-312), n envs with the poses of seeds seed0 + i.  Records what the physics was driven with: ctrl [T, n, nu] in
+    actuator units (double copies of the device's values, exact in both precisions).
+    -> dict(poses, home, ctrl, reward [T, n], success [T, n], qpos [T, n, nq], ncon [T, n], diverged [n], capped [n])"""
+    from av_aloha_amd.sim_env import make_sim_env
+    seed0 = TASK_SEED[task] if seed0 is None else seed0
+    env = make_sim_env("sim_" + task, cameras=[], num_envs=n, f64=f64)
+    poses = W.object_poses(task, np.arange(n), seed0)
+    env.sim.reset(poses)
+    obs = env.get_obs()
+    q0 = obs["qpos"].reshape(n, -1)
+    home = {k: obs["poses"][k].reshape(n, 7).copy() for k in ("left", "right", "middle")}
+    script = make_script(task, home, q0)
+    T = script.steps()
+    out = dict(poses=poses, home=home, ctrl=np.zeros((T, n, env.sim.nu)), reward=np.zeros((T, n), np.int32), success=np.zeros((T, n), bool),
+               qpos=np.zeros((T, n, env.sim.nq)) if record_qpos else None, ncon=np.zeros((T, n), np.int32),
+               diverged=np.zeros(n, bool), capped=np.zeros(n, bool))
+    q = q0
+    for t in range(T):
+        _, rw, su = env.sim.step_cartesian(script.action(q))
+        q, _, c, _ = env.sim.get_state()
+        d = env.sim.diag()
+        out["ctrl"][t], out["reward"][t], out["success"][t], out["ncon"][t] = c, rw, su, d[:, 0]
+        if record_qpos:
+            out["qpos"][t] = q
+        out["diverged"] |= (d[:, 3] & 1) != 0
+        out["capped"] |= d[:, 2] != 0
+    env.close()
+    return out
+
+
+def compare_with_replay(task, dev, envs=None):
+    """The oracle replays every env's recorded ctrl sequence; per env: first step at which the reward differs (-1 = never), final
+    success on both sides, largest joint / object position distance over the episode.  -> list of dicts"""
+    n = dev["ctrl"].shape[1]
+    envs = list(range(n)) if envs is None else list(envs)
+    res = pool_map(replay_worker, [(task, dev["poses"][k], np.ascontiguousarray(dev["ctrl"][:, k])) for k in envs])
+    rows = []
+    for k, (rw, su, qs, nc) in zip(envs, res):
+        diff = np.nonzero(rw != dev["reward"][:, k])[0]
+        err = np.abs(qs - dev["qpos"][:, k]) if dev["qpos"] is not None else np.zeros((1, 1))
+        rows.append(dict(env=k, first_reward_diff=int(diff[0]) if diff.size else -1, n_reward_diff=int(diff.size),
+                         dev_success=bool(dev["success"][-1, k]), orc_success=bool(su[-1]), dev_max_reward=int(dev["reward"][:, k].max()),
+                         orc_max_reward=int(rw.max()), dev_final_reward=int(dev["reward"][-1, k]), orc_final_reward=int(rw[-1]),
+                         max_qpos_err=float(err.max()), final_qpos_err=float(err[-1].max()),
+                         ncon_diff_steps=int((nc != dev["ncon"][:, k]).sum())))
+    return rows

@@ -1,0 +1,41 @@
+"""Whole-episode parity table, device vs CPU oracle (tests/episode_util.py; run on the MI355X box):
+    python tools/report_episode_parity.py [out.json]
+f64 device mode and the f32 product mode of the scripted SlotInsertion (grasp - carry - insert, 350 env-steps) and SewNeedle (reach -
+grasp - lift, 250 env-steps) episodes against the oracle stepping the same ctrl sequences: per-step reward agreement, final
+is_success (env.py:224) on both sides, position distance over the episode."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import episode_util as U
+
+out = {}
+for task, n64, n32 in (("slot_insertion", 16, 128), ("sew_needle", 16, 128)):
+    for mode, n in (("f64", n64), ("f32", n32)):
+        dev = U.device_episode(task, n, f64=mode == "f64")
+        rows = U.compare_with_replay(task, dev)
+        e = np.array([r["max_qpos_err"] for r in rows])
+        mism = [r for r in rows if r["dev_success"] != r["orc_success"]]
+        fin = [r for r in rows if r["dev_final_reward"] != r["orc_final_reward"]]
+        out[f"{task}_{mode}"] = {
+            "envs": n, "steps": int(dev["ctrl"].shape[0]), "seeds": f"{U.TASK_SEED[task]} + i",
+            "device_success_rate": float(np.mean([r["dev_success"] for r in rows])), "oracle_success_rate": float(np.mean([r["orc_success"] for r in rows])),
+            "device_final_reward_hist": np.bincount([r["dev_final_reward"] for r in rows], minlength=6).tolist(),
+            "oracle_final_reward_hist": np.bincount([r["orc_final_reward"] for r in rows], minlength=6).tolist(),
+            "success_flag_mismatches": len(mism), "final_reward_mismatches": len(fin),
+            "envs_with_identical_reward_sequence": int(sum(r["first_reward_diff"] == -1 for r in rows)),
+            "envs_with_identical_contact_counts": int(sum(r["ncon_diff_steps"] == 0 for r in rows)),
+            "max_qpos_err_p50_p90_max": [float(np.percentile(e, 50)), float(np.percentile(e, 90)), float(e.max())],
+            "diverged_envs": int(dev["diverged"].sum()), "capped_envs": int(dev["capped"].sum()),
+            "mismatching_envs": mism[:16], "reward_diff_envs": [r for r in rows if r["first_reward_diff"] != -1][:16],
+        }
+        print(task, mode, json.dumps({k: v for k, v in out[f"{task}_{mode}"].items() if not k.endswith("_envs") or k in ("diverged_envs", "capped_envs")}), flush=True)
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r03_episode_parity.json")
+os.makedirs(os.path.dirname(path), exist_ok=True)
+json.dump(out, open(path, "w"), indent=1)
+print("wrote", path)
