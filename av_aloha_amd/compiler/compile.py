@@ -684,15 +684,25 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--assets", default="/root/reference/gym_guided_vision/gym_guided_vision/assets")
+    ap.add_argument("--assets", default=None)
+    ap.add_argument("--variant", choices=["gym", "data_collection"], default="gym",
+                    help="gym: gym_guided_vision/gym_guided_vision/assets (the gym envs, env.py); data_collection: "
+                         "data_collection_scripts/assets, the model sim_env.py / record_sim_episodes.py load (constants.py:5 XML_DIR): "
+                         "needle and peg without the gym assets' solref=\"0.01 1\" (task_sew_needle.xml:17, task_insert_peg.xml:7), "
+                         "ZED cameras with fovy 90 (aloha_sim.xml:357-358); written as models/dc_<task>_3arms.*")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "..", "models"))
     ap.add_argument("--tasks", nargs="*", default=list(TASKS))
     args = ap.parse_args()
+    if args.assets is None:
+        args.assets = {"gym": "/root/reference/gym_guided_vision/gym_guided_vision/assets",
+                       "data_collection": "/root/reference/data_collection_scripts/assets"}[args.variant]
+    prefix = "dc_" if args.variant == "data_collection" else ""
     os.makedirs(args.out, exist_ok=True)
     for t in args.tasks:
-        for na in (2, 3):
+        for na in ((3,) if prefix else (2, 3)):          # sim_env.py always simulates the three arms
             arrays, man = compile_task(args.assets, t, na)
-            base = os.path.join(args.out, f"{t}_{na}arms")
+            man["variant"] = args.variant
+            base = os.path.join(args.out, f"{prefix}{t}_{na}arms")
             write_blob(base + ".avm", arrays)
             with open(base + ".json", "w") as f:
                 json.dump(man, f, indent=1)

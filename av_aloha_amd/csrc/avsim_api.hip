@@ -35,13 +35,24 @@ static thread_local std::string g_create_error;
 struct DevGuard {
     int prev = -1;
     bool switched = false;
+    hipError_t err = hipSuccess;      // a failed switch is an error of the entry point (AVS_ON_DEVICE), never a silent run on the caller's device
     explicit DevGuard(int dev) {
-        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
     }
     ~DevGuard() {
         if (switched) (void)hipSetDevice(prev);
     }
 };
+#define AVS_ON_DEVICE(h)                                                                                          \
+    DevGuard dev_guard_((h)->device);                                                                       \
+    if (dev_guard_.err != hipSuccess) {                                                                     \
+        (h)->set_error("hipSetDevice(%d) failed: %s", (h)->device, hipGetErrorString(dev_guard_.err));      \
+        return AVSIM_EHIP;                                                                                  \
+    }
 
 struct avsim {
     int device = 0;
@@ -254,13 +265,17 @@ __global__ void __launch_bounds__(64) k_cart_ctrl(IkParams P, int mode, int arm0
 template <typename real>
 __global__ void k_reset(int N, int nq, int nv, int nu, int nobj, const unsigned char* __restrict__ mask,
                         const double* __restrict__ obj, const double* __restrict__ qhome, const double* __restrict__ chome,
-                        const int* __restrict__ objadr, real* qpos, real* qvel, real* ctrl, real* warm, int* latch) {
+                        const int* __restrict__ objadr, real* qpos, real* qvel, real* ctrl, real* warm, int* latch, double* obj_keep) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     if (mask && !mask[i]) return;
     for (int k = 0; k < nq; k++) qpos[(size_t)i * nq + k] = (real)qhome[k];
     for (int o = 0; o < nobj; o++)
-        for (int k = 0; k < 7; k++) qpos[(size_t)i * nq + objadr[o] + k] = (real)obj[((size_t)i * nobj + o) * 7 + k];
+        for (int k = 0; k < 7; k++) {
+            const double v = obj[((size_t)i * nobj + o) * 7 + k];
+            qpos[(size_t)i * nq + objadr[o] + k] = (real)v;
+            obj_keep[((size_t)i * nobj + o) * 7 + k] = v;      // where a diverged env of this episode is put back (check_divergence)
+        }
     for (int k = 0; k < nv; k++) { qvel[(size_t)i * nv + k] = 0; warm[(size_t)i * nv + k] = 0; }
     for (int k = 0; k < nu; k++) ctrl[(size_t)i * nu + k] = (real)chome[k];
     latch[i] = 0;
@@ -417,12 +432,18 @@ int avsim_dims(const avsim_t* h, int32_t d[AVSIM_NDIMS]) {
 
 int avsim_set_option(avsim_t* h, const char* name, double value) {
     if (!h || !name) return AVSIM_EINVAL;
+    AVS_ON_DEVICE(h);               // "maxefc" / "maxcon" / "profile_phases" allocate on the handle's device
     if (!std::strcmp(name, "kernel_timing")) { h->ktiming = value != 0; return AVSIM_OK; }
     if (!std::strcmp(name, "diffik_iters")) { h->ik.diff_iters = (int)value; return AVSIM_OK; }
     if (!std::strcmp(name, "gradik_iters")) { h->ik.grad_iters = (int)value; return AVSIM_OK; }
-    if (h->phys.set_option(name, value)) {
-        if (!std::strcmp(name, "num_joints")) h->nj = (int)value;
-        return AVSIM_OK;
+    try {
+        if (h->phys.set_option(name, value)) {
+            if (!std::strcmp(name, "num_joints")) h->nj = (int)value;
+            return AVSIM_OK;
+        }
+    } catch (const std::exception& ex) {
+        h->set_error("avsim_set_option(%s): %s", name, ex.what());
+        return AVSIM_EHIP;
     }
     h->set_error("avsim_set_option: unknown option '%s'", name);
     return AVSIM_EINVAL;
@@ -430,14 +451,14 @@ int avsim_set_option(avsim_t* h, const char* name, double value) {
 
 int avsim_sync(avsim_t* h) {
     if (!h) return AVSIM_EINVAL;
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return AVSIM_OK;
 }
 
 int avsim_set_stream(avsim_t* h, void* s) {
     if (!h) return AVSIM_EINVAL;
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     h->stream = (hipStream_t)s;
@@ -447,14 +468,14 @@ int avsim_set_stream(avsim_t* h, void* s) {
 
 int avsim_event_record(avsim_t* h, int slot) {
     if (!h || slot < 0 || slot >= 16) return AVSIM_EINVAL;
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     HIPCHK(h, hipEventRecord(h->ev[slot], h->stream));
     return AVSIM_OK;
 }
 
 int avsim_event_elapsed_ms(avsim_t* h, int a, int b, float* ms) {
     if (!h || !ms || a < 0 || a >= 16 || b < 0 || b >= 16) return AVSIM_EINVAL;
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     HIPCHK(h, hipEventSynchronize(h->ev[b]));
     HIPCHK(h, hipEventElapsedTime(ms, h->ev[a], h->ev[b]));
     return AVSIM_OK;
@@ -462,7 +483,7 @@ int avsim_event_elapsed_ms(avsim_t* h, int a, int b, float* ms) {
 
 int avsim_kernel_time(avsim_t* h, int reset, double* total_ms, int64_t* launches) {
     if (!h) return AVSIM_EINVAL;
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     double tot = 0;
     for (size_t i = 0; i + 1 < h->kev_used; i += 2) {
         float ms = 0;
@@ -478,7 +499,7 @@ int avsim_kernel_time(avsim_t* h, int reset, double* total_ms, int64_t* launches
 
 int avsim_observe(avsim_t* h, double* agent_pos, int32_t* reward, uint8_t* success) {
     if (!h) return AVSIM_EINVAL;
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     int rc;
     void *dap = nullptr, *drw = nullptr, *dsu = nullptr;
     size_t N = h->N;
@@ -498,7 +519,7 @@ int avsim_observe(avsim_t* h, double* agent_pos, int32_t* reward, uint8_t* succe
 
 int avsim_fk_jac(avsim_t* h, int arm, int n, const double* q, double* T, double* J) {
     if (!h || arm < 0 || arm > 2 || n <= 0 || !q) { if (h) h->set_error("avsim_fk_jac: bad arguments"); return AVSIM_EINVAL; }
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     int nj = h->ik.arm[arm].n, rc;
     const void* dq;
     void *dT = nullptr, *dJ = nullptr;
@@ -521,7 +542,7 @@ int avsim_ik(avsim_t* h, int arm, int controller, int max_iters, int n, const do
         return AVSIM_EINVAL;
     }
     if (controller == 1 && arm == 2) { h->set_error("avsim_ik: GradIK is defined for the 6-DoF manipulators only"); return AVSIM_EINVAL; }
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     int nj = h->ik.arm[arm].n, rc;
     int iters = max_iters > 0 ? max_iters : (controller == 0 ? h->ik.diff_iters : h->ik.grad_iters);
     const void *dq, *dp, *dqt;
@@ -552,7 +573,7 @@ static int reset_impl(avsim_t* h, const uint8_t* mask, const double* obj) {
     if ((rc = h->in(1, obj, sizeof(double) * h->N * h->nobj * 7, &dobj))) return rc;
     hipLaunchKernelGGL(k_reset<real>, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->N, h->nq, h->nv, h->nu, h->nobj,
                        (const unsigned char*)dm, (const double*)dobj, h->phys.d_qpos_home, h->phys.d_ctrl_home, h->phys.d_obj_qadr,
-                       (real*)h->d_qpos, (real*)h->d_qvel, (real*)h->d_ctrl, (real*)h->d_warm, h->d_latch);
+                       (real*)h->d_qpos, (real*)h->d_qvel, (real*)h->d_ctrl, (real*)h->d_warm, h->d_latch, h->phys.d_obj_reset);
     HIPCHK(h, hipGetLastError());
     // mj_forward (env.py:244, 538): refresh kinematics + contacts of the new state, no time stepping
     if ((rc = h->phys.launch(h->stream, h->N, 0, nullptr, h->nj, h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, h->d_latch, nullptr, nullptr,
@@ -565,7 +586,7 @@ extern "C" {
 
 int avsim_reset(avsim_t* h, const uint8_t* mask, const double* obj_qpos) {
     if (!h || !obj_qpos) { if (h) h->set_error("avsim_reset: obj_qpos is required"); return AVSIM_EINVAL; }
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     return h->f64 ? reset_impl<double>(h, mask, obj_qpos) : reset_impl<float>(h, mask, obj_qpos);
 }
 
@@ -595,7 +616,7 @@ static int step_common(avsim_t* h, const float* d_action, int nsub, double* agen
 
 int avsim_step(avsim_t* h, const float* action, int nsub, double* agent_pos, int32_t* reward, uint8_t* success) {
     if (!h || !action || nsub < 0) { if (h) h->set_error("avsim_step: bad arguments"); return AVSIM_EINVAL; }
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     const void* da;
     int rc;
     if ((rc = h->in(0, action, sizeof(float) * h->N * h->nj, &da))) return rc;
@@ -609,7 +630,7 @@ int avsim_step_cartesian(avsim_t* h, const double* action23, int ik_mode, int ns
         return AVSIM_EINVAL;
     }
     if (h->num_arms != 3) { h->set_error("avsim_step_cartesian: the 23-D Cartesian action drives three arms (sim_env.py:277-282)"); return AVSIM_EINVAL; }
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     const void* da;
     int rc;
     if ((rc = h->in(0, action23, sizeof(double) * h->N * 23, &da))) return rc;
@@ -656,7 +677,7 @@ static int get(avsim_t* h, int slot, double* dst, const void* src, size_t n) {
 
 int avsim_get_state(avsim_t* h, double* qpos, double* qvel, double* ctrl, double* warm) {
     if (!h) return AVSIM_EINVAL;
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     size_t N = h->N;
     int rc;
     if ((rc = get(h, 0, qpos, h->d_qpos, N * h->nq))) return rc;
@@ -669,7 +690,7 @@ int avsim_get_state(avsim_t* h, double* qpos, double* qvel, double* ctrl, double
 
 int avsim_set_state(avsim_t* h, const double* qpos, const double* qvel, const double* ctrl, const double* warm) {
     if (!h) return AVSIM_EINVAL;
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     size_t N = h->N;
     int rc;
     if ((rc = put(h, 0, qpos, h->d_qpos, N * h->nq))) return rc;
@@ -683,6 +704,20 @@ int avsim_set_state(avsim_t* h, const double* qpos, const double* qvel, const do
     return h->finish();
 }
 
+int avsim_get_latch(avsim_t* h, int32_t* latch) {
+    if (!h || !latch) return AVSIM_EINVAL;
+    AVS_ON_DEVICE(h);
+    HIPCHK(h, hipMemcpyAsync(latch, h->d_latch, sizeof(int32_t) * (size_t)h->N, h->io_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    return h->finish();
+}
+
+int avsim_set_latch(avsim_t* h, const int32_t* latch) {
+    if (!h || !latch) return AVSIM_EINVAL;
+    AVS_ON_DEVICE(h);
+    HIPCHK(h, hipMemcpyAsync(h->d_latch, latch, sizeof(int32_t) * (size_t)h->N, h->io_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    return h->finish();
+}
+
 int avsim_set_qpos(avsim_t* h, const double* qpos) {
     if (!h || !qpos) return AVSIM_EINVAL;
     return avsim_set_state(h, qpos, nullptr, nullptr, nullptr);
@@ -690,7 +725,7 @@ int avsim_set_qpos(avsim_t* h, const double* qpos) {
 
 int avsim_get_contacts(avsim_t* h, int32_t* ncon, int32_t* pairs, double* dist) {
     if (!h) return AVSIM_EINVAL;
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     size_t N = h->N, cap = h->phys.maxcon;
     if (h->io_device) {
         if (ncon) HIPCHK(h, hipMemcpyAsync(ncon, h->phys.d_ncon, N * 4, hipMemcpyDeviceToDevice, h->stream));
@@ -708,7 +743,7 @@ int avsim_get_contacts(avsim_t* h, int32_t* ncon, int32_t* pairs, double* dist) 
 /* debug: per-env cycle counters of the 8 physics phases of the last launch (option "profile_phases"); int64[N][10] */
 int avsim_get_phase_cycles(avsim_t* h, int64_t* out) {
     if (!h || !out || !h->phys.d_prof) return AVSIM_EINVAL;
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, h->phys.d_prof, (size_t)h->N * avs::PROF_W * 8, h->io_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return AVSIM_OK;
@@ -716,7 +751,7 @@ int avsim_get_phase_cycles(avsim_t* h, int64_t* out) {
 
 int avsim_get_diag(avsim_t* h, int32_t* diag) {
     if (!h || !diag) return AVSIM_EINVAL;
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     size_t N = h->N;
     if (h->io_device) {
         HIPCHK(h, hipMemcpyAsync(diag, h->phys.d_diag, N * 16, hipMemcpyDeviceToDevice, h->stream));
@@ -736,7 +771,7 @@ extern "C" {
 static int render_images(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, void* out, bool rgb) {
     const char* who = rgb ? "avsim_render_rgb" : "avsim_render_depth";
     if (!h || !cam_ids || !out) { if (h) h->set_error("%s: bad arguments", who); return AVSIM_EINVAL; }
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     int rc;
     void* dout = nullptr;
     const size_t bytes = (rgb ? 3 : sizeof(float)) * (size_t)h->N * ncam * height * width;
@@ -764,7 +799,7 @@ int avsim_camera_count(const avsim_t* h) { return h ? h->render.m.ncam : 0; }
 int avsim_reward_from_pairs(avsim_t* h, const int32_t* geom_pairs, int nsets, int cap, int32_t* latch, int32_t* reward) {
     if (!h || (!geom_pairs && cap > 0) || !reward || nsets < 0 || cap < 0) { if (h) h->set_error("avsim_reward_from_pairs: bad arguments"); return AVSIM_EINVAL; }
     if (nsets == 0) return AVSIM_OK;
-    DevGuard dev_guard_(h->device);
+    AVS_ON_DEVICE(h);
     int *dp = nullptr, *dl = nullptr, *dr = nullptr;
     const size_t pb = sizeof(int) * (size_t)nsets * (cap ? cap : 1) * 2, nb = sizeof(int) * (size_t)nsets;
     HIPCHK(h, hipMalloc(&dp, pb + 2 * nb));

@@ -110,6 +110,9 @@ struct DevModel {
     GLB_PTR(const real) eq_solimp;
     GLB_PTR(const real) qpos0;
     GLB_PTR(const real) qpos_home;   // state an env falls back to when its simulation diverges
+    int nobj;                        // free objects; their qpos addresses and the poses the env's episode started with (avsim_reset)
+    GLB_PTR(const int) obj_qadr;
+    const double* obj_reset;         // double[N][nobj][7]
     // geoms
     GLB_PTR(const int) geom_type;
     GLB_PTR(const int) geom_body;
@@ -2249,8 +2252,9 @@ struct Env {
     }
 
     // MuJoCo's mj_checkPos / mj_checkVel [EXT]: a state with NaN / Inf / huge entries is unusable; MuJoCo warns and resets
-    // the data, dm_control raises PhysicsError.  Batched: the env goes back to the home pose (default object poses), zero
-    // velocity, and the launch reports it through the NaN flag of avsim_get_diag; its neighbours are not affected.
+    // the data, dm_control raises PhysicsError.  Batched: the env goes back to the state its episode started from (home pose,
+    // the objects where avsim_reset put them), zero velocity, and the launch reports it through the NaN flag of avsim_get_diag;
+    // its neighbours are not affected.
     __device__ void check_divergence() {
         LDS_BASES();
         real *qpos = r + ka->lay.qpos, *qvel = r + ka->lay.qvel, *warm = r + ka->lay.warm;
@@ -2260,6 +2264,8 @@ struct Env {
         if (!__any(bad)) return;
         diverged = 1;
         for (int i = lane; i < ka->m.nq; i += G) qpos[i] = ka->m.qpos_home[i];
+        GSYNC();
+        for (int i = lane; i < ka->m.nobj * 7; i += G) qpos[ka->m.obj_qadr[i / 7] + i % 7] = (real)ka->m.obj_reset[((size_t)env * ka->m.nobj) * 7 + i];
         for (int i = lane; i < ka->m.nv; i += G) { qvel[i] = 0; warm[i] = 0; }
         if (lane == 0) (ii + ka->lay.misc)[7] = 0;      // the Verlet list is stale
         GSYNC();
@@ -2499,7 +2505,7 @@ struct PhysHost {
     DevModel<float> mf;
     DevModel<double> md;
     Layout lay;
-    double *d_qpos_home = nullptr, *d_ctrl_home = nullptr;
+    double *d_qpos_home = nullptr, *d_ctrl_home = nullptr, *d_obj_reset = nullptr;
     int* d_obj_qadr = nullptr;
     int *d_ncon = nullptr, *d_cpairs = nullptr, *d_diag = nullptr;
     int *d_cost = nullptr, *d_order = nullptr;     // per-env cost of the last step and the launch order made from it (k_env_order)
@@ -2643,6 +2649,13 @@ struct PhysHost {
         m.eq_polycoef = upr<real>(F("eq_polycoef")); m.eq_solref = upr<real>(F("eq_solref")); m.eq_solimp = upr<real>(F("eq_solimp"));
         m.qpos0 = upr<real>(F("qpos0"));
         m.qpos_home = upr<real>(F("qpos_home"));
+        m.obj_qadr = up(I("objects_qposadr")); m.nobj = (int)I("objects_qposadr").size();
+        {   // the poses an episode starts with: the model's own until avsim_reset says otherwise
+            auto home = F("qpos_home"); auto oa = I("objects_qposadr");
+            std::vector<double> o((size_t)N * oa.size() * 7);
+            for (int e = 0; e < N; e++) for (size_t k = 0; k < oa.size(); k++) for (int c = 0; c < 7; c++) o[((size_t)e * oa.size() + k) * 7 + c] = home[oa[k] + c];
+            d_obj_reset = up(o); m.obj_reset = d_obj_reset;
+        }
         // geoms: local rotation matrices, interior point in the body frame, world constants for static geoms
         auto gbody = I("geom_body");
         auto gpos = F("geom_pos"), gquat = F("geom_quat"), gbc = F("geom_bcenter");

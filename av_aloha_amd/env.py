@@ -144,8 +144,8 @@ class GuidedVisionEnv(_EnvBase):
         return {"pixels": self._pixels(), "agent_pos": self._squeeze(self._agent_pos).copy()}
 
     def _check_diverged(self):
-        """Divergence flag of the last step (bit 0 of diag[3], include/avsim.h): the library has put such an env back to the home
-        pose with the model's default object poses, so its rewards from here on belong to a different episode."""
+        """Divergence flag of the last step (bit 0 of diag[3], include/avsim.h): the library has put such an env back to the state
+        its episode started from (home pose, the objects where reset() put them, zero velocity)."""
         div = (self.sim.diag()[:, 3] & 1).astype(bool)
         if self.num_envs == 1 and div[0]:
             raise PhysicsError("the simulation state diverged (NaN / Inf / > 1e6) during the step; the env was put back to the "
@@ -223,11 +223,13 @@ class GuidedVisionEnv(_EnvBase):
         if self._model_arms == arms:
             return
         q, v, c, w = self.sim.get_state()
+        latch = self.sim.get_latch()                 # SewNeedle's threaded_needle stage carries over (env.py:596, :686-689)
         old = self.sim
         self.sim = BatchedSim(self.task, arms, self.num_envs, device=self._device, f64=self._f64, options=self._options)
         self.sim.set_option("num_joints", self.num_joints)
         self.sim.nj = self.sim.h.nj = self.num_joints
         self.sim.set_state(q, v, c, w)
+        self.sim.set_latch(latch)
         old.close()
         self._model_arms = arms
         self._refresh_agent_pos()

@@ -14,8 +14,14 @@ from .constants import MODEL_DIR, SIM_PHYSICS_ENV_STEP_RATIO
 TASK_KEYS = ("insert_peg", "slot_insertion", "sew_needle", "tube_transfer", "hook_package")
 
 
-def load_blob(task, num_arms):
-    base = os.path.join(MODEL_DIR, f"{task}_{num_arms}arms")
+VARIANT_PREFIX = {"gym": "", "data_collection": "dc_"}
+
+
+def load_blob(task, num_arms, variant="gym"):
+    """variant "gym": compiled from gym_guided_vision/gym_guided_vision/assets (the gym envs); "data_collection": from
+    data_collection_scripts/assets, which sim_env.py loads (data_collection_scripts/constants.py:5): default solref on the needle
+    and the peg, ZED fovy 90 (compiler --variant)."""
+    base = os.path.join(MODEL_DIR, f"{VARIANT_PREFIX[variant]}{task}_{num_arms}arms")
     with open(base + ".avm", "rb") as f:
         blob = f.read()
     with open(base + ".json") as f:
@@ -24,9 +30,9 @@ def load_blob(task, num_arms):
 
 
 class BatchedSim:
-    def __init__(self, task, num_arms=3, num_envs=1, device=0, f64=False, options=None):
+    def __init__(self, task, num_arms=3, num_envs=1, device=0, f64=False, options=None, variant="gym"):
         assert task in TASK_KEYS, task
-        blob, self.manifest = load_blob(task, num_arms)
+        blob, self.manifest = load_blob(task, num_arms, variant)
         self.h = _ffi.Handle(blob, num_envs, device, _ffi.AVSIM_F64_PHYSICS if f64 else 0)
         self.N = num_envs
         for k in ("nq", "nv", "nu", "nj", "nobj", "max_reward", "maxcon", "maxefc"):
@@ -67,6 +73,16 @@ class BatchedSim:
     def set_state(self, qpos=None, qvel=None, ctrl=None, warm=None):
         arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (qpos, qvel, ctrl, warm)]
         self.h.check(self.h.L.avsim_set_state(self.h.h, *[_ffi.ptr(a) for a in arrs]))
+
+    def get_latch(self):
+        """Per-env reward latch int32 [N] (SewNeedle's _threaded_needle, env.py:602): state next to qpos / qvel / ctrl."""
+        l = np.empty(self.N, dtype=np.int32)
+        self.h.check(self.h.L.avsim_get_latch(self.h.h, l.ctypes.data))
+        return l
+
+    def set_latch(self, latch):
+        l = np.ascontiguousarray(latch, dtype=np.int32).reshape(self.N)
+        self.h.check(self.h.L.avsim_set_latch(self.h.h, l.ctypes.data))
 
     def set_qpos(self, qpos):
         q = np.ascontiguousarray(qpos, dtype=np.float64).reshape(self.N, self.nq)

@@ -47,18 +47,24 @@ class GuidedVisionEnv:
 
     task = None
 
-    def __init__(self, cameras=CAMERAS, num_envs: int = 1, device: int = 0, f64: bool = False, options: dict | None = None):
+    def __init__(self, cameras=CAMERAS, num_envs: int = 1, device: int = 0, f64: bool = False, options: dict | None = None,
+                 variant: str = "data_collection"):
         for camera in cameras:
             assert camera in CAMERAS, f"Invalid camera name: {camera}"
         self._cameras = list(cameras)
         if self.task is None:
             raise NotImplementedError("use one of the task classes or make_sim_env()")
         self.num_envs = int(num_envs)
-        self.sim = BatchedSim(self.task, 3, self.num_envs, device=device, f64=f64, options=options)
+        # the reference's sim_env.py loads data_collection_scripts/assets (constants.py:5), not the gym package's assets: the needle
+        # and the peg have MuJoCo's default solref there (task_sew_needle.xml:17, task_insert_peg.xml:7) and the ZED cameras fovy 90
+        # (aloha_sim.xml:357-358); variant="gym" runs the Cartesian env on the gym assets' model instead
+        self.variant = variant
+        self.sim = BatchedSim(self.task, 3, self.num_envs, device=device, f64=f64, options=options, variant=variant)
         from .compiler.compile import read_blob
         from .constants import MODEL_DIR
+        from .sim import VARIANT_PREFIX
         import os
-        md = read_blob(os.path.join(MODEL_DIR, f"{self.task}_3arms.avm"))
+        md = read_blob(os.path.join(MODEL_DIR, f"{VARIANT_PREFIX[variant]}{self.task}_3arms.avm"))
         self._qadr = md["obs_qposadr"].astype(np.int64)          # LEFT(6+left_left_finger), RIGHT(6+right_right_finger), MIDDLE(7)
         self._dadr = md["obs_dofadr"].astype(np.int64)
         lo, hi = md["grip_range"]

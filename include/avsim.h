@@ -107,10 +107,15 @@ int avsim_set_qpos(avsim_t* h, const double* qpos);
 /* full state for checkpoint / tests: qpos[N][nq], qvel[N][nv], ctrl[N][nu], warmstart[N][nv]; NULL = skip */
 int avsim_get_state(avsim_t* h, double* qpos, double* qvel, double* ctrl, double* warmstart);
 int avsim_set_state(avsim_t* h, const double* qpos, const double* qvel, const double* ctrl, const double* warmstart);
+/* the per-env reward latch int32[N] (SewNeedle's _threaded_needle, env.py:602, :631, :673, :686-689; 0 for the other tasks): part
+ * of an env's state next to qpos / qvel / ctrl -- a checkpoint or a move of the env to another handle carries it along */
+int avsim_get_latch(avsim_t* h, int32_t* latch);
+int avsim_set_latch(avsim_t* h, const int32_t* latch);
 /* contacts of the current state, env.py:436-441 view: ncon int32[N], geom pairs int32[N][cap][2], dist double[N][cap] */
 int avsim_get_contacts(avsim_t* h, int32_t* ncon, int32_t* geom_pairs, double* dist);
 /* per-env diagnostics of the last step: int32[N][4] = {ncon, nefc, overflow flags, packed}; packed = divergence flag (bit 0: the state became NaN / Inf / > 1e6 during the step and the env was put back to the
- * home pose with zero velocity, as MuJoCo resets its data on a bad state) |
+ * state its episode started from -- home pose, the objects where the last avsim_reset put them, zero velocity --, as MuJoCo resets
+ * its data on a bad state) |
  * broad-phase survivors (bits 8-15) | Newton iterations summed over the substeps (bits 16-27) | their maximum, saturated at 15 (bits 28-31) */
 int avsim_get_diag(avsim_t* h, int32_t* diag);
 

@@ -15,11 +15,12 @@ from orc_ffi import dp
 
 TASK_SEED = {"slot_insertion": 1000, "sew_needle": 2000}
 GRIP_RANGE = (0.002, 0.037)
+VARIANT = "data_collection"        # the model av_aloha_amd.sim_env runs (data_collection_scripts/assets, as the reference's sim_env.py)
 
 
 def oracle_home(task="slot_insertion"):
     """{'left','right','middle'} -> [7] eef poses (xyz + quat wxyz) at the home ctrl, through the oracle's FK (kinematics.py:17-24)."""
-    e = OrcEnv(task, 3)
+    e = OrcEnv(task, 3, VARIANT)
     ch = np.array(e.ctrl, dtype=np.float64)
     Ts = []
     for arm, sl in ((0, slice(0, 6)), (1, slice(7, 13)), (2, slice(14, 21))):
@@ -54,7 +55,7 @@ def make_script(task, home, qpos0):
 
 
 def _new_env(task, pose):
-    e = OrcEnv(task, 3)
+    e = OrcEnv(task, 3, VARIANT)
     e.d.solver = 1                  # Newton, the reference's solver (MuJoCo default; aloha_sim.xml:4 does not change it)
     e.reset(pose)
     return e

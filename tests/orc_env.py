@@ -35,10 +35,10 @@ class Data(C.Structure):
 
 
 class OrcEnv:
-    def __init__(self, task="slot_insertion", num_arms=3):
+    def __init__(self, task="slot_insertion", num_arms=3, variant="gym"):
         self.L = lib()
-        self.m = load_model(task, num_arms)
-        self.man = json.load(open(os.path.join(ROOT, "models", f"{task}_{num_arms}arms.json")))
+        self.m = load_model(task, num_arms, variant)
+        self.man = json.load(open(os.path.join(ROOT, "models", f"{'dc_' if variant == 'data_collection' else ''}{task}_{num_arms}arms.json")))
         self.nq, self.nv, self.nu = self.man["nq"], self.man["nv"], self.man["nu"]
         self.nj = 21 if num_arms == 3 else 14
         self.L.orc_data_new.restype = C.c_void_p

@@ -36,8 +36,8 @@ def lib():
     return _LIB
 
 
-def load_model(task="slot_insertion", num_arms=3):
-    path = os.path.join(ROOT, "models", f"{task}_{num_arms}arms.avm")
+def load_model(task="slot_insertion", num_arms=3, variant="gym"):
+    path = os.path.join(ROOT, "models", f"{'dc_' if variant == 'data_collection' else ''}{task}_{num_arms}arms.avm")
     b = open(path, "rb").read()
     m = lib().orc_model_load(b, C.c_size_t(len(b)))
     assert m

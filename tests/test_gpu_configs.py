@@ -101,7 +101,7 @@ def test_config3_scripted_grasp_and_lift():
     from av_aloha_amd.sim_env import make_sim_env
     from scripted import grasp_lift_targets
     n = 256
-    env = make_sim_env("sim_sew_needle", cameras=[], num_envs=n)
+    env = make_sim_env("sim_sew_needle", cameras=[], num_envs=n, variant="gym")      # config 3 is the gym env's model
     poses = poses_for("sew_needle", np.arange(n), 2000)
     env.sim.reset(poses)
     obs = env.get_obs()
@@ -149,6 +149,9 @@ def test_divergence_is_contained_and_flagged():
     assert np.isfinite(q2).all() and np.isfinite(v2).all() and np.isfinite(ap).all()
     assert (d[:, 3] & 1).tolist() == [0, 0, 1, 0]
     assert np.abs(q2[2, :23] - md["qpos_home"][:23]).max() < 0.2 and np.abs(v2[2]).max() < 10      # back near the home pose
+    # ... with the objects where THIS episode's reset put them (not at the model's default poses), resting on the table
+    assert np.abs(q2[2, 23:25] - poses[2, 0, :2]).max() < 1e-3 and np.abs(q2[2, 30:32] - poses[2, 1, :2]).max() < 1e-3
+    assert np.abs(q2[2, 23:25] - md["qpos_home"][23:25]).max() > 1e-3 or np.abs(q2[2, 30:32] - md["qpos_home"][30:32]).max() > 1e-3
     # the other envs did exactly what they do without the bad neighbour
     ref = make("slot_insertion", 3, n)
     ref.reset(poses)

@@ -97,3 +97,21 @@ def test_hide_and_show_middle_arm_move_the_camera_arm_base():
     env2.hide_middle_arm()                           # no-op on a 2-arm env
     env2.close()
     env.close()
+
+
+def test_hide_middle_arm_keeps_the_sew_needle_latch():
+    """The staged SewNeedle reward remembers that the needle was threaded (env.py:602, :673, :686-689).  hide_middle_arm only moves a
+    body in the reference, so the memory must survive it here too (the env continues on the task's other compiled model)."""
+    from av_aloha_amd.env import make
+    env = make("gym_guided_vision/SewNeedle-3Arms-v0", cameras=[], num_envs=3)
+    np.random.seed(5)
+    env.reset()
+    assert env.sim.get_latch().tolist() == [0, 0, 0]
+    env.sim.set_latch(np.array([0, 1, 0], dtype=np.int32))
+    env.hide_middle_arm()
+    assert env.sim.get_latch().tolist() == [0, 1, 0]
+    env.show_middle_arm()
+    assert env.sim.get_latch().tolist() == [0, 1, 0]
+    env.reset()
+    assert env.sim.get_latch().tolist() == [0, 0, 0]           # env.py:631: reset clears it
+    env.close()
