@@ -13,14 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _bench(extra, dump, nproc):
+def _bench(extra, dump, nproc, port="29533"):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     common = ["--config", "4", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--dump", dump] + extra
     if nproc == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-               "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--backend", "gloo", "--share-gpu"] + common
+               "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--backend", "gloo", "--share-gpu"] + common
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-3000:]
@@ -39,3 +39,20 @@ def test_two_ranks_gather_what_one_rank_computes(tmp_path):
     for k in ("ret", "succ", "agent_sum"):
         assert a[k].shape == (8192,) and np.array_equal(a[k], b[k]), k
     assert np.isfinite(a["agent_sum"]).all() and np.ptp(a["agent_sum"]) > 0      # per-env random walks: the rows differ
+
+
+def test_eight_ranks_keep_the_rank_order_of_the_gathered_vector(tmp_path):
+    """The 8-GPU form of BASELINE configs[3] as a dry run on one GPU: eight ranks x 512 envs (gloo rendezvous, all on cuda:0).  The
+    gathered vector is ordered by rank = by global env id: entry i is the env a single rank computes as its env i."""
+    d8, d1 = str(tmp_path / "eight.npz"), str(tmp_path / "one.npz")
+    eight = _bench(["--envs-per-gpu", "512"], d8, 8, port="29541")
+    assert eight["n_gpus"] == 8 and eight["n_ranks_seen"] == 8 and eight["config"]["gathered_envs"] == 4096 and eight["scaling"] == "weak"
+    assert eight["is_headline_metric"] is False and "HookPackage" in eight["metric"]
+    one = _bench(["--envs-per-gpu", "4096"], d1, 1)
+    assert one["n_ranks_seen"] == 1
+    a, b = np.load(d8), np.load(d1)
+    for k in ("ret", "succ", "agent_sum"):
+        assert a[k].shape == (4096,) and np.array_equal(a[k], b[k]), k
+    # strong-scaling flag: a fixed total split over the ranks
+    st = _bench(["--envs-total", "1024"], str(tmp_path / "s.npz"), 2, port="29547")
+    assert st["scaling"] == "strong" and st["config"]["envs_per_gpu"] == 512 and st["config"]["envs_total"] == 1024
