@@ -2337,36 +2337,45 @@ struct Env {
     }
 };
 
-// WPB wavefronts per block, one env per wavefront; the block shares one LDS copy of the hot model tables
-template <typename real, int G, int WPB>
+// Persistent workgroups: one per CU (two where two fit its LDS), up to MAXW wavefronts each, one env per wavefront at a time.  The
+// block copies the hot model tables into LDS once; after that every wave works on its own: it takes the next env of the launch from
+// a global counter (most expensive first when env_order is given), runs the env's whole step out of its own LDS record, and comes
+// back for another.  A slow env therefore holds up one wave's slot, not its block's LDS (static block -> env maps made a block
+// wait for the slowest of its eight).  No block barrier after the table copy.
+template <typename real, int G, int MAXW>
 #ifndef AVSIM_PHYS_ATTR
 #ifdef AVSIM_TU_F64
 #define AVSIM_PHYS_ATTR
 #else
-// two waves per SIMD for every block size (<= 256 VGPRs): two small blocks per CU then hold as many envs as one large block
+// two waves per SIMD (<= 256 VGPRs)
 #define AVSIM_PHYS_ATTR __attribute__((amdgpu_waves_per_eu(2)))
 #endif
 #endif
-__global__ void __launch_bounds__(64 * WPB) AVSIM_PHYS_ATTR k_phys(KPtr<real> ka, const real* __restrict__ img_real, const int* __restrict__ img_int, int N, int nsub, int pgs_iters, const float* __restrict__ action,
+__global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> ka, const real* __restrict__ img_real, const int* __restrict__ img_int, int N, int nsub, int pgs_iters, const float* __restrict__ action,
                                              int want_reward, real* __restrict__ g_qpos, real* __restrict__ g_qvel, real* __restrict__ g_ctrl,
                                              real* __restrict__ g_warm, int* __restrict__ g_latch, double* __restrict__ o_agent,
                                              int* __restrict__ o_reward, unsigned char* __restrict__ o_success, int* __restrict__ o_ncon,
                                              int* __restrict__ o_cpairs, double* __restrict__ o_cdist, int* __restrict__ o_diag, int max_reward, int export_contacts, long long* __restrict__ o_prof, float* __restrict__ o_xpose,
-                                             const int* __restrict__ env_order, int* __restrict__ o_cost) {
+                                             const int* __restrict__ env_order, int* __restrict__ o_cost, int* __restrict__ work_head, int* __restrict__ work_next) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(G == 64, "one env per wavefront");
+    const int wpb = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = 0;
-    // wave -> env: in the order of the previous launch's cost, most expensive first (k_env_order), or the identity
-    const int slot = blockIdx.x * WPB + wave;
-    const int env = (env_order && slot < N) ? env_order[slot] : slot;
-    const long long t_launch = __builtin_readcyclecounter();
     // hot model tables -> LDS, once per block
-    real* lr = reinterpret_cast<real*>(smem + (size_t)WPB * ka->lay.bytes_per_env);
+    real* lr = reinterpret_cast<real*>(smem + (size_t)wpb * ka->lay.bytes_per_env);
     int* li = reinterpret_cast<int*>(lr + ka->mo.nreal);
-    for (int i = threadIdx.x; i < ka->mo.nreal; i += 64 * WPB) lr[i] = img_real[i];
-    for (int i = threadIdx.x; i < ka->mo.nint; i += 64 * WPB) li[i] = img_int[i];
-    if (WPB > 1) __syncthreads(); else GSYNC();
-    if (env >= N) return;  // whole groups drop out together; no block barrier is used below
+    for (int i = threadIdx.x; i < ka->mo.nreal; i += blockDim.x) lr[i] = img_real[i];
+    for (int i = threadIdx.x; i < ka->mo.nint; i += blockDim.x) li[i] = img_int[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *work_next = 0;      // the NEXT launch's counter (launches of a handle follow each other on its stream)
+    __syncthreads();
+  for (;;) {
+    // wave -> env: next slot of the launch, in the order of the previous launch's cost (k_env_order) or in index order
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(work_head, 1);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot >= N) break;
+    const int env = env_order ? env_order[slot] : slot;
+    const long long t_launch = __builtin_readcyclecounter();
     real* r = reinterpret_cast<real*>(smem + (size_t)wave * ka->lay.bytes_per_env);
     int* ii = reinterpret_cast<int*>(r + ka->lay.nreal);
     Env<real, G> E(ka, r, ii, lane, grp, lr, li);
@@ -2460,6 +2469,8 @@ __global__ void __launch_bounds__(64 * WPB) AVSIM_PHYS_ATTR k_phys(KPtr<real> ka
         for (int i = 0; i < ka->m.nq; i++) bad |= !(fabs(r[ka->lay.qpos + i]) < real(1e6));
         o_diag[4 * env] = ncon; o_diag[4 * env + 1] = nefc_last; o_diag[4 * env + 2] = ii[ka->lay.misc + 2]; o_diag[4 * env + 3] = (bad ? 1 : 0) | ((ii[ka->lay.misc + 3] & 0xff) << 8) | ((E.nit_sum & 0xfff) << 16) | ((E.nit_max < 15 ? E.nit_max : 15) << 28);
     }
+    GSYNC();      // the record is reused by the wave's next env
+  }
 }
 
 // Launch order of the envs: by the cost (shader-clock cycles) of their last step, most expensive first.  A block holds its LDS
@@ -2522,7 +2533,11 @@ struct PhysHost {
     int* d_img_int = nullptr;
     void* d_kargs = nullptr;        // KArgs<float|double> in device memory
     bool kargs_dirty = true;
-    unsigned attr_done = 0;         // kernel instances whose LDS-size attribute this handle has set (bit WPB, bit 0 = f64)
+    unsigned attr_done = 0;         // the kernel's LDS-size attribute, the CU count and the work counters are set up (once per handle)
+    int num_cu = 256;               // CUs of the handle's device (persistent blocks: one per CU's LDS share)
+    int persist_over = 1;           // option "persist_blocks": blocks launched per resident slot (1 = exactly what the CUs hold)
+    int* d_head = nullptr;          // two work counters, used alternately: a launch takes envs from one and zeroes the other
+    unsigned long long launch_count = 0;
     // device pointer that converts to the plain and to the global-address-space pointer types
     template <typename T>
     struct DevPtr {
@@ -2847,6 +2862,7 @@ struct PhysHost {
         if (n == "num_joints") { if (v != 14 && v != 21) return false; mf.nj = md.nj = (int)v; return true; }
         if (n == "order_envs") { order_envs = v != 0; return true; }
         if (n == "noslip_per_tree") { mf.noslip_per_tree = md.noslip_per_tree = v != 0; return true; }
+        if (n == "persist_blocks") { int x = (int)v; if (x >= 1 && x <= 64) { persist_over = x; return true; } return false; }
         if (n == "waves_per_block") { int x = (int)v; if (x >= 0 && x <= 8) { wpb_override = x; return true; } return false; }
         if (n == "profile_phases") {
             if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * PROF_W, 0));
@@ -2865,21 +2881,33 @@ struct PhysHost {
         return false;
     }
 
-    template <typename real, int G, int WPB>
+    template <typename real, int G, int MAXW>
     int launch_t(hipStream_t st, const DevModel<real>& m, int nsub, const float* action, void* qpos, void* qvel, void* ctrl, void* warm,
-                 int* latch, double* agent, int32_t* reward, uint8_t* success, std::string& err) {
-        int epb = WPB;
-        size_t shmem = (size_t)lay.bytes_per_env * epb + (size_t)moff.nreal * sizeof(real) + (size_t)moff.nint * 4;
-        auto kern = k_phys<real, G, WPB>;
-        // once per handle (= per device) and kernel instance: a second handle on another GPU of the same process sets its own
-        const unsigned attr_bit = 1u << (sizeof(real) == 8 ? 0 : WPB);     // WPB <= 16
-        if (!(attr_done & attr_bit)) {
+                 int* latch, double* agent, int32_t* reward, uint8_t* success, int wpb, std::string& err) {
+        if (wpb > MAXW) wpb = MAXW;
+        if (wpb < 1) wpb = 1;
+        const size_t tables = (size_t)moff.nreal * sizeof(real) + (size_t)moff.nint * 4;
+        size_t shmem = (size_t)lay.bytes_per_env * wpb + tables;
+        auto kern = k_phys<real, G, MAXW>;
+        if (!attr_done) {    // once per handle (= per device): a second handle on another GPU of the same process sets its own
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); return -3; }
-            attr_done |= attr_bit;
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) num_cu = prop.multiProcessorCount;
+            if (!d_head) {
+                if (hipMalloc((void**)&d_head, 2 * sizeof(int)) != hipSuccess) { err = "hipMalloc(work counters) failed"; return -3; }
+                allocs.push_back(d_head);
+                (void)hipMemset(d_head, 0, 2 * sizeof(int));
+            }
+            attr_done = 1;
         }
-        if (shmem > 160 * 1024) { err = "per-block LDS exceeds 160 KiB; lower maxefc/maxcon or raise the group size"; return -1; }
-        dim3 grid((N + epb - 1) / epb);
+        if (shmem > 160 * 1024) { err = "per-block LDS exceeds 160 KiB; lower maxefc/maxcon"; return -1; }
+        // persistent blocks: as many as the CUs hold at once (LDS bound), never more than the envs need
+        const int per_cu = (int)((160 * 1024) / shmem) > 0 ? (int)((160 * 1024) / shmem) : 1;
+        int nblk = num_cu * per_cu * (persist_over > 0 ? persist_over : 1);
+        if (nblk > (N + wpb - 1) / wpb) nblk = (N + wpb - 1) / wpb;
+        dim3 grid(nblk);
         if (kargs_dirty) {
             KArgs<real> ka{m, lay, moff};
             if (!d_kargs) { if (hipMalloc(&d_kargs, sizeof(KArgs<double>)) != hipSuccess) { err = "hipMalloc(kernel arguments) failed"; return -3; } allocs.push_back(d_kargs); }
@@ -2889,13 +2917,16 @@ struct PhysHost {
         }
         // launch order from the previous step's per-env cost
         const int* order = nullptr;
-        if (order_envs && have_cost && nsub > 0 && N > WPB) {
+        if (order_envs && have_cost && nsub > 0 && N > wpb) {
             hipLaunchKernelGGL(k_env_order, dim3(1), dim3(1024), 0, st, (const int*)d_cost, d_order, N);
             order = d_order;
         }
-        hipLaunchKernelGGL(kern, grid, dim3(64 * WPB), shmem, st, (KPtr<real>)d_kargs, (const real*)d_img_real, (const int*)d_img_int, N, nsub, pgs_iters, action, (reward || success) && (nsub > 0 || force_reward) ? 1 : 0,
+        int* head = d_head + (launch_count & 1);
+        int* next = d_head + ((launch_count + 1) & 1);
+        launch_count++;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * wpb), shmem, st, (KPtr<real>)d_kargs, (const real*)d_img_real, (const int*)d_img_int, N, nsub, pgs_iters, action, (reward || success) && (nsub > 0 || force_reward) ? 1 : 0,
                            (real*)qpos, (real*)qvel, (real*)ctrl, (real*)warm, latch, agent, (int*)reward, (unsigned char*)success, d_ncon,
-                           d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof, d_xpose, order, order_envs ? d_cost : (int*)nullptr);
+                           d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof, d_xpose, order, order_envs ? d_cost : (int*)nullptr, head, next);
         if (nsub > 0) have_cost = true;
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("physics kernel launch: ") + hipGetErrorString(e); return -3; }
@@ -2908,22 +2939,12 @@ struct PhysHost {
         (void)N_; (void)nj;
         // the double-precision kernel lives in its own translation unit (avsim_phys_f64.hip), compiled without FMA contraction
         if (f64) return phys_launch_f64(*this, st, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
-        // as many envs (wavefronts) per block as fit next to one copy of the tables in 160 KiB, at most 4 (one per SIMD)
+        // as many envs (wavefronts) per block as fit next to one copy of the tables in 160 KiB, at most 8 (two per SIMD)
         size_t tables = (size_t)moff.nreal * 4 + (size_t)moff.nint * 4;
         int wpb = (int)((160 * 1024 - tables) / (size_t)lay.bytes_per_env);
         if (wpb > 8) wpb = 8;
-        // two blocks of half the size per CU when they fit (each with its own copy of the tables): the same number of envs in flight,
-        // but a block waits for the slowest of fewer envs
-        if (wpb >= 4 && wpb % 2 == 0 && 2 * (tables + (size_t)(wpb / 2) * lay.bytes_per_env) <= 160 * 1024) wpb /= 2;
         if (wpb_override > 0) wpb = wpb_override;
-        if (wpb >= 8) return launch_t<float, 64, 8>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
-        if (wpb >= 7) return launch_t<float, 64, 7>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
-        if (wpb >= 6) return launch_t<float, 64, 6>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
-        if (wpb >= 5) return launch_t<float, 64, 5>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
-        if (wpb >= 4) return launch_t<float, 64, 4>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
-        if (wpb >= 3) return launch_t<float, 64, 3>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
-        if (wpb >= 2) return launch_t<float, 64, 2>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
-        return launch_t<float, 64, 1>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
+        return launch_t<float, 64, 8>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, wpb, err);
     }
 #endif
 };

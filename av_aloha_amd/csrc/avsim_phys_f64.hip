@@ -11,7 +11,7 @@ namespace avs {
 int phys_launch_f64(PhysHost& ph, hipStream_t st, int nsub, const float* action, void* qpos, void* qvel, void* ctrl, void* warm, int* latch,
                     double* agent, int32_t* reward, uint8_t* success, std::string& err) {
     // double precision doubles the LDS record; one env per wave only
-    return ph.launch_t<double, 64, 1>(st, ph.md, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
+    return ph.launch_t<double, 64, 1>(st, ph.md, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, 1, err);
 }
 
 }  // namespace avs

@@ -166,7 +166,8 @@ class GuidedVisionEnv(_EnvBase):
         self.sim.reset(poses)
         self._refresh_agent_pos()
         self._reward[:] = 0
-        return self._obs(), {"is_success": self._squeeze(np.zeros(self.num_envs, dtype=bool))}
+        # env.py:249: a plain False for one env; a batch gets one flag per env
+        return self._obs(), {"is_success": False if self.num_envs == 1 else np.zeros(self.num_envs, dtype=bool)}
 
     def step(self, action):
         a = np.asarray(action, dtype=np.float32).reshape(self.num_envs, self.num_joints)
