@@ -10,16 +10,16 @@ mkdir -p $o
 python bench.py --steps 100 --warmup 10 > $o/bench_config2.json 2> $o/bench2.err
 python bench.py --config 3 --steps 240 --warmup 5 > $o/bench_config3.json 2> $o/bench3.err
 python bench.py --config 4 --steps 100 --warmup 10 > $o/bench_config4.json 2> $o/bench4.err
-python bench.py --config 5 --steps 10 --warmup 2 --no-cpu-baseline > $o/bench_config5.json 2> $o/bench5.err
-python bench.py --f64 --steps 20 --warmup 3 --no-cpu-baseline > $o/bench_config2_f64.json 2> $o/bench2f64.err
-rocprofv3 --kernel-trace --stats -d $o/trace2 -o t -f csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $o/trace2.log 2>&1
-rocprofv3 --kernel-trace --stats -d $o/trace3 -o t -f csv -- python bench.py --config 3 --steps 60 --warmup 150 --no-cpu-baseline > $o/trace3.log 2>&1
-rocprofv3 --kernel-trace --stats -d $o/trace4 -o t -f csv -- python bench.py --config 4 --steps 20 --warmup 30 --no-cpu-baseline > $o/trace4.log 2>&1
-rocprofv3 --kernel-trace --stats -d $o/trace5 -o t -f csv -- python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline > $o/trace5.log 2>&1
+python bench.py --config 5 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $o/bench_config5.json 2> $o/bench5.err
+python bench.py --f64 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $o/bench_config2_f64.json 2> $o/bench2f64.err
+rocprofv3 --kernel-trace --stats -d $o/trace2 -o t -f csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $o/trace2.log 2>&1
+rocprofv3 --kernel-trace --stats -d $o/trace3 -o t -f csv -- python bench.py --config 3 --steps 60 --warmup 150 --no-cpu-baseline --no-extras > $o/trace3.log 2>&1
+rocprofv3 --kernel-trace --stats -d $o/trace4 -o t -f csv -- python bench.py --config 4 --steps 20 --warmup 30 --no-cpu-baseline --no-extras > $o/trace4.log 2>&1
+rocprofv3 --kernel-trace --stats -d $o/trace5 -o t -f csv -- python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $o/trace5.log 2>&1
 for c in 2 3; do
   extra=""; [ $c = 3 ] && extra="--config 3 --warmup 150"
-  rocprofv3 --pmc FETCH_SIZE -d $o/fetch$c -o p -f csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline $extra > $o/fetch$c.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE -d $o/write$c -o p -f csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline $extra > $o/write$c.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE -d $o/fetch$c -o p -f csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras $extra > $o/fetch$c.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE -d $o/write$c -o p -f csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras $extra > $o/write$c.log 2>&1
 done
 python - <<PY
 import csv, glob, json

@@ -4,7 +4,7 @@ out=$1; shift
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$out
-A="--steps 3 --warmup 1 --no-cpu-baseline $@"
+A="--steps 3 --warmup 1 --no-cpu-baseline --no-extras $@"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM -d gpurun_out/$out/pmc1 -o p -f csv -- python bench.py $A > gpurun_out/$out/pmc1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH -d gpurun_out/$out/pmc2 -o p -f csv -- python bench.py $A > gpurun_out/$out/pmc2.log 2>&1
 python - <<PY

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 o=gpurun_out/lds_pmc
 mkdir -p $o
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ATOMIC_RETURN SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS -d $o/p -o p -f csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $o/log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ATOMIC_RETURN SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS -d $o/p -o p -f csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $o/log 2>&1
 python - <<PY
 import csv, glob, collections
 for f in glob.glob("$o/p/**/*counter_collection.csv", recursive=True):

@@ -5,8 +5,8 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 o=gpurun_out/traffic_$tag
 mkdir -p $o
-rocprofv3 --pmc FETCH_SIZE -d $o/fetch -o p -f csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $o/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $o/write -o p -f csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $o/write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $o/fetch -o p -f csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $o/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $o/write -o p -f csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $o/write.log 2>&1
 python - <<PY
 import csv, glob
 res = {}
