@@ -452,14 +452,32 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
     # half-space form of every hull for the depth ray-caster: rows [nx ny nz d], inside = {x : n.x <= d}, geom-local frame
     plane_of = {}
     planes = []
+    # ... and what the rasteriser needs to outline a hull in an image: the vertices of every face and the edges with their two faces
+    # (vertex indices local to the hull, face indices local to the hull's planes)
+    edge_of = {}
+    fv_adr, fv_num, fv_idx, hedges = [], [], [], []
     for name, (adr, cnt) in hull_info.items():
-        pl = hullmod.hull_planes(md["hull_vert"][adr:adr + cnt])
+        pl, fverts, E = hullmod.hull_topology(md["hull_vert"][adr:adr + cnt])
+        assert np.array_equal(pl, hullmod.hull_planes(md["hull_vert"][adr:adr + cnt]))
         plane_of[(adr, cnt)] = (sum(len(q) for q in planes), len(pl))
         planes.append(pl)
+        for fv in fverts:
+            fv_adr.append(len(fv_idx))
+            fv_num.append(len(fv))
+            fv_idx.extend(fv)
+        edge_of[(adr, cnt)] = (sum(len(q) for q in hedges), len(E))
+        hedges.append(E)
     g_hplane = np.zeros((ng, 2), dtype=np.int32)
+    g_hedge = np.zeros((ng, 2), dtype=np.int32)
     for k in range(ng):
         if g_type[k] == 7:
             g_hplane[k] = plane_of[(int(g_hull[k][0]), int(g_hull[k][1]))]
+            g_hedge[k] = edge_of[(int(g_hull[k][0]), int(g_hull[k][1]))]
+    md["geom_hedge"] = g_hedge
+    md["hull_face_vadr"] = np.array(fv_adr, dtype=np.int32)
+    md["hull_face_vnum"] = np.array(fv_num, dtype=np.int32)
+    md["hull_face_vidx"] = np.array(fv_idx, dtype=np.int32)
+    md["hull_edge"] = np.concatenate(hedges).astype(np.int32) if hedges else np.zeros((0, 4), dtype=np.int32)
     md["geom_hplane"] = g_hplane
     # depth render proxies: the collision geoms stand in for the visual meshes; reward-only pins (group 3, gap=100) and
     # the 0.6 mm finger pad spheres (inside the finger hulls) are not drawn

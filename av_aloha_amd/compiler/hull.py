@@ -72,3 +72,34 @@ def hull_planes(verts, tol=1e-9):
         if not any(np.abs(row - o).max() < 1e-7 for o in out):
             out.append(row)
     return np.array(out)
+
+
+def hull_topology(verts):
+    """Facet planes as hull_planes(), plus what a rasteriser needs to find a hull's outline: the vertices of every (merged) face
+    and the edges between two different faces.  Taken from qhull's triangulation itself (simplices and their neighbours), not
+    from vertex / plane distances: end caps made of almost-coplanar triangles would fool a tolerance.
+    -> planes [F, 4], face_verts (list of F sorted vertex-index lists), edges [E, 4] = (v0, v1, f0, f1)."""
+    h = ConvexHull(np.asarray(verts, dtype=np.float64))
+    assert len(h.vertices) == len(verts), "hull_topology expects the vertices of a convex hull"
+    planes, tri_face = [], []
+    for e in h.equations:
+        row = np.array([e[0], e[1], e[2], -e[3]])
+        for k, o in enumerate(planes):
+            if np.abs(row - o).max() < 1e-7:
+                tri_face.append(k)
+                break
+        else:
+            tri_face.append(len(planes))
+            planes.append(row)
+    face_verts = [set() for _ in planes]
+    for t, f in enumerate(tri_face):
+        face_verts[f].update(int(v) for v in h.simplices[t])
+    edges = {}
+    for t, nb in enumerate(h.neighbors):
+        for k, u in enumerate(nb):              # neighbour k lies opposite vertex k: the shared edge is the other two vertices
+            if u < t or tri_face[u] == tri_face[t]:
+                continue
+            a, b = sorted(int(v) for j, v in enumerate(h.simplices[t]) if j != k)
+            edges[(a, b)] = (tri_face[t], tri_face[u])
+    E = np.array([[a, b, f0, f1] for (a, b), (f0, f1) in sorted(edges.items())], dtype=np.int32).reshape(-1, 4)
+    return np.array(planes), [sorted(s) for s in face_verts], E

@@ -19,8 +19,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <array>
 #include <cmath>
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "avsim_model.h"
@@ -49,10 +53,17 @@ __device__ unsigned long long g_rstat[8];   // debug build: tiles, bin-list entr
 #define RSTAT(i, n) ((void)0)
 #endif
 
+// Polyhedra of the rasteriser: every visible mesh hull and box as vertices, face planes, the vertices of each face and the edges with
+// their two faces (made on the host from the hull's vertices and planes, RenderHost::build).  rg[g][8] = vertex adr / count, plane
+// adr / count, edge adr / count of geom g's polyhedron (shared by the geoms of one mesh), and the geom's own offsets into a camera's
+// face (tplanes / fbox) and silhouette-edge scratch.
+constexpr int RG_W = 8, RVERT_MAX = 32, RFACE_MAX = 64;
 struct RenderModel {
-    int ngeom, ncam, nbody, nplane;   // nplane: faces summed over the visible mesh geoms
-    const int *geom_type, *geom_body, *geom_hplane, *geom_hull, *geom_visible, *cam_body;
-    const float *geom_pos, *geom_mat, *geom_size, *geom_bcen, *geom_rbound, *hull_plane, *hull_vert, *cam_pos, *cam_mat, *cam_fovy;   // cam_fovy: tan(fovy / 2) per camera
+    int ngeom, ncam, nbody, nplane, nedge;   // nplane / nedge: faces / edges summed over the visible polyhedra (one camera's scratch)
+    const int *rg, *r_fvadr, *r_fvnum, *r_fvidx, *r_edge;
+    const float *r_vert, *r_plane;
+    const int *geom_type, *geom_body, *geom_visible, *cam_body;
+    const float *geom_pos, *geom_mat, *geom_size, *geom_bcen, *geom_rbound, *cam_pos, *cam_mat, *cam_fovy;   // cam_fovy: tan(fovy / 2) per camera
     const float *geom_rgba, *light;   // colour render: material colours; [ambient, headlight, light, -, light dir (world) 4, sky zenith rgb 4, sky nadir rgb 4]
     float znear, zfar;
 };
@@ -67,8 +78,9 @@ __device__ inline void mul33(const float* A, const float* B, float* C) {   // C 
 // grid (ncam_sel, N), block 64
 __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float* __restrict__ xpose, const int* __restrict__ cam_ids, int ncam_sel,
                                                      int H, int W, float* __restrict__ recs, int* __restrict__ counts, int* __restrict__ order, float* __restrict__ tplanes,
-                                                     float* __restrict__ camaux) {
+                                                     float* __restrict__ camaux, float* __restrict__ fbox, float* __restrict__ sedge) {
     __shared__ float keys[128];
+    __shared__ float vsx[RVERT_MAX][64], vsy[RVERT_MAX][64];      // projected vertices of the lane's polyhedron (vertex major: no bank conflicts)
     const int lane = threadIdx.x, cs = blockIdx.x, env = blockIdx.y, cam = cam_ids[cs];
     const float* xb = xpose + (size_t)env * m.nbody * 12;
     // camera pose in the world
@@ -120,18 +132,22 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
             rec[12] = c[0]; rec[13] = c[1]; rec[14] = c[2]; rec[15] = r;
             rec[16] = m.geom_size[3 * g]; rec[17] = m.geom_size[3 * g + 1]; rec[18] = m.geom_size[3 * g + 2];
             rec[19] = __int_as_float(m.geom_type[g]);
-            rec[20] = __int_as_float(m.geom_hplane[2 * g]); rec[21] = __int_as_float(m.geom_hplane[2 * g + 1]);
+            rec[20] = 0; rec[21] = 0;
             rec[22] = __int_as_float(g); rec[23] = 0;
-            // screen box of the geom's vertices (hull vertices, box corners, bounding box of spheres / cylinders)
+            // screen box of the geom's vertices (polyhedron vertices, bounding box of spheres / cylinders)
             float bx0 = 1e30f, bx1 = -1e30f, by0 = 1e30f, by1 = -1e30f, zmin = 1e30f, bu0 = 1e30f, bu1 = -1e30f, bv0 = 1e30f, bv1 = -1e30f;
             bool crossing = false;
             const int type = m.geom_type[g];
-            const int nvert = type == 7 ? m.geom_hull[2 * g + 1] : 8;
-            const float* hv = m.hull_vert + 3 * (size_t)m.geom_hull[2 * g];
-            const float ex = type == 6 ? rec[16] : rec[16], ey = type == 6 ? rec[17] : rec[16], ez = type == 6 ? rec[18] : (type == 5 ? rec[17] : rec[16]);
+            const bool poly = type == 7 || type == 6;
+            const int* G = m.rg + RG_W * g;
+            const int nvert = poly ? G[1] : 8;
+            const float* hv = m.r_vert + 3 * (size_t)(poly ? G[0] : 0);
+            const float ex = rec[16], ey = rec[16], ez = type == 5 ? rec[17] : rec[16];
+            float cxs = 0, cys = 0;
+            if (poly && (nvert > RVERT_MAX || G[3] > RFACE_MAX)) crossing = true;     // (no such polyhedron in the models: general path)
             for (int k = 0; k < nvert; k++) {
                 float pl[3];
-                if (type == 7) { pl[0] = hv[3 * k]; pl[1] = hv[3 * k + 1]; pl[2] = hv[3 * k + 2]; }
+                if (poly) { pl[0] = hv[3 * k]; pl[1] = hv[3 * k + 1]; pl[2] = hv[3 * k + 2]; }
                 else { pl[0] = (k & 1) ? ex : -ex; pl[1] = (k & 2) ? ey : -ey; pl[2] = (k & 4) ? ez : -ez; }
                 const float d0 = pl[0] - rec[0], d1 = pl[1] - rec[1], d2 = pl[2] - rec[2];
                 // p_c = A^T (p_l - o_l)
@@ -140,9 +156,70 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
                 if (depth < 0.5f * m.znear) { crossing = true; continue; }
                 const float iz = 1.0f / depth;
                 const float sxp = xc * iz, syp = yc * iz;
+                if (poly && k < RVERT_MAX) { vsx[k][lane] = sxp; vsy[k][lane] = syp; cxs += sxp; cys += syp; }
                 bx0 = fminf(bx0, sxp); bx1 = fmaxf(bx1, sxp); by0 = fminf(by0, syp); by1 = fmaxf(by1, syp);
                 bu0 = fminf(bu0, sxp + syp); bu1 = fmaxf(bu1, sxp + syp); bv0 = fminf(bv0, sxp - syp); bv1 = fmaxf(bv1, sxp - syp);
                 zmin = fminf(zmin, depth);
+            }
+            if (poly) {
+                // (a polyhedron outside the image gets no face data: nothing will look at it)
+                const float pd0 = 1e-4f;
+                const bool seen = crossing || ((c[2] - r < -m.znear) && bx0 - pd0 <= tx && bx1 + pd0 >= -tx && by0 - pd0 <= ty && by1 + pd0 >= -ty);
+                if (seen) {
+                // The polyhedron for the rasteriser: every face in camera-ray form (for the ray (x, y, -1) t: n.v = a x + b y - c, crossing
+                // at t = no / n.v, no = d - n.o_l), the screen box of each face seen from outside, and the silhouette: an edge between a
+                // face seen from outside and one seen from inside, as the line through its projected end points, positive towards
+                // the projected centroid (the silhouette polygon is convex and the mean of the projected vertices lies inside it).
+                const int np = G[3], poff = G[6], eoff = G[7];
+                const size_t cbase = (size_t)env * ncam_sel + cs;
+                float4* tp = reinterpret_cast<float4*>(tplanes) + cbase * m.nplane + poff;
+                float4* fb = reinterpret_cast<float4*>(fbox) + cbase * m.nplane + poff;
+                float4* se = reinterpret_cast<float4*>(sedge) + cbase * m.nedge + eoff;
+                unsigned long long front = 0;
+                const float fpad = 1e-4f;
+                for (int p = 0; p < np; p++) {
+                    const float* n = m.r_plane + 4 * (size_t)(G[2] + p);
+                    float4 q;
+                    q.x = n[0] * rec[3] + n[1] * rec[6] + n[2] * rec[9];
+                    q.y = n[0] * rec[4] + n[1] * rec[7] + n[2] * rec[10];
+                    q.z = n[0] * rec[5] + n[1] * rec[8] + n[2] * rec[11];
+                    q.w = n[3] - (n[0] * rec[0] + n[1] * rec[1] + n[2] * rec[2]);
+                    tp[p] = q;
+                    float4 b = make_float4(1e30f, -1e30f, 1e30f, -1e30f);
+                    if (q.w < 0) {
+                        if (p < 64) front |= 1ull << p;
+                        if (!crossing) {
+                            const int fa = m.r_fvadr[G[2] + p], fn = m.r_fvnum[G[2] + p];
+                            for (int j = 0; j < fn; j++) {
+                                const int v = m.r_fvidx[fa + j];
+                                const float x = vsx[v][lane], y = vsy[v][lane];
+                                b.x = fminf(b.x, x); b.y = fmaxf(b.y, x); b.z = fminf(b.z, y); b.w = fmaxf(b.w, y);
+                            }
+                            b.x -= fpad; b.y += fpad; b.z -= fpad; b.w += fpad;
+                        }
+                    }
+                    fb[p] = b;
+                }
+                int nsil = 0;
+                if (!crossing) {
+                    const float icn = 1.0f / (float)nvert, cx = cxs * icn, cy = cys * icn;
+                    const int ne = G[5];
+                    for (int e = 0; e < ne; e++) {
+                        const int* E = m.r_edge + 4 * (size_t)(G[4] + e);
+                        if ((((front >> E[2]) ^ (front >> E[3])) & 1ull) == 0) continue;
+                        const float x0 = vsx[E[0]][lane], y0 = vsy[E[0]][lane], x1 = vsx[E[1]][lane], y1 = vsy[E[1]][lane];
+                        float A = y0 - y1, B = x1 - x0;
+                        const float il = rsqrtf(fmaxf(A * A + B * B, 1e-30f));
+                        A *= il; B *= il;
+                        float C = -(A * x0 + B * y0);
+                        if (A * cx + B * cy + C < 0) { A = -A; B = -B; C = -C; }
+                        se[nsil++] = make_float4(A, B, C, 0.0f);
+                    }
+                }
+                rec[16] = __int_as_float(eoff); rec[17] = __int_as_float(nsil); rec[18] = __int_as_float(crossing ? 1 : 0);
+                rec[20] = __int_as_float(poff); rec[21] = __int_as_float(np);
+                }
+                rec[19] = __int_as_float(7);                                   // boxes are drawn as polyhedra too
             }
             if (type != 7 && type != 6) {   // spheres / cylinders: the corners of their bounding box are not on the surface; box only
                 bu0 = bv0 = -1e30f; bu1 = bv1 = 1e30f;
@@ -171,26 +248,6 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
         int rank = 0;
         for (int j = 0; j < base; j++) { const float kj = keys[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
         ord[rank] = i;
-    }
-    // faces of the kept hulls in camera-ray form: for the ray (x, y, -1) t through the camera, n.v = a x + b y - c and the
-    // crossing is t = no / n.v with no = d - n.o_l.  One face per lane; the record's plane address becomes the offset here.
-    float* tp = tplanes + ((size_t)env * ncam_sel + cs) * m.nplane * 4;
-    int poff = 0;
-    for (int k = 0; k < base; k++) {
-        const float* rk = out + k * REC_W;
-        if (__float_as_int(rk[19]) != 7) continue;
-        const int adr = __float_as_int(rk[20]), np = __float_as_int(rk[21]);
-        for (int p = lane; p < np; p += 64) {
-            const float* n = m.hull_plane + 4 * (size_t)(adr + p);
-            float4 q;
-            q.x = n[0] * rk[3] + n[1] * rk[6] + n[2] * rk[9];
-            q.y = n[0] * rk[4] + n[1] * rk[7] + n[2] * rk[10];
-            q.z = n[0] * rk[5] + n[1] * rk[8] + n[2] * rk[11];
-            q.w = n[3] - (n[0] * rk[0] + n[1] * rk[1] + n[2] * rk[2]);
-            reinterpret_cast<float4*>(tp)[poff + p] = q;
-        }
-        if (lane == 0) out[k * REC_W + 20] = __int_as_float(poff);
-        poff += np;
     }
 }
 
@@ -253,7 +310,7 @@ __device__ inline bool ray_prim(int type, const float* sz, const float* o, const
 // light, sky gradient where nothing is hit) into u8[H][W][3]
 template <bool RGB>
 __device__ __forceinline__ void render_tile(const int lane, const int tx0, const int ty0, const int cs, const int env, const unsigned short* blist, const int cnt,
-                                            const float* __restrict__ R, const float4* __restrict__ tplanes, int nplane, const float scale, int ncam_sel, int H,
+                                            const float* __restrict__ R, const float4* __restrict__ tplanes, const float4* __restrict__ fboxes, const float4* __restrict__ sedges, int nplane, int nedge, const float scale, int ncam_sel, int H,
                                             int W, float znear, float zfar, float* __restrict__ out, const float* __restrict__ geom_rgba, const float* __restrict__ light,
                                             const float* __restrict__ camaux, unsigned char* __restrict__ out_rgb) {
     // lane -> 4 adjacent pixels in each of TILE_R rows (rows 8 apart, so that a row of the tile is still written by 8 lanes)
@@ -291,87 +348,71 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
             const float o[3] = {rec[0], rec[1], rec[2]};
             const int type = __float_as_int(rec[19]);
             if (type == 7) {
-                // Faces of the hull in camera-ray form, one per lane, evaluated on the four corner rays of the tile.  A face's
-                // crossing t = no / (a x + b y - c) is a ratio of affine functions, so over the tile it takes its extremes at the
-                // corners (as long as the denominator keeps its sign).  That sorts the faces once per tile:
-                //  * a face seen from outside (no < 0) that no corner ray approaches separates the tile from the hull;
-                //  * the entry of a ray is the LARGEST crossing over those faces, so a face whose largest crossing over the tile is
-                //    below L = the largest of the faces' smallest crossings can never be the entry face of a ray of this tile;
-                //  * the other faces only veto entries that lie behind them: a face whose nearest crossing over the tile is beyond
-                //    the farthest possible entry U never does.
-                // Interior tiles of a hull keep one or two entry faces and no vetoing face instead of all ~40.
-                const float4* P = tplanes + ((size_t)env * ncam_sel + cs) * nplane + __float_as_int(rec[20]);
-                const int np = __float_as_int(rec[21]);
-                unsigned long long mF = 0, mB = 0;     // np <= 64 (hulls are decimated to <= 32 vertices); larger hulls keep every face
-                float L = -1e30f, U = 1e30f;
-                bool sep = false;
-                float4 fl = make_float4(0.f, 0.f, 0.f, 0.f);      // this lane's face: the casting loops fetch the kept faces from here (v_readlane)
-                if (np <= 64) {
-                    const bool on = lane < np;
-                    const float4 f = P[on ? lane : 0];
-                    fl = f;
-                    const float n00 = f.x * xl + f.y * yb - f.z, n10 = f.x * xr + f.y * yb - f.z, n01 = f.x * xl + f.y * yt - f.z, n11 = f.x * xr + f.y * yt - f.z;
-                    const bool front = on && f.w < 0;
-                    const bool allneg = n00 < 0 && n10 < 0 && n01 < 0 && n11 < 0, allpos = n00 >= 0 && n10 >= 0 && n01 >= 0 && n11 >= 0;
-                    sep = front && allpos;
-                    const float t00 = f.w * __builtin_amdgcn_rcpf(n00), t10 = f.w * __builtin_amdgcn_rcpf(n10), t01 = f.w * __builtin_amdgcn_rcpf(n01), t11 = f.w * __builtin_amdgcn_rcpf(n11);
-                    float tmn = -1e30f, tmx = 1e30f;
-                    if (front && allneg) { tmn = fminf(fminf(t00, t10), fminf(t01, t11)); tmx = fmaxf(fmaxf(t00, t10), fmaxf(t01, t11)); }
-                    L = wave_max(front ? tmn : -1e30f);
-                    U = wave_max(front ? tmx : -1e30f);
-                    const bool keepF = front && tmx >= L - (1e-5f * fabsf(L) + 1e-6f);
-                    // the other faces (camera inside their half space) bound the EXIT of a ray, the smallest crossing over the faces it
-                    // leaves through; an entry is valid iff it is not beyond the exit.  Mirror image of the entry faces: a face whose
-                    // smallest crossing over the tile is above X = the smallest of the faces' largest crossings is never the exit face
-                    // (nor is one that no corner ray leaves through); and none matters when even X is beyond the farthest entry U
-                    float bmin = 1e30f, bmax = 1e30f;
-                    const bool back = on && !front;
-                    const bool allpos_s = n00 > 0 && n10 > 0 && n01 > 0 && n11 > 0, allneg_b = n00 <= 0 && n10 <= 0 && n01 <= 0 && n11 <= 0;
-                    if (back && allpos_s) { bmin = fminf(fminf(t00, t10), fminf(t01, t11)); bmax = fmaxf(fmaxf(t00, t10), fmaxf(t01, t11)); }
-                    else if (back && !allneg_b) bmin = -1e30f;     // sign change inside the tile: keep, no bound from it
-                    const float X = -wave_max(back ? -bmax : -1e30f);
-                    const bool keepB = back && !allneg_b && bmin <= X + (1e-5f * fabsf(X) + 1e-6f) && bmin <= U + (1e-5f * fabsf(U) + 1e-6f);
-                    mF = __ballot(keepF);
-                    mB = __ballot(keepB);
-                } else {
-                    for (int p = lane; p < np; p += 64) {
-                        const float4 f = P[p];
-                        sep = sep || (f.w < 0 && f.x * xl + f.y * yt - f.z >= 0 && f.x * xr + f.y * yt - f.z >= 0 && f.x * xl + f.y * yb - f.z >= 0 &&
-                                      f.x * xr + f.y * yb - f.z >= 0);
-                    }
-                }
-                if (__any(sep)) continue;
-                if (np <= 64 && L >= far) continue;
-                RSTAT(3, 1); RSTAT(4, __popcll(mF)); RSTAT(5, __popcll(mB));        // nothing of this hull in the tile is nearer than what the tile already shows
-                // Pass 1, candidate entry faces: the entry is the largest crossing, a ray that does not approach such a face misses.
-                // Pass 2, vetoing faces: the entry point must lie behind them (lo * n.v <= no; no division).
+                // A convex polyhedron (mesh hull or box), rasterised from what k_render_geoms projected once per camera:
+                //  * every face seen from outside has a screen box; only those whose box meets the tile can cover one of its pixels
+                //    (the faces seen from outside tile the silhouette without overlap), and the depth of a pixel is the LARGEST
+                //    crossing t = no / (a x + b y - c) over them -- faces that do not cover the pixel cross earlier, so extra
+                //    candidates are harmless and no per-face inside test is needed;
+                //  * whether a pixel sees the polyhedron at all is decided by the silhouette edges, lines in the image, positive
+                //    inside: an edge with all four tile corners outside discards the polyhedron for the tile, one with all four
+                //    inside needs no per-pixel test, the (few) others are evaluated per pixel.
+                // One face and one edge per lane for the tile tests; the kept ones are fetched from those lanes' registers.
+                const size_t cb = (size_t)env * ncam_sel + cs;
+                const int poff = __float_as_int(rec[20]), np = __float_as_int(rec[21]);
+                const float4* P = tplanes + cb * nplane + poff;
                 float lo[NPX];
                 bool ok[NPX];
                 int face[NPX];
 #pragma unroll
                 for (int q = 0; q < NPX; q++) { lo[q] = -1e30f; ok[q] = true; face[q] = 0; }
-                if (np <= 64) {
+                if (__float_as_int(rec[18]) == 0) {
+                    const float4* FB = fboxes + cb * nplane + poff;
+                    const float4* SE = sedges + cb * nedge + __float_as_int(rec[16]);
+                    const int nsil = __float_as_int(rec[17]);
+                    const bool onf = lane < np, one = lane < nsil;
+                    const float4 fl = P[onf ? lane : 0], bb = FB[onf ? lane : 0], eg = SE[one ? lane : 0];
+                    const bool keepF = onf && bb.x <= xr && bb.y >= xl && bb.z <= yt && bb.w >= yb;
+                    const float e00 = eg.x * xl + eg.y * yb + eg.z, e10 = eg.x * xr + eg.y * yb + eg.z, e01 = eg.x * xl + eg.y * yt + eg.z, e11 = eg.x * xr + eg.y * yt + eg.z;
+                    const bool allout = e00 < 0 && e10 < 0 && e01 < 0 && e11 < 0, allin = e00 >= 0 && e10 >= 0 && e01 >= 0 && e11 >= 0;
+                    if (__any(one && allout)) continue;
+                    unsigned long long mF = __ballot(keepF), mS = __ballot(one && !allin);
+                    if (!mF) continue;
+                    RSTAT(3, 1); RSTAT(4, __popcll(mF)); RSTAT(5, __popcll(mS));
                     while (mF) {
                         const int p = __builtin_ctzll(mF);
                         mF &= mF - 1;
-                        float4 f;
-                        f.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.x), p));
-                        f.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.y), p));
-                        f.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.z), p));
-                        f.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.w), p));
+                        const float fa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.x), p));
+                        const float fb_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.y), p));
+                        const float fc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.z), p));
+                        const float fw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.w), p));
                         float nb[TILE_R];
 #pragma unroll
-                        for (int r = 0; r < TILE_R; r++) nb[r] = f.y * dyr[r] - f.z;
+                        for (int r = 0; r < TILE_R; r++) nb[r] = fb_ * dyr[r] - fc;
 #pragma unroll
                         for (int q = 0; q < NPX; q++) {
-                            const float nv = nb[q >> 2] + f.x * dx[q & 3];
-                            const float t = f.w * __builtin_amdgcn_rcpf(nv);
-                            ok[q] = ok[q] && nv < 0;
+                            const float nv = nb[q >> 2] + fa * dx[q & 3];
+                            // (a pixel inside the silhouette approaches every face seen from outside: nv < 0 there; elsewhere the value is unused)
+                            const float t = fw * __builtin_amdgcn_rcpf(nv);
                             if (RGB) { if (t > lo[q]) face[q] = p; }
                             lo[q] = fmaxf(lo[q], t);
                         }
                     }
+                    while (mS) {
+                        const int e = __builtin_ctzll(mS);
+                        mS &= mS - 1;
+                        const float ea = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.x), e));
+                        const float eb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.y), e));
+                        const float ec = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.z), e));
+                        float nb[TILE_R];
+#pragma unroll
+                        for (int r = 0; r < TILE_R; r++) nb[r] = eb * dyr[r] + ec;
+#pragma unroll
+                        for (int q = 0; q < NPX; q++) ok[q] = ok[q] && nb[q >> 2] + ea * dx[q & 3] >= 0;
+                    }
                 } else {
+                    // general path (a vertex behind the near plane, or more faces / vertices than the per-lane tables hold): entry =
+                    // largest crossing over the faces seen from outside, valid if the ray approaches all of them and the entry point
+                    // lies inside every other half space
                     for (int p = 0; p < np; p++) {
                         const float4 f = P[p];
                         if (!(f.w < 0)) continue;
@@ -387,30 +428,6 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                             lo[q] = fmaxf(lo[q], t);
                         }
                     }
-                }
-                // no ray of the tile can still improve on what it already sees: skip the validity pass
-                {
-                    bool need = false;
-#pragma unroll
-                    for (int q = 0; q < NPX; q++) need = need || (ok[q] && lo[q] >= znear && lo[q] < best[q]);
-                    if (!__any(need)) continue;
-                }
-                if (np <= 64) {
-                    while (mB) {
-                        const int p = __builtin_ctzll(mB);
-                        mB &= mB - 1;
-                        float4 f;
-                        f.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.x), p));
-                        f.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.y), p));
-                        f.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.z), p));
-                        f.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.w), p));
-                        float nb[TILE_R];
-#pragma unroll
-                        for (int r = 0; r < TILE_R; r++) nb[r] = f.y * dyr[r] - f.z;
-#pragma unroll
-                        for (int q = 0; q < NPX; q++) ok[q] = ok[q] && lo[q] * (nb[q >> 2] + f.x * dx[q & 3]) <= f.w;
-                    }
-                } else {
                     for (int p = 0; p < np; p++) {
                         const float4 f = P[p];
                         if (f.w < 0) continue;
@@ -421,10 +438,11 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                         for (int q = 0; q < NPX; q++) ok[q] = ok[q] && lo[q] * (nb[q >> 2] + f.x * dx[q & 3]) <= f.w;
                     }
                 }
+                bool any_new = false;
 #pragma unroll
                 for (int q = 0; q < NPX; q++)
-                    if (ok[q] && lo[q] >= znear && lo[q] < best[q]) { best[q] = lo[q]; if (RGB) win[q] = k | (face[q] << 8); }
-                {
+                    if (ok[q] && lo[q] >= znear && lo[q] < best[q]) { best[q] = lo[q]; any_new = true; if (RGB) win[q] = k | (face[q] << 8); }
+                if (__any(any_new)) {
                     float bm = best[0];
 #pragma unroll
                     for (int q = 1; q < NPX; q++) bm = fmaxf(bm, best[q]);
@@ -543,7 +561,7 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
 
 template <bool RGB>
 __global__ void __launch_bounds__(256) k_render_depth(const float* __restrict__ recs, const int* __restrict__ counts, const int* __restrict__ order,
-                                                      const float4* __restrict__ tplanes, int nplane,
+                                                      const float4* __restrict__ tplanes, const float4* __restrict__ fboxes, const float4* __restrict__ sedges, int nplane, int nedge,
                                                       const float* __restrict__ cam_fovy, const int* __restrict__ cam_ids, int ncam_sel, int ngeom, int H,
                                                       int W, float znear, float zfar, float* __restrict__ out, const float* __restrict__ geom_rgba, const float* __restrict__ light,
                                                       const float* __restrict__ camaux, unsigned char* __restrict__ out_rgb) {
@@ -561,7 +579,6 @@ __global__ void __launch_bounds__(256) k_render_depth(const float* __restrict__ 
         const int px0 = btx * TILE_W, py0 = bty * TILE_H;
         const int px1 = px0 + BIN_TX * TILE_W < W ? px0 + BIN_TX * TILE_W : W, py1 = py0 + BIN_TY * TILE_H < H ? py0 + BIN_TY * TILE_H : H;
         const float xl = (px0 - 0.5f * W) * scale, xr = (px1 - 0.5f * W) * scale, yt = -(py0 - 0.5f * H) * scale, yb = -(py1 - 0.5f * H) * scale;
-        const float4* TP = tplanes + ((size_t)env * ncam_sel + cs) * nplane;
         int n = 0;
         for (int k0 = 0; k0 < cnt; k0 += 64) {
             bool keep = false;
@@ -570,13 +587,13 @@ __global__ void __launch_bounds__(256) k_render_depth(const float* __restrict__ 
                 mine = ord[k0 + lane];
                 const float* rec = R + (size_t)mine * REC_W;
                 keep = rec[24] <= xr && rec[25] >= xl && rec[26] <= yt && rec[27] >= yb && rec[28] <= xr + yt && rec[29] >= xl + yb && rec[30] <= xr - yb && rec[31] >= xl - yt;
-                if (keep && __float_as_int(rec[19]) == 7) {
-                    // hulls: no face seen from outside may have all four corner rays of the bin on its outer side
-                    const float4* P = TP + __float_as_int(rec[20]);
-                    const int np = __float_as_int(rec[21]);
-                    for (int p = 0; p < np; p++) {
-                        const float4 f = P[p];
-                        if (f.w < 0 && f.x * xl + f.y * yt - f.z >= 0 && f.x * xr + f.y * yt - f.z >= 0 && f.x * xl + f.y * yb - f.z >= 0 && f.x * xr + f.y * yb - f.z >= 0) {
+                if (keep && __float_as_int(rec[19]) == 7 && __float_as_int(rec[18]) == 0) {
+                    // polyhedra: no silhouette edge may have all four corners of the bin on its outer side
+                    const float4* SE = sedges + ((size_t)env * ncam_sel + cs) * nedge + __float_as_int(rec[16]);
+                    const int nsil = __float_as_int(rec[17]);
+                    for (int e = 0; e < nsil; e++) {
+                        const float4 g = SE[e];
+                        if (g.x * xl + g.y * yt + g.z < 0 && g.x * xr + g.y * yt + g.z < 0 && g.x * xl + g.y * yb + g.z < 0 && g.x * xr + g.y * yb + g.z < 0) {
                             keep = false;
                             break;
                         }
@@ -594,7 +611,7 @@ __global__ void __launch_bounds__(256) k_render_depth(const float* __restrict__ 
     for (int t = wave; t < BIN_TX * BIN_TY; t += 4) {
         const int tix = btx + (t % BIN_TX), tiy = bty + (t / BIN_TX);
         if (tix >= tiles_x || tiy >= tiles_y) continue;
-        render_tile<RGB>(lane, tix * TILE_W, tiy * TILE_H, cs, env, blist, cnt, R, tplanes, nplane, scale, ncam_sel, H, W, znear, zfar, out, geom_rgba, light, camaux, out_rgb);
+        render_tile<RGB>(lane, tix * TILE_W, tiy * TILE_H, cs, env, blist, cnt, R, tplanes, fboxes, sedges, nplane, nedge, scale, ncam_sel, H, W, znear, zfar, out, geom_rgba, light, camaux, out_rgb);
     }
 }
 
@@ -606,7 +623,9 @@ struct RenderHost {
     float* d_recs = nullptr;
     int* d_counts = nullptr;
     int* d_order = nullptr;
-    float* d_tplanes = nullptr;     // [N][ncam][nplane][4] hull faces in camera-ray form
+    float* d_tplanes = nullptr;     // [N][ncam][nplane][4] faces of the polyhedra in camera-ray form
+    float* d_fbox = nullptr;        // [N][ncam][nplane][4] screen boxes of the faces seen from outside
+    float* d_sedge = nullptr;       // [N][ncam][nedge][4] silhouette edges (lines in the image, positive inside), compacted per polyhedron
     float* d_camaux = nullptr;      // [N][16][8] light direction and world up axis in the camera frame
     int* d_cam_ids = nullptr;
     size_t recs_cap = 0;
@@ -627,12 +646,73 @@ struct RenderHost {
         R[3] = 2 * (x * y + w * z); R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * (y * z - w * x);
         R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = w * w - x * x - y * y + z * z;
     }
+    // The convex polyhedra the rasteriser draws: vertices, face planes, the vertices of every face and the edges with their two
+    // faces.  Mesh hulls bring theirs in the blob (compiler/hull.py hull_topology: qhull's own triangulation, shared by the geoms of
+    // one mesh); boxes are made here from their half extents.
+    void build_polyhedra(const Blob& b) {
+        auto gt = b.i("geom_type"), gv = b.i("geom_visible"), gh = b.i("geom_hull"), hp = b.i("geom_hplane"), he = b.i("geom_hedge");
+        auto hfa = b.i("hull_face_vadr"), hfn = b.i("hull_face_vnum"), hfi = b.i("hull_face_vidx"), hed = b.i("hull_edge");
+        auto gs = b.f("geom_size"), hv = b.f("hull_vert"), hpl = b.f("hull_plane");
+        std::vector<float> rvert, rplane;
+        std::vector<int> fvadr, fvnum, fvidx, redge, rg((size_t)m.ngeom * RG_W, 0);
+        std::map<std::pair<int, int>, std::array<int, 6>> cache;
+        m.nplane = 0; m.nedge = 0;
+        for (int g = 0; g < m.ngeom; g++) {
+            if (!gv[g] || (gt[g] != 7 && gt[g] != 6)) continue;
+            const std::pair<int, int> key = gt[g] == 7 ? std::make_pair(gh[2 * g], hp[2 * g]) : std::make_pair(-1, g);
+            auto it = cache.find(key);
+            if (it == cache.end()) {
+                std::array<int, 6> a{(int)rvert.size() / 3, 0, (int)rplane.size() / 4, 0, (int)redge.size() / 4, 0};
+                if (gt[g] == 7) {
+                    a[1] = gh[2 * g + 1]; a[3] = hp[2 * g + 1]; a[5] = he[2 * g + 1];
+                    for (int k = 0; k < 3 * a[1]; k++) rvert.push_back((float)hv[3 * (size_t)gh[2 * g] + k]);
+                    for (int k = 0; k < 4 * a[3]; k++) rplane.push_back((float)hpl[4 * (size_t)hp[2 * g] + k]);
+                    for (int f = 0; f < a[3]; f++) {
+                        fvadr.push_back((int)fvidx.size());
+                        fvnum.push_back(hfn[hp[2 * g] + f]);
+                        for (int j = 0; j < hfn[hp[2 * g] + f]; j++) fvidx.push_back(hfi[hfa[hp[2 * g] + f] + j]);
+                    }
+                    for (int k = 0; k < 4 * a[5]; k++) redge.push_back(hed[4 * (size_t)he[2 * g] + k]);
+                } else {
+                    // box: vertex k = corner with bit c of k choosing the sign on axis c; face 2 c + s = axis c, side s
+                    a[1] = 8; a[3] = 6; a[5] = 12;
+                    const double e[3] = {gs[3 * g], gs[3 * g + 1], gs[3 * g + 2]};
+                    for (int k = 0; k < 8; k++) for (int c = 0; c < 3; c++) rvert.push_back((float)(((k >> c) & 1) ? e[c] : -e[c]));
+                    for (int c = 0; c < 3; c++)
+                        for (int sd = 0; sd < 2; sd++) {
+                            float n[4] = {0, 0, 0, (float)e[c]};
+                            n[c] = sd ? 1.0f : -1.0f;
+                            for (float x : n) rplane.push_back(x);
+                            fvadr.push_back((int)fvidx.size());
+                            fvnum.push_back(4);
+                            for (int k = 0; k < 8; k++) if (((k >> c) & 1) == sd) fvidx.push_back(k);
+                        }
+                    for (int u = 0; u < 8; u++)
+                        for (int c = 0; c < 3; c++) {
+                            const int v = u | (1 << c);
+                            if (v == u) continue;
+                            // the edge along axis c: its two faces are the sides of the other two axes that u and v share
+                            int f[2], nf = 0;
+                            for (int o = 0; o < 3; o++) if (o != c) f[nf++] = 2 * o + ((u >> o) & 1);
+                            redge.push_back(u); redge.push_back(v); redge.push_back(f[0]); redge.push_back(f[1]);
+                        }
+                }
+                it = cache.emplace(key, a).first;
+            }
+            const auto& a = it->second;
+            int* G = &rg[(size_t)g * RG_W];
+            for (int k = 0; k < 6; k++) G[k] = a[k];
+            G[6] = m.nplane; G[7] = m.nedge;
+            m.nplane += a[3]; m.nedge += a[5];
+        }
+        m.rg = up(rg); m.r_vert = up(rvert); m.r_plane = up(rplane); m.r_fvadr = up(fvadr); m.r_fvnum = up(fvnum); m.r_fvidx = up(fvidx); m.r_edge = up(redge);
+    }
     void build(const Blob& b, int N_) {
         N = N_;
         m.ngeom = b.scalar("ngeom"); m.nbody = b.scalar("nbody");
         auto cam_body = b.i("cam_body");
         m.ncam = (int)cam_body.size();
-        m.geom_type = up(b.i("geom_type")); m.geom_body = up(b.i("geom_body")); m.geom_hplane = up(b.i("geom_hplane")); m.geom_hull = up(b.i("geom_hull"));
+        m.geom_type = up(b.i("geom_type")); m.geom_body = up(b.i("geom_body"));
         m.geom_visible = up(b.i("geom_visible")); m.cam_body = up(cam_body);
         auto gq = b.f("geom_quat"), cq = b.f("cam_quat");
         std::vector<double> gm(9 * m.ngeom), cm(9 * m.ncam);
@@ -640,12 +720,8 @@ struct RenderHost {
         for (int c = 0; c < m.ncam; c++) quat2mat(&cq[4 * c], &cm[9 * c]);
         m.geom_pos = up(tofloat(b.f("geom_pos"))); m.geom_mat = up(tofloat(gm)); m.geom_size = up(tofloat(b.f("geom_size")));
         m.geom_bcen = up(tofloat(b.f("geom_bcenter"))); m.geom_rbound = up(tofloat(b.f("geom_rbound")));
-        {   // capacity of one camera's face list: every visible mesh geom brings its own copy (geoms share hulls)
-            auto hp = b.i("geom_hplane"); auto gt = b.i("geom_type"); auto gv = b.i("geom_visible");
-            m.nplane = 0;
-            for (int g = 0; g < m.ngeom; g++) if (gt[g] == 7 && gv[g]) m.nplane += hp[2 * g + 1];
-        }
-        m.hull_plane = up(tofloat(b.f("hull_plane"))); m.hull_vert = up(tofloat(b.f("hull_vert"))); m.cam_pos = up(tofloat(b.f("cam_pos"))); m.cam_mat = up(tofloat(cm));
+        build_polyhedra(b);
+        m.cam_pos = up(tofloat(b.f("cam_pos"))); m.cam_mat = up(tofloat(cm));
         {   // the kernels only need tan(fovy / 2)
             auto fv = b.f("cam_fovy");
             std::vector<float> th(fv.size());
@@ -665,8 +741,10 @@ struct RenderHost {
         if (d_counts) (void)hipFree(d_counts);
         if (d_order) (void)hipFree(d_order);
         if (d_tplanes) (void)hipFree(d_tplanes);
+        if (d_fbox) (void)hipFree(d_fbox);
+        if (d_sedge) (void)hipFree(d_sedge);
         if (d_cam_ids) (void)hipFree(d_cam_ids);
-        d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; d_cam_ids = nullptr; recs_cap = 0;
+        d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; d_fbox = nullptr; d_sedge = nullptr; d_cam_ids = nullptr; recs_cap = 0;
     }
     // d_out: device float[N][ncam_sel][H][W], or (rgb) u8[N][ncam_sel][H][W][3]; body poses must already be in d_xpose (same stream)
     int launch(hipStream_t st, const int* cam_ids_host, int ncam_sel, int H, int W, void* d_out, bool rgb, std::string& err) {
@@ -679,10 +757,14 @@ struct RenderHost {
             if (d_counts) (void)hipFree(d_counts);
             if (d_order) (void)hipFree(d_order);
             if (d_tplanes) (void)hipFree(d_tplanes);
-            d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; recs_cap = 0;
+            if (d_fbox) (void)hipFree(d_fbox);
+            if (d_sedge) (void)hipFree(d_sedge);
+            d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; d_fbox = nullptr; d_sedge = nullptr; recs_cap = 0;
             if (hipMalloc((void**)&d_recs, need * sizeof(float)) != hipSuccess || hipMalloc((void**)&d_counts, (size_t)N * 16 * sizeof(int)) != hipSuccess ||
                 hipMalloc((void**)&d_order, (size_t)N * ncam_sel * m.ngeom * sizeof(int)) != hipSuccess ||
-                hipMalloc((void**)&d_tplanes, (size_t)N * ncam_sel * (m.nplane + 1) * 4 * sizeof(float)) != hipSuccess) {
+                hipMalloc((void**)&d_tplanes, (size_t)N * ncam_sel * (m.nplane + 1) * 4 * sizeof(float)) != hipSuccess ||
+                hipMalloc((void**)&d_fbox, (size_t)N * ncam_sel * (m.nplane + 1) * 4 * sizeof(float)) != hipSuccess ||
+                hipMalloc((void**)&d_sedge, (size_t)N * ncam_sel * (m.nedge + 1) * 4 * sizeof(float)) != hipSuccess) {
                 err = "hipMalloc(render records) failed";
                 return -3;
             }
@@ -690,13 +772,13 @@ struct RenderHost {
         }
         if (!d_cam_ids && hipMalloc((void**)&d_cam_ids, 16 * sizeof(int)) != hipSuccess) { err = "hipMalloc(camera ids) failed"; return -3; }
         if (hipMemcpyAsync(d_cam_ids, cam_ids_host, ncam_sel * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { err = "camera id copy failed"; return -3; }
-        hipLaunchKernelGGL(k_render_geoms, dim3(ncam_sel, N), dim3(64), 0, st, m, (const float*)d_xpose, (const int*)d_cam_ids, ncam_sel, H, W, d_recs, d_counts, d_order, d_tplanes, d_camaux);
+        hipLaunchKernelGGL(k_render_geoms, dim3(ncam_sel, N), dim3(64), 0, st, m, (const float*)d_xpose, (const int*)d_cam_ids, ncam_sel, H, W, d_recs, d_counts, d_order, d_tplanes, d_camaux, d_fbox, d_sedge);
         const int tiles = (((W + TILE_W - 1) / TILE_W + BIN_TX - 1) / BIN_TX) * (((H + TILE_H - 1) / TILE_H + BIN_TY - 1) / BIN_TY);     // bins
         if (rgb)
-            hipLaunchKernelGGL(k_render_depth<true>, dim3(tiles, ncam_sel, N), dim3(256), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, m.nplane,
+            hipLaunchKernelGGL(k_render_depth<true>, dim3(tiles, ncam_sel, N), dim3(256), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, (const float4*)d_fbox, (const float4*)d_sedge, m.nplane, m.nedge,
                                m.cam_fovy, (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, (float*)nullptr, m.geom_rgba, m.light, (const float*)d_camaux, (unsigned char*)d_out);
         else
-            hipLaunchKernelGGL(k_render_depth<false>, dim3(tiles, ncam_sel, N), dim3(256), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, m.nplane,
+            hipLaunchKernelGGL(k_render_depth<false>, dim3(tiles, ncam_sel, N), dim3(256), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, (const float4*)d_fbox, (const float4*)d_sedge, m.nplane, m.nedge,
                                m.cam_fovy, (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, (float*)d_out, m.geom_rgba, m.light, (const float*)d_camaux, (unsigned char*)nullptr);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("render kernel launch: ") + hipGetErrorString(e); return -3; }
