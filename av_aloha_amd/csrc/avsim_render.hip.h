@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
                                                      int H, int W, float* __restrict__ recs, int* __restrict__ counts, int* __restrict__ order, float* __restrict__ tplanes,
                                                      float* __restrict__ camaux, float* __restrict__ fbox, float* __restrict__ sedge) {
     __shared__ float keys[128];
-    __shared__ float vsx[RVERT_MAX][64], vsy[RVERT_MAX][64];      // projected vertices of the lane's polyhedron (vertex major: no bank conflicts)
+    __shared__ float vcx[RVERT_MAX][64], vcy[RVERT_MAX][64], vcz[RVERT_MAX][64];      // the lane's polyhedron in the camera frame (vertex major: no bank conflicts)
     const int lane = threadIdx.x, cs = blockIdx.x, env = blockIdx.y, cam = cam_ids[cs];
     const float* xb = xpose + (size_t)env * m.nbody * 12;
     // camera pose in the world
@@ -143,8 +143,9 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
             const int nvert = poly ? G[1] : 8;
             const float* hv = m.r_vert + 3 * (size_t)(poly ? G[0] : 0);
             const float ex = rec[16], ey = rec[16], ez = type == 5 ? rec[17] : rec[16];
-            float cxs = 0, cys = 0;
-            if (poly && (nvert > RVERT_MAX || G[3] > RFACE_MAX)) crossing = true;     // (no such polyhedron in the models: general path)
+            float c3x = 0, c3y = 0, c3z = 0;
+            unsigned behind = 0;                      // vertices nearer than half the near plane distance (or behind the camera)
+            const bool big = poly && (nvert > RVERT_MAX || G[3] > RFACE_MAX);      // (no such polyhedron in the models: general path)
             for (int k = 0; k < nvert; k++) {
                 float pl[3];
                 if (poly) { pl[0] = hv[3 * k]; pl[1] = hv[3 * k + 1]; pl[2] = hv[3 * k + 2]; }
@@ -153,10 +154,10 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
                 // p_c = A^T (p_l - o_l)
                 const float xc = rec[3] * d0 + rec[6] * d1 + rec[9] * d2, yc = rec[4] * d0 + rec[7] * d1 + rec[10] * d2, zc = rec[5] * d0 + rec[8] * d1 + rec[11] * d2;
                 const float depth = -zc;
-                if (depth < 0.5f * m.znear) { crossing = true; continue; }
+                if (poly && k < RVERT_MAX) { vcx[k][lane] = xc; vcy[k][lane] = yc; vcz[k][lane] = zc; c3x += xc; c3y += yc; c3z += zc; }
+                if (depth < 0.5f * m.znear) { crossing = true; behind |= 1u << (k & 31); continue; }
                 const float iz = 1.0f / depth;
                 const float sxp = xc * iz, syp = yc * iz;
-                if (poly && k < RVERT_MAX) { vsx[k][lane] = sxp; vsy[k][lane] = syp; cxs += sxp; cys += syp; }
                 bx0 = fminf(bx0, sxp); bx1 = fmaxf(bx1, sxp); by0 = fminf(by0, syp); by1 = fmaxf(by1, syp);
                 bu0 = fminf(bu0, sxp + syp); bu1 = fmaxf(bu1, sxp + syp); bv0 = fminf(bv0, sxp - syp); bv1 = fmaxf(bv1, sxp - syp);
                 zmin = fminf(zmin, depth);
@@ -164,12 +165,15 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
             if (poly) {
                 // (a polyhedron outside the image gets no face data: nothing will look at it)
                 const float pd0 = 1e-4f;
-                const bool seen = crossing || ((c[2] - r < -m.znear) && bx0 - pd0 <= tx && bx1 + pd0 >= -tx && by0 - pd0 <= ty && by1 + pd0 >= -ty);
+                const bool seen = (c[2] - r < -m.znear) && (crossing || (bx0 - pd0 <= tx && bx1 + pd0 >= -tx && by0 - pd0 <= ty && by1 + pd0 >= -ty));
                 if (seen) {
                 // The polyhedron for the rasteriser: every face in camera-ray form (for the ray (x, y, -1) t: n.v = a x + b y - c, crossing
-                // at t = no / n.v, no = d - n.o_l), the screen box of each face seen from outside, and the silhouette: an edge between a
-                // face seen from outside and one seen from inside, as the line through its projected end points, positive towards
-                // the projected centroid (the silhouette polygon is convex and the mean of the projected vertices lies inside it).
+                // at t = no / n.v, no = d - n.o_l), the screen box of each face seen from outside (the whole image for a face with a
+                // vertex behind the near plane), and the silhouette: an edge between a face seen from outside and one seen from
+                // inside.  The plane through the eye and such an edge touches the polyhedron, which lies on one side of it: with
+                // N = P0 x P1 (camera frame) turned towards the vertices' centroid, a pixel ray (x, y, -1) sees the polyhedron iff
+                // N . (x, y, -1) >= 0 for every silhouette edge -- a line in the image, and no vertex needs to be projected, so
+                // polyhedra that reach behind the camera (the table, the frame, the camera's own arm) are outlined like the others.
                 const int np = G[3], poff = G[6], eoff = G[7];
                 const size_t cbase = (size_t)env * ncam_sel + cs;
                 float4* tp = reinterpret_cast<float4*>(tplanes) + cbase * m.nplane + poff;
@@ -188,35 +192,35 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
                     float4 b = make_float4(1e30f, -1e30f, 1e30f, -1e30f);
                     if (q.w < 0) {
                         if (p < 64) front |= 1ull << p;
-                        if (!crossing) {
+                        if (!big) {
                             const int fa = m.r_fvadr[G[2] + p], fn = m.r_fvnum[G[2] + p];
+                            bool clipped = false;
                             for (int j = 0; j < fn; j++) {
                                 const int v = m.r_fvidx[fa + j];
-                                const float x = vsx[v][lane], y = vsy[v][lane];
+                                clipped = clipped || ((behind >> v) & 1u);
+                                const float iz = -1.0f / vcz[v][lane];
+                                const float x = vcx[v][lane] * iz, y = vcy[v][lane] * iz;
                                 b.x = fminf(b.x, x); b.y = fmaxf(b.y, x); b.z = fminf(b.z, y); b.w = fmaxf(b.w, y);
                             }
                             b.x -= fpad; b.y += fpad; b.z -= fpad; b.w += fpad;
+                            if (clipped) b = make_float4(-1e30f, 1e30f, -1e30f, 1e30f);
                         }
                     }
                     fb[p] = b;
                 }
                 int nsil = 0;
-                if (!crossing) {
-                    const float icn = 1.0f / (float)nvert, cx = cxs * icn, cy = cys * icn;
+                if (!big) {
                     const int ne = G[5];
                     for (int e = 0; e < ne; e++) {
                         const int* E = m.r_edge + 4 * (size_t)(G[4] + e);
                         if ((((front >> E[2]) ^ (front >> E[3])) & 1ull) == 0) continue;
-                        const float x0 = vsx[E[0]][lane], y0 = vsy[E[0]][lane], x1 = vsx[E[1]][lane], y1 = vsy[E[1]][lane];
-                        float A = y0 - y1, B = x1 - x0;
-                        const float il = rsqrtf(fmaxf(A * A + B * B, 1e-30f));
-                        A *= il; B *= il;
-                        float C = -(A * x0 + B * y0);
-                        if (A * cx + B * cy + C < 0) { A = -A; B = -B; C = -C; }
-                        se[nsil++] = make_float4(A, B, C, 0.0f);
+                        const float x0 = vcx[E[0]][lane], y0 = vcy[E[0]][lane], z0 = vcz[E[0]][lane], x1 = vcx[E[1]][lane], y1 = vcy[E[1]][lane], z1 = vcz[E[1]][lane];
+                        float A = y0 * z1 - z0 * y1, B = z0 * x1 - x0 * z1, Cz = x0 * y1 - y0 * x1;
+                        const float il = rsqrtf(fmaxf(A * A + B * B + Cz * Cz, 1e-30f)) * ((A * c3x + B * c3y + Cz * c3z < 0) ? -1.0f : 1.0f);
+                        se[nsil++] = make_float4(A * il, B * il, -Cz * il, 0.0f);          // N . (x, y, -1) = A x + B y - Cz
                     }
                 }
-                rec[16] = __int_as_float(eoff); rec[17] = __int_as_float(nsil); rec[18] = __int_as_float(crossing ? 1 : 0);
+                rec[16] = __int_as_float(eoff); rec[17] = __int_as_float(nsil); rec[18] = __int_as_float(big ? 1 : 0);
                 rec[20] = __int_as_float(poff); rec[21] = __int_as_float(np);
                 }
                 rec[19] = __int_as_float(7);                                   // boxes are drawn as polyhedra too
@@ -377,6 +381,15 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                     if (__any(one && allout)) continue;
                     unsigned long long mF = __ballot(keepF), mS = __ballot(one && !allin);
                     if (!mF) continue;
+                    {   // nothing of this polyhedron is nearer in this tile than what the tile already shows: a pixel's depth is the
+                        // crossing of its covering face, a ratio of affine functions of the pixel, so over the tile it is not below the
+                        // smallest corner value of the candidate faces (a face some corner ray does not approach gives no bound)
+                        const float n00 = fl.x * xl + fl.y * yb - fl.z, n10 = fl.x * xr + fl.y * yb - fl.z, n01 = fl.x * xl + fl.y * yt - fl.z, n11 = fl.x * xr + fl.y * yt - fl.z;
+                        const float t00 = fl.w * __builtin_amdgcn_rcpf(n00), t10 = fl.w * __builtin_amdgcn_rcpf(n10), t01 = fl.w * __builtin_amdgcn_rcpf(n01), t11 = fl.w * __builtin_amdgcn_rcpf(n11);
+                        const bool allneg = n00 < 0 && n10 < 0 && n01 < 0 && n11 < 0;
+                        const float tmn = keepF ? (allneg ? fminf(fminf(t00, t10), fminf(t01, t11)) : -1e30f) : 1e30f;
+                        if (-wave_max(-tmn) >= far) continue;
+                    }
                     RSTAT(3, 1); RSTAT(4, __popcll(mF)); RSTAT(5, __popcll(mS));
                     while (mF) {
                         const int p = __builtin_ctzll(mF);
@@ -410,9 +423,78 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                         for (int q = 0; q < NPX; q++) ok[q] = ok[q] && nb[q >> 2] + ea * dx[q & 3] >= 0;
                     }
                 } else {
-                    // general path (a vertex behind the near plane, or more faces / vertices than the per-lane tables hold): entry =
-                    // largest crossing over the faces seen from outside, valid if the ray approaches all of them and the entry point
-                    // lies inside every other half space
+                    // general path (a vertex behind the near plane -- the links around the camera itself --, or more faces / vertices
+                    // than the per-lane tables hold): the faces in camera-ray form, one per lane, evaluated on the four corner rays of
+                    // the tile.  A crossing t = no / (a x + b y - c) is a ratio of affine functions, so over the tile it takes its
+                    // extremes at the corners.  A face seen from outside that no corner ray approaches separates the tile from the
+                    // polyhedron; the entry of a ray is the LARGEST crossing over the faces seen from outside, so one whose largest
+                    // crossing over the tile is below L = the largest of those faces' smallest crossings is never the entry face; the
+                    // other faces bound the exit, and only those that can be the exit face of some ray of the tile are kept.
+                unsigned long long mF = 0, mB = 0;     // np <= 64 (hulls are decimated to <= 32 vertices); larger hulls keep every face
+                float L = -1e30f, U = 1e30f;
+                bool sep = false;
+                float4 fl = make_float4(0.f, 0.f, 0.f, 0.f);      // this lane's face: the casting loops fetch the kept faces from here (v_readlane)
+                if (np <= 64) {
+                    const bool on = lane < np;
+                    const float4 f = P[on ? lane : 0];
+                    fl = f;
+                    const float n00 = f.x * xl + f.y * yb - f.z, n10 = f.x * xr + f.y * yb - f.z, n01 = f.x * xl + f.y * yt - f.z, n11 = f.x * xr + f.y * yt - f.z;
+                    const bool front = on && f.w < 0;
+                    const bool allneg = n00 < 0 && n10 < 0 && n01 < 0 && n11 < 0, allpos = n00 >= 0 && n10 >= 0 && n01 >= 0 && n11 >= 0;
+                    sep = front && allpos;
+                    const float t00 = f.w * __builtin_amdgcn_rcpf(n00), t10 = f.w * __builtin_amdgcn_rcpf(n10), t01 = f.w * __builtin_amdgcn_rcpf(n01), t11 = f.w * __builtin_amdgcn_rcpf(n11);
+                    float tmn = -1e30f, tmx = 1e30f;
+                    if (front && allneg) { tmn = fminf(fminf(t00, t10), fminf(t01, t11)); tmx = fmaxf(fmaxf(t00, t10), fmaxf(t01, t11)); }
+                    L = wave_max(front ? tmn : -1e30f);
+                    U = wave_max(front ? tmx : -1e30f);
+                    const bool keepF = front && tmx >= L - (1e-5f * fabsf(L) + 1e-6f);
+                    // the other faces (camera inside their half space) bound the EXIT of a ray, the smallest crossing over the faces it
+                    // leaves through; an entry is valid iff it is not beyond the exit.  Mirror image of the entry faces: a face whose
+                    // smallest crossing over the tile is above X = the smallest of the faces' largest crossings is never the exit face
+                    // (nor is one that no corner ray leaves through); and none matters when even X is beyond the farthest entry U
+                    float bmin = 1e30f, bmax = 1e30f;
+                    const bool back = on && !front;
+                    const bool allpos_s = n00 > 0 && n10 > 0 && n01 > 0 && n11 > 0, allneg_b = n00 <= 0 && n10 <= 0 && n01 <= 0 && n11 <= 0;
+                    if (back && allpos_s) { bmin = fminf(fminf(t00, t10), fminf(t01, t11)); bmax = fmaxf(fmaxf(t00, t10), fmaxf(t01, t11)); }
+                    else if (back && !allneg_b) bmin = -1e30f;     // sign change inside the tile: keep, no bound from it
+                    const float X = -wave_max(back ? -bmax : -1e30f);
+                    const bool keepB = back && !allneg_b && bmin <= X + (1e-5f * fabsf(X) + 1e-6f) && bmin <= U + (1e-5f * fabsf(U) + 1e-6f);
+                    mF = __ballot(keepF);
+                    mB = __ballot(keepB);
+                } else {
+                    for (int p = lane; p < np; p += 64) {
+                        const float4 f = P[p];
+                        sep = sep || (f.w < 0 && f.x * xl + f.y * yt - f.z >= 0 && f.x * xr + f.y * yt - f.z >= 0 && f.x * xl + f.y * yb - f.z >= 0 &&
+                                      f.x * xr + f.y * yb - f.z >= 0);
+                    }
+                }
+                if (__any(sep)) continue;
+                if (np <= 64 && L >= far) continue;
+                RSTAT(6, 1);        // nothing of this hull in the tile is nearer than what the tile already shows
+                // Pass 1, candidate entry faces: the entry is the largest crossing, a ray that does not approach such a face misses.
+                // Pass 2, vetoing faces: the entry point must lie behind them (lo * n.v <= no; no division).
+                if (np <= 64) {
+                    while (mF) {
+                        const int p = __builtin_ctzll(mF);
+                        mF &= mF - 1;
+                        float4 f;
+                        f.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.x), p));
+                        f.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.y), p));
+                        f.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.z), p));
+                        f.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.w), p));
+                        float nb[TILE_R];
+#pragma unroll
+                        for (int r = 0; r < TILE_R; r++) nb[r] = f.y * dyr[r] - f.z;
+#pragma unroll
+                        for (int q = 0; q < NPX; q++) {
+                            const float nv = nb[q >> 2] + f.x * dx[q & 3];
+                            const float t = f.w * __builtin_amdgcn_rcpf(nv);
+                            ok[q] = ok[q] && nv < 0;
+                            if (RGB) { if (t > lo[q]) face[q] = p; }
+                            lo[q] = fmaxf(lo[q], t);
+                        }
+                    }
+                } else {
                     for (int p = 0; p < np; p++) {
                         const float4 f = P[p];
                         if (!(f.w < 0)) continue;
@@ -428,6 +510,30 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                             lo[q] = fmaxf(lo[q], t);
                         }
                     }
+                }
+                // no ray of the tile can still improve on what it already sees: skip the validity pass
+                {
+                    bool need = false;
+#pragma unroll
+                    for (int q = 0; q < NPX; q++) need = need || (ok[q] && lo[q] >= znear && lo[q] < best[q]);
+                    if (!__any(need)) continue;
+                }
+                if (np <= 64) {
+                    while (mB) {
+                        const int p = __builtin_ctzll(mB);
+                        mB &= mB - 1;
+                        float4 f;
+                        f.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.x), p));
+                        f.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.y), p));
+                        f.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.z), p));
+                        f.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.w), p));
+                        float nb[TILE_R];
+#pragma unroll
+                        for (int r = 0; r < TILE_R; r++) nb[r] = f.y * dyr[r] - f.z;
+#pragma unroll
+                        for (int q = 0; q < NPX; q++) ok[q] = ok[q] && lo[q] * (nb[q >> 2] + f.x * dx[q & 3]) <= f.w;
+                    }
+                } else {
                     for (int p = 0; p < np; p++) {
                         const float4 f = P[p];
                         if (f.w < 0) continue;
@@ -437,6 +543,7 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
 #pragma unroll
                         for (int q = 0; q < NPX; q++) ok[q] = ok[q] && lo[q] * (nb[q >> 2] + f.x * dx[q & 3]) <= f.w;
                     }
+                }
                 }
                 bool any_new = false;
 #pragma unroll
@@ -587,7 +694,18 @@ __global__ void __launch_bounds__(256) k_render_depth(const float* __restrict__ 
                 mine = ord[k0 + lane];
                 const float* rec = R + (size_t)mine * REC_W;
                 keep = rec[24] <= xr && rec[25] >= xl && rec[26] <= yt && rec[27] >= yb && rec[28] <= xr + yt && rec[29] >= xl + yb && rec[30] <= xr - yb && rec[31] >= xl - yt;
-                if (keep && __float_as_int(rec[19]) == 7 && __float_as_int(rec[18]) == 0) {
+                if (keep && __float_as_int(rec[19]) == 7 && __float_as_int(rec[18]) != 0) {
+                    // (general path) no face seen from outside may have all four corner rays of the bin on its outer side
+                    const float4* P = tplanes + ((size_t)env * ncam_sel + cs) * nplane + __float_as_int(rec[20]);
+                    const int np = __float_as_int(rec[21]);
+                    for (int p = 0; p < np; p++) {
+                        const float4 f = P[p];
+                        if (f.w < 0 && f.x * xl + f.y * yt - f.z >= 0 && f.x * xr + f.y * yt - f.z >= 0 && f.x * xl + f.y * yb - f.z >= 0 && f.x * xr + f.y * yb - f.z >= 0) {
+                            keep = false;
+                            break;
+                        }
+                    }
+                } else if (keep && __float_as_int(rec[19]) == 7) {
                     // polyhedra: no silhouette edge may have all four corners of the bin on its outer side
                     const float4* SE = sedges + ((size_t)env * ncam_sel + cs) * nedge + __float_as_int(rec[16]);
                     const int nsil = __float_as_int(rec[17]);
