@@ -42,10 +42,10 @@ constexpr int REC_W = 32;   // floats per geom record: o_l[3], A[9] (camera dir 
 constexpr int TILE_R = AVSIM_TILE_R, NPX = 4 * TILE_R;      // rows of 4 pixels per lane (2 rows = 32 x 16 tiles measured slower: 71-74 ms against 67)
 constexpr int TILE_W = 32, TILE_H = 8 * TILE_R;
 #ifndef AVSIM_BIN_TX
-#define AVSIM_BIN_TX 2
+#define AVSIM_BIN_TX 8
 #define AVSIM_BIN_TY 4
 #endif
-constexpr int BIN_TX = AVSIM_BIN_TX, BIN_TY = AVSIM_BIN_TY;           // a block's bin: 2 x 4 tiles = 64 x 32 pixels (measured best of 4x8, 2x4, 2x2, 1x4)
+constexpr int BIN_TX = AVSIM_BIN_TX, BIN_TY = AVSIM_BIN_TY;           // a block's bin: 8 x 4 tiles = 256 x 32 pixels (measured: 2x4 7.7 ms per 1024 envs, 4x4 6.5, 8x4 6.2, 4x8 7.4, 8x8 8.3)
 #ifdef AVSIM_RENDER_STATS
 __device__ unsigned long long g_rstat[8];   // debug build: tiles, bin-list entries seen, box hits, records cast, entry faces, veto faces, primitives, -
 #define RSTAT(i, n) do { if (lane == 0) atomicAdd(&g_rstat[i], (unsigned long long)(n)); } while (0)
@@ -706,16 +706,20 @@ __global__ void __launch_bounds__(256) k_render_depth(const float* __restrict__ 
                         }
                     }
                 } else if (keep && __float_as_int(rec[19]) == 7) {
-                    // polyhedra: no silhouette edge may have all four corners of the bin on its outer side
+                    // polyhedra: no silhouette edge may have all four corners of the bin on its outer side.  Four edges per round trip
+                    // to memory (a loop that stops at the first such edge waits for every load in turn)
                     const float4* SE = sedges + ((size_t)env * ncam_sel + cs) * nedge + __float_as_int(rec[16]);
                     const int nsil = __float_as_int(rec[17]);
-                    for (int e = 0; e < nsil; e++) {
-                        const float4 g = SE[e];
-                        if (g.x * xl + g.y * yt + g.z < 0 && g.x * xr + g.y * yt + g.z < 0 && g.x * xl + g.y * yb + g.z < 0 && g.x * xr + g.y * yb + g.z < 0) {
-                            keep = false;
-                            break;
-                        }
+                    bool out = false;
+                    for (int e = 0; e < nsil; e += 4) {
+                        float4 g[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) g[j] = SE[e + j < nsil ? e + j : e];
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            out = out || (g[j].x * xl + g[j].y * yt + g[j].z < 0 && g[j].x * xr + g[j].y * yt + g[j].z < 0 && g[j].x * xl + g[j].y * yb + g[j].z < 0 && g[j].x * xr + g[j].y * yb + g[j].z < 0);
                     }
+                    keep = !out;
                 }
             }
             const unsigned long long bal = __ballot(keep);
