@@ -37,15 +37,15 @@ constexpr int REC_W = 32;   // floats per geom record: o_l[3], A[9] (camera dir 
                             // the projected vertices [28..31]: with the box an octagon, tight for the long thin frame bars that cross the
                             // image at an angle
 #ifndef AVSIM_TILE_R
-#define AVSIM_TILE_R 1
+#define AVSIM_TILE_R 2
 #endif
-constexpr int TILE_R = AVSIM_TILE_R, NPX = 4 * TILE_R;      // rows of 4 pixels per lane (2 rows = 32 x 16 tiles measured slower: 71-74 ms against 67)
+constexpr int TILE_R = AVSIM_TILE_R, NPX = 4 * TILE_R;      // rows of 4 pixels per lane: 2 rows = 32 x 16 tiles (the per-polyhedron tile tests are paid once per 512 pixels)
 constexpr int TILE_W = 32, TILE_H = 8 * TILE_R;
 #ifndef AVSIM_BIN_TX
 #define AVSIM_BIN_TX 8
-#define AVSIM_BIN_TY 4
+#define AVSIM_BIN_TY 2
 #endif
-constexpr int BIN_TX = AVSIM_BIN_TX, BIN_TY = AVSIM_BIN_TY;           // a block's bin: 8 x 4 tiles = 256 x 32 pixels (measured: 2x4 7.7 ms per 1024 envs, 4x4 6.5, 8x4 6.2, 4x8 7.4, 8x8 8.3)
+constexpr int BIN_TX = AVSIM_BIN_TX, BIN_TY = AVSIM_BIN_TY;           // a block's bin: 8 x 2 tiles of 32 x 16 = 256 x 32 pixels (measured per 1024 envs x 4 cameras x 480 x 640: 5.4 ms; 32 x 8 tiles in bins of 8 x 4: 6.0, 4 x 4: 6.3, 2 x 4: 7.2, 16 x 4: 8.9)
 #ifdef AVSIM_RENDER_STATS
 __device__ unsigned long long g_rstat[8];   // debug build: tiles, bin-list entries seen, box hits, records cast, entry faces, veto faces, primitives, -
 #define RSTAT(i, n) do { if (lane == 0) atomicAdd(&g_rstat[i], (unsigned long long)(n)); } while (0)

@@ -30,9 +30,10 @@ def load_blob(task, num_arms, variant="gym"):
 
 
 class BatchedSim:
-    def __init__(self, task, num_arms=3, num_envs=1, device=0, f64=False, options=None, variant="gym"):
+    def __init__(self, task, num_arms=3, num_envs=1, device=0, f64=False, options=None, variant="gym", blob=None):
         assert task in TASK_KEYS, task
-        blob, self.manifest = load_blob(task, num_arms, variant)
+        file_blob, self.manifest = load_blob(task, num_arms, variant)
+        blob = file_blob if blob is None else blob        # (tests: the task's model with an edited constant, e.g. gravity)
         self.h = _ffi.Handle(blob, num_envs, device, _ffi.AVSIM_F64_PHYSICS if f64 else 0)
         self.N = num_envs
         for k in ("nq", "nv", "nu", "nj", "nobj", "max_reward", "maxcon", "maxefc"):

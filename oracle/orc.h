@@ -144,6 +144,7 @@ int orc_max_reward(const orc_model* m);
 void orc_kinematics(orc_data* d);
 void orc_crb(orc_data* d);
 void orc_rne_bias(orc_data* d);
+void orc_smooth(orc_data* d);   /* passive + actuator forces, smooth acceleration (needs crb + rne_bias) */
 void orc_collide(orc_data* d);
 void orc_make_constraints(orc_data* d);
 void orc_solve(orc_data* d);

@@ -361,6 +361,8 @@ static void smooth_forces(orc_data* d) {
     chol_solve(d->L, d->qacc_smooth, nv);
 }
 
+void orc_smooth(orc_data* d) { smooth_forces(d); }   /* exposed for the stage-by-stage tests */
+
 /* translational (rows 0..2) and rotational (3..5) Jacobian of body b at world point p: 6 x nv */
 static void body_jac(const orc_data* d, int b, const double* p, double* J) {
     const orc_model* m = d->m;

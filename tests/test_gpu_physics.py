@@ -235,3 +235,34 @@ def test_noslip_through_the_row_groups_matches_the_oracle_too():
         np.testing.assert_allclose(qpos[0], ref[t][0], atol=1e-10, err_msg=f"qpos step {t}")
         np.testing.assert_allclose(qvel[0], ref[t][1], atol=1e-8, err_msg=f"qvel step {t}")
     sim.close()
+
+
+@pytest.mark.parametrize("f64", [True, False])
+def test_friction_angle_on_the_device(f64, tmp_path):
+    """Coulomb friction known answer on the device (the oracle's twin is tests/test_oracle_constraints.py): gravity tilted by theta
+    about y in the model blob; the stick on the table (friction 1.0) stays below 45 degrees and slides with g (sin - mu cos) above."""
+    from av_aloha_amd.compiler.compile import read_blob, write_blob
+    from av_aloha_amd.sim import BatchedSim
+    from test_oracle_physics import ROOT
+    md = model_dict()
+    a = home_action(md).astype(np.float32)
+    res = {}
+    for deg in (35.0, 55.0):
+        arrays = read_blob(f"{ROOT}/models/slot_insertion_3arms.avm")
+        th = np.deg2rad(deg)
+        arrays["opt"] = arrays["opt"].copy()
+        arrays["opt"][1:4] = [9.81 * np.sin(th), 0.0, -9.81 * np.cos(th)]
+        path = str(tmp_path / f"tilt{int(deg)}.avm")
+        write_blob(path, arrays)
+        sim = BatchedSim("slot_insertion", 3, 2, f64=f64, options={"solver": 1}, blob=open(path, "rb").read())
+        sim.reset(np.repeat(OBJ[None], 2, 0))
+        x0 = sim.get_state()[0][0, 30]
+        T = 10
+        for _ in range(T):
+            sim.step(np.repeat(a[None], 2, 0))
+        res[deg] = sim.get_state()[0][0, 30] - x0
+        sim.close()
+    t = 10 * 0.04
+    assert abs(res[35.0]) < 5e-4, res                                   # holds (the first steps settle the stick onto the tilted support)
+    acc = 9.81 * (np.sin(np.deg2rad(55.0)) - np.cos(np.deg2rad(55.0)))
+    assert abs(res[55.0] - 0.5 * acc * t * t) < 0.15 * 0.5 * acc * t * t, res
