@@ -256,13 +256,16 @@ def test_friction_angle_on_the_device(f64, tmp_path):
         write_blob(path, arrays)
         sim = BatchedSim("slot_insertion", 3, 2, f64=f64, options={"solver": 1}, blob=open(path, "rb").read())
         sim.reset(np.repeat(OBJ[None], 2, 0))
-        x0 = sim.get_state()[0][0, 30]
-        T = 10
-        for _ in range(T):
+        xs = []
+        for _ in range(10):
             sim.step(np.repeat(a[None], 2, 0))
-        res[deg] = sim.get_state()[0][0, 30] - x0
+            xs.append(sim.get_state()[0][0, 30])
+        res[deg] = np.array(xs)
         sim.close()
-    t = 10 * 0.04
-    assert abs(res[35.0]) < 5e-4, res                                   # holds (the first steps settle the stick onto the tilted support)
+    # the first env-step settles the stick onto the tilted support (1.03 mm in the oracle and on the device alike); after it:
+    hold = res[35.0]
+    assert abs(hold[9] - hold[1]) < (1e-6 if f64 else 2e-5), hold       # holds below the friction angle
     acc = 9.81 * (np.sin(np.deg2rad(55.0)) - np.cos(np.deg2rad(55.0)))
-    assert abs(res[55.0] - 0.5 * acc * t * t) < 0.15 * 0.5 * acc * t * t, res
+    x = res[55.0]
+    acc_seen = (x[9] - 2 * x[5] + x[1]) / (4 * 0.04) ** 2               # second difference: no assumption on the velocity after settling
+    assert abs(acc_seen - acc) < 0.05 * acc, (acc_seen, acc)
