@@ -42,6 +42,7 @@ struct DevModel {
     int nq, nv, nu, nbody, njnt, ngeom, npair, ntree, neq, nfloss, nlimited, nment, task_id, nj, msize;
     real timestep, gravity[3], impratio, grip_lo, grip_hi;
     int noslip_iters;
+    int qcqp_tridiag;             // 1: sliding contacts' multiplier iteration through the tridiagonal form (f32 default), 0: MuJoCo's Cholesky per iterate (f64 default); option "qcqp_tridiag"
     int noslip_per_tree;          // 1: the dry-friction rows of the noslip pass go per kinematic tree (needs <= 8 trees); option "noslip_per_tree"
     int solver, newton_iters;     // 0 = PGS (dual), 1 = Newton (primal, the reference's default solver)
     real newton_tol, nscale;      // MuJoCo tolerance and 1/(meaninertia*nv) scaling of the termination tests
@@ -398,6 +399,7 @@ struct NoslipLead {
     LDS_PTR(const int) floss_dof;    // dry-friction row -> dof (increasing)
     LDS_PTR(int) dmap;               // nv ints of dead LDS: dof -> row
     LDS_PTR(int) prof;               // probe slots (8 ints) or null
+    int tridiag;                     // the multiplier iteration of a sliding contact's QCQP on the tridiagonal form (option "qcqp_tridiag")
     int ntree, nv, neq, nfloss, nlg; // nlg = groups of leading (non-contact) rows; -1: no per-tree pass (more than 8 trees)
 };
 
@@ -421,7 +423,7 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
     noslip_tol_scaled = lane_get(noslip_tol_scaled, 0);
     nl.Minv = uni_lds(nl.Minv); nl.tadr = uni_lds(nl.tadr); nl.tnum = uni_lds(nl.tnum); nl.floss_dof = uni_lds(nl.floss_dof); nl.dmap = uni_lds(nl.dmap); nl.prof = uni_lds(nl.prof);
     nl.ntree = __builtin_amdgcn_readfirstlane(nl.ntree); nl.nv = __builtin_amdgcn_readfirstlane(nl.nv); nl.neq = __builtin_amdgcn_readfirstlane(nl.neq);
-    nl.nfloss = __builtin_amdgcn_readfirstlane(nl.nfloss); nl.nlg = __builtin_amdgcn_readfirstlane(nl.nlg);
+    nl.nfloss = __builtin_amdgcn_readfirstlane(nl.nfloss); nl.nlg = __builtin_amdgcn_readfirstlane(nl.nlg); nl.tridiag = __builtin_amdgcn_readfirstlane(nl.tridiag);
     // lane 8 d + k serves row d of the group (d < 6) and dof slot k of BOTH of the row's tree windows
     const int lane = threadIdx.x & 63, d = lane >> 3, k8 = lane & 7, dr = d < GRP_MAX ? d : 0;
     const int lr = lane < GRP_MAX ? lane : 0;          // row slot owned in the sequential phase
@@ -484,7 +486,6 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         nsweep++;
-        if (prof && lane == 0) prof[2] += (int)(__builtin_readcyclecounter() - tf0);
     };
     const int first_ns = fl ? nl.nlg : 0;               // first group of a noslip sweep
     const int per_ns = ngrp - first_ns;                 // (contact groups only when the dry-friction rows go per tree)
@@ -526,7 +527,6 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
     // the first group's look-ahead loads land here: with one of them still pending at the loop entry, the compiler's wait for it
     // inside the loop body (in-order counter, sized for the first pass) would also drain the loads every later step has just issued
     __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
-    if (prof && lane == 0) prof[3] += (int)(__builtin_readcyclecounter() - tq0);
     if (fl && iters == 0 && noslip_iters > 0) floss_sweep();
     for (int step = 0; step < total; step++) {
         nstep++;
@@ -598,6 +598,7 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
                 }
             }
             if (n >= 1 && !done) {
+                const long long tsl0 = prof ? __builtin_readcyclecounter() : 0; int nit_q = 0; long long tsl1 = 0;
                 const real fn = lane_get(f0, 0);
                 real acs[GRP_MAX - 1];      // this group's couplings, fetched here: the sliding case pays the memory round trip, not every step
 #pragma unroll
@@ -623,6 +624,7 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
                     bq[j] = t;
                     v[j] = 0;
                 }
+                if (prof) { asm volatile("" :: "v"(bq[0]), "v"(bq[1]), "v"(bq[2]), "v"(bq[3]), "v"(bq[4])); tsl1 = __builtin_readcyclecounter(); }
                 if (!(fn < real(1e-15))) {
                     const real r2 = fn * fn, vtol = QTol<real>::abs + QTol<real>::rel * r2;
                     real la = 0;
@@ -649,54 +651,157 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
                         v[1] = singular ? real(0) : v2 * dq[1];
                         active = !singular && la != 0;
                     } else {
-                        real As[5][5], bs[5], L[5][5], y[5], w[5], rd[5];
-#pragma unroll
-                        for (int j = 0; j < 5; j++) {
-                            bs[j] = j < n ? bq[j] * dq[j] : real(0);
-                            y[j] = 0;
-#pragma unroll
-                            for (int k = 0; k < 5; k++) As[j][k] = (j < n && k < n) ? Aq[j][k] * dq[j] * dq[k] : (j == k ? real(1) : real(0));
-                        }
+                        real y[5];
                         bool singular = false;
-                        for (int iter = 0; iter < 20; iter++) {
+                        if (nl.tridiag) {
+                            // mju_QCQP's Newton iteration on the multiplier needs y = -(As + la I)^-1 bs and (As + la I)^-1 y for a dozen
+                            // values of la.  MuJoCo factors As + la I afresh every time (a 5 x 5 Cholesky: a chain of ~150 dependent
+                            // instructions, 1.2 k cycles, redundantly on every lane).  Here As is reduced once to tridiagonal form by
+                            // three Householder reflections, As = H T H^T; (As + la I)^-1 = H (T + la I)^-1 H^T, |y| and y . w are the
+                            // same in the rotated basis, and T + la I is factored by the four-step LDL^T recurrence: the same iterates
+                            // up to rounding, a quarter of the instructions per iterate.  Singularity is MuJoCo's pivot rule at la = 0
+                            // (the flag make_constraints left with the block's inverse; the pivots only grow with la).
+                            real As[5][5], cs[5], w[5], hv[3][5], hb[3];
 #pragma unroll
                             for (int j = 0; j < 5; j++) {
-                                real dd = As[j][j] + (j < n ? la : real(0));
+                                cs[j] = j < n ? bq[j] * dq[j] : real(0);
+                                y[j] = 0;
 #pragma unroll
-                                for (int k = 0; k < j; k++) dd -= L[j][k] * L[j][k];
-                                if (j < n && dd < real(1e-10)) singular = true;
-                                dd = tmax(dd, real(1e-30));
-                                if (sizeof(real) == 4) { rd[j] = qrsqrt(dd); dd = dd * rd[j]; }
-                                else { dd = sqrt(dd); rd[j] = real(1) / dd; }
-                                L[j][j] = dd;
+                                for (int k = 0; k < 5; k++) As[j][k] = (j < n && k < n) ? Aq[j][k] * dq[j] * dq[k] : (j == k ? real(1) : real(0));
+                            }
+                            singular = lane_get(qc[5], 1) != real(0);
+                            if (!singular) {
 #pragma unroll
-                                for (int i = j + 1; i < 5; i++) {
-                                    real t = As[i][j];
+                                for (int k = 0; k < 3; k++) {
+                                    real sigma = 0;
 #pragma unroll
-                                    for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
-                                    L[i][j] = qdiv(t, dd, rd[j]);
+                                    for (int i = k + 2; i < 5; i++) sigma += As[i][k] * As[i][k];
+                                    const real x0 = As[k + 1][k];
+#pragma unroll
+                                    for (int i = 0; i < 5; i++) hv[k][i] = 0;
+                                    hb[k] = 0;
+                                    if (sigma != real(0)) {       // (wave-uniform: the column is tridiagonal already otherwise)
+                                        const real nrm = sqrt(x0 * x0 + sigma), alpha = x0 > 0 ? -nrm : nrm;
+                                        hv[k][k + 1] = x0 - alpha;
+#pragma unroll
+                                        for (int i = k + 2; i < 5; i++) hv[k][i] = As[i][k];
+                                        const real beta = real(2) / (hv[k][k + 1] * hv[k][k + 1] + sigma);
+                                        hb[k] = beta;
+                                        real pv[5], vp = 0;
+#pragma unroll
+                                        for (int i = k + 1; i < 5; i++) {
+                                            real t = 0;
+#pragma unroll
+                                            for (int j = k + 1; j < 5; j++) t += As[i][j] * hv[k][j];
+                                            pv[i] = beta * t;
+                                            vp += hv[k][i] * pv[i];
+                                        }
+                                        const real K = real(0.5) * beta * vp;
+#pragma unroll
+                                        for (int i = k + 1; i < 5; i++) pv[i] -= K * hv[k][i];
+#pragma unroll
+                                        for (int i = k + 1; i < 5; i++)
+#pragma unroll
+                                            for (int j = k + 1; j <= i; j++) { As[i][j] -= hv[k][i] * pv[j] + pv[i] * hv[k][j]; As[j][i] = As[i][j]; }
+                                        As[k + 1][k] = alpha; As[k][k + 1] = alpha;
+#pragma unroll
+                                        for (int i = k + 2; i < 5; i++) { As[i][k] = 0; As[k][i] = 0; }
+                                        // right-hand side into the rotated basis
+                                        real t = 0;
+#pragma unroll
+                                        for (int i = k + 1; i < 5; i++) t += hv[k][i] * cs[i];
+                                        t *= beta;
+#pragma unroll
+                                        for (int i = k + 1; i < 5; i++) cs[i] -= t * hv[k][i];
+                                    }
+                                }
+                                const real b0 = As[1][0], b1 = As[2][1], b2 = As[3][2], b3 = As[4][3];
+                                for (int iter = 0; iter < 20; iter++) {
+                                    nit_q++;
+                                    // LDL^T of T + la I (la on the contact's own dimensions only, as in mju_QCQP's padded loops)
+                                    const real d0 = As[0][0] + la, r0 = real(1) / d0, l0 = b0 * r0;
+                                    const real d1 = As[1][1] + la - l0 * b0, r1 = real(1) / d1, l1 = b1 * r1;
+                                    const real d2 = As[2][2] + la - l1 * b1, r2_ = real(1) / d2, l2 = b2 * r2_;
+                                    const real d3 = As[3][3] + (3 < n ? la : real(0)) - l2 * b2, r3 = real(1) / d3, l3 = b3 * r3;
+                                    const real d4 = As[4][4] + (4 < n ? la : real(0)) - l3 * b3, r4 = real(1) / d4;
+                                    real z0 = -cs[0], z1 = -cs[1] - l0 * z0, z2 = -cs[2] - l1 * z1, z3 = -cs[3] - l2 * z2, z4 = -cs[4] - l3 * z3;
+                                    y[4] = z4 * r4; y[3] = z3 * r3 - l3 * y[4]; y[2] = z2 * r2_ - l2 * y[3]; y[1] = z1 * r1 - l1 * y[2]; y[0] = z0 * r0 - l0 * y[1];
+                                    real val = -r2;
+#pragma unroll
+                                    for (int i = 0; i < 5; i++) val += y[i] * y[i];
+                                    if (val < vtol) break;
+                                    z0 = y[0]; z1 = y[1] - l0 * z0; z2 = y[2] - l1 * z1; z3 = y[3] - l2 * z2; z4 = y[4] - l3 * z3;
+                                    w[4] = z4 * r4; w[3] = z3 * r3 - l3 * w[4]; w[2] = z2 * r2_ - l2 * w[3]; w[1] = z1 * r1 - l1 * w[2]; w[0] = z0 * r0 - l0 * w[1];
+                                    real deriv = 0;
+#pragma unroll
+                                    for (int i = 0; i < 5; i++) deriv += y[i] * w[i];
+                                    deriv *= -2;
+                                    const real delta = -val / deriv;
+                                    if (delta < QTol<real>::abs + QTol<real>::rel * la) break;
+                                    la += delta;
+                                }
+                                // back to the contact's basis: y <- H y
+#pragma unroll
+                                for (int k = 2; k >= 0; k--) {
+                                    real t = 0;
+#pragma unroll
+                                    for (int i = k + 1; i < 5; i++) t += hv[k][i] * y[i];
+                                    t *= hb[k];
+#pragma unroll
+                                    for (int i = k + 1; i < 5; i++) y[i] -= t * hv[k][i];
                                 }
                             }
-                            if (singular) break;
+                        } else {
+                            // MuJoCo's own evaluation (the f64 parity mode's default: the oracle's arithmetic, operation for operation)
+                            real As[5][5], bs[5], L[5][5], w[5], rd[5];
 #pragma unroll
-                            for (int i = 0; i < 5; i++) { real t = -bs[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = qdiv(t, L[i][i], rd[i]); }
+                            for (int j = 0; j < 5; j++) {
+                                bs[j] = j < n ? bq[j] * dq[j] : real(0);
+                                y[j] = 0;
 #pragma unroll
-                            for (int i = 4; i >= 0; i--) { real t = y[i]; for (int k = i + 1; k < 5; k++) t -= L[k][i] * y[k]; y[i] = qdiv(t, L[i][i], rd[i]); }
-                            real val = -r2;
+                                for (int k = 0; k < 5; k++) As[j][k] = (j < n && k < n) ? Aq[j][k] * dq[j] * dq[k] : (j == k ? real(1) : real(0));
+                            }
+                            for (int iter = 0; iter < 20; iter++) {
+                                nit_q++;
 #pragma unroll
-                            for (int i = 0; i < 5; i++) val += y[i] * y[i];
-                            if (val < vtol) break;
+                                for (int j = 0; j < 5; j++) {
+                                    real dd = As[j][j] + (j < n ? la : real(0));
 #pragma unroll
-                            for (int i = 0; i < 5; i++) { real t = y[i]; for (int k = 0; k < i; k++) t -= L[i][k] * w[k]; w[i] = qdiv(t, L[i][i], rd[i]); }
+                                    for (int k = 0; k < j; k++) dd -= L[j][k] * L[j][k];
+                                    if (j < n && dd < real(1e-10)) singular = true;
+                                    dd = tmax(dd, real(1e-30));
+                                    if (sizeof(real) == 4) { rd[j] = qrsqrt(dd); dd = dd * rd[j]; }
+                                    else { dd = sqrt(dd); rd[j] = real(1) / dd; }
+                                    L[j][j] = dd;
 #pragma unroll
-                            for (int i = 4; i >= 0; i--) { real t = w[i]; for (int k = i + 1; k < 5; k++) t -= L[k][i] * w[k]; w[i] = qdiv(t, L[i][i], rd[i]); }
-                            real deriv = 0;
+                                    for (int i = j + 1; i < 5; i++) {
+                                        real t = As[i][j];
 #pragma unroll
-                            for (int i = 0; i < 5; i++) deriv += y[i] * w[i];
-                            deriv *= -2;
-                            const real delta = -val / deriv;
-                            if (delta < QTol<real>::abs + QTol<real>::rel * la) break;
-                            la += delta;
+                                        for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+                                        L[i][j] = qdiv(t, dd, rd[j]);
+                                    }
+                                }
+                                if (singular) break;
+#pragma unroll
+                                for (int i = 0; i < 5; i++) { real t = -bs[i]; for (int k = 0; k < i; k++) t -= L[i][k] * y[k]; y[i] = qdiv(t, L[i][i], rd[i]); }
+#pragma unroll
+                                for (int i = 4; i >= 0; i--) { real t = y[i]; for (int k = i + 1; k < 5; k++) t -= L[k][i] * y[k]; y[i] = qdiv(t, L[i][i], rd[i]); }
+                                real val = -r2;
+#pragma unroll
+                                for (int i = 0; i < 5; i++) val += y[i] * y[i];
+                                if (val < vtol) break;
+#pragma unroll
+                                for (int i = 0; i < 5; i++) { real t = y[i]; for (int k = 0; k < i; k++) t -= L[i][k] * w[k]; w[i] = qdiv(t, L[i][i], rd[i]); }
+#pragma unroll
+                                for (int i = 4; i >= 0; i--) { real t = w[i]; for (int k = i + 1; k < 5; k++) t -= L[k][i] * w[k]; w[i] = qdiv(t, L[i][i], rd[i]); }
+                                real deriv = 0;
+#pragma unroll
+                                for (int i = 0; i < 5; i++) deriv += y[i] * w[i];
+                                deriv *= -2;
+                                const real delta = -val / deriv;
+                                if (delta < QTol<real>::abs + QTol<real>::rel * la) break;
+                                la += delta;
+                            }
                         }
 #pragma unroll
                         for (int j = 0; j < 5; j++) v[j] = (singular || !(j < n)) ? real(0) : y[j] * dq[j];
@@ -725,6 +830,7 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
 #pragma unroll
                     for (int j = 0; j < 5; j++) if (lane == j + 1 && j < n) f = v[j];
                 }
+                if (prof && lane == 0) { prof[2] += (int)(__builtin_readcyclecounter() - tsl0); prof[3] += 1; prof[4] += nit_q; prof[1] += (int)(tsl1 - tsl0); }
             }
         } else {
         // ---- sequential relaxation on lanes 0..cnt-1 (lane r = row start + r) ----
@@ -790,7 +896,7 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
             if (fl && it >= iters && step + 1 < total) floss_sweep();
         }
     }
-    if (prof && lane == 0) { prof[0] += nstep; prof[1] += nsweep; prof[4] += (int)(tq0 - tent); prof[5] += (int)(__builtin_readcyclecounter() - tent); }
+    if (prof && lane == 0) { prof[0] += nstep; prof[5] += (int)(__builtin_readcyclecounter() - tent); }
     if (fl && per_ns <= 0) {
         for (int sw = 0; sw < noslip_only; sw++) {
             imp = 0;
@@ -2245,7 +2351,7 @@ struct Env {
         nl.Minv = (LDS_PTR(const real))(r + ka->lay.Minv);
         nl.tadr = (LDS_PTR(const int))tree_dofadr_(); nl.tnum = (LDS_PTR(const int))tree_dofnum_(); nl.floss_dof = (LDS_PTR(const int))floss_dof_();
         nl.dmap = (LDS_PTR(int))(r + ka->lay.ng);       // the Newton gradient's words: dead once the primal solve has returned
-        nl.ntree = ka->m.ntree; nl.nv = ka->m.nv; nl.neq = ka->m.neq; nl.nfloss = ka->m.nfloss;
+        nl.ntree = ka->m.ntree; nl.nv = ka->m.nv; nl.neq = ka->m.neq; nl.nfloss = ka->m.nfloss; nl.tridiag = ka->m.qcqp_tridiag;
         nl.prof = profiling ? (LDS_PTR(int))(ii + ka->lay.nprof + 8) : (LDS_PTR(int))nullptr;
         nl.nlg = lead_per_tree() ? ((ii + ka->lay.misc)[4] + GRP_MAX - 1) / GRP_MAX : -1;
         return nl;
@@ -2571,7 +2677,7 @@ struct PhysHost {
         m.nj = b.scalar("num_arms") == 3 ? 21 : 14;
         auto opt = F("opt");
         m.timestep = (real)opt[0]; m.gravity[0] = (real)opt[1]; m.gravity[1] = (real)opt[2]; m.gravity[2] = (real)opt[3];
-        m.impratio = (real)opt[4]; m.noslip_iters = (int)opt[5]; m.noslip_per_tree = 1;
+        m.impratio = (real)opt[4]; m.noslip_iters = (int)opt[5]; m.noslip_per_tree = 1; m.qcqp_tridiag = sizeof(real) == 4 ? 1 : 0;
         m.solver = 1; m.newton_iters = 100; m.newton_tol = sizeof(real) == 8 ? (real)1e-8 : (real)1e-6;     // MuJoCo defaults: iterations 100, tolerance 1e-8
         m.nscale = (real)(1.0 / ((opt.size() > 7 && opt[7] > 0 ? opt[7] : 1.0) * std::max(1, m.nv)));
         auto gr = F("grip_range");
@@ -2861,6 +2967,7 @@ struct PhysHost {
         if (n == "export_contacts") { export_contacts = v != 0; return true; }
         if (n == "num_joints") { if (v != 14 && v != 21) return false; mf.nj = md.nj = (int)v; return true; }
         if (n == "order_envs") { order_envs = v != 0; return true; }
+        if (n == "qcqp_tridiag") { mf.qcqp_tridiag = md.qcqp_tridiag = v != 0; return true; }
         if (n == "noslip_per_tree") { mf.noslip_per_tree = md.noslip_per_tree = v != 0; return true; }
         if (n == "persist_blocks") { int x = (int)v; if (x >= 1 && x <= 64) { persist_over = x; return true; } return false; }
         if (n == "waves_per_block") { int x = (int)v; if (x >= 0 && x <= 8) { wpb_override = x; return true; } return false; }

@@ -40,6 +40,12 @@ print("inside solve (Newton):", "  ".join(f"{n} {v:.0f}" for n, v in zip(nn, mn)
 tot = out[:, :8].sum(1) / 20
 print("per-env total cycles/substep percentiles 50/90/99/max:", np.percentile(tot, [50, 90, 99, 100]).round(0), " noslip 50/90/99/max:", np.percentile(out[:, 16] / 20, [50, 90, 99, 100]).round(0),
       " narrow 50/90/99/max:", np.percentile(out[:, 9] / 21, [50, 90, 99, 100]).round(0))
-print("probe slots per substep:", (out[:, 18:26].mean(0) / 20).round(1))
+# noslip probes (pgs_groups): group steps, cycles gathering a sliding contact's block, cycles in sliding-contact branches, sliding steps,
+# multiplier iterations, cycles in the pass; then box-box and other narrow-phase cycles (collide)
+print("probe slots per substep [nstep, gather cyc, sliding cyc, sliding steps, multiplier its, noslip cyc, boxbox cyc, narrow cyc]:", (out[:, 18:26].mean(0) / 20).round(1))
 d = sim.diag()
 print("ncon percentiles", np.percentile(d[:, 0], [50, 90, 99, 100]), "newton max iters", np.percentile((d[:, 3] >> 28) & 0xf, [50, 90, 99, 100]))
+# the most expensive envs of the launch on their own
+top = np.argsort(-tot)[: max(1, N // 100)]
+print("slowest 1 % of the envs: total", tot[top].mean().round(0), " phases", (out[top, :8].mean(0) / 20).round(0), " noslip", (out[top, 16].mean() / 20).round(0),
+      " narrow", (out[top, 9].mean() / 21).round(0), " ncon", d[top, 0].mean().round(1), " probe slots", (out[top, 18:26].mean(0) / 20).round(1))
