@@ -52,6 +52,8 @@ def lib():
         L.avsim_render_depth.argtypes = [vp, vp, i32, i32, i32, vp]
         L.avsim_render_rgb.argtypes = [vp, vp, i32, i32, i32, vp]
         L.avsim_camera_count.argtypes = [vp]
+        L.avsim_load_visual.argtypes = [vp, vp, C.c_size_t]
+        L.avsim_visual_info.argtypes = [vp, vp]
         L.avsim_reward_from_pairs.argtypes = [vp, vp, i32, i32, vp, vp]
         L.avsim_sync.argtypes = [vp]
         L.avsim_set_stream.argtypes = [vp, vp]

@@ -21,6 +21,7 @@ import numpy as np
 
 from . import hull as hullmod
 from . import refdyn
+from . import vismesh
 from .mjcf import parse, quat_mul, quat_to_mat
 
 GEOM_SPHERE, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = 2, 5, 6, 7
@@ -180,7 +181,7 @@ def read_blob(path):
     return out
 
 
-def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbose=False):
+def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbose=False, vis_ids=None):
     xml, task_id = TASKS[task]
     m = parse(os.path.join(assets, xml))
     if num_arms == 2:
@@ -488,6 +489,17 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
     # skybox gradient (scene.xml:34): [headlight ambient, headlight diffuse, light diffuse, 0], light direction (world),
     # sky rgb at the zenith, sky rgb at the nadir
     md["render_light"] = np.array([0.3, 0.6, 0.7, 0.0,  0.0, 0.0, -1.0, 0.0,  0.3, 0.5, 0.7, 0.0,  0.0, 0.0, 0.0, 0.0])
+    # instances of the visual mesh library (models/visual_meshes.avv, compiler/vismesh.py): what the colour renderer draws
+    if vis_ids is not None:
+        rows = vismesh.instance_table(m, lambda g: geom_colour(m, g))
+        key = lambda r: r["mesh"] if r["mesh"].startswith("__") else os.path.basename(r["mesh"])
+        md["vis_inst_mesh"] = np.array([vis_ids[key(r)] for r in rows], dtype=np.int32)
+        md["vis_inst_body"] = np.array([r["body"] for r in rows], dtype=np.int32)
+        md["vis_inst_pos"] = np.array([r["pos"] for r in rows])
+        md["vis_inst_mat"] = np.array([r["mat"].reshape(9) for r in rows])
+        md["vis_inst_scale"] = np.array([r["scale"] for r in rows])
+        md["vis_inst_rgba"] = np.array([r["rgba"] for r in rows])
+        md["vis_inst_tex"] = np.array([r["tex"] for r in rows], dtype=np.int32)
 
     # ---- candidate pair list -------------------------------------------------------------
     excl = set()
@@ -710,15 +722,28 @@ def main():
                          "ZED cameras with fovy 90 (aloha_sim.xml:357-358); written as models/dc_<task>_3arms.*")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "..", "models"))
     ap.add_argument("--tasks", nargs="*", default=list(TASKS))
+    ap.add_argument("--vis-budget", type=int, default=20000, help="triangles of the biggest visual scene after decimation")
     args = ap.parse_args()
     if args.assets is None:
         args.assets = {"gym": "/root/reference/gym_guided_vision/gym_guided_vision/assets",
                        "data_collection": "/root/reference/data_collection_scripts/assets"}[args.variant]
     prefix = "dc_" if args.variant == "data_collection" else ""
     os.makedirs(args.out, exist_ok=True)
+    # the visual mesh library, shared by every model (the gym and data-collection assets hold the same meshes): decimated so that the
+    # biggest scene stays under the triangle budget
+    lib_path = os.path.join(args.out, "visual_meshes.avv")
+    scenes = [parse(os.path.join(args.assets, TASKS[t][0])) for t in TASKS]
+    lib, vis_ids, info = vismesh.build_library(scenes, os.path.join(args.assets, "meshes", "small_meta_table_diffuse.png"), budget=args.vis_budget, verbose=True)
+    if args.variant == "gym" or not os.path.exists(lib_path):
+        write_blob(lib_path, lib)
+        with open(os.path.join(args.out, "visual_meshes.json"), "w") as f:
+            json.dump({"mesh_ids": vis_ids, **info}, f, indent=1)
+        print(f"visual mesh library: cell {info['cell_m'] * 1e3:.2f} mm, scenes {info['scene_triangles']} triangles, {os.path.getsize(lib_path)} B")
+    else:
+        vis_ids = json.load(open(os.path.join(args.out, "visual_meshes.json")))["mesh_ids"]
     for t in args.tasks:
         for na in ((3,) if prefix else (2, 3)):          # sim_env.py always simulates the three arms
-            arrays, man = compile_task(args.assets, t, na)
+            arrays, man = compile_task(args.assets, t, na, vis_ids=vis_ids)
             man["variant"] = args.variant
             base = os.path.join(args.out, f"{prefix}{t}_{na}arms")
             write_blob(base + ".avm", arrays)

@@ -16,6 +16,7 @@
 #include "avsim_model.h"
 #include "avsim_phys.hip.h"
 #include "avsim_render.hip.h"
+#include "avsim_vis.hip.h"
 
 using namespace avs;
 
@@ -70,6 +71,8 @@ struct avsim {
     std::vector<double> qpos_home, ctrl_home;
     PhysHost phys;  // device model image + launch configuration (avsim_phys.hip.h)
     RenderHost render;   // depth renderer (avsim_render.hip.h)
+    VisHost vis;         // colour images of the visual meshes (avsim_vis.hip.h), once avsim_load_visual has run
+    bool render_proxies = false;   // option "render_proxies": avsim_render_rgb draws the collision proxies even with a visual scene loaded
     // device state (real = float, or double with AVSIM_F64_PHYSICS)
     void *d_qpos = nullptr, *d_qvel = nullptr, *d_ctrl = nullptr, *d_warm = nullptr;
     int* d_latch = nullptr;
@@ -369,6 +372,7 @@ int avsim_create(const void* blob, size_t nbytes, int num_envs, int device, uint
         std::string perr;
         if (!h->phys.init(b, num_envs, h->f64, perr)) { g_create_error = perr; return AVSIM_EMODEL; }
         h->render.build(b, num_envs);
+        h->vis.keep_instances(b);
     } catch (const std::exception& ex) {
         g_create_error = std::string("avsim_create: ") + ex.what();
         return AVSIM_EMODEL;
@@ -410,6 +414,7 @@ void avsim_destroy(avsim_t* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->phys.destroy();
     h->render.destroy();
+    h->vis.destroy();
     for (void* p : {h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, (void*)h->d_latch})
         if (p) (void)hipFree(p);
     for (void* p : h->d_io)
@@ -434,6 +439,7 @@ int avsim_set_option(avsim_t* h, const char* name, double value) {
     if (!h || !name) return AVSIM_EINVAL;
     AVS_ON_DEVICE(h);               // "maxefc" / "maxcon" / "profile_phases" allocate on the handle's device
     if (!std::strcmp(name, "kernel_timing")) { h->ktiming = value != 0; return AVSIM_OK; }
+    if (!std::strcmp(name, "render_proxies")) { h->render_proxies = value != 0; return AVSIM_OK; }
     if (!std::strcmp(name, "diffik_iters")) { h->ik.diff_iters = (int)value; return AVSIM_OK; }
     if (!std::strcmp(name, "gradik_iters")) { h->ik.grad_iters = (int)value; return AVSIM_OK; }
     try {
@@ -780,7 +786,11 @@ static int render_images(avsim_t* h, const int32_t* cam_ids, int ncam, int heigh
     rc = h->phys.launch(h->stream, h->N, 0, nullptr, h->nj, h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, h->d_latch, nullptr, nullptr, nullptr, h->err);
     h->phys.d_xpose = nullptr;
     if (rc) return rc;
-    if ((rc = h->render.launch(h->stream, (const int*)cam_ids, ncam, height, width, dout, rgb, h->err))) return rc < -1 ? AVSIM_EHIP : AVSIM_EINVAL;
+    if (rgb && h->vis.loaded && !h->render_proxies)
+        rc = h->vis.launch(h->stream, h->N, h->render.d_xpose, (const int*)cam_ids, ncam, h->render.m.ncam, height, width, dout, h->err);
+    else
+        rc = h->render.launch(h->stream, (const int*)cam_ids, ncam, height, width, dout, rgb, h->err);
+    if (rc) return rc < -1 ? AVSIM_EHIP : AVSIM_EINVAL;
     if ((rc = h->out_end(7, out, bytes))) return rc;
     return h->finish();
 }
@@ -790,6 +800,35 @@ int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height,
 // E6 as colour images of the same proxies (env.py:180-188 "pixels" u8[H][W][3], :195-200 render)
 int avsim_render_rgb(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, uint8_t* out) {
     return render_images(h, cam_ids, ncam, height, width, out, true);
+}
+
+// The visual scene of avsim_render_rgb: the mesh library (models/visual_meshes.avv, compiler/vismesh.py) against the instances the
+// model blob carries.  From then on avsim_render_rgb draws the visual meshes (option "render_proxies" 1: the collision proxies again).
+int avsim_load_visual(avsim_t* h, const void* library_blob, size_t nbytes) {
+    if (!h || !library_blob) { if (h) h->set_error("avsim_load_visual: bad arguments"); return AVSIM_EINVAL; }
+    AVS_ON_DEVICE(h);
+    try {
+        Blob lib(library_blob, nbytes);
+        h->vis.load(lib, h->render.m.nbody, h->render.m.cam_pos, h->render.m.cam_mat, h->render.m.cam_fovy, h->render.m.cam_body, h->render.m.light, h->render.m.znear);
+    } catch (const std::exception& e) {
+        h->set_error("avsim_load_visual: %s", e.what());
+        return AVSIM_EMODEL;
+    }
+    return AVSIM_OK;
+}
+// triangles / vertices of the loaded visual scene (0 when none is loaded); overflow flags of the last visual render: bit 0 a view ran
+// out of triangle records, bit 1 out of tile-list entries (the image then lacks triangles); synchronises the stream
+int avsim_visual_info(avsim_t* h, int32_t info[4]) {
+    if (!h || !info) return AVSIM_EINVAL;
+    AVS_ON_DEVICE(h);
+    info[0] = h->vis.loaded ? h->vis.S.ntri : 0; info[1] = h->vis.loaded ? h->vis.S.nvert : 0; info[2] = 0; info[3] = h->vis.have_inst ? (int)h->vis.inst_mesh.size() : 0;
+    if (h->vis.loaded && h->vis.X.flags && h->vis.nviews_cap > 0) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::vector<int> f((size_t)h->vis.nviews_cap);
+        HIPCHK(h, hipMemcpy(f.data(), h->vis.X.flags, f.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int v : f) info[2] |= v;
+    }
+    return AVSIM_OK;
 }
 
 int avsim_camera_count(const avsim_t* h) { return h ? h->render.m.ncam : 0; }

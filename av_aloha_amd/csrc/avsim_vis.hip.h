@@ -1,0 +1,421 @@
+// avsim_vis.hip.h -- colour images of the VISUAL meshes: what the reference's cameras show through MuJoCo's
+// OpenGL pipeline (gym_guided_vision/gym_guided_vision/env.py:180-188 get_obs "pixels", :195-200 render) -- the robot's visual
+// meshes (assets/aloha_sim.xml class "visual"), the frame and the table with its texture (assets/scene.xml), the task objects --
+// as a software triangle rasteriser, one image per (env, camera).
+//
+// Scene = the model's instances of the decimated mesh library (compiler/vismesh.py: <= 20 k triangles per scene), expanded once on
+// the host into body-frame vertices and triangles.  One workgroup (4 wavefronts) per view, persistent over the views:
+//   1. camera-from-body transforms into LDS, every vertex into the camera frame (global scratch of the workgroup's slot);
+//   2. triangle set-up, one triangle per thread: clipped against the near plane (a camera sits inside its own mount), projected,
+//      its three edge functions and the plane of 1 / depth normalised into a 16-float record, flat Lambert shade (headlight +
+//      the scene's directional light, the terms of avsim_render.hip.h's proxy image) folded into an rgb8 colour;
+//   3. binning into 8 x 8 pixel tiles: count (LDS counters, tile-vs-edge test) -> prefix sum -> fill;
+//   4. one wavefront per tile, lane = pixel: the tile's records are wave-uniform loads, the depth test is on 1 / depth with the
+//      triangle index as tie-break (the image does not depend on the order of the lists); the winner's colour -- for the textured
+//      table the pixel ray is intersected with the triangle for perspective-correct texture coordinates -- or the sky gradient.
+// No shadows, specular terms, anti-aliasing or transparency: parity with the reference's OpenGL pixels is unpinned.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "avsim_model.h"
+
+namespace avs {
+
+constexpr int VIS_TILE = 8, VIS_THREADS = 256, VIS_MAXBODY = 64, VIS_MAXTILES = 16384, VIS_REC = 16;
+
+struct VisScene {
+    int nvert, ntri, nbody, ncam;
+    const float* vert;      // [nvert][3] body frame
+    const int* vbody;       // [nvert]
+    const int* tri;         // [ntri][3]
+    const float* rgb;       // [ntri][3]
+    const float* uv;        // [ntri][6]
+    const int* tex;         // [ntri]
+    const unsigned* texel;  // [VIS_TEX][VIS_TEX] r | g << 8 | b << 16, row 0 = top
+    int texn;
+    const int* cam_body;
+    const float *cam_pos, *cam_mat, *cam_fovy;   // cam_fovy: tan(fovy / 2)
+    const float* light;     // as RenderModel::light
+    float znear;
+};
+
+// per-slot scratch (a workgroup's view in flight)
+struct VisScratch {
+    float4* vcam;     // [slots][nvert]
+    float4* rec;      // [slots][reccap][4]
+    int* bbox;        // [slots][reccap][4] tile ranges
+    int* list;        // [slots][listcap]
+    int* flags;       // [nviews] bit 0: record overflow, bit 1: list overflow
+    int reccap, listcap;
+};
+
+__device__ inline unsigned vis_pack(float r, float g, float b) {
+    const unsigned R = (unsigned)(fminf(fmaxf(r, 0.0f), 1.0f) * 255.0f + 0.5f), G = (unsigned)(fminf(fmaxf(g, 0.0f), 1.0f) * 255.0f + 0.5f),
+                   B = (unsigned)(fminf(fmaxf(b, 0.0f), 1.0f) * 255.0f + 0.5f);
+    return R | (G << 8) | (B << 16);
+}
+
+// is the tile [x0, x0 + 8) x [y0, y0 + 8) (pixel centres) entirely outside one of the triangle's edges?
+__device__ inline bool vis_tile_outside(const float4 r0, const float4 r1, const float4 r2, float x0, float y0) {
+    const float xa = x0 + 0.5f, xb = x0 + VIS_TILE - 0.5f, ya = y0 + 0.5f, yb = y0 + VIS_TILE - 0.5f;
+    const float e0 = r0.x * (r0.x > 0 ? xb : xa) + r0.y * (r0.y > 0 ? yb : ya) + r0.z;
+    const float e1 = r0.w * (r0.w > 0 ? xb : xa) + r1.x * (r1.x > 0 ? yb : ya) + r1.y;
+    const float e2 = r1.z * (r1.z > 0 ? xb : xa) + r1.w * (r1.w > 0 ? yb : ya) + r2.x;
+    return e0 < 0 || e1 < 0 || e2 < 0;
+}
+
+__global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScratch X, const float* __restrict__ xpose, const int* __restrict__ cam_ids, int ncam_sel,
+                                                            int N, int H, int W, unsigned char* __restrict__ out) {
+    __shared__ float Rcb[VIS_MAXBODY * 12];
+    __shared__ float cam[24];                // Rc (9), pc (3), light dir in the camera frame (3), world up in the camera frame (3), scale
+    extern __shared__ int vis_dyn[];         // toff[ntile + 1]: tile -> first list entry (after the scan), counters before; tcur[ntile]
+    __shared__ int nrec_s, wsum[VIS_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tw = (W + VIS_TILE - 1) / VIS_TILE, th = (H + VIS_TILE - 1) / VIS_TILE, ntile = tw * th;
+    const int nviews = N * ncam_sel, slot = blockIdx.x;
+    int* const toff = vis_dyn;
+    int* const tcur = vis_dyn + ntile + 1;
+    float4* vcam = X.vcam + (size_t)slot * S.nvert;
+    float4* rec = X.rec + (size_t)slot * X.reccap * 4;
+    int* bbox = X.bbox + (size_t)slot * X.reccap * 4;
+    int* list = X.list + (size_t)slot * X.listcap;
+    for (int view = blockIdx.x; view < nviews; view += gridDim.x) {
+        const int env = view / ncam_sel, cs = view - env * ncam_sel, cid = cam_ids[cs];
+        const float* xb = xpose + (size_t)env * S.nbody * 12;
+        __syncthreads();     // the previous view's tiles are done with the shared tables
+        if (tid == 0) {
+            const int b = S.cam_body[cid];
+            const float *pb = xb + 12 * b, *Rb = pb + 3, *cp = S.cam_pos + 3 * cid, *cm = S.cam_mat + 9 * cid;
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) cam[3 * i + j] = Rb[3 * i] * cm[j] + Rb[3 * i + 1] * cm[3 + j] + Rb[3 * i + 2] * cm[6 + j];
+            for (int i = 0; i < 3; i++) cam[9 + i] = pb[i] + Rb[3 * i] * cp[0] + Rb[3 * i + 1] * cp[1] + Rb[3 * i + 2] * cp[2];
+            const float* L = S.light + 4;
+            const float il = 1.0f / sqrtf(L[0] * L[0] + L[1] * L[1] + L[2] * L[2]);
+            for (int j = 0; j < 3; j++) {
+                cam[12 + j] = (cam[j] * L[0] + cam[3 + j] * L[1] + cam[6 + j] * L[2]) * il;      // Rc^T l
+                cam[15 + j] = cam[6 + j];                                                          // Rc^T e_z
+            }
+            cam[18] = 2.0f * S.cam_fovy[cid] / (float)H;
+            nrec_s = 0;
+        }
+        for (int t = tid; t <= ntile; t += VIS_THREADS) toff[t] = 0;
+        __syncthreads();
+        // 1. camera-from-body transforms, vertices into the camera frame
+        for (int b = tid; b < S.nbody; b += VIS_THREADS) {
+            const float *pb = xb + 12 * b, *Rb = pb + 3;
+            float* o = Rcb + 12 * b;
+            for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++) o[3 * i + j] = cam[i] * Rb[j] + cam[3 + i] * Rb[3 + j] + cam[6 + i] * Rb[6 + j];      // Rc^T Rb
+                o[9 + i] = cam[i] * (pb[0] - cam[9]) + cam[3 + i] * (pb[1] - cam[10]) + cam[6 + i] * (pb[2] - cam[11]);
+            }
+        }
+        __syncthreads();
+        for (int v = tid; v < S.nvert; v += VIS_THREADS) {
+            const float* o = Rcb + 12 * S.vbody[v];
+            const float x = S.vert[3 * v], y = S.vert[3 * v + 1], z = S.vert[3 * v + 2];
+            vcam[v] = make_float4(o[0] * x + o[1] * y + o[2] * z + o[9], o[3] * x + o[4] * y + o[5] * z + o[10], o[6] * x + o[7] * y + o[8] * z + o[11], 0.0f);
+        }
+        __threadfence_block();
+        __syncthreads();
+        // 2. triangle set-up + tile counts
+        const float scale = cam[18], iscale = 1.0f / scale, znear = S.znear;
+        const float amb = S.light[0], hd = S.light[1], ld = S.light[2];
+        int flag = 0;
+        for (int t0 = 0; t0 < S.ntri; t0 += VIS_THREADS) {
+            const int t = t0 + tid;
+            int nout = 0;
+            float px[4], py[4], pw[4];
+            unsigned colour = 0;
+            if (t < S.ntri) {
+                const float4 a = vcam[S.tri[3 * t]], b = vcam[S.tri[3 * t + 1]], c = vcam[S.tri[3 * t + 2]];
+                const float da = -a.z, db = -b.z, dc = -c.z;
+                if (!(da < znear && db < znear && dc < znear)) {
+                    // clip the triangle against depth = znear (Sutherland-Hodgman on one plane: 3 or 4 corners)
+                    const float P[3][3] = {{a.x, a.y, a.z}, {b.x, b.y, b.z}, {c.x, c.y, c.z}};
+                    const float D[3] = {da, db, dc};
+                    float Q[4][3];
+                    int nq = 0;
+                    for (int i = 0; i < 3; i++) {
+                        const int j = i == 2 ? 0 : i + 1;
+                        const bool in_i = D[i] >= znear, in_j = D[j] >= znear;
+                        if (in_i) { Q[nq][0] = P[i][0]; Q[nq][1] = P[i][1]; Q[nq][2] = P[i][2]; nq++; }
+                        if (in_i != in_j) {
+                            const float s = (znear - D[i]) / (D[j] - D[i]);
+                            Q[nq][0] = P[i][0] + s * (P[j][0] - P[i][0]); Q[nq][1] = P[i][1] + s * (P[j][1] - P[i][1]); Q[nq][2] = -znear; nq++;
+                        }
+                    }
+                    for (int i = 0; i < nq; i++) {
+                        const float w = -1.0f / Q[i][2];
+                        px[i] = Q[i][0] * w * iscale + 0.5f * W;
+                        py[i] = -Q[i][1] * w * iscale + 0.5f * H;
+                        pw[i] = w;
+                    }
+                    nout = nq >= 3 ? nq - 2 : 0;
+                    // flat shade from the (unclipped) triangle's normal in the camera frame, turned towards the camera
+                    float n[3] = {(b.y - a.y) * (c.z - a.z) - (b.z - a.z) * (c.y - a.y), (b.z - a.z) * (c.x - a.x) - (b.x - a.x) * (c.z - a.z),
+                                  (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x)};
+                    const float g[3] = {(a.x + b.x + c.x) * (1.0f / 3), (a.y + b.y + c.y) * (1.0f / 3), (a.z + b.z + c.z) * (1.0f / 3)};
+                    const float nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2], gg = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+                    if (!(nn > 0) || !(gg > 0)) nout = 0;
+                    else {
+                        const float in = rsqrtf(nn), ig = rsqrtf(gg);
+                        float ch = -(n[0] * g[0] + n[1] * g[1] + n[2] * g[2]) * in * ig;
+                        float sgn = 1.0f;
+                        if (ch < 0) { ch = -ch; sgn = -1.0f; }
+                        const float cl = -sgn * (n[0] * cam[12] + n[1] * cam[13] + n[2] * cam[14]) * in;
+                        const float lum = fminf(1.0f, amb + hd * ch + ld * fmaxf(cl, 0.0f));
+                        if (S.tex[t]) colour = 0x80000000u | (unsigned)(lum * 65535.0f + 0.5f);      // textured: the shade, colour at the pixel
+                        else colour = vis_pack(S.rgb[3 * t] * lum, S.rgb[3 * t + 1] * lum, S.rgb[3 * t + 2] * lum);
+                    }
+                }
+            }
+            for (int k = 0; k < 2; k++) {
+                bool keep = k < nout;
+                float4 r0, r1, r2, r3;
+                int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1;
+                if (keep) {
+                    const int i0 = 0, i1 = k + 1, i2 = k + 2;
+                    const float x0 = px[i0], y0 = py[i0], x1 = px[i1], y1 = py[i1], x2 = px[i2], y2 = py[i2];
+                    const float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+                    const float xmin = fminf(x0, fminf(x1, x2)), xmax = fmaxf(x0, fmaxf(x1, x2)), ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
+                    // pixel centres covered by the bounding box
+                    const int ix0 = max(0, (int)ceilf(xmin - 0.5f)), ix1 = min(W - 1, (int)floorf(xmax - 0.5f));
+                    const int iy0 = max(0, (int)ceilf(ymin - 0.5f)), iy1 = min(H - 1, (int)floorf(ymax - 0.5f));
+                    if (!(fabsf(area) > 1e-12f) || ix0 > ix1 || iy0 > iy1 || !(xmax - xmin < 1e7f) || !(ymax - ymin < 1e7f)) keep = false;
+                    else {
+                        const float ia = 1.0f / area;
+                        // lambda_0 = edge (1 -> 2), lambda_1 = edge (2 -> 0), lambda_2 = edge (0 -> 1), each / area: >= 0 inside either winding
+                        const float a0 = (y1 - y2) * ia, b0 = (x2 - x1) * ia, c0 = (x1 * y2 - x2 * y1) * ia;
+                        const float a1 = (y2 - y0) * ia, b1 = (x0 - x2) * ia, c1 = (x2 * y0 - x0 * y2) * ia;
+                        const float a2 = (y0 - y1) * ia, b2 = (x1 - x0) * ia, c2 = (x0 * y1 - x1 * y0) * ia;
+                        const float w0 = pw[i0], w1 = pw[i1], w2 = pw[i2];
+                        r0 = make_float4(a0, b0, c0, a1);
+                        r1 = make_float4(b1, c1, a2, b2);
+                        r2 = make_float4(c2, a0 * w0 + a1 * w1 + a2 * w2, b0 * w0 + b1 * w1 + b2 * w2, c0 * w0 + c1 * w1 + c2 * w2);
+                        r3 = make_float4(__uint_as_float(colour), __int_as_float(t), 0.0f, 0.0f);
+                        bx0 = ix0 / VIS_TILE; bx1 = ix1 / VIS_TILE; by0 = iy0 / VIS_TILE; by1 = iy1 / VIS_TILE;
+                    }
+                }
+                // ordered compaction of the block's records: the record index follows the triangle index
+                const unsigned long long m = __ballot(keep);
+                if (lane == 0) wsum[wave] = __popcll(m);
+                __syncthreads();
+                int base = nrec_s;
+                for (int w2_ = 0; w2_ < wave; w2_++) base += wsum[w2_];
+                const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (keep && idx < X.reccap) {
+                    rec[4 * idx] = r0; rec[4 * idx + 1] = r1; rec[4 * idx + 2] = r2; rec[4 * idx + 3] = r3;
+                    for (int ty = by0; ty <= by1; ty++)
+                        for (int tx = bx0; tx <= bx1; tx++)
+                            if (!vis_tile_outside(r0, r1, r2, (float)(tx * VIS_TILE), (float)(ty * VIS_TILE))) atomicAdd(&toff[ty * tw + tx], 1);
+                    ((int4*)bbox)[idx] = make_int4(bx0, bx1, by0, by1);
+                } else if (keep) flag |= 1;
+                __syncthreads();
+                if (tid == 0) { int s = nrec_s; for (int w2_ = 0; w2_ < VIS_THREADS / 64; w2_++) s += wsum[w2_]; nrec_s = s < X.reccap ? s : X.reccap; }
+                __syncthreads();
+            }
+        }
+        // 3. exclusive scan of the tile counts (one wave), then the fill pass
+        if (wave == 0) {
+            int carry = 0;
+            for (int t0 = 0; t0 < ntile; t0 += 64) {
+                const int t = t0 + lane;
+                const int c = t < ntile ? toff[t] : 0;
+                int s = c;
+                for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(s, o, 64); if (lane >= o) s += y; }
+                if (t < ntile) { toff[t] = carry + s - c; tcur[t] = carry + s - c; }
+                carry += __shfl(s, 63, 64);
+            }
+            if (lane == 0) toff[ntile] = carry;
+        }
+        __syncthreads();
+        const int nrec = nrec_s;
+        for (int i = tid; i < nrec; i += VIS_THREADS) {
+            const float4 r0 = rec[4 * i], r1 = rec[4 * i + 1], r2 = rec[4 * i + 2];
+            const int4 bb = ((const int4*)bbox)[i];
+            for (int ty = bb.z; ty <= bb.w; ty++)
+                for (int tx = bb.x; tx <= bb.y; tx++)
+                    if (!vis_tile_outside(r0, r1, r2, (float)(tx * VIS_TILE), (float)(ty * VIS_TILE))) {
+                        const int p = atomicAdd(&tcur[ty * tw + tx], 1);
+                        if (p < X.listcap) list[p] = i; else flag |= 2;
+                    }
+        }
+        __threadfence_block();
+        __syncthreads();
+        // 4. tiles: one wavefront each, lane = pixel
+        unsigned char* img = out + (size_t)view * H * W * 3;
+        for (int tile = wave; tile < ntile; tile += VIS_THREADS / 64) {
+            const int ty = tile / tw, tx = tile - ty * tw;
+            const int ix = tx * VIS_TILE + (lane & 7), iy = ty * VIS_TILE + (lane >> 3);
+            const float fx = ix + 0.5f, fy = iy + 0.5f;
+            const int e0 = toff[tile], e1 = min(toff[tile + 1], X.listcap);
+            float bw = 0.0f;
+            int bi = -1, bt = 0x7fffffff;
+            for (int e = e0; e < e1; e++) {
+                const int i = __builtin_amdgcn_readfirstlane(list[e]);
+                const float4 r0 = rec[4 * i], r1 = rec[4 * i + 1], r2 = rec[4 * i + 2], r3 = rec[4 * i + 3];
+                const float l0 = r0.x * fx + r0.y * fy + r0.z, l1 = r0.w * fx + r1.x * fy + r1.y, l2 = r1.z * fx + r1.w * fy + r2.x;
+                const float w = r2.y * fx + r2.z * fy + r2.w;
+                const int t = __float_as_int(r3.y);
+                if (l0 >= 0 && l1 >= 0 && l2 >= 0 && w > 0 && (w > bw || (w == bw && t < bt))) { bw = w; bi = i; bt = t; }
+            }
+            if (ix < W && iy < H) {
+                unsigned col;
+                const float dx = (fx - 0.5f * W) * scale, dy = -(fy - 0.5f * H) * scale;
+                if (bi >= 0) {
+                    col = __float_as_uint(rec[4 * bi + 3].x);
+                    if (col & 0x80000000u) {
+                        // textured: pixel ray against the triangle's plane in the camera frame -> barycentric -> uv -> texel
+                        const float lum = (float)(col & 0xffffu) * (1.0f / 65535.0f);
+                        const float4 a = vcam[S.tri[3 * bt]], b = vcam[S.tri[3 * bt + 1]], c = vcam[S.tri[3 * bt + 2]];
+                        const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z, e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+                        // Moeller-Trumbore with origin 0 and direction (dx, dy, -1)
+                        const float hx = dy * e2z + e2y, hy = -e2x - dx * e2z, hz = dx * e2y - dy * e2x;      // d x e2
+                        const float det = e1x * hx + e1y * hy + e1z * hz;
+                        const float idet = fabsf(det) > 1e-20f ? 1.0f / det : 0.0f;
+                        const float sx = -a.x, sy = -a.y, sz = -a.z;
+                        float u = (sx * hx + sy * hy + sz * hz) * idet;
+                        const float qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;      // s x e1
+                        float v = (dx * qx + dy * qy - qz) * idet;
+                        u = fminf(fmaxf(u, 0.0f), 1.0f); v = fminf(fmaxf(v, 0.0f), 1.0f - u);
+                        const float* uv = S.uv + 6 * bt;
+                        const float tu = uv[0] + u * (uv[2] - uv[0]) + v * (uv[4] - uv[0]), tv = uv[1] + u * (uv[3] - uv[1]) + v * (uv[5] - uv[1]);
+                        const float fu = tu - floorf(tu), fv = tv - floorf(tv);
+                        const int txi = min(S.texn - 1, (int)(fu * S.texn)), tyi = min(S.texn - 1, (int)((1.0f - fv) * S.texn));
+                        const unsigned tx_ = S.texel[tyi * S.texn + txi];
+                        col = vis_pack((float)(tx_ & 255u) * (lum / 255.0f), (float)((tx_ >> 8) & 255u) * (lum / 255.0f), (float)((tx_ >> 16) & 255u) * (lum / 255.0f));
+                    }
+                } else {
+                    const float idn = rsqrtf(dx * dx + dy * dy + 1.0f);
+                    const float w = 0.5f + 0.5f * (cam[15] * dx + cam[16] * dy - cam[17]) * idn;
+                    col = vis_pack(S.light[12] + (S.light[8] - S.light[12]) * w, S.light[13] + (S.light[9] - S.light[13]) * w, S.light[14] + (S.light[10] - S.light[14]) * w);
+                }
+                unsigned char* d = img + ((size_t)iy * W + ix) * 3;
+                d[0] = (unsigned char)(col & 255u); d[1] = (unsigned char)((col >> 8) & 255u); d[2] = (unsigned char)((col >> 16) & 255u);
+            }
+        }
+        if (flag) atomicOr(&X.flags[view], flag);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct VisHost {
+    // the model's instances (kept from the model blob), the scene once a library is loaded
+    std::vector<int> inst_mesh, inst_body, inst_tex;
+    std::vector<double> inst_pos, inst_mat, inst_scale, inst_rgba;
+    bool have_inst = false, loaded = false;
+    VisScene S{};
+    VisScratch X{};
+    std::vector<void*> allocs;
+    int slots = 0, nviews_cap = 0;
+    bool attr_done = false;
+    int* d_cam_ids = nullptr;
+
+    template <typename T>
+    T* up(const std::vector<T>& v) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (v.size() ? v.size() : 1) * sizeof(T)) != hipSuccess) throw std::runtime_error("hipMalloc failed while uploading the visual scene");
+        if (v.size() && hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("hipMemcpy failed while uploading the visual scene");
+        allocs.push_back(p);
+        return (T*)p;
+    }
+    void keep_instances(const Blob& b) {
+        try {
+            inst_mesh = b.i("vis_inst_mesh"); inst_body = b.i("vis_inst_body"); inst_tex = b.i("vis_inst_tex");
+            inst_pos = b.f("vis_inst_pos"); inst_mat = b.f("vis_inst_mat"); inst_scale = b.f("vis_inst_scale"); inst_rgba = b.f("vis_inst_rgba");
+            have_inst = true;
+        } catch (const std::exception&) { have_inst = false; }      // a model compiled without the visual scene: the proxy image only
+    }
+    // library blob (models/visual_meshes.avv) x instances -> the scene's triangles in body frames, uploaded
+    void load(const Blob& lib, int nbody, const float* d_cam_pos, const float* d_cam_mat, const float* d_cam_fovy, const int* d_cam_body, const float* d_light, float znear) {
+        if (!have_inst) throw std::runtime_error("the model blob carries no visual instances (vis_inst_*): recompile it with av_aloha_amd.compiler.compile");
+        if (loaded) return;
+        auto vadr = lib.i("lib_vadr"), vnum = lib.i("lib_vnum"), tadr = lib.i("lib_tadr"), tnum = lib.i("lib_tnum"), ltri = lib.i("lib_tri"), ltex = lib.i("lib_tex");
+        auto lvert = lib.f("lib_vert"), luv = lib.f("lib_uv");
+        std::vector<float> vert, rgb, uv;
+        std::vector<int> vbody, tri, tex;
+        const int ninst = (int)inst_mesh.size();
+        for (int k = 0; k < ninst; k++) {
+            const int mid = inst_mesh[k];
+            if (mid < 0 || mid >= (int)vadr.size()) throw std::runtime_error("visual instance refers to a mesh the library lacks");
+            const int v0 = (int)vbody.size();
+            const double *sc = &inst_scale[3 * k], *R = &inst_mat[9 * k], *p = &inst_pos[3 * k];
+            for (int v = 0; v < vnum[mid]; v++) {
+                const double* q = &lvert[3 * (size_t)(vadr[mid] + v)];
+                const double s[3] = {q[0] * sc[0], q[1] * sc[1], q[2] * sc[2]};
+                for (int i = 0; i < 3; i++) vert.push_back((float)(R[3 * i] * s[0] + R[3 * i + 1] * s[1] + R[3 * i + 2] * s[2] + p[i]));
+                vbody.push_back(inst_body[k]);
+            }
+            const bool flip = sc[0] * sc[1] * sc[2] < 0;
+            for (int t = 0; t < tnum[mid]; t++) {
+                const int* f = &ltri[3 * (size_t)(tadr[mid] + t)];
+                const double* u = &luv[6 * (size_t)(tadr[mid] + t)];
+                const int o[3] = {0, flip ? 2 : 1, flip ? 1 : 2};
+                for (int c = 0; c < 3; c++) { tri.push_back(v0 + f[o[c]]); uv.push_back((float)u[2 * o[c]]); uv.push_back((float)u[2 * o[c] + 1]); }
+                for (int c = 0; c < 3; c++) rgb.push_back((float)inst_rgba[4 * k + c]);
+                tex.push_back(inst_tex[k]);
+            }
+        }
+        if (nbody > VIS_MAXBODY) throw std::runtime_error("visual renderer: more than 64 bodies");
+        S.nvert = (int)vbody.size(); S.ntri = (int)tex.size(); S.nbody = nbody;
+        S.vert = up(vert); S.vbody = up(vbody); S.tri = up(tri); S.rgb = up(rgb); S.uv = up(uv); S.tex = up(tex);
+        std::vector<unsigned> texel(ltex.begin(), ltex.end());
+        S.texel = up(texel);
+        S.texn = (int)std::lround(std::sqrt((double)texel.size()));
+        S.cam_body = d_cam_body; S.cam_pos = d_cam_pos; S.cam_mat = d_cam_mat; S.cam_fovy = d_cam_fovy; S.light = d_light; S.znear = znear;
+        loaded = true;
+    }
+    void destroy() {
+        for (void* p : allocs) (void)hipFree(p);
+        allocs.clear();
+        for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.flags, (void*)d_cam_ids}) if (p) (void)hipFree(p);
+        X = VisScratch{}; d_cam_ids = nullptr; loaded = false; slots = 0; nviews_cap = 0;
+    }
+    // overflow flags of the last launch, OR over the views (bit 0: triangle records, bit 1: tile lists); synchronises the stream
+    int launch(hipStream_t st, int N, const float* d_xpose, const int* cam_ids_host, int ncam_sel, int ncam_model, int H, int W, void* d_out, std::string& err) {
+        if (!loaded) { err = "avsim_render_rgb: no visual scene loaded (avsim_load_visual)"; return -1; }
+        if (ncam_sel < 1 || ncam_sel > 16 || H < 1 || W < 1) { err = "avsim_render_rgb: bad camera count or image size"; return -1; }
+        const int ntile = ((W + VIS_TILE - 1) / VIS_TILE) * ((H + VIS_TILE - 1) / VIS_TILE);
+        if (ntile > VIS_MAXTILES) { err = "avsim_render_rgb: the visual-mesh image is limited to 16384 tiles of 8 x 8 pixels (1024 x 1024)"; return -1; }
+        for (int c = 0; c < ncam_sel; c++)
+            if (cam_ids_host[c] < 0 || cam_ids_host[c] >= ncam_model) { err = "avsim_render_rgb: camera index out of range"; return -1; }
+        const int nviews = N * ncam_sel;
+        if (!slots) {
+            int dev = 0, cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+            slots = 2 * cus;
+            X.reccap = S.ntri + 2048;                  // near-plane clipping can split a triangle in two
+            X.listcap = 8 * S.ntri + 4 * VIS_MAXTILES;
+            if (hipMalloc((void**)&X.vcam, (size_t)slots * S.nvert * sizeof(float4)) != hipSuccess || hipMalloc((void**)&X.rec, (size_t)slots * X.reccap * 4 * sizeof(float4)) != hipSuccess ||
+                hipMalloc((void**)&X.bbox, (size_t)slots * X.reccap * 4 * sizeof(int)) != hipSuccess || hipMalloc((void**)&X.list, (size_t)slots * X.listcap * sizeof(int)) != hipSuccess ||
+                hipMalloc((void**)&d_cam_ids, 16 * sizeof(int)) != hipSuccess) { err = "hipMalloc(visual render scratch) failed"; slots = 0; return -3; }
+        }
+        if (nviews > nviews_cap) {
+            if (X.flags) (void)hipFree(X.flags);
+            X.flags = nullptr;
+            if (hipMalloc((void**)&X.flags, (size_t)nviews * sizeof(int)) != hipSuccess) { err = "hipMalloc(visual render flags) failed"; nviews_cap = 0; return -3; }
+            nviews_cap = nviews;
+        }
+        if (hipMemsetAsync(X.flags, 0, (size_t)nviews * sizeof(int), st) != hipSuccess || hipMemcpyAsync(d_cam_ids, cam_ids_host, ncam_sel * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { err = "visual render set-up copy failed"; return -3; }
+        const int grid = nviews < slots ? nviews : slots;
+        const size_t shmem = (size_t)(2 * ntile + 1) * sizeof(int);
+        if (!attr_done) {
+            if (hipFuncSetAttribute((const void*)k_vis_render, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) { err = "hipFuncSetAttribute(visual render) failed"; return -3; }
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(k_vis_render, dim3(grid), dim3(VIS_THREADS), shmem, st, S, X, d_xpose, (const int*)d_cam_ids, ncam_sel, N, H, W, (unsigned char*)d_out);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { err = std::string("visual render kernel launch: ") + hipGetErrorString(e); return -3; }
+        return 0;
+    }
+};
+
+}  // namespace avs

@@ -105,9 +105,29 @@ class BatchedSim:
         self.h.check(self.h.L.avsim_render_depth(self.h.h, ids.ctypes.data, len(ids), height, width, out.ctypes.data))
         return out
 
-    def render_rgb(self, cameras, height, width):
+    def load_visual(self, path=None):
+        """The visual scene of render_rgb: the decimated mesh library models/visual_meshes.avv (compiler/vismesh.py) against the
+        instances in the model blob; from then on render_rgb rasterises the visual meshes (robot, frame, textured table, task
+        objects) instead of the collision proxies."""
+        path = path or os.path.join(MODEL_DIR, "visual_meshes.avv")
+        with open(path, "rb") as f:
+            lib = f.read()
+        self.h.check(self.h.L.avsim_load_visual(self.h.h, lib, len(lib)))
+        self._visual = True
+
+    def visual_info(self):
+        """{triangles, vertices, overflow flags of the last visual render, instances in the model}."""
+        info = np.zeros(4, dtype=np.int32)
+        self.h.check(self.h.L.avsim_visual_info(self.h.h, info.ctypes.data))
+        return dict(zip(("triangles", "vertices", "overflow", "instances"), (int(x) for x in info)))
+
+    def render_rgb(self, cameras, height, width, visual=True):
         """Colour images uint8 [N, len(cameras), height, width, 3] of the named cameras at the current state (the layout
-        of the reference's "pixels" observation, env.py:180-188)."""
+        of the reference's "pixels" observation, env.py:180-188).  visual: the scene's visual meshes (loaded on first use from
+        models/visual_meshes.avv); False: the collision proxies in flat colours (the depth renderer's geometry)."""
+        if visual and not getattr(self, "_visual", False):
+            self.load_visual()
+        self.set_option("render_proxies", 0 if visual else 1)
         names = self.manifest["camera_names"]
         ids = np.array([names.index(c) if isinstance(c, str) else int(c) for c in cameras], dtype=np.int32)
         out = np.empty((self.N, len(ids), height, width, 3), dtype=np.uint8)

@@ -8,7 +8,7 @@ unnorm(1 - trigger) (:300-301) and steps 20 substeps; `step_joints(action[21])` 
 gripper ctrl range), qpos, control, poses.{left,right,middle} = FK of the *commanded* joints as [xyz, quat wxyz], images.
 IK, FK and physics run in libavsim (avsim_step_cartesian, avsim_fk_jac); this file is host glue only.  Rewards are 0 here
 exactly as in the reference (:307).  `images` follow the reference's naming and sizes (:187-203: zed_cam = left | right 720 x 720
-side by side, the others 480 x 640), drawn by the library's proxy ray caster (avsim_render_rgb)."""
+side by side, the others 480 x 640), drawn by the library's rasteriser over the visual meshes (avsim_load_visual + avsim_render_rgb)."""
 from __future__ import annotations
 
 import numpy as np

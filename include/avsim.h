@@ -140,6 +140,15 @@ int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height,
  * Lambert terms, over the skybox gradient (scene.xml:34); no textures, shadows, specular terms or transparency, so the
  * images are a stand-in for MuJoCo's OpenGL output, not a pixel match.  Pointer conventions as avsim_render_depth. */
 int avsim_render_rgb(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, uint8_t* out);
+/* The visual scene of avsim_render_rgb (env.py:180-188, :195-200 draw the visual meshes of aloha_sim.xml class
+ * "visual", the frame and the textured table of scene.xml, the task objects): library_blob = models/visual_meshes.avv, the decimated
+ * mesh library of av_aloha_amd/compiler/vismesh.py; the model blob given to avsim_create carries the instances (vis_inst_*).  After
+ * it avsim_render_rgb rasterises those triangles (flat Lambert shading, table texture) instead of the collision proxies; option
+ * "render_proxies" 1 switches back.  AVSIM_EMODEL when the model was compiled without instances or the library lacks a mesh. */
+int avsim_load_visual(avsim_t* h, const void* library_blob, size_t nbytes);
+/* info = {triangles, vertices of the loaded visual scene (0: none), overflow flags of the last visual render (bit 0: a view ran out
+ * of triangle records, bit 1: of tile-list entries), instances in the model blob}; synchronises the stream */
+int avsim_visual_info(avsim_t* h, int32_t info[4]);
 int avsim_camera_count(const avsim_t* h);
 
 /* get_reward of the handle's task (gym_guided_vision/gym_guided_vision/env.py:425-863, five subclasses) evaluated on

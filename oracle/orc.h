@@ -128,6 +128,9 @@ void orc_data_free(orc_data* d);
  * the optical axis, out[H][W] row 0 = top; returns the number of pixels that hit a geom */
 int orc_render_depth(const orc_data* d, int cam, int H, int W, float* out);
 int orc_render_rgb(const orc_data* d, int cam, int H, int W, unsigned char* out, float* depth);
+/* colour image of the visual meshes (orc_vis.c): brute-force ray caster over the expanded scene of compiler/vismesh.py */
+int orc_vis_render(const orc_data* d, int cam, int nvert, const double* vert, const int* vbody, int ntri, const int* tri, const double* rgb,
+                   const double* uv, const int* tex, const int* texel, int texn, int H, int W, unsigned char* out, int* tri_out, double* depth_out);
 
 /* env-level (env.py:203-249): reset to home pose with given object free-joint poses (nobj x 7) */
 void orc_reset(orc_data* d, const double* obj_qpos);

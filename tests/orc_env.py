@@ -97,5 +97,24 @@ class OrcEnv:
         assert hits >= 0
         return out, dep
 
+    def render_visual(self, cam, H, W, scene):
+        """Colour image uint8 [H, W, 3] of the visual scene (scene = vismesh.expand_instances(library, model blob)), the index of the
+        triangle every pixel sees (-1: sky) and its depth: oracle/orc_vis.c, one ray per pixel against every triangle."""
+        ci = self.man["camera_names"].index(cam) if isinstance(cam, str) else int(cam)
+        vert, vbody, tri, rgb, uv, tex, texel = scene
+        vert = np.ascontiguousarray(vert, dtype=np.float64); vbody = np.ascontiguousarray(vbody, dtype=np.int32)
+        tri = np.ascontiguousarray(tri, dtype=np.int32); rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+        uv = np.ascontiguousarray(uv, dtype=np.float64); tex = np.ascontiguousarray(tex, dtype=np.int32)
+        texel = np.ascontiguousarray(texel, dtype=np.int32)
+        out = np.empty((H, W, 3), dtype=np.uint8)
+        tid = np.empty((H, W), dtype=np.int32)
+        dep = np.empty((H, W), dtype=np.float64)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.L.orc_vis_render.restype = C.c_int
+        hits = self.L.orc_vis_render(self.dptr, ci, len(vbody), vp(vert), vp(vbody), len(tex), vp(tri), vp(rgb), vp(uv), vp(tex), vp(texel),
+                                     int(round(len(texel) ** 0.5)), H, W, vp(out), vp(tid), vp(dep))
+        assert hits >= 0
+        return out, tid, dep
+
     def close(self):
         self.L.orc_data_free(self.dptr)

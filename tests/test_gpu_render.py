@@ -98,7 +98,7 @@ def test_rgb_matches_oracle_after_motion():
     for a in acts:
         sim.step(np.repeat(a[None], 2, 0))
         e.env_step(a)
-    img = sim.render_rgb(CAMS, H, W)
+    img = sim.render_rgb(CAMS, H, W, visual=False)
     assert img.shape == (2, len(CAMS), H, W, 3) and img.dtype == np.uint8
     assert np.array_equal(img[0], img[1])
     dep = sim.render_depth(CAMS, H, W)
@@ -108,11 +108,11 @@ def test_rgb_matches_oracle_after_motion():
         compare(dep[0, ci], rdep)
         assert len(np.unique(ref.reshape(-1, 3), axis=0)) > 20            # shaded surfaces, not a flat picture
     # the reference's render() size (env.py:195-200: 225 x 300, overhead camera): odd height, width not a tile multiple
-    big = sim.render_rgb(["overhead_cam"], 225, 300)[0, 0]
+    big = sim.render_rgb(["overhead_cam"], 225, 300, visual=False)[0, 0]
     ref, _ = e.render_rgb("overhead_cam", 225, 300)
     compare_rgb(big, ref)
     # a width that is not a multiple of 4 takes the bytewise store path
-    odd = sim.render_rgb(["zed_cam_left"], 33, 50)[0, 0]
+    odd = sim.render_rgb(["zed_cam_left"], 33, 50, visual=False)[0, 0]
     ref, _ = e.render_rgb("zed_cam_left", 33, 50)
     compare_rgb(odd, ref, frac=0.02)
     sim.close()
@@ -125,7 +125,7 @@ def test_rgb_objects_have_their_colours():
     from av_aloha_amd.sim import BatchedSim
     sim = BatchedSim("slot_insertion", 3, 1)
     sim.reset(OBJ[None])
-    img = sim.render_rgb(["overhead_cam"], 120, 160)[0, 0].astype(np.int32)
+    img = sim.render_rgb(["overhead_cam"], 120, 160, visual=False)[0, 0].astype(np.int32)
     r, g, b = img[..., 0], img[..., 1], img[..., 2]
     red = (r > 1.8 * g) & (np.abs(g - b) <= 1) & (r > 60)
     green = (g > 1.8 * r) & (np.abs(r - b) <= 1) & (g > 60)
@@ -146,7 +146,7 @@ def test_rgb_and_depth_other_tasks(task):
     sim.reset(poses)
     e.reset(poses[0])
     cams = ["overhead_cam", "wrist_cam_left", "zed_cam_left"]
-    img = sim.render_rgb(cams, H, W)
+    img = sim.render_rgb(cams, H, W, visual=False)
     dep = sim.render_depth(cams, H, W)
     for ci, cam in enumerate(cams):
         ref, rdep = e.render_rgb(cam, H, W)

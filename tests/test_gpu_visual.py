@@ -1,0 +1,108 @@
+"""Colour images of the VISUAL meshes (env.py:180-188 "pixels", :195-200 render) -- the device's triangle
+rasteriser (avsim_load_visual + avsim_render_rgb through the C-ABI) against the oracle's brute-force f64 ray caster
+(oracle/orc_vis.c) over the same expanded scene (compiler/vismesh.py) and the same body poses.
+
+The two differ in method (projection + near-plane clipping + tile binning + a depth test on 1 / depth in f32, against one ray per
+pixel through every triangle in f64), so they can disagree only where a pixel centre lies within rounding of a triangle edge or
+where two surfaces are closer than f32 resolves: bounded at 2 % of the pixels; the others agree to +-2 levels.  Parity with the
+reference's OpenGL pixels is unpinned."""
+import os
+
+import numpy as np
+import pytest
+
+from orc_env import OrcEnv
+from test_gpu_physics import actions_wiggle
+from test_oracle_physics import OBJ, ROOT, model_dict
+
+pytestmark = pytest.mark.gpu
+CAMS = ["zed_cam_left", "zed_cam_right", "wrist_cam_left", "wrist_cam_right", "overhead_cam", "worms_eye_cam"]
+
+
+def scene_of(task, arms):
+    from av_aloha_amd.compiler import vismesh
+    from av_aloha_amd.compiler.compile import read_blob
+    lib = read_blob(os.path.join(ROOT, "models", "visual_meshes.avv"))
+    mdl = read_blob(os.path.join(ROOT, "models", f"{task}_{arms}arms.avm"))
+    return vismesh.expand_instances(lib, mdl) + (lib["lib_tex"],)
+
+
+def agree(img, ref, frac):
+    bad = (np.abs(img.astype(np.int32) - ref.astype(np.int32)) > 2).any(-1)
+    assert bad.mean() <= frac, f"{bad.sum()} of {bad.size} pixels differ"
+    return bad.mean()
+
+
+def test_visual_images_match_the_oracle_after_motion():
+    from av_aloha_amd.sim import BatchedSim
+    H, W = 60, 80
+    md = model_dict()
+    acts = actions_wiggle(md, 6)
+    sim = BatchedSim("slot_insertion", 3, 3, f64=True, options={"solver": 1})
+    e = OrcEnv()
+    e.d.solver = 1
+    sim.reset(np.repeat(OBJ[None], 3, 0))
+    e.reset(OBJ)
+    for a in acts:
+        sim.step(np.repeat(a[None], 3, 0))
+        e.env_step(a)
+    img = sim.render_rgb(CAMS, H, W)
+    info = sim.visual_info()
+    assert info["triangles"] > 15000 and info["overflow"] == 0, info
+    assert img.shape == (3, len(CAMS), H, W, 3) and img.dtype == np.uint8
+    assert np.array_equal(img[0], img[1]) and np.array_equal(img[0], img[2])       # identical envs, identical images
+    scene = scene_of("slot_insertion", 3)
+    for ci, cam in enumerate(CAMS):
+        ref, tid, dep = e.render_visual(cam, H, W, scene)
+        agree(img[0, ci], ref, 0.02)
+        assert (tid >= 0).mean() > 0.3                                             # the scene fills the view
+    # known answers in the overhead view: the stick is green (task_slot_insertion.xml rgba), the table shows its wood texture
+    ref, tid, dep = e.render_visual("overhead_cam", H, W, scene)
+    o = img[0, CAMS.index("overhead_cam")].astype(int)
+    green = (o[..., 1] > 1.7 * o[..., 0]) & (o[..., 1] > 1.7 * o[..., 2]) & (o[..., 1] > 80)      # rgba .4 .8 .4
+    assert green.sum() >= 5
+    tex = scene[5]
+    table_px = tex[np.maximum(tid, 0)].astype(bool) & (tid >= 0)
+    assert table_px.mean() > 0.2
+    wood = o[table_px].mean(0)
+    assert wood[0] > wood[1] > wood[2] and wood[0] > 60, wood                      # small_meta_table_diffuse.png is brown
+    # the proxy image is still there, and it is a different picture (hull proxies in flat colours)
+    prox = sim.render_rgb(CAMS[:1], H, W, visual=False)
+    assert prox.shape == (3, 1, H, W, 3) and not np.array_equal(prox[0, 0], img[0, 0])
+    sim.close()
+    e.close()
+
+
+def test_visual_full_size_ragged_size_and_two_arm_model():
+    """480 x 640 (env.py:39-40) and the Cartesian env's 720 x 720 ZED images (sim_env.py) run without exhausting the triangle or
+    tile-list capacity; a size that is not a multiple of the 8-pixel tile and the 2-arm model are checked against the oracle; the
+    low-resolution image samples the same scene as the full-size one."""
+    from av_aloha_amd.sim import BatchedSim
+    sim = BatchedSim("slot_insertion", 3, 2)
+    sim.reset(np.repeat(OBJ[None], 2, 0))
+    e = OrcEnv()
+    e.reset(OBJ)
+    big = sim.render_rgb(CAMS, 480, 640)
+    assert big.shape == (2, 6, 480, 640, 3) and sim.visual_info()["overflow"] == 0
+    assert np.array_equal(big[0], big[1])
+    z = sim.render_rgb(["zed_cam_left", "zed_cam_right"], 720, 720)
+    assert z.shape == (2, 2, 720, 720, 3) and sim.visual_info()["overflow"] == 0
+    scene = scene_of("slot_insertion", 3)
+    small = sim.render_rgb(["wrist_cam_right"], 45, 75)[0, 0]
+    agree(small, e.render_visual("wrist_cam_right", 45, 75, scene)[0], 0.025)
+    # 120 x 160 samples the scene at the corners shared by 4 x 4 full-size pixels: most of its pixels lie within the range of their block
+    low = sim.render_rgb(["overhead_cam"], 120, 160)[0, 0].astype(int)
+    blk = big[0, CAMS.index("overhead_cam")].astype(int).reshape(120, 4, 160, 4, 3)
+    inside = ((low >= blk.min(axis=(1, 3)) - 3) & (low <= blk.max(axis=(1, 3)) + 3)).all(-1)
+    assert inside.mean() > 0.93
+    sim.close()
+    e.close()
+    sim2 = BatchedSim("hook_package", 2, 1)
+    md2 = model_dict("hook_package", 2)
+    obj = md2["qpos_home"][md2["objects_qposadr"][0]:].reshape(-1, 7)
+    sim2.reset(obj[None])
+    e2 = OrcEnv("hook_package", 2)
+    e2.reset(obj)
+    agree(sim2.render_rgb(["overhead_cam"], 60, 80)[0, 0], e2.render_visual("overhead_cam", 60, 80, scene_of("hook_package", 2))[0], 0.02)
+    sim2.close()
+    e2.close()
