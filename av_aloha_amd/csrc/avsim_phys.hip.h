@@ -503,7 +503,13 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         // unconditional loads (every row record is 16 words, zero padded; a lane outside the group reads the group's first row): no
         // exec-mask detours, and nothing touches the values before the step that uses them, which masks them (inA / inB)
         (void)a; (void)b;
-        ja = Jr[0]; jb = Jr[TREE_W]; ba = Br[0]; bb = Br[TREE_W];
+        // a contact between one kinematic tree and the world keeps J M^-1 in the idle second window of its J record (make_constraints):
+        // one 64-byte line per row instead of two, and the J M^-1 buffer is not touched at all by such contacts (group-uniform branch)
+        const bool packed = ((hdr >> 24) & 1) && ((__builtin_amdgcn_readfirstlane(win) >> 19) & 15) == 0;
+        ja = Jr[0];
+        const real x = Jr[TREE_W];
+        if (packed) { jb = 0; ba = x; bb = 0; }
+        else { jb = x; ba = Br[0]; bb = Br[TREE_W]; }
     };
     // wrap-around of the group index at the end of a sweep: a noslip sweep starts at first_ns
     auto nextg = [&](int gq, int itq) { return gq + 1 < ngrp ? gq + 1 : (itq + 1 >= iters ? first_ns : 0); };
@@ -2106,7 +2112,14 @@ struct Env {
                 }
             }
             }
-            if (!LEAD || !lead_slim) {       // (the Newton solver and the per-tree noslip pass read the leading rows' descriptors)
+            if (!LEAD && tB < 0) {
+                // one-tree contact row: [J (8) | J M^-1 (8)] in one record; every reader of J masks the second window by the row's dof
+                // counts (nB = 0), the Gauss-Seidel sweeps and the couplings below know where J M^-1 is
+                real JB_[ROW_W];
+#pragma unroll
+                for (int k = 0; k < TREE_W; k++) { JB_[k] = J[k]; JB_[TREE_W + k] = Bv[k]; }
+                store_row16(rJ + ROW_S * i, JB_);
+            } else if (!LEAD || !lead_slim) {       // (the Newton solver and the per-tree noslip pass read the leading rows' descriptors)
                 store_row16(rJ + ROW_S * i, J);
                 store_row16(rowsB_() + ROW_S * i, Bv);
             }
@@ -2204,7 +2217,8 @@ struct Env {
                 // J_r . (J_s M^-1) over the tree windows the two rows share: the stored rows of J M^-1 are zero-padded, and a
                 // window of row r matches a window of row s iff it is the same kinematic tree
                 GLB_PTR(const real) Jr = rJ + ROW_S * ir;
-                GLB_PTR(const real) Bs = rowsB_() + ROW_S * is;
+                const bool packed_s = g >= nlg && ((rs >> 19) & 15) == 0;       // (J M^-1 of a one-tree contact row: second window of its J record)
+                GLB_PTR(const real) Bs = packed_s ? (GLB_PTR(const real))(rJ + ROW_S * is + TREE_W) : (GLB_PTR(const real))(rowsB_() + ROW_S * is);
 #pragma unroll
                 for (int wr = 0; wr < 2; wr++) {
                     const bool on_r = ((ra >> (13 * wr + 6)) & 15) != 0;
@@ -2465,6 +2479,9 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
                                              const int* __restrict__ env_order, int* __restrict__ o_cost, int* __restrict__ work_head, int* __restrict__ work_next) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(G == 64, "one env per wavefront");
+#ifdef AVSIM_NO_PROF
+    o_prof = nullptr;
+#endif
     const int wpb = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = 0;
     // hot model tables -> LDS, once per block
