@@ -54,6 +54,7 @@ def lib():
         L.avsim_camera_count.argtypes = [vp]
         L.avsim_load_visual.argtypes = [vp, vp, C.c_size_t]
         L.avsim_visual_info.argtypes = [vp, vp]
+        L.avsim_visual_profile.argtypes = [vp, vp, i32]
         L.avsim_reward_from_pairs.argtypes = [vp, vp, i32, i32, vp, vp]
         L.avsim_sync.argtypes = [vp]
         L.avsim_set_stream.argtypes = [vp, vp]

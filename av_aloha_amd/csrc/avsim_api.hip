@@ -824,10 +824,20 @@ int avsim_visual_info(avsim_t* h, int32_t info[4]) {
     info[0] = h->vis.loaded ? h->vis.S.ntri : 0; info[1] = h->vis.loaded ? h->vis.S.nvert : 0; info[2] = 0; info[3] = h->vis.have_inst ? (int)h->vis.inst_mesh.size() : 0;
     if (h->vis.loaded && h->vis.X.flags && h->vis.nviews_cap > 0) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        std::vector<int> f((size_t)h->vis.nviews_cap);
+        std::vector<int> f((size_t)h->vis.nviews_cap * 8);
         HIPCHK(h, hipMemcpy(f.data(), h->vis.X.flags, f.size() * sizeof(int), hipMemcpyDeviceToHost));
-        for (int v : f) info[2] |= v;
+        for (size_t v = 0; v < f.size(); v += 8) info[2] |= f[v];
     }
+    return AVSIM_OK;
+}
+
+// debug: per-view records of the last visual render, int32[nviews][8] = {overflow bits, cycles / 1024 of the stages transform, set-up,
+// count, fill, tiles, triangle records, tile-list entries}; nviews = num_envs x cameras of that call
+int avsim_visual_profile(avsim_t* h, int32_t* out, int nviews) {
+    if (!h || !out || nviews < 0 || nviews > h->vis.nviews_cap || !h->vis.X.flags) { if (h) h->set_error("avsim_visual_profile: no visual render of that size yet"); return AVSIM_EINVAL; }
+    AVS_ON_DEVICE(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->vis.X.flags, (size_t)nviews * 8 * sizeof(int), hipMemcpyDeviceToHost));
     return AVSIM_OK;
 }
 

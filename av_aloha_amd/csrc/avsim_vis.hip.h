@@ -13,7 +13,7 @@
 //   4. one wavefront per tile, lane = pixel: the tile's records are wave-uniform loads, the depth test is on 1 / depth with the
 //      triangle index as tie-break (the image does not depend on the order of the lists); the winner's colour -- for the textured
 //      table the pixel ray is intersected with the triangle for perspective-correct texture coordinates -- or the sky gradient.
-// No shadows, specular terms, anti-aliasing or transparency: parity with the reference's OpenGL pixels is unpinned.
+// Back faces are culled.  No shadows, specular terms, anti-aliasing or transparency: parity with the reference's OpenGL pixels is unpinned.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -50,7 +50,7 @@ struct VisScratch {
     float4* rec;      // [slots][reccap][4]
     int* bbox;        // [slots][reccap][4] tile ranges
     int* list;        // [slots][listcap]
-    int* flags;       // [nviews] bit 0: record overflow, bit 1: list overflow
+    int* flags;       // [nviews][8]: overflow bits (0: records, 1: lists), shader-clock cycles / 1024 of the five stages, records, list entries
     int reccap, listcap;
 };
 
@@ -69,12 +69,49 @@ __device__ inline bool vis_tile_outside(const float4 r0, const float4 r1, const 
     return e0 < 0 || e1 < 0 || e2 < 0;
 }
 
+// Tile lists.  Records are taken 64 at a time by a wavefront, one per lane.  A triangle whose box covers a few tiles is walked by its
+// own lane; a big one (the table top covers every tile of the overhead view, a frame bar crosses the image) is handed to the whole
+// wavefront in turn, lane k taking every 64th tile of its box -- otherwise the wave waits for one lane walking thousands of tiles.
+// FILL = false counts (cnt[tile]++), FILL = true appends the record index at cur[tile]++.
+template <bool FILL>
+__device__ inline void vis_bin(const float4* __restrict__ rec, const int* __restrict__ bbox, int nrec, int* cnt, int* __restrict__ list, int listcap, int tw, int lane, int wave,
+                               int& flag) {
+    for (int i0 = wave * 64; i0 < nrec; i0 += VIS_THREADS) {
+        const int i = i0 + lane;
+        const bool valid = i < nrec;
+        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+        int4 bb = make_int4(0, -1, 0, -1);
+        if (valid) { r0 = rec[4 * i]; r1 = rec[4 * i + 1]; r2 = rec[4 * i + 2]; bb = ((const int4*)bbox)[i]; }
+        const int bw = bb.y - bb.x + 1, nt = valid ? bw * (bb.w - bb.z + 1) : 0;
+        auto visit = [&](const float4 q0, const float4 q1, const float4 q2, int tx, int ty, int idx) {
+            if (vis_tile_outside(q0, q1, q2, (float)(tx * VIS_TILE), (float)(ty * VIS_TILE))) return;
+            const int p = atomicAdd(&cnt[ty * tw + tx], 1);
+            if (FILL) { if (p < listcap) list[p] = idx; else flag |= 2; }
+        };
+        const bool big = nt > 16;
+        if (valid && !big)
+            for (int ty = bb.z; ty <= bb.w; ty++)
+                for (int tx = bb.x; tx <= bb.y; tx++) visit(r0, r1, r2, tx, ty, i);
+        unsigned long long m = __ballot(big);
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            float4 q0, q1, q2;
+            q0.x = __shfl(r0.x, src, 64); q0.y = __shfl(r0.y, src, 64); q0.z = __shfl(r0.z, src, 64); q0.w = __shfl(r0.w, src, 64);
+            q1.x = __shfl(r1.x, src, 64); q1.y = __shfl(r1.y, src, 64); q1.z = __shfl(r1.z, src, 64); q1.w = __shfl(r1.w, src, 64);
+            q2.x = __shfl(r2.x, src, 64); q2.y = 0; q2.z = 0; q2.w = 0;
+            const int x0 = __shfl(bb.x, src, 64), y0 = __shfl(bb.z, src, 64), w = __shfl(bw, src, 64), n = __shfl(nt, src, 64);
+            for (int k = lane; k < n; k += 64) visit(q0, q1, q2, x0 + k % w, y0 + k / w, i0 + src);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScratch X, const float* __restrict__ xpose, const int* __restrict__ cam_ids, int ncam_sel,
                                                             int N, int H, int W, unsigned char* __restrict__ out) {
     __shared__ float Rcb[VIS_MAXBODY * 12];
     __shared__ float cam[24];                // Rc (9), pc (3), light dir in the camera frame (3), world up in the camera frame (3), scale
     extern __shared__ int vis_dyn[];         // toff[ntile + 1]: tile -> first list entry (after the scan), counters before; tcur[ntile]
-    __shared__ int nrec_s, wsum[VIS_THREADS / 64];
+    __shared__ int wsum[2 * (VIS_THREADS / 64)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tw = (W + VIS_TILE - 1) / VIS_TILE, th = (H + VIS_TILE - 1) / VIS_TILE, ntile = tw * th;
     const int nviews = N * ncam_sel, slot = blockIdx.x;
@@ -88,6 +125,7 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
         const int env = view / ncam_sel, cs = view - env * ncam_sel, cid = cam_ids[cs];
         const float* xb = xpose + (size_t)env * S.nbody * 12;
         __syncthreads();     // the previous view's tiles are done with the shared tables
+        const long long tc0 = __builtin_readcyclecounter();
         if (tid == 0) {
             const int b = S.cam_body[cid];
             const float *pb = xb + 12 * b, *Rb = pb + 3, *cp = S.cam_pos + 3 * cid, *cm = S.cam_mat + 9 * cid;
@@ -101,7 +139,6 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
                 cam[15 + j] = cam[6 + j];                                                          // Rc^T e_z
             }
             cam[18] = 2.0f * S.cam_fovy[cid] / (float)H;
-            nrec_s = 0;
         }
         for (int t = tid; t <= ntile; t += VIS_THREADS) toff[t] = 0;
         __syncthreads();
@@ -122,10 +159,11 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
         }
         __threadfence_block();
         __syncthreads();
-        // 2. triangle set-up + tile counts
+        const long long tc1 = __builtin_readcyclecounter();
+        // 2. triangle set-up
         const float scale = cam[18], iscale = 1.0f / scale, znear = S.znear;
         const float amb = S.light[0], hd = S.light[1], ld = S.light[2];
-        int flag = 0;
+        int flag = 0, nrec_run = 0;
         for (int t0 = 0; t0 < S.ntri; t0 += VIS_THREADS) {
             const int t = t0 + tid;
             int nout = 0;
@@ -164,29 +202,34 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
                     if (!(nn > 0) || !(gg > 0)) nout = 0;
                     else {
                         const float in = rsqrtf(nn), ig = rsqrtf(gg);
-                        float ch = -(n[0] * g[0] + n[1] * g[1] + n[2] * g[2]) * in * ig;
-                        float sgn = 1.0f;
-                        if (ch < 0) { ch = -ch; sgn = -1.0f; }
-                        const float cl = -sgn * (n[0] * cam[12] + n[1] * cam[13] + n[2] * cam[14]) * in;
+                        // back faces are not drawn (MuJoCo's renderer culls them too [EXT]): the meshes are closed surfaces wound
+                        // outwards, a face turned away from the camera is hidden by a front face -- half the records and list entries
+                        const float ch = -(n[0] * g[0] + n[1] * g[1] + n[2] * g[2]) * in * ig;
+                        if (!(ch > 0)) nout = 0;
+                        const float cl = -(n[0] * cam[12] + n[1] * cam[13] + n[2] * cam[14]) * in;
                         const float lum = fminf(1.0f, amb + hd * ch + ld * fmaxf(cl, 0.0f));
                         if (S.tex[t]) colour = 0x80000000u | (unsigned)(lum * 65535.0f + 0.5f);      // textured: the shade, colour at the pixel
                         else colour = vis_pack(S.rgb[3 * t] * lum, S.rgb[3 * t + 1] * lum, S.rgb[3 * t + 2] * lum);
                     }
                 }
             }
+            // the (at most two) records of this thread's triangle
+            float4 R[2][4];
+            int4 B[2];
+            bool keep[2];
+#pragma unroll
             for (int k = 0; k < 2; k++) {
-                bool keep = k < nout;
-                float4 r0, r1, r2, r3;
-                int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1;
-                if (keep) {
+                keep[k] = k < nout;
+                B[k] = make_int4(0, -1, 0, -1);
+                if (keep[k]) {
                     const int i0 = 0, i1 = k + 1, i2 = k + 2;
                     const float x0 = px[i0], y0 = py[i0], x1 = px[i1], y1 = py[i1], x2 = px[i2], y2 = py[i2];
                     const float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
                     const float xmin = fminf(x0, fminf(x1, x2)), xmax = fmaxf(x0, fmaxf(x1, x2)), ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
                     // pixel centres covered by the bounding box
-                    const int ix0 = max(0, (int)ceilf(xmin - 0.5f)), ix1 = min(W - 1, (int)floorf(xmax - 0.5f));
-                    const int iy0 = max(0, (int)ceilf(ymin - 0.5f)), iy1 = min(H - 1, (int)floorf(ymax - 0.5f));
-                    if (!(fabsf(area) > 1e-12f) || ix0 > ix1 || iy0 > iy1 || !(xmax - xmin < 1e7f) || !(ymax - ymin < 1e7f)) keep = false;
+                    const int ix0 = max(0, (int)ceilf(fmaxf(xmin, -1e6f) - 0.5f)), ix1 = min(W - 1, (int)floorf(fminf(xmax, 1e6f) - 0.5f));
+                    const int iy0 = max(0, (int)ceilf(fmaxf(ymin, -1e6f) - 0.5f)), iy1 = min(H - 1, (int)floorf(fminf(ymax, 1e6f) - 0.5f));
+                    if (!(fabsf(area) > 1e-12f) || ix0 > ix1 || iy0 > iy1 || !(xmax - xmin < 1e7f) || !(ymax - ymin < 1e7f)) keep[k] = false;
                     else {
                         const float ia = 1.0f / area;
                         // lambda_0 = edge (1 -> 2), lambda_1 = edge (2 -> 0), lambda_2 = edge (0 -> 1), each / area: >= 0 inside either winding
@@ -194,32 +237,39 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
                         const float a1 = (y2 - y0) * ia, b1 = (x0 - x2) * ia, c1 = (x2 * y0 - x0 * y2) * ia;
                         const float a2 = (y0 - y1) * ia, b2 = (x1 - x0) * ia, c2 = (x0 * y1 - x1 * y0) * ia;
                         const float w0 = pw[i0], w1 = pw[i1], w2 = pw[i2];
-                        r0 = make_float4(a0, b0, c0, a1);
-                        r1 = make_float4(b1, c1, a2, b2);
-                        r2 = make_float4(c2, a0 * w0 + a1 * w1 + a2 * w2, b0 * w0 + b1 * w1 + b2 * w2, c0 * w0 + c1 * w1 + c2 * w2);
-                        r3 = make_float4(__uint_as_float(colour), __int_as_float(t), 0.0f, 0.0f);
-                        bx0 = ix0 / VIS_TILE; bx1 = ix1 / VIS_TILE; by0 = iy0 / VIS_TILE; by1 = iy1 / VIS_TILE;
+                        R[k][0] = make_float4(a0, b0, c0, a1);
+                        R[k][1] = make_float4(b1, c1, a2, b2);
+                        R[k][2] = make_float4(c2, a0 * w0 + a1 * w1 + a2 * w2, b0 * w0 + b1 * w1 + b2 * w2, c0 * w0 + c1 * w1 + c2 * w2);
+                        R[k][3] = make_float4(__uint_as_float(colour), __int_as_float(t), 0.0f, 0.0f);
+                        B[k] = make_int4(ix0 / VIS_TILE, ix1 / VIS_TILE, iy0 / VIS_TILE, iy1 / VIS_TILE);
                     }
                 }
-                // ordered compaction of the block's records: the record index follows the triangle index
-                const unsigned long long m = __ballot(keep);
-                if (lane == 0) wsum[wave] = __popcll(m);
-                __syncthreads();
-                int base = nrec_s;
-                for (int w2_ = 0; w2_ < wave; w2_++) base += wsum[w2_];
-                const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (keep && idx < X.reccap) {
-                    rec[4 * idx] = r0; rec[4 * idx + 1] = r1; rec[4 * idx + 2] = r2; rec[4 * idx + 3] = r3;
-                    for (int ty = by0; ty <= by1; ty++)
-                        for (int tx = bx0; tx <= bx1; tx++)
-                            if (!vis_tile_outside(r0, r1, r2, (float)(tx * VIS_TILE), (float)(ty * VIS_TILE))) atomicAdd(&toff[ty * tw + tx], 1);
-                    ((int4*)bbox)[idx] = make_int4(bx0, bx1, by0, by1);
-                } else if (keep) flag |= 1;
-                __syncthreads();
-                if (tid == 0) { int s = nrec_s; for (int w2_ = 0; w2_ < VIS_THREADS / 64; w2_++) s += wsum[w2_]; nrec_s = s < X.reccap ? s : X.reccap; }
-                __syncthreads();
             }
+            // ordered compaction of the block's records (the record index follows the triangle index): one barrier per pass, the
+            // per-wave totals double-buffered, the running total kept by every thread
+            const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]), lower = (1ull << lane) - 1ull;
+            int* ws = wsum + 4 * ((t0 / VIS_THREADS) & 1);
+            if (lane == 0) ws[wave] = __popcll(m0) + __popcll(m1);
+            __syncthreads();
+            int idx = nrec_run;
+            for (int w2_ = 0; w2_ < VIS_THREADS / 64; w2_++) { if (w2_ < wave) idx += ws[w2_]; nrec_run += ws[w2_]; }
+            idx += __popcll(m0 & lower) + __popcll(m1 & lower);
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+                if (keep[k]) {
+                    if (idx < X.reccap) {
+                        rec[4 * idx] = R[k][0]; rec[4 * idx + 1] = R[k][1]; rec[4 * idx + 2] = R[k][2]; rec[4 * idx + 3] = R[k][3];
+                        ((int4*)bbox)[idx] = B[k];
+                    } else flag |= 1;
+                    idx++;
+                }
         }
+        const int nrec = nrec_run < X.reccap ? nrec_run : X.reccap;
+        __threadfence_block();
+        __syncthreads();
+        const long long tc2 = __builtin_readcyclecounter();
+        vis_bin<false>(rec, bbox, nrec, toff, list, X.listcap, tw, lane, wave, flag);
+        __syncthreads();
         // 3. exclusive scan of the tile counts (one wave), then the fill pass
         if (wave == 0) {
             int carry = 0;
@@ -234,42 +284,60 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
             if (lane == 0) toff[ntile] = carry;
         }
         __syncthreads();
-        const int nrec = nrec_s;
-        for (int i = tid; i < nrec; i += VIS_THREADS) {
-            const float4 r0 = rec[4 * i], r1 = rec[4 * i + 1], r2 = rec[4 * i + 2];
-            const int4 bb = ((const int4*)bbox)[i];
-            for (int ty = bb.z; ty <= bb.w; ty++)
-                for (int tx = bb.x; tx <= bb.y; tx++)
-                    if (!vis_tile_outside(r0, r1, r2, (float)(tx * VIS_TILE), (float)(ty * VIS_TILE))) {
-                        const int p = atomicAdd(&tcur[ty * tw + tx], 1);
-                        if (p < X.listcap) list[p] = i; else flag |= 2;
-                    }
-        }
+        const long long tc3 = __builtin_readcyclecounter();
+        vis_bin<true>(rec, bbox, nrec, tcur, list, X.listcap, tw, lane, wave, flag);
         __threadfence_block();
         __syncthreads();
+        const long long tc4 = __builtin_readcyclecounter();
         // 4. tiles: one wavefront each, lane = pixel
         unsigned char* img = out + (size_t)view * H * W * 3;
+        // (the first 64 records of the wave's NEXT tile are fetched while it works on the current one: a tile is otherwise two dependent
+        // round trips to memory -- list, then records -- with nothing to do in between)
+        struct Batch { int mi, qt; unsigned qc; float4 q0, q1, q2; };
+        auto fetch = [&](int tile_, int eb, Batch& b) {
+            const int e1_ = tile_ < ntile ? min(toff[tile_ + 1], X.listcap) : 0;
+            b.mi = (tile_ < ntile && eb + lane < e1_) ? list[eb + lane] : 0;
+            b.q0 = rec[4 * b.mi]; b.q1 = rec[4 * b.mi + 1]; b.q2 = rec[4 * b.mi + 2];
+            const float4 q3 = rec[4 * b.mi + 3];
+            b.qc = __float_as_uint(q3.x); b.qt = __float_as_int(q3.y);
+        };
+        Batch cur, nxt;
+        fetch(wave, wave < ntile ? toff[wave] : 0, cur);
         for (int tile = wave; tile < ntile; tile += VIS_THREADS / 64) {
             const int ty = tile / tw, tx = tile - ty * tw;
             const int ix = tx * VIS_TILE + (lane & 7), iy = ty * VIS_TILE + (lane >> 3);
             const float fx = ix + 0.5f, fy = iy + 0.5f;
             const int e0 = toff[tile], e1 = min(toff[tile + 1], X.listcap);
+            const int tnext = tile + VIS_THREADS / 64;
+            fetch(tnext, tnext < ntile ? toff[tnext] : 0, nxt);
             float bw = 0.0f;
             int bi = -1, bt = 0x7fffffff;
-            for (int e = e0; e < e1; e++) {
-                const int i = __builtin_amdgcn_readfirstlane(list[e]);
-                const float4 r0 = rec[4 * i], r1 = rec[4 * i + 1], r2 = rec[4 * i + 2], r3 = rec[4 * i + 3];
-                const float l0 = r0.x * fx + r0.y * fy + r0.z, l1 = r0.w * fx + r1.x * fy + r1.y, l2 = r1.z * fx + r1.w * fy + r2.x;
-                const float w = r2.y * fx + r2.z * fy + r2.w;
-                const int t = __float_as_int(r3.y);
-                if (l0 >= 0 && l1 >= 0 && l2 >= 0 && w > 0 && (w > bw || (w == bw && t < bt))) { bw = w; bi = i; bt = t; }
+            unsigned bcol = 0;
+            auto bc = [](float x, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), j)); };
+            for (int eb = e0; eb < e1; eb += 64) {
+                if (eb > e0) fetch(tile, eb, cur);       // (a tile with more than 64 entries: the later batches are fetched in place)
+                const int n = min(64, e1 - eb);
+                for (int j = 0; j < n; j++) {
+                    const float l0 = bc(cur.q0.x, j) * fx + bc(cur.q0.y, j) * fy + bc(cur.q0.z, j);
+                    const float l1 = bc(cur.q0.w, j) * fx + bc(cur.q1.x, j) * fy + bc(cur.q1.y, j);
+                    const float l2 = bc(cur.q1.z, j) * fx + bc(cur.q1.w, j) * fy + bc(cur.q2.x, j);
+                    const float w = bc(cur.q2.y, j) * fx + bc(cur.q2.z, j) * fy + bc(cur.q2.w, j);
+                    const int t = __builtin_amdgcn_readlane(cur.qt, j), i = __builtin_amdgcn_readlane(cur.mi, j);
+                    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)cur.qc, j);
+                    if (l0 >= 0 && l1 >= 0 && l2 >= 0 && w > 0 && (w > bw || (w == bw && t < bt))) { bw = w; bi = i; bt = t; bcol = c; }
+                }
             }
+            cur = nxt;
             if (ix < W && iy < H) {
                 unsigned col;
                 const float dx = (fx - 0.5f * W) * scale, dy = -(fy - 0.5f * H) * scale;
                 if (bi >= 0) {
-                    col = __float_as_uint(rec[4 * bi + 3].x);
+                    col = bcol;
+#ifdef VIS_NO_TEX
+                    if (false) {
+#else
                     if (col & 0x80000000u) {
+#endif
                         // textured: pixel ray against the triangle's plane in the camera frame -> barycentric -> uv -> texel
                         const float lum = (float)(col & 0xffffu) * (1.0f / 65535.0f);
                         const float4 a = vcam[S.tri[3 * bt]], b = vcam[S.tri[3 * bt + 1]], c = vcam[S.tri[3 * bt + 2]];
@@ -299,7 +367,13 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
                 d[0] = (unsigned char)(col & 255u); d[1] = (unsigned char)((col >> 8) & 255u); d[2] = (unsigned char)((col >> 16) & 255u);
             }
         }
-        if (flag) atomicOr(&X.flags[view], flag);
+        if (flag) atomicOr(&X.flags[8 * view], flag);
+        if (tid == 0) {
+            const long long tc5 = __builtin_readcyclecounter();
+            int* f = X.flags + 8 * view;
+            f[1] = (int)((tc1 - tc0) >> 10); f[2] = (int)((tc2 - tc1) >> 10); f[3] = (int)((tc3 - tc2) >> 10); f[4] = (int)((tc4 - tc3) >> 10); f[5] = (int)((tc5 - tc4) >> 10);
+            f[6] = nrec; f[7] = toff[ntile];
+        }
     }
 }
 
@@ -391,7 +465,7 @@ struct VisHost {
             int dev = 0, cus = 256;
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-            slots = 2 * cus;
+            slots = 4 * cus;
             X.reccap = S.ntri + 2048;                  // near-plane clipping can split a triangle in two
             X.listcap = 8 * S.ntri + 4 * VIS_MAXTILES;
             if (hipMalloc((void**)&X.vcam, (size_t)slots * S.nvert * sizeof(float4)) != hipSuccess || hipMalloc((void**)&X.rec, (size_t)slots * X.reccap * 4 * sizeof(float4)) != hipSuccess ||
@@ -401,10 +475,10 @@ struct VisHost {
         if (nviews > nviews_cap) {
             if (X.flags) (void)hipFree(X.flags);
             X.flags = nullptr;
-            if (hipMalloc((void**)&X.flags, (size_t)nviews * sizeof(int)) != hipSuccess) { err = "hipMalloc(visual render flags) failed"; nviews_cap = 0; return -3; }
+            if (hipMalloc((void**)&X.flags, (size_t)nviews * 8 * sizeof(int)) != hipSuccess) { err = "hipMalloc(visual render flags) failed"; nviews_cap = 0; return -3; }
             nviews_cap = nviews;
         }
-        if (hipMemsetAsync(X.flags, 0, (size_t)nviews * sizeof(int), st) != hipSuccess || hipMemcpyAsync(d_cam_ids, cam_ids_host, ncam_sel * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { err = "visual render set-up copy failed"; return -3; }
+        if (hipMemsetAsync(X.flags, 0, (size_t)nviews * 8 * sizeof(int), st) != hipSuccess || hipMemcpyAsync(d_cam_ids, cam_ids_host, ncam_sel * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { err = "visual render set-up copy failed"; return -3; }
         const int grid = nviews < slots ? nviews : slots;
         const size_t shmem = (size_t)(2 * ntile + 1) * sizeof(int);
         if (!attr_done) {

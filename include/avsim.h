@@ -149,6 +149,9 @@ int avsim_load_visual(avsim_t* h, const void* library_blob, size_t nbytes);
 /* info = {triangles, vertices of the loaded visual scene (0: none), overflow flags of the last visual render (bit 0: a view ran out
  * of triangle records, bit 1: of tile-list entries), instances in the model blob}; synchronises the stream */
 int avsim_visual_info(avsim_t* h, int32_t info[4]);
+/* debug: per-view records of the last visual render, int32[nviews][8] = {overflow bits, shader-clock cycles / 1024 of the stages
+ * (vertex transform, triangle set-up, tile count, tile fill, tiles), triangle records, tile-list entries} */
+int avsim_visual_profile(avsim_t* h, int32_t* out, int nviews);
 int avsim_camera_count(const avsim_t* h);
 
 /* get_reward of the handle's task (gym_guided_vision/gym_guided_vision/env.py:425-863, five subclasses) evaluated on

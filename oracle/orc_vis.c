@@ -4,7 +4,7 @@
  * get_obs "pixels", :195-200 render [EXT]); like the device's rasteriser (av_aloha_amd/csrc/avsim_vis.hip.h) it draws the decimated
  * visual scene of compiler/vismesh.py with flat Lambert shading, and PARITY with the reference's OpenGL pixels is UNPINNED.
  * What it checks is the device's projection / clipping / binning / depth test: here every pixel's ray is intersected with every
- * triangle (Moeller-Trumbore, f64, two-sided, depth along the optical axis >= znear), no projection and no tiles.
+ * triangle that faces the camera (Moeller-Trumbore, f64, depth along the optical axis >= znear), no projection and no tiles.
  *
  * The caller passes the expanded scene (tests: vismesh.expand_instances) and the body poses of an orc_data. */
 #include <math.h>
@@ -51,6 +51,15 @@ int orc_vis_render(const orc_data* d, int cam, int nvert, const double* vert, co
         for (int i = 0; i < 3; i++) w[i] = R[3 * i] * x[0] + R[3 * i + 1] * x[1] + R[3 * i + 2] * x[2] + p[i] - pc[i];
         for (int j = 0; j < 3; j++) vc[3 * v + j] = Rc[j] * w[0] + Rc[3 + j] * w[1] + Rc[6 + j] * w[2];
     }
+    /* a triangle faces the camera when its outward normal points against the direction from the eye to its centroid */
+    unsigned char* front = (unsigned char*)malloc((size_t)ntri + 1);
+    if (!front) { free(vc); return -2; }
+    for (int t = 0; t < ntri; t++) {
+        const double *a = vc + 3 * tri[3 * t], *bb = vc + 3 * tri[3 * t + 1], *c = vc + 3 * tri[3 * t + 2];
+        const double n[3] = {(bb[1] - a[1]) * (c[2] - a[2]) - (bb[2] - a[2]) * (c[1] - a[1]), (bb[2] - a[2]) * (c[0] - a[0]) - (bb[0] - a[0]) * (c[2] - a[2]),
+                             (bb[0] - a[0]) * (c[1] - a[1]) - (bb[1] - a[1]) * (c[0] - a[0])};
+        front[t] = n[0] * (a[0] + bb[0] + c[0]) + n[1] * (a[1] + bb[1] + c[1]) + n[2] * (a[2] + bb[2] + c[2]) < 0;
+    }
     int hits = 0;
     for (int i = 0; i < H; i++)
         for (int j = 0; j < W; j++) {
@@ -70,6 +79,7 @@ int orc_vis_render(const orc_data* d, int cam, int nvert, const double* vert, co
                 const double v = (dir[0] * q[0] + dir[1] * q[1] + dir[2] * q[2]) / det;
                 if (v < 0 || u + v > 1) continue;
                 const double tt = (e2[0] * q[0] + e2[1] * q[1] + e2[2] * q[2]) / det;      /* = depth along the optical axis (dir z = -1) */
+                if (!front[t]) continue;                                                     /* back faces are culled (as MuJoCo's renderer does [EXT]) */
                 if (tt >= znear && tt < best) { best = tt; bt = t; bu = u; bv = v; }
             }
             double col[3];
@@ -80,9 +90,8 @@ int orc_vis_render(const orc_data* d, int cam, int nvert, const double* vert, co
                                (bb[0] - a[0]) * (c[1] - a[1]) - (bb[1] - a[1]) * (c[0] - a[0])};
                 const double g[3] = {(a[0] + bb[0] + c[0]) / 3, (a[1] + bb[1] + c[1]) / 3, (a[2] + bb[2] + c[2]) / 3};
                 const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), gg = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
-                double ch = -(n[0] * g[0] + n[1] * g[1] + n[2] * g[2]) / (nn * gg), sgn = 1;     /* headlight term at the centroid: flat per triangle */
-                if (ch < 0) { ch = -ch; sgn = -1; }
-                const double cl = -sgn * (n[0] * lc[0] + n[1] * lc[1] + n[2] * lc[2]) / nn;
+                const double ch = -(n[0] * g[0] + n[1] * g[1] + n[2] * g[2]) / (nn * gg);     /* headlight term at the centroid: flat per triangle */
+                const double cl = -(n[0] * lc[0] + n[1] * lc[1] + n[2] * lc[2]) / nn;
                 double lum = amb + hd * ch + ld * (cl > 0 ? cl : 0);
                 if (lum > 1) lum = 1;
                 if (tex[bt]) {
@@ -105,5 +114,6 @@ int orc_vis_render(const orc_data* d, int cam, int nvert, const double* vert, co
             if (depth_out) depth_out[(size_t)i * W + j] = bt >= 0 ? best : 0.0;
         }
     free(vc);
+    free(front);
     return hits;
 }
