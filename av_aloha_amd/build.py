@@ -19,9 +19,19 @@ def _stale(target, sources):
 def build_hip(force=False, verbose=False):
     """hipcc --offload-arch=gfx950: avsim_api.hip (C-ABI, f32 product kernels, IK, render) and avsim_phys_f64.hip (the f64 parity
     kernel, -ffp-contract=off so that it rounds like the oracle) compiled side by side, linked into libavsim.so."""
-    srcs = [os.path.join(SRC, f) for f in sorted(os.listdir(SRC)) if not f.endswith(".o")] + [os.path.join(ROOT, "include", "avsim.h")]
+    srcs = [os.path.join(SRC, f) for f in sorted(os.listdir(SRC)) if not f.endswith(".o") and not f.startswith(".")] + [os.path.join(ROOT, "include", "avsim.h")]
     if not force and not _stale(LIB, srcs):
         return LIB
+    # one builder at a time (pytest next to bench.py, several ranks): the objects go to fixed paths
+    import fcntl
+    with open(os.path.join(SRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale(LIB, srcs):       # somebody else built it while we waited
+            return LIB
+        return _build_hip_locked(verbose)
+
+
+def _build_hip_locked(verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-c"]
     units = [
