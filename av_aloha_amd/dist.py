@@ -21,13 +21,14 @@ def _all_gather(t, dist):
     return torch.cat(out, dim=0).to(dev)
 
 
-def gather_episode_stats(ret, success, dist=None):
+def gather_episode_stats(ret, success, dist=None, always=False):
     """All-gather of the local envs' (return f32, success i32) into rank-ordered [world*N] tensors on every rank: one
     collective per dtype, sendcount N words each.  `ret` / `success` are torch tensors on the rank's
-    device; `dist` is torch.distributed (None = single process)."""
+    device; `dist` is torch.distributed (None = single process).  always: run the collective for a world of one rank too (the
+    RCCL call path on a one-GPU box)."""
     import torch
     ret = ret.to(torch.float32).contiguous()
     success = success.to(torch.int32).contiguous()
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not always):
         return ret.clone(), success.clone()
     return _all_gather(ret, dist), _all_gather(success, dist)

@@ -298,6 +298,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the side runs (f64, whole episode, configs 3 and 4) that the default single-GPU config-2 line carries")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for testing the multi-rank path on a one-GPU box together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="testing aid: every rank uses cuda:0")
+    ap.add_argument("--dist-always", action="store_true", help="testing aid: initialise torch.distributed and run the collectives for a world of ONE rank too (RCCL init, barrier, all-reduce and all-gather on a one-GPU box)")
     ap.add_argument("--render", default="", help="HxW: render depth images of the 4 zed/wrist cameras every step (config 5 default 480x640)")
     ap.add_argument("--dump", default="", help="testing aid: rank 0 saves the gathered per-env returns / successes to this .npz")
     args = ap.parse_args()
@@ -312,9 +313,12 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.dist_always:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -351,7 +355,7 @@ def main():
         w.step(t)
         w.render(True)
     # end-of-rollout exchange: one all-gather (RCCL) of (return f32, success i32) per env
-    all_ret, all_succ = gather_episode_stats(w.ret, w.succ_any, dist)
+    all_ret, all_succ = gather_episode_stats(w.ret, w.succ_any, dist, always=args.dist_always)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()

@@ -56,3 +56,24 @@ def test_eight_ranks_keep_the_rank_order_of_the_gathered_vector(tmp_path):
     # strong-scaling flag: a fixed total split over the ranks
     st = _bench(["--envs-total", "1024"], str(tmp_path / "s.npz"), 2, port="29547")
     assert st["scaling"] == "strong" and st["config"]["envs_per_gpu"] == 512 and st["config"]["envs_total"] == 1024
+
+
+def test_rccl_collectives_execute_for_a_world_of_one_rank(tmp_path):
+    """The RCCL call path on the one GPU of the test box (two ranks cannot share a GPU under RCCL): `bench.py --dist-always` initialises
+    torch.distributed with backend nccl (= RCCL) for a world of one rank and runs its barrier, the max-over-ranks all-reduce of the
+    elapsed time and the end-of-rollout all-gather of (return, success) through it; the gathered vector equals the plain single-process
+    run's."""
+    dn, d1 = str(tmp_path / "rccl.npz"), str(tmp_path / "plain.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--dist-always", "--config", "4", "--steps", "6", "--warmup", "2",
+           "--no-cpu-baseline", "--envs-per-gpu", "1024", "--dump", dn]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-3000:]
+    r = json.loads(lines[-1])
+    assert r["n_ranks_seen"] == 1 and r["config"]["gathered_envs"] == 1024
+    plain = _bench(["--envs-per-gpu", "1024"], d1, 1)
+    assert plain["config"]["gathered_envs"] == 1024
+    a, b = np.load(dn), np.load(d1)
+    for k in ("ret", "succ", "agent_sum"):
+        assert np.array_equal(a[k], b[k]), k
