@@ -462,7 +462,11 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
         fdiag = finv != 0 ? real(1) / finv : real(0);
     }
     real imp = 0, imp_c = 0;      // improvement of the dual cost over the current noslip sweep (per-lane parts, uniform part)
+#ifdef AVSIM_PROBE_ROWS
+    LDS_PTR(int) prof = (LDS_PTR(int))nullptr;
+#else
     LDS_PTR(int) prof = nl.prof;
+#endif
     const long long tq0 = prof ? __builtin_readcyclecounter() : 0;
     int nstep = 0, nsweep = 0;
     auto floss_sweep = [&]() {
@@ -1873,6 +1877,12 @@ struct Env {
     // the call goes through a throw-away copy: the caller's object never has its address taken and stays in registers too
     __device__ __attribute__((always_inline)) void make_constraints_i() {
         PHASE_BEGIN();
+#ifdef AVSIM_PROBE_ROWS
+        long long tpr_ = __builtin_readcyclecounter();
+#define ROWPROBE(k) do { if (profiling) { const long long t_ = __builtin_readcyclecounter(); if (lane == 0) (ii + ka->lay.nprof)[8 + (k)] += (int)(t_ - tpr_); tpr_ = t_; } } while (0)
+#else
+#define ROWPROBE(k) ((void)0)
+#endif
         real *qpos = r + ka->lay.qpos, *qvel = r + ka->lay.qvel;
         int *misc = ii + ka->lay.misc, *rmeta = ii + ka->lay.rmeta, *cpair = ii + ka->lay.cpair, *cefc = ii + ka->lay.cefc;
         real *cdist = r + ka->lay.cdist, *cpos = r + ka->lay.cpos, *cnrm = r + ka->lay.cnrm;
@@ -1931,6 +1941,7 @@ struct Env {
         nefc = cend;
         if (lane == 0) { misc[1] = nefc; if (ovf) misc[2] |= 2; }
         GSYNC();
+        ROWPROBE(0);
         // --- fill rows (one row per lane) ---
         GLB_PTR(real) rJ = rows_();
         real *rowS = r + ka->lay.rowS, *warm = r + ka->lay.warm, *Minv = r + ka->lay.Minv, *asm_ = r + ka->lay.asm_;
@@ -2168,8 +2179,10 @@ struct Env {
             rmeta[i] = (meta & 0xfffff) | ((tA + 1) << 20) | ((tB + 1) << 24);
         };
         for (int i = lane; i < nlead0; i += G) fill(i, BoolTag<true>{});
+        ROWPROBE(1);
         for (int i = nlead0 + lane; i < nefc; i += G) fill(i, BoolTag<false>{});
         GSYNC();
+        ROWPROBE(2);
         // --- Gauss-Seidel groups: the leading non-contact rows in packs of GRP_MAX, then one group per contact ---
         int* gI = ii + ka->lay.gI;
         GLB_PTR(real) gA = coup_();
@@ -2190,6 +2203,7 @@ struct Env {
         if (ngrp > ka->lay.maxgrp) ngrp = ka->lay.maxgrp;
         if (lane == 0) misc[5] = ngrp;
         GSYNC();
+        ROWPROBE(3);
         // couplings A_rs = J_r . B_s (r > s) inside each group, one pair per lane
         // Under the Newton solver only the noslip sweeps use them, and those never move a contact's normal row: a contact group
         // then needs the 10 pairs among its friction rows (the 5 pairs with the normal row are stored as zeros)
@@ -2236,6 +2250,7 @@ struct Env {
             gA[GA_W * g + e] = v;
         }
         GSYNC();
+        ROWPROBE(4);
         // noslip QCQP rows (mj_solNoSlip [EXT], see pgs_groups): one contact per lane builds the friction block A of its group from the
         // couplings just written and the rows' diagonals, scales it by the friction coefficients, inverts it through its Cholesky
         // factor (qc_inverse of oracle/orc_dyn.c, same loops) and leaves, per friction row, A's row, the inverse's row and mu
@@ -2295,6 +2310,7 @@ struct Env {
             }
         }
         GSYNC();
+        ROWPROBE(5);
     }
 
     // ---- P8 ------------------------------------------------------------------------------------
