@@ -42,7 +42,7 @@ struct DevModel {
     int nq, nv, nu, nbody, njnt, ngeom, npair, ntree, neq, nfloss, nlimited, nment, task_id, nj, msize;
     real timestep, gravity[3], impratio, grip_lo, grip_hi;
     int noslip_iters;
-    int qcqp_tridiag;             // 1: sliding contacts' multiplier iteration through the tridiagonal form (f32 default), 0: MuJoCo's Cholesky per iterate (f64 default); option "qcqp_tridiag"
+    int qcqp_tridiag;             // sliding contacts' multiplier iteration: 0 MuJoCo's Cholesky per iterate (f64 default), 1 the same iterates through the tridiagonal form, 2 tridiagonal form + secular-equation steps (f32 default); option "qcqp_tridiag"
     int noslip_per_tree;          // 1: the dry-friction rows of the noslip pass go per kinematic tree (needs <= 8 trees); option "noslip_per_tree"
     int solver, newton_iters;     // 0 = PGS (dual), 1 = Newton (primal, the reference's default solver)
     real newton_tol, nscale;      // MuJoCo tolerance and 1/(meaninertia*nv) scaling of the termination tests
@@ -412,6 +412,17 @@ template <typename T> AVS_DEV GLB_PTR(T) uni_glb(GLB_PTR(T) p) {
     return (GLB_PTR(T))(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v));
 }
 
+// Step of the multiplier iteration of a sliding contact's QCQP, |y(la)| = r with y = -(A + la I)^-1 b.  MuJoCo's mju_QCQP takes
+// Newton steps on |y|^2 - r^2 from la = 0 (val / (2 y.w), w = (A + la I)^-1 y); that function is strongly convex in la and the
+// iteration needs about nine steps on a dragging arm.  1 / |y(la)| is nearly linear in la (the trust-region secular equation, More
+// and Sorensen 1983), so Newton on 1 / r - 1 / |y| reaches the SAME root in two to four steps, also monotonically from the left:
+// delta = (|y| - r) / r * |y|^2 / (y.w), with |y| - r taken as val / (|y| + r).  Product mode (f32, option qcqp_tridiag = 2); the
+// f64 parity kernel keeps MuJoCo's steps.
+template <typename T> AVS_DEV T secular_step(T val, T r2, T r, T yw) {
+    const T yy = val + r2, ny = sqrt(yy);
+    return val * yy / ((ny + r) * r * yw);
+}
+
 template <typename real>
 __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
                                                      LDS_PTR(real) q, LDS_PTR(const int) gI, GLB_PTR(const real) gA, int ngrp, int iters,
@@ -652,8 +663,8 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
                             v2 = -P12 * b1 - P22 * b2;
                             const real val = v1 * v1 + v2 * v2 - r2;
                             if (val < vtol) break;
-                            const real deriv = -2 * (P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2);
-                            const real delta = -val / deriv;
+                            const real yw = P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2;
+                            const real delta = nl.tridiag == 2 ? secular_step(val, r2, fn, yw) : val / (2 * yw);
                             if (delta < QTol<real>::abs + QTol<real>::rel * la) break;
                             la += delta;
                         }
@@ -742,11 +753,10 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
                                     if (val < vtol) break;
                                     z0 = y[0]; z1 = y[1] - l0 * z0; z2 = y[2] - l1 * z1; z3 = y[3] - l2 * z2; z4 = y[4] - l3 * z3;
                                     w[4] = z4 * r4; w[3] = z3 * r3 - l3 * w[4]; w[2] = z2 * r2_ - l2 * w[3]; w[1] = z1 * r1 - l1 * w[2]; w[0] = z0 * r0 - l0 * w[1];
-                                    real deriv = 0;
+                                    real yw = 0;
 #pragma unroll
-                                    for (int i = 0; i < 5; i++) deriv += y[i] * w[i];
-                                    deriv *= -2;
-                                    const real delta = -val / deriv;
+                                    for (int i = 0; i < 5; i++) yw += y[i] * w[i];
+                                    const real delta = nl.tridiag == 2 ? secular_step(val, r2, fn, yw) : val / (2 * yw);
                                     if (delta < QTol<real>::abs + QTol<real>::rel * la) break;
                                     la += delta;
                                 }
@@ -2710,7 +2720,7 @@ struct PhysHost {
         m.nj = b.scalar("num_arms") == 3 ? 21 : 14;
         auto opt = F("opt");
         m.timestep = (real)opt[0]; m.gravity[0] = (real)opt[1]; m.gravity[1] = (real)opt[2]; m.gravity[2] = (real)opt[3];
-        m.impratio = (real)opt[4]; m.noslip_iters = (int)opt[5]; m.noslip_per_tree = 1; m.qcqp_tridiag = sizeof(real) == 4 ? 1 : 0;
+        m.impratio = (real)opt[4]; m.noslip_iters = (int)opt[5]; m.noslip_per_tree = 1; m.qcqp_tridiag = sizeof(real) == 4 ? 2 : 0;
         m.solver = 1; m.newton_iters = 100; m.newton_tol = sizeof(real) == 8 ? (real)1e-8 : (real)1e-6;     // MuJoCo defaults: iterations 100, tolerance 1e-8
         m.nscale = (real)(1.0 / ((opt.size() > 7 && opt[7] > 0 ? opt[7] : 1.0) * std::max(1, m.nv)));
         auto gr = F("grip_range");
@@ -3000,7 +3010,7 @@ struct PhysHost {
         if (n == "export_contacts") { export_contacts = v != 0; return true; }
         if (n == "num_joints") { if (v != 14 && v != 21) return false; mf.nj = md.nj = (int)v; return true; }
         if (n == "order_envs") { order_envs = v != 0; return true; }
-        if (n == "qcqp_tridiag") { mf.qcqp_tridiag = md.qcqp_tridiag = v != 0; return true; }
+        if (n == "qcqp_tridiag") { mf.qcqp_tridiag = md.qcqp_tridiag = v < 0 ? 0 : (v > 2 ? 2 : (int)v); return true; }
         if (n == "noslip_per_tree") { mf.noslip_per_tree = md.noslip_per_tree = v != 0; return true; }
         if (n == "persist_blocks") { int x = (int)v; if (x >= 1 && x <= 64) { persist_over = x; return true; } return false; }
         if (n == "waves_per_block") { int x = (int)v; if (x >= 0 && x <= 8) { wpb_override = x; return true; } return false; }
