@@ -42,10 +42,12 @@ constexpr int REC_W = 32;   // floats per geom record: o_l[3], A[9] (camera dir 
 constexpr int TILE_R = AVSIM_TILE_R, NPX = 4 * TILE_R;      // rows of 4 pixels per lane: 2 rows = 32 x 16 tiles (the per-polyhedron tile tests are paid once per 512 pixels)
 constexpr int TILE_W = 32, TILE_H = 8 * TILE_R;
 #ifndef AVSIM_BIN_TX
-#define AVSIM_BIN_TX 8
+#define AVSIM_BIN_TX 10
 #define AVSIM_BIN_TY 2
 #endif
-constexpr int BIN_TX = AVSIM_BIN_TX, BIN_TY = AVSIM_BIN_TY;           // a block's bin: 8 x 2 tiles of 32 x 16 = 256 x 32 pixels (measured per 1024 envs x 4 cameras x 480 x 640: 5.4 ms; 32 x 8 tiles in bins of 8 x 4: 6.0, 4 x 4: 6.3, 2 x 4: 7.2, 16 x 4: 8.9)
+constexpr int BIN_TX = AVSIM_BIN_TX, BIN_TY = AVSIM_BIN_TY;           // a block's bin: at most 10 x 2 tiles of 32 x 16 pixels; the width is chosen per launch so that the bin columns are equally wide (bin_width: 20 tiles of a 640-pixel row = 2 x 10; the fixed 8 left a third column of 4 with half its block idle).  Measured per 1024 envs x 4 cameras x 480 x 640 (round 3): 10 x 2 4.72 ms, 20 x 2 4.73, 20 x 1 4.86, 8 x 2 5.02, 7 x 2 5.12, 4 x 3 5.22, 5 x 2 and 10 x 1 5.47, 10 x 3 5.59, 8 x 4 6.76; 32 x 32 tiles (TILE_R 4) in 8 x 1 5.19
+// bin width in tiles for an image `tiles_x` tiles wide: the smallest number of columns of at most BIN_TX tiles, equally wide
+inline int bin_width(int tiles_x) { const int cols = (tiles_x + BIN_TX - 1) / BIN_TX; return (tiles_x + cols - 1) / cols; }
 #ifdef AVSIM_RENDER_STATS
 __device__ unsigned long long g_rstat[8];   // debug build: tiles, bin-list entries seen, box hits, records cast, entry faces, veto faces, primitives, -
 #define RSTAT(i, n) do { if (lane == 0) atomicAdd(&g_rstat[i], (unsigned long long)(n)); } while (0)
@@ -256,6 +258,11 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
 }
 
 // max over the 64 lanes, broadcast: DPP butterflies inside each row of 16, then four v_readlane
+// max / min as ONE instruction: fmaxf / fminf on a loop-carried value come with a canonicalising v_max x, x, x in front (IEEE quieting
+// of signalling NaNs, which the compiler cannot rule out for a phi); none of the depths and edge values here is a NaN that matters
+__device__ __forceinline__ float vmax1(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin1(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 __device__ inline float wave_max(float x) {
 #define AVS_DPP_MAX(ctrl) x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false)))
     AVS_DPP_MAX(0xB1);    // quad_perm [1,0,3,2]
@@ -365,10 +372,11 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                 const int poff = __float_as_int(rec[20]), np = __float_as_int(rec[21]);
                 const float4* P = tplanes + cb * nplane + poff;
                 float lo[NPX];
-                bool ok[NPX];
+                float em[NPX];    // the smallest silhouette-edge value of the pixel so far (negative: outside the polyhedron); a float,
+                                  // not a flag: an array of bools is packed into bytes by the compiler and unpacked again in every round
                 int face[NPX];
 #pragma unroll
-                for (int q = 0; q < NPX; q++) { lo[q] = -1e30f; ok[q] = true; face[q] = 0; }
+                for (int q = 0; q < NPX; q++) { lo[q] = -1e30f; em[q] = 1e30f; face[q] = 0; }
                 if (__float_as_int(rec[18]) == 0) {
                     const float4* FB = fboxes + cb * nplane + poff;
                     const float4* SE = sedges + cb * nedge + __float_as_int(rec[16]);
@@ -388,7 +396,7 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                         const float t00 = fl.w * __builtin_amdgcn_rcpf(n00), t10 = fl.w * __builtin_amdgcn_rcpf(n10), t01 = fl.w * __builtin_amdgcn_rcpf(n01), t11 = fl.w * __builtin_amdgcn_rcpf(n11);
                         const bool allneg = n00 < 0 && n10 < 0 && n01 < 0 && n11 < 0;
                         const float tmn = keepF ? (allneg ? fminf(fminf(t00, t10), fminf(t01, t11)) : -1e30f) : 1e30f;
-                        if (-wave_max(-tmn) >= far) continue;
+                        if (!__any(tmn < far)) continue;
                     }
                     RSTAT(3, 1); RSTAT(4, __popcll(mF)); RSTAT(5, __popcll(mS));
                     while (mF) {
@@ -407,7 +415,7 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                             // (a pixel inside the silhouette approaches every face seen from outside: nv < 0 there; elsewhere the value is unused)
                             const float t = fw * __builtin_amdgcn_rcpf(nv);
                             if (RGB) { if (t > lo[q]) face[q] = p; }
-                            lo[q] = fmaxf(lo[q], t);
+                            lo[q] = vmax1(lo[q], t);
                         }
                     }
                     while (mS) {
@@ -420,7 +428,7 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
 #pragma unroll
                         for (int r = 0; r < TILE_R; r++) nb[r] = eb * dyr[r] + ec;
 #pragma unroll
-                        for (int q = 0; q < NPX; q++) ok[q] = ok[q] && nb[q >> 2] + ea * dx[q & 3] >= 0;
+                        for (int q = 0; q < NPX; q++) em[q] = vmin1(em[q], nb[q >> 2] + ea * dx[q & 3]);
                     }
                 } else {
                     // general path (a vertex behind the near plane -- the links around the camera itself --, or more faces / vertices
@@ -489,9 +497,9 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                         for (int q = 0; q < NPX; q++) {
                             const float nv = nb[q >> 2] + f.x * dx[q & 3];
                             const float t = f.w * __builtin_amdgcn_rcpf(nv);
-                            ok[q] = ok[q] && nv < 0;
+                            if (!(nv < 0)) em[q] = -1.0f;
                             if (RGB) { if (t > lo[q]) face[q] = p; }
-                            lo[q] = fmaxf(lo[q], t);
+                            lo[q] = vmax1(lo[q], t);
                         }
                     }
                 } else {
@@ -505,9 +513,9 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                         for (int q = 0; q < NPX; q++) {
                             const float nv = nb[q >> 2] + f.x * dx[q & 3];
                             const float t = f.w * __builtin_amdgcn_rcpf(nv);
-                            ok[q] = ok[q] && nv < 0;
+                            if (!(nv < 0)) em[q] = -1.0f;
                             if (RGB) { if (t > lo[q]) face[q] = p; }
-                            lo[q] = fmaxf(lo[q], t);
+                            lo[q] = vmax1(lo[q], t);
                         }
                     }
                 }
@@ -515,7 +523,7 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                 {
                     bool need = false;
 #pragma unroll
-                    for (int q = 0; q < NPX; q++) need = need || (ok[q] && lo[q] >= znear && lo[q] < best[q]);
+                    for (int q = 0; q < NPX; q++) need = need || (em[q] >= 0 && lo[q] >= znear && lo[q] < best[q]);
                     if (!__any(need)) continue;
                 }
                 if (np <= 64) {
@@ -531,7 +539,7 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
 #pragma unroll
                         for (int r = 0; r < TILE_R; r++) nb[r] = f.y * dyr[r] - f.z;
 #pragma unroll
-                        for (int q = 0; q < NPX; q++) ok[q] = ok[q] && lo[q] * (nb[q >> 2] + f.x * dx[q & 3]) <= f.w;
+                        for (int q = 0; q < NPX; q++) if (!(lo[q] * (nb[q >> 2] + f.x * dx[q & 3]) <= f.w)) em[q] = -1.0f;
                     }
                 } else {
                     for (int p = 0; p < np; p++) {
@@ -541,14 +549,14 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
 #pragma unroll
                         for (int r = 0; r < TILE_R; r++) nb[r] = f.y * dyr[r] - f.z;
 #pragma unroll
-                        for (int q = 0; q < NPX; q++) ok[q] = ok[q] && lo[q] * (nb[q >> 2] + f.x * dx[q & 3]) <= f.w;
+                        for (int q = 0; q < NPX; q++) if (!(lo[q] * (nb[q >> 2] + f.x * dx[q & 3]) <= f.w)) em[q] = -1.0f;
                     }
                 }
                 }
                 bool any_new = false;
 #pragma unroll
                 for (int q = 0; q < NPX; q++)
-                    if (ok[q] && lo[q] >= znear && lo[q] < best[q]) { best[q] = lo[q]; any_new = true; if (RGB) win[q] = k | (face[q] << 8); }
+                    if (em[q] >= 0 && lo[q] >= znear && lo[q] < best[q]) { best[q] = lo[q]; any_new = true; if (RGB) win[q] = k | (face[q] << 8); }
                 if (__any(any_new)) {
                     float bm = best[0];
 #pragma unroll
@@ -660,7 +668,7 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
     }
 }
 
-// grid (bins_x * bins_y, ncam_sel, N), block 256 = 4 wavefronts.  A block owns a bin of BIN_TX x BIN_TY tiles (64 x 32 pixels).
+// grid (bins_x * bins_y, ncam_sel, N), block 256 = 4 wavefronts.  A block owns a bin of bin_tx x BIN_TY tiles (bin_width: equally wide columns of at most BIN_TX tiles).
 // Wave 0 first makes the bin's record list: one record per lane in front-to-back order, kept if its screen octagon (box + the
 // extents of x + y and x - y) meets the bin's rectangle and -- hulls -- no face seen from outside has all four corner rays of the
 // bin on its outer side; ordered ballot compaction into LDS.  The four waves then cast the bin's
@@ -671,20 +679,20 @@ __global__ void __launch_bounds__(256) k_render_depth(const float* __restrict__ 
                                                       const float4* __restrict__ tplanes, const float4* __restrict__ fboxes, const float4* __restrict__ sedges, int nplane, int nedge,
                                                       const float* __restrict__ cam_fovy, const int* __restrict__ cam_ids, int ncam_sel, int ngeom, int H,
                                                       int W, float znear, float zfar, float* __restrict__ out, const float* __restrict__ geom_rgba, const float* __restrict__ light,
-                                                      const float* __restrict__ camaux, unsigned char* __restrict__ out_rgb) {
+                                                      const float* __restrict__ camaux, unsigned char* __restrict__ out_rgb, const int bin_tx) {
     __shared__ unsigned short blist[512];
     __shared__ int bcount;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cs = blockIdx.y, env = blockIdx.z;
-    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H, bins_x = (tiles_x + BIN_TX - 1) / BIN_TX;
-    const int btx = (blockIdx.x % bins_x) * BIN_TX, bty = (blockIdx.x / bins_x) * BIN_TY;
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H, bins_x = (tiles_x + bin_tx - 1) / bin_tx;
+    const int btx = (blockIdx.x % bins_x) * bin_tx, bty = (blockIdx.x / bins_x) * BIN_TY;
     const float scale = 2.0f * cam_fovy[cam_ids[cs]] / (float)H;     // cam_fovy holds tan(fovy / 2)
     const float* R = recs + ((size_t)env * ncam_sel + cs) * ngeom * REC_W;
     if (wave == 0) {
         const int cnt = counts[(size_t)env * ncam_sel + cs];
         const int* ord = order + ((size_t)env * ncam_sel + cs) * ngeom;
         const int px0 = btx * TILE_W, py0 = bty * TILE_H;
-        const int px1 = px0 + BIN_TX * TILE_W < W ? px0 + BIN_TX * TILE_W : W, py1 = py0 + BIN_TY * TILE_H < H ? py0 + BIN_TY * TILE_H : H;
+        const int px1 = px0 + bin_tx * TILE_W < W ? px0 + bin_tx * TILE_W : W, py1 = py0 + BIN_TY * TILE_H < H ? py0 + BIN_TY * TILE_H : H;
         const float xl = (px0 - 0.5f * W) * scale, xr = (px1 - 0.5f * W) * scale, yt = -(py0 - 0.5f * H) * scale, yb = -(py1 - 0.5f * H) * scale;
         int n = 0;
         for (int k0 = 0; k0 < cnt; k0 += 64) {
@@ -730,8 +738,8 @@ __global__ void __launch_bounds__(256) k_render_depth(const float* __restrict__ 
     }
     __syncthreads();
     const int cnt = bcount;
-    for (int t = wave; t < BIN_TX * BIN_TY; t += 4) {
-        const int tix = btx + (t % BIN_TX), tiy = bty + (t / BIN_TX);
+    for (int t = wave; t < bin_tx * BIN_TY; t += 4) {
+        const int tix = btx + (t % bin_tx), tiy = bty + (t / bin_tx);
         if (tix >= tiles_x || tiy >= tiles_y) continue;
         render_tile<RGB>(lane, tix * TILE_W, tiy * TILE_H, cs, env, blist, cnt, R, tplanes, fboxes, sedges, nplane, nedge, scale, ncam_sel, H, W, znear, zfar, out, geom_rgba, light, camaux, out_rgb);
     }
@@ -895,13 +903,14 @@ struct RenderHost {
         if (!d_cam_ids && hipMalloc((void**)&d_cam_ids, 16 * sizeof(int)) != hipSuccess) { err = "hipMalloc(camera ids) failed"; return -3; }
         if (hipMemcpyAsync(d_cam_ids, cam_ids_host, ncam_sel * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { err = "camera id copy failed"; return -3; }
         hipLaunchKernelGGL(k_render_geoms, dim3(ncam_sel, N), dim3(64), 0, st, m, (const float*)d_xpose, (const int*)d_cam_ids, ncam_sel, H, W, d_recs, d_counts, d_order, d_tplanes, d_camaux, d_fbox, d_sedge);
-        const int tiles = (((W + TILE_W - 1) / TILE_W + BIN_TX - 1) / BIN_TX) * (((H + TILE_H - 1) / TILE_H + BIN_TY - 1) / BIN_TY);     // bins
+        const int bin_tx = bin_width((W + TILE_W - 1) / TILE_W);
+        const int tiles = (((W + TILE_W - 1) / TILE_W + bin_tx - 1) / bin_tx) * (((H + TILE_H - 1) / TILE_H + BIN_TY - 1) / BIN_TY);     // bins
         if (rgb)
             hipLaunchKernelGGL(k_render_depth<true>, dim3(tiles, ncam_sel, N), dim3(256), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, (const float4*)d_fbox, (const float4*)d_sedge, m.nplane, m.nedge,
-                               m.cam_fovy, (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, (float*)nullptr, m.geom_rgba, m.light, (const float*)d_camaux, (unsigned char*)d_out);
+                               m.cam_fovy, (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, (float*)nullptr, m.geom_rgba, m.light, (const float*)d_camaux, (unsigned char*)d_out, bin_tx);
         else
             hipLaunchKernelGGL(k_render_depth<false>, dim3(tiles, ncam_sel, N), dim3(256), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, (const float4*)d_fbox, (const float4*)d_sedge, m.nplane, m.nedge,
-                               m.cam_fovy, (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, (float*)d_out, m.geom_rgba, m.light, (const float*)d_camaux, (unsigned char*)nullptr);
+                               m.cam_fovy, (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, (float*)d_out, m.geom_rgba, m.light, (const float*)d_camaux, (unsigned char*)nullptr, bin_tx);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("render kernel launch: ") + hipGetErrorString(e); return -3; }
 #ifdef AVSIM_RENDER_STATS
