@@ -220,6 +220,7 @@ struct Layout {
     int cand, cpair, cefc, rmeta, rowI, gI, misc, nprof, nint;
     int maxgrp;
     int maxcon, maxefc;
+    int expcon;                   // stride of the contact export arrays (the full capacity, whatever this layout's own)
     int bytes_per_env;
 };
 
@@ -2344,7 +2345,9 @@ struct Env {
             real* warm = r + ka->lay.warm;
             for (int k = lane; k < ka->m.nv; k += G) qacc[k] = warm[k];
             GSYNC();
-            int used = ka->lay.maxcon <= 64
+            // (one or two contacts per lane by the env's own contact count, not by the capacity: the sums then run in the same order
+            // whatever LDS layout the env is stepped with -- the two capacity tiers of PhysHost::launch_t give identical results)
+            int used = __builtin_amdgcn_readfirstlane(ncon) <= 64
                 ? newton_solve<real, 1>(ka, (GLB_PTR(const real))rJ, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0)
                 : newton_solve<real, 2>(ka, (GLB_PTR(const real))rJ, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0);
             nit_sum += used; nit_max = used > nit_max ? used : nit_max;
@@ -2488,7 +2491,7 @@ struct Env {
 // a global counter (most expensive first when env_order is given), runs the env's whole step out of its own LDS record, and comes
 // back for another.  A slow env therefore holds up one wave's slot, not its block's LDS (static block -> env maps made a block
 // wait for the slowest of its eight).  No block barrier after the table copy.
-template <typename real, int G, int MAXW>
+template <typename real, int G, int MAXW, bool RETRY>
 #ifndef AVSIM_PHYS_ATTR
 #ifdef AVSIM_TU_F64
 #define AVSIM_PHYS_ATTR
@@ -2502,8 +2505,21 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
                                              real* __restrict__ g_warm, int* __restrict__ g_latch, double* __restrict__ o_agent,
                                              int* __restrict__ o_reward, unsigned char* __restrict__ o_success, int* __restrict__ o_ncon,
                                              int* __restrict__ o_cpairs, double* __restrict__ o_cdist, int* __restrict__ o_diag, int max_reward, int export_contacts, long long* __restrict__ o_prof, float* __restrict__ o_xpose,
-                                             const int* __restrict__ env_order, int* __restrict__ o_cost, int* __restrict__ work_head, int* __restrict__ work_next) {
+                                             const int* __restrict__ env_order, int* __restrict__ o_cost, int* __restrict__ work_head, int* __restrict__ work_next,
+                                             int* __restrict__ retry, int retry_mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // Two passes over a launch's envs (PhysHost::launch_t).  The first runs every env with the SMALL contact / row capacities -- the
+    // LDS record that lets the most envs share a CU; an env that runs out of them in any substep is abandoned before anything of it is
+    // written back and its index appended to retry_list.  The second pass (n_dev: the number of such envs, read here) steps those
+    // envs again from their untouched state with the large capacities.  Results are those of the large capacities throughout.
+    // retry[0], retry[1]: the list's length, used alternately by successive steps; retry + 2: the list.  retry_mode 1 / 3: first pass
+    // (appends, to counter 0 / 1); 2 / 4: second pass (reads counter 0 / 1 as its N and zeroes the other one for the next step).
+    // RETRY = false: the one-pass kernel, none of this compiled in.
+    if (RETRY && (retry_mode == 2 || retry_mode == 4)) {
+        N = retry[retry_mode == 4];
+        if (blockIdx.x == 0 && threadIdx.x == 0) { *work_next = 0; retry[retry_mode == 2] = 0; }     // the next launch's counters
+        if (N <= 0) return;
+    }
     static_assert(G == 64, "one env per wavefront");
 #ifdef AVSIM_NO_PROF
     o_prof = nullptr;
@@ -2585,6 +2601,13 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
         }
     }
     E.collide();
+    // first pass: an env that ran out of contact slots or rows in some substep (sticky flags) is left to the second pass -- nothing of
+    // it has been written back yet, so that pass steps it from the same state
+    if (RETRY && (retry_mode & 1) && (ii[ka->lay.misc + 2] & 3)) {
+        if (lane == 0) retry[2 + atomicAdd(retry + (retry_mode == 3), 1)] = env;
+        GSYNC();      // the record is reused by the wave's next env
+        continue;
+    }
 
     // ---- write back ---------------------------------------------------------------------------
     if (nsub > 0) {
@@ -2605,11 +2628,14 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
         }
     }
     if (export_contacts)
-    for (int c = lane; c < ka->lay.maxcon; c += G) {
+    {
+    const int expcon = RETRY ? ka->lay.expcon : ka->lay.maxcon;      // (the export arrays have the full capacity's stride in both passes)
+    for (int c = lane; c < expcon; c += G) {
         int p = c < ncon ? ii[ka->lay.cpair + c] : -1;
-        o_cpairs[((size_t)env * ka->lay.maxcon + c) * 2] = p >= 0 ? ka->m.pair_geom[2 * p] : -1;
-        o_cpairs[((size_t)env * ka->lay.maxcon + c) * 2 + 1] = p >= 0 ? ka->m.pair_geom[2 * p + 1] : -1;
-        o_cdist[(size_t)env * ka->lay.maxcon + c] = c < ncon ? (double)r[ka->lay.cdist + c] : 0.0;
+        o_cpairs[((size_t)env * expcon + c) * 2] = p >= 0 ? ka->m.pair_geom[2 * p] : -1;
+        o_cpairs[((size_t)env * expcon + c) * 2 + 1] = p >= 0 ? ka->m.pair_geom[2 * p + 1] : -1;
+        o_cdist[(size_t)env * expcon + c] = c < ncon ? (double)r[ka->lay.cdist + c] : 0.0;
+    }
     }
     if (lane == 0 && o_cost && nsub > 0) o_cost[env] = (int)((__builtin_readcyclecounter() - t_launch) >> 6);    // this env's cost, for the next launch's order
     if (lane == 0 && !o_xpose) {   // the render path's pose-export pass leaves the step diagnostics alone
@@ -2659,12 +2685,21 @@ int phys_launch_f64(PhysHost& ph, hipStream_t st, int nsub, const float* action,
 
 struct PhysHost {
     int maxcon = 48, maxefc = 144, pgs_iters = 20, group = 64, export_contacts = 1, force_reward = 0, wpb_override = 0;
+    // Capacities in two tiers.  maxcon / maxefc are what an env can hold (the stride of the contact export, the size of the global row
+    // scratch); maxcon1 / maxefc1 <= those size the LDS record of the FIRST pass of a launch, chosen so that the most envs share a CU.
+    // An env that needs more in some substep is stepped again by a second pass with the full capacities (k_phys, retry_list): the
+    // results are those of the full capacities, the common case runs at the residency of the small ones.  Equal tiers: one pass.
+    int maxcon1 = 48, maxefc1 = 144;
     bool f64 = false;
     int N = 0, max_reward = 0;
     std::vector<void*> allocs;
     DevModel<float> mf;
     DevModel<double> md;
-    Layout lay;
+    Layout lay, lay2;               // first pass / second pass (lay2 == lay with one tier)
+    bool two_pass() const { return maxcon1 < maxcon || maxefc1 < maxefc; }
+    int* d_retry = nullptr;         // two counters (used alternately, like d_head) + the list of envs for the second pass
+    unsigned long long retry_parity = 0;
+    void* d_kargs2 = nullptr;       // KArgs of the second pass
     double *d_qpos_home = nullptr, *d_ctrl_home = nullptr, *d_obj_reset = nullptr;
     int* d_obj_qadr = nullptr;
     int *d_ncon = nullptr, *d_cpairs = nullptr, *d_diag = nullptr;
@@ -2891,7 +2926,12 @@ struct PhysHost {
     }
 
     void make_layout(int nq, int nv, int nu, int nb, int ng, int msize, int ntree) {
-        Layout& L = lay;
+        if (maxcon1 > maxcon) maxcon1 = maxcon;
+        if (maxefc1 > maxefc) maxefc1 = maxefc;
+        make_layout_of(lay, maxcon1, maxefc1, nq, nv, nu, nb, ng, msize, ntree);
+        make_layout_of(lay2, maxcon, maxefc, nq, nv, nu, nb, ng, msize, ntree);
+    }
+    void make_layout_of(Layout& L, const int maxcon, const int maxefc, int nq, int nv, int nu, int nb, int ng, int msize, int ntree) {
         kargs_dirty = true;
         int o = 0;
         auto R = [&](int n) { int a = o; o += n; return a; };
@@ -2923,6 +2963,7 @@ struct PhysHost {
         L.nint = (io + 3) & ~3;
         L.maxcon = maxcon;
         L.maxefc = maxefc;
+        L.expcon = this->maxcon;
         size_t rs = f64 ? 8 : 4;
         L.bytes_per_env = (int)((L.nreal * rs + (size_t)L.nint * 4 + 15) & ~(size_t)15);
         if (getenv("AVSIM_DEBUG_LAYOUT"))
@@ -2931,7 +2972,7 @@ struct PhysHost {
     }
 
     int dims[7] = {0, 0, 0, 0, 0, 0, 0};
-    size_t lds_bytes() const { return (size_t)lay.bytes_per_env + (size_t)moff.nreal * (f64 ? 8 : 4) + (size_t)moff.nint * 4; }   // WPB = 1 figure
+    size_t lds_bytes() const { return (size_t)lay.bytes_per_env + (size_t)moff.nreal * (f64 ? 8 : 4) + (size_t)moff.nint * 4; }   // WPB = 1 figure (first pass)
     void* d_rows = nullptr;
     void* d_coup = nullptr;
     int* d_near = nullptr;
@@ -2948,7 +2989,7 @@ struct PhysHost {
         d_coup = nullptr; d_near = nullptr; d_gref = nullptr;
         if (hipMalloc(&d_gref, (size_t)N * dims[4] * 3 * (f64 ? 8 : 4)) != hipSuccess) throw std::runtime_error("hipMalloc of the Verlet reference buffer failed");
         mf.gref_glob = (float*)d_gref; md.gref_glob = (double*)d_gref;
-        if (hipMalloc(&d_coup, (size_t)N * lay.maxgrp * GA_W * (f64 ? 8 : 4)) != hipSuccess || hipMalloc((void**)&d_near, (size_t)N * (NEAR_MAX + CAND_MAX) * 4) != hipSuccess)
+        if (hipMalloc(&d_coup, (size_t)N * lay2.maxgrp * GA_W * (f64 ? 8 : 4)) != hipSuccess || hipMalloc((void**)&d_near, (size_t)N * (NEAR_MAX + CAND_MAX) * 4) != hipSuccess)
             throw std::runtime_error("hipMalloc of the coupling / neighbour buffers failed");
         mf.gA_glob = (float*)d_coup; md.gA_glob = (double*)d_coup; mf.near_glob = d_near; md.near_glob = d_near; mf.cand_glob = md.cand_glob = d_near + (size_t)N * NEAR_MAX;
         kargs_dirty = true;
@@ -2970,9 +3011,14 @@ struct PhysHost {
             int ms = f64 ? md.msize : mf.msize;
             // row / contact capacities per task: every box of a compound object resting on the condim-6 table
             // contributes 4 contacts x 6 rows (SewNeedle 24 contacts / 128 rows, TubeTransfer 40 / 248 at rest)
-            static const int cap_efc[5] = {176, 176, 240, 336, 176}, cap_con[5] = {48, 48, 56, 72, 48};
+            // Two tiers where the smaller first one lets more envs share a CU (SewNeedle: 8 instead of 6; TubeTransfer): the second
+            // pass costs a launch and, when its list is not empty, the latency of one env-step, so the other tasks keep one tier.
+            static const int cap_efc[5] = {176, 176, 336, 480, 176}, cap_con[5] = {48, 48, 72, 96, 48};
+            static const int cap_efc1[5] = {176, 176, 176, 288, 176}, cap_con1[5] = {48, 48, 48, 64, 48};
             maxefc = cap_efc[b.scalar("task_id")];
             maxcon = cap_con[b.scalar("task_id")];
+            maxefc1 = cap_efc1[b.scalar("task_id")];
+            maxcon1 = cap_con1[b.scalar("task_id")];
             dims[0] = b.scalar("nq"); dims[1] = b.scalar("nv"); dims[2] = b.scalar("nu"); dims[3] = b.scalar("nbody"); dims[4] = b.scalar("ngeom"); dims[5] = ms; dims[6] = b.scalar("ntree");
             make_layout(dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], dims[6]);
             d_qpos_home = up(b.f("qpos_home"));
@@ -2982,6 +3028,7 @@ struct PhysHost {
             d_diag = up(std::vector<int>((size_t)N * 4, 0));
             d_cost = up(std::vector<int>((size_t)N, 0));
             d_order = up(std::vector<int>((size_t)N, 0));
+            d_retry = up(std::vector<int>((size_t)N + 2, 0));
             alloc_contacts();
         } catch (const std::exception& e) {
             err = std::string("physics init: ") + e.what();
@@ -3019,11 +3066,13 @@ struct PhysHost {
             if (v == 0) d_prof = nullptr;
             return true;
         }
-        if (n == "maxefc" || n == "maxcon") {
+        if (n == "maxefc" || n == "maxcon" || n == "maxefc_first" || n == "maxcon_first") {
+            // "maxefc" / "maxcon" set both tiers (one pass with exactly this capacity); "*_first" the first tier alone
             int x = (int)v;
             if (x < 16 || x > 1000) return false;
             (void)hipDeviceSynchronize();
-            if (n == "maxefc") maxefc = x; else maxcon = x;
+            if (n == "maxefc") maxefc = maxefc1 = x; else if (n == "maxcon") maxcon = maxcon1 = x;
+            else if (n == "maxefc_first") maxefc1 = x < maxefc ? x : maxefc; else maxcon1 = x < maxcon ? x : maxcon;
             make_layout(dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], dims[6]);
             try { alloc_contacts(); } catch (...) { return false; }
             return true;
@@ -3031,16 +3080,25 @@ struct PhysHost {
         return false;
     }
 
+    // envs (wavefronts) per workgroup for a layout: as many as fit next to one copy of the tables in 160 KiB, at most MAXW
+    template <typename real, int MAXW>
+    int waves_per_block(const Layout& L) const {
+        const size_t tables = (size_t)moff.nreal * sizeof(real) + (size_t)moff.nint * 4;
+        int wpb = tables < 160 * 1024 ? (int)((160 * 1024 - tables) / (size_t)L.bytes_per_env) : 0;
+        if (wpb > MAXW) wpb = MAXW;
+        if (wpb_override > 0) wpb = wpb_override < MAXW ? wpb_override : MAXW;
+        return wpb < 1 ? 1 : wpb;
+    }
+
     template <typename real, int G, int MAXW>
     int launch_t(hipStream_t st, const DevModel<real>& m, int nsub, const float* action, void* qpos, void* qvel, void* ctrl, void* warm,
-                 int* latch, double* agent, int32_t* reward, uint8_t* success, int wpb, std::string& err) {
-        if (wpb > MAXW) wpb = MAXW;
-        if (wpb < 1) wpb = 1;
+                 int* latch, double* agent, int32_t* reward, uint8_t* success, std::string& err) {
         const size_t tables = (size_t)moff.nreal * sizeof(real) + (size_t)moff.nint * 4;
-        size_t shmem = (size_t)lay.bytes_per_env * wpb + tables;
-        auto kern = k_phys<real, G, MAXW>;
+        auto kern1 = k_phys<real, G, MAXW, false>;      // one pass
+        auto kern2 = k_phys<real, G, MAXW, true>;       // the two passes of the two-tier capacities
         if (!attr_done) {    // once per handle (= per device): a second handle on another GPU of the same process sets its own
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); return -3; }
             int dev = 0;
             hipDeviceProp_t prop;
@@ -3052,17 +3110,20 @@ struct PhysHost {
             }
             attr_done = 1;
         }
-        if (shmem > 160 * 1024) { err = "per-block LDS exceeds 160 KiB; lower maxefc/maxcon"; return -1; }
+        const bool two = two_pass();
+        const int wpb = waves_per_block<real, MAXW>(lay), wpb2 = waves_per_block<real, MAXW>(lay2);
+        const size_t shmem = (size_t)lay.bytes_per_env * wpb + tables, shmem2 = (size_t)lay2.bytes_per_env * wpb2 + tables;
+        if (shmem > 160 * 1024 || (two && shmem2 > 160 * 1024)) { err = "per-block LDS exceeds 160 KiB; lower maxefc/maxcon"; return -1; }
         // persistent blocks: as many as the CUs hold at once (LDS bound), never more than the envs need
         const int per_cu = (int)((160 * 1024) / shmem) > 0 ? (int)((160 * 1024) / shmem) : 1;
         int nblk = num_cu * per_cu * (persist_over > 0 ? persist_over : 1);
         if (nblk > (N + wpb - 1) / wpb) nblk = (N + wpb - 1) / wpb;
-        dim3 grid(nblk);
         if (kargs_dirty) {
-            KArgs<real> ka{m, lay, moff};
+            KArgs<real> ka{m, lay, moff}, ka2{m, lay2, moff};
             if (!d_kargs) { if (hipMalloc(&d_kargs, sizeof(KArgs<double>)) != hipSuccess) { err = "hipMalloc(kernel arguments) failed"; return -3; } allocs.push_back(d_kargs); }
+            if (!d_kargs2) { if (hipMalloc(&d_kargs2, sizeof(KArgs<double>)) != hipSuccess) { err = "hipMalloc(kernel arguments) failed"; return -3; } allocs.push_back(d_kargs2); }
             (void)hipStreamSynchronize(st);
-            if (hipMemcpy(d_kargs, &ka, sizeof(ka), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy(kernel arguments) failed"; return -3; }
+            if (hipMemcpy(d_kargs, &ka, sizeof(ka), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_kargs2, &ka2, sizeof(ka2), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy(kernel arguments) failed"; return -3; }
             kargs_dirty = false;
         }
         // launch order from the previous step's per-env cost
@@ -3071,12 +3132,32 @@ struct PhysHost {
             hipLaunchKernelGGL(k_env_order, dim3(1), dim3(1024), 0, st, (const int*)d_cost, d_order, N);
             order = d_order;
         }
-        int* head = d_head + (launch_count & 1);
-        int* next = d_head + ((launch_count + 1) & 1);
-        launch_count++;
-        hipLaunchKernelGGL(kern, grid, dim3(64 * wpb), shmem, st, (KPtr<real>)d_kargs, (const real*)d_img_real, (const int*)d_img_int, N, nsub, pgs_iters, action, (reward || success) && (nsub > 0 || force_reward) ? 1 : 0,
-                           (real*)qpos, (real*)qvel, (real*)ctrl, (real*)warm, latch, agent, (int*)reward, (unsigned char*)success, d_ncon,
-                           d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof, d_xpose, order, order_envs ? d_cost : (int*)nullptr, head, next);
+        const int want_reward = (reward || success) && (nsub > 0 || force_reward) ? 1 : 0;
+        const int par = (int)(retry_parity & 1);      // which of the two list counters this step uses (its second pass zeroes the other)
+        int* const rlist = d_retry + 2;
+        {
+            int* head = d_head + (launch_count & 1);
+            int* next = d_head + ((launch_count + 1) & 1);
+            launch_count++;
+            hipLaunchKernelGGL(two ? kern2 : kern1, dim3(nblk), dim3(64 * wpb), shmem, st, (KPtr<real>)d_kargs, (const real*)d_img_real, (const int*)d_img_int, N, nsub, pgs_iters, action, want_reward,
+                               (real*)qpos, (real*)qvel, (real*)ctrl, (real*)warm, latch, agent, (int*)reward, (unsigned char*)success, d_ncon,
+                               d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof, d_xpose, order, order_envs ? d_cost : (int*)nullptr, head, next,
+                               d_retry, two ? 1 + 2 * par : 0);
+        }
+        if (two) {
+            // second pass: the envs the first one gave up on, with the full capacities; one workgroup per CU is plenty for the few there
+            // are (the workgroups loop over the list), and a launch that finds the list empty returns at once
+            int* head = d_head + (launch_count & 1);
+            int* next = d_head + ((launch_count + 1) & 1);
+            launch_count++;
+            retry_parity++;
+            int nblk2 = num_cu;
+            if (nblk2 > (N + wpb2 - 1) / wpb2) nblk2 = (N + wpb2 - 1) / wpb2;
+            hipLaunchKernelGGL(kern2, dim3(nblk2), dim3(64 * wpb2), shmem2, st, (KPtr<real>)d_kargs2, (const real*)d_img_real, (const int*)d_img_int, 0, nsub, pgs_iters, action, want_reward,
+                               (real*)qpos, (real*)qvel, (real*)ctrl, (real*)warm, latch, agent, (int*)reward, (unsigned char*)success, d_ncon,
+                               d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof, d_xpose, (const int*)rlist, order_envs ? d_cost : (int*)nullptr, head, next,
+                               d_retry, 2 + 2 * par);
+        }
         if (nsub > 0) have_cost = true;
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("physics kernel launch: ") + hipGetErrorString(e); return -3; }
@@ -3090,11 +3171,7 @@ struct PhysHost {
         // the double-precision kernel lives in its own translation unit (avsim_phys_f64.hip), compiled without FMA contraction
         if (f64) return phys_launch_f64(*this, st, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
         // as many envs (wavefronts) per block as fit next to one copy of the tables in 160 KiB, at most 8 (two per SIMD)
-        size_t tables = (size_t)moff.nreal * 4 + (size_t)moff.nint * 4;
-        int wpb = (int)((160 * 1024 - tables) / (size_t)lay.bytes_per_env);
-        if (wpb > 8) wpb = 8;
-        if (wpb_override > 0) wpb = wpb_override;
-        return launch_t<float, 64, 8>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, wpb, err);
+        return launch_t<float, 64, 8>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
     }
 #endif
 };

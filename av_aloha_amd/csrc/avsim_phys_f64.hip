@@ -13,12 +13,7 @@ int phys_launch_f64(PhysHost& ph, hipStream_t st, int nsub, const float* action,
     // double precision doubles the LDS record and the registers (492 unified VGPRs: one wave per SIMD): as many envs (wavefronts) per
     // workgroup as fit next to ONE copy of the tables in 160 KiB, at most four -- three for the 35 KB records, where one env per
     // workgroup with its own table copy fitted two per CU
-    const size_t tables = (size_t)ph.moff.nreal * 8 + (size_t)ph.moff.nint * 4;
-    int wpb = (int)((160 * 1024 - tables) / (size_t)ph.lay.bytes_per_env);
-    if (wpb > 4) wpb = 4;
-    if (wpb < 1) wpb = 1;
-    if (ph.wpb_override > 0) wpb = ph.wpb_override < 4 ? ph.wpb_override : 4;
-    return ph.launch_t<double, 64, 4>(st, ph.md, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, wpb, err);
+    return ph.launch_t<double, 64, 4>(st, ph.md, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
 }
 
 }  // namespace avs

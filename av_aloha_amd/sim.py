@@ -43,6 +43,10 @@ class BatchedSim:
 
     def set_option(self, name, value):
         self.h.check(self.h.L.avsim_set_option(self.h.h, name.encode(), float(value)))
+        if name in ("maxcon", "maxefc"):       # the capacities size the contact export
+            d = np.zeros(_ffi.NDIMS, dtype=np.int32)
+            self.h.check(self.h.L.avsim_dims(self.h.h, d.ctypes.data))
+            self.maxcon, self.maxefc = int(d[8]), int(d[9])
 
     def reset(self, obj_qpos, mask=None):
         obj = np.ascontiguousarray(obj_qpos, dtype=np.float64).reshape(self.N, self.nobj * 7)
