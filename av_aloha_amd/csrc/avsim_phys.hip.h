@@ -221,6 +221,7 @@ struct Layout {
     int maxgrp;
     int maxcon, maxefc;
     int expcon;                   // stride of the contact export arrays (the full capacity, whatever this layout's own)
+    int gefc, ggrp;               // rows / groups per env in the global scratch (the full capacities)
     int bytes_per_env;
 };
 
@@ -1168,9 +1169,11 @@ struct Env {
     // hot model tables live in LDS (copied once per block); the accessors rebuild the pointer from the kernarg offset
     AVS_DEV const int* LI() const { const int* p = li; AVS_ASSUME_LDS(p); return p; }
     AVS_DEV const real* LR() const { const real* p = lr; AVS_ASSUME_LDS(p); return p; }
-    AVS_DEV GLB_PTR(real) rows_() const { return (GLB_PTR(real))ka->m.rJ_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
-    AVS_DEV GLB_PTR(real) rowsB_() const { return (GLB_PTR(real))ka->m.rB_glob + (size_t)env * ka->lay.maxefc * ROW_S; }
-    AVS_DEV GLB_PTR(real) coup_() const { return (GLB_PTR(real))ka->m.gA_glob + (size_t)env * ka->lay.maxgrp * GA_W; }
+    // (the env's share of the global scratch is sized by the FULL capacities in both layouts of a two-tier handle: envs stepped with
+    // the small and with the full record run side by side)
+    AVS_DEV GLB_PTR(real) rows_() const { return (GLB_PTR(real))ka->m.rJ_glob + (size_t)env * ka->lay.gefc * ROW_S; }
+    AVS_DEV GLB_PTR(real) rowsB_() const { return (GLB_PTR(real))ka->m.rB_glob + (size_t)env * ka->lay.gefc * ROW_S; }
+    AVS_DEV GLB_PTR(real) coup_() const { return (GLB_PTR(real))ka->m.gA_glob + (size_t)env * ka->lay.ggrp * GA_W; }
     AVS_DEV GLB_PTR(int) near_() const { return (GLB_PTR(int))ka->m.near_glob + (size_t)env * NEAR_MAX; }
     AVS_DEV GLB_PTR(int) cand_() const { return (GLB_PTR(int))ka->m.cand_glob + (size_t)env * CAND_MAX; }
     AVS_DEV GLB_PTR(real) gref_() const { return (GLB_PTR(real))ka->m.gref_glob + (size_t)env * ka->m.ngeom * 3; }
@@ -2500,26 +2503,39 @@ template <typename real, int G, int MAXW, bool RETRY>
 #define AVSIM_PHYS_ATTR __attribute__((amdgpu_waves_per_eu(2)))
 #endif
 #endif
-__global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> ka, const real* __restrict__ img_real, const int* __restrict__ img_int, int N, int nsub, int pgs_iters, const float* __restrict__ action,
+__global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> ka_small, const real* __restrict__ img_real, const int* __restrict__ img_int, int N, int nsub, int pgs_iters, const float* __restrict__ action,
                                              int want_reward, real* __restrict__ g_qpos, real* __restrict__ g_qvel, real* __restrict__ g_ctrl,
                                              real* __restrict__ g_warm, int* __restrict__ g_latch, double* __restrict__ o_agent,
                                              int* __restrict__ o_reward, unsigned char* __restrict__ o_success, int* __restrict__ o_ncon,
                                              int* __restrict__ o_cpairs, double* __restrict__ o_cdist, int* __restrict__ o_diag, int max_reward, int export_contacts, long long* __restrict__ o_prof, float* __restrict__ o_xpose,
                                              const int* __restrict__ env_order, int* __restrict__ o_cost, int* __restrict__ work_head, int* __restrict__ work_next,
-                                             int* __restrict__ retry, int retry_mode) {
+                                             int* __restrict__ retry, int retry_mode, KPtr<real> ka_big) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // Two passes over a launch's envs (PhysHost::launch_t).  The first runs every env with the SMALL contact / row capacities -- the
     // LDS record that lets the most envs share a CU; an env that runs out of them in any substep is abandoned before anything of it is
     // written back and its index appended to retry_list.  The second pass (n_dev: the number of such envs, read here) steps those
     // envs again from their untouched state with the large capacities.  Results are those of the large capacities throughout.
-    // retry[0], retry[1]: the list's length, used alternately by successive steps; retry + 2: the list.  retry_mode 1 / 3: first pass
-    // (appends, to counter 0 / 1); 2 / 4: second pass (reads counter 0 / 1 as its N and zeroes the other one for the next step).
+    // retry[0], retry[1]: the list's length, used alternately by successive steps; retry + 2: the list; retry + 2 + N: one flag per
+    // env, "needed the full capacities in its last step".  retry_mode & 7 = 1 / 3: first pass (appends, to counter 0 / 1); 2 / 4:
+    // second pass (reads counter 0 / 1 as its number of envs and zeroes the other one for the next step).
+    // In the first pass most such envs never reach the list (retry_mode & 8): the waves of a workgroup are paired, and a wave whose
+    // env needs the full capacities -- predicted by the env's flag, or found out by running out of the small ones -- steps it in the
+    // TWO adjacent records of the pair while its partner waits (handshake through LDS flags, below).  The list and the second pass
+    // remain for what the pairs cannot take: the odd wave of a workgroup, two partners that want the pair at the same time.
     // RETRY = false: the one-pass kernel, none of this compiled in.
-    if (RETRY && (retry_mode == 2 || retry_mode == 4)) {
-        N = retry[retry_mode == 4];
-        if (blockIdx.x == 0 && threadIdx.x == 0) { *work_next = 0; retry[retry_mode == 2] = 0; }     // the next launch's counters
-        if (N <= 0) return;
+    int nwork = N;
+    const bool pass2 = RETRY && ((retry_mode & 7) == 2 || (retry_mode & 7) == 4);
+    const bool pass1 = RETRY && ((retry_mode & 7) == 1 || (retry_mode & 7) == 3);
+    if (pass2) {
+        nwork = retry[(retry_mode & 7) == 4];
+        if (blockIdx.x == 0 && threadIdx.x == 0) { *work_next = 0; retry[(retry_mode & 7) == 2] = 0; }     // the next launch's counters
+        if (nwork <= 0) return;
     }
+    int* const bigflag = retry + 2 + N;
+    // (the pairs' flags: 2 x MAXW / 2 ints behind the tables in the dynamic LDS of a RETRY launch)
+    int* const pair_want = reinterpret_cast<int*>(smem + (size_t)(blockDim.x >> 6) * ka_small->lay.bytes_per_env + (size_t)ka_small->mo.nreal * sizeof(real) + (size_t)ka_small->mo.nint * 4);
+    int* const pair_grant = pair_want + MAXW / 2;
+    if (RETRY && threadIdx.x < MAXW) pair_want[threadIdx.x] = 0;
     static_assert(G == 64, "one env per wavefront");
 #ifdef AVSIM_NO_PROF
     o_prof = nullptr;
@@ -2527,22 +2543,71 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
     const int wpb = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = 0;
     // hot model tables -> LDS, once per block
-    real* lr = reinterpret_cast<real*>(smem + (size_t)wpb * ka->lay.bytes_per_env);
-    int* li = reinterpret_cast<int*>(lr + ka->mo.nreal);
-    for (int i = threadIdx.x; i < ka->mo.nreal; i += blockDim.x) lr[i] = img_real[i];
-    for (int i = threadIdx.x; i < ka->mo.nint; i += blockDim.x) li[i] = img_int[i];
+    real* lr = reinterpret_cast<real*>(smem + (size_t)wpb * ka_small->lay.bytes_per_env);
+    int* li = reinterpret_cast<int*>(lr + ka_small->mo.nreal);
+    for (int i = threadIdx.x; i < ka_small->mo.nreal; i += blockDim.x) lr[i] = img_real[i];
+    for (int i = threadIdx.x; i < ka_small->mo.nint; i += blockDim.x) li[i] = img_int[i];
     if (blockIdx.x == 0 && threadIdx.x == 0) *work_next = 0;      // the NEXT launch's counter (launches of a handle follow each other on its stream)
     __syncthreads();
+    // ---- pairs (first pass of the two-tier capacities) ----
+    const int pr = wave >> 1;
+    const bool paired = pass1 && (retry_mode & 8) && (wave | 1) < wpb;
+    auto lds_get = [&](int* p) { int v = 0; if (lane == 0) v = __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); return __builtin_amdgcn_readfirstlane(v); };
+    auto lds_put = [&](int* p, int v) { if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto to_list = [&](int e) { if (lane == 0) retry[2 + atomicAdd(retry + ((retry_mode & 7) == 3), 1)] = e; };
+    // the partner wants both records: wait here (this wave's record is dead between two envs) until it is done
+    auto park = [&]() {
+        const int w = lds_get(&pair_want[pr]);
+        if (w != 0 && w != wave + 1) {
+            lds_put(&pair_grant[pr], 1);
+            while (lds_get(&pair_want[pr]) != 0) __builtin_amdgcn_s_sleep(32);
+        }
+    };
+    int redo_env = -1;      // the env this wave has just abandoned with the small record
   for (;;) {
     // wave -> env: next slot of the launch, in the order of the previous launch's cost (k_env_order) or in index order
-    int slot = 0;
-    if (lane == 0) slot = atomicAdd(work_head, 1);
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    if (slot >= N) break;
-    const int env = env_order ? env_order[slot] : slot;
+    int env_ = 0;
+    bool big = false;
+    if (RETRY && redo_env >= 0) { env_ = redo_env; redo_env = -1; big = true; }
+    else {
+        if (RETRY && paired) park();
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(work_head, 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= nwork) break;
+        env_ = env_order ? env_order[slot] : slot;
+        if (RETRY && pass1 && (retry_mode & 8)) big = __builtin_amdgcn_readfirstlane(bigflag[env_]) != 0;
+    }
+    const int env = env_;
+    if (RETRY && big) {
+        // take the pair: the claim is an LDS compare-and-swap, the partner answers at its next env boundary (or has left: grant 2)
+        bool mine = false;
+        if (paired) {
+            int got = 0;
+            if (lane == 0) { int expect = 0; got = __hip_atomic_compare_exchange_strong(&pair_want[pr], &expect, wave + 1, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0; }
+            mine = __builtin_amdgcn_readfirstlane(got) != 0;
+        }
+        if (!mine && paired) {
+            // the partner has claimed the pair for an env of its own: let it (this wave's record is dead), then claim in turn -- the
+            // partner answers at its next env boundary.  (The most expensive envs come first in a launch's order, and those are the
+            // ones that need the full capacities: at the start of a launch both waves of a pair usually hold one.)
+            for (int tries = 0; tries < 64 && !mine; tries++) {
+                park();
+                int got = 0;
+                if (lane == 0) { int expect = 0; got = __hip_atomic_compare_exchange_strong(&pair_want[pr], &expect, wave + 1, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0; }
+                mine = __builtin_amdgcn_readfirstlane(got) != 0;
+            }
+        }
+        if (!mine) { to_list(env); continue; }      // (an unpaired wave; the partner's claim, if any, is answered by park() at the top)
+        int polls = 0;
+        while (lds_get(&pair_grant[pr]) == 0 && polls < (1 << 18)) { __builtin_amdgcn_s_sleep(32); polls++; }
+        if (polls >= (1 << 18)) { to_list(env); lds_put(&pair_want[pr], 0); continue; }      // (never seen: a partner's env-step is ~2000 polls)
+    }
+    KPtr<real> ka = (RETRY && big) ? ka_big : ka_small;
     const long long t_launch = __builtin_readcyclecounter();
-    real* r = reinterpret_cast<real*>(smem + (size_t)wave * ka->lay.bytes_per_env);
+    real* r = reinterpret_cast<real*>(smem + (size_t)((RETRY && big) ? (wave & ~1) : wave) * ka_small->lay.bytes_per_env);
     int* ii = reinterpret_cast<int*>(r + ka->lay.nreal);
+    bool beyond = false;      // this env needed more than the small capacities in some substep
     Env<real, G> E(ka, r, ii, lane, grp, lr, li);
     E.env = env;
 
@@ -2577,6 +2642,7 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
         }
         PROF(4, E.collide());
         PROF(5, E.make_constraints());
+        if (RETRY) beyond = beyond || ii[ka->lay.misc + 0] > ka_small->lay.maxcon || ii[ka->lay.misc + 1] > ka_small->lay.maxefc;
         PROF(6, E.solve(pgs_iters, ka->m.solver, ka->m.newton_iters, ka->m.newton_tol, ka->m.nscale));
         {
             Env<real, G> e(E);
@@ -2603,10 +2669,14 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
     E.collide();
     // first pass: an env that ran out of contact slots or rows in some substep (sticky flags) is left to the second pass -- nothing of
     // it has been written back yet, so that pass steps it from the same state
-    if (RETRY && (retry_mode & 1) && (ii[ka->lay.misc + 2] & 3)) {
-        if (lane == 0) retry[2 + atomicAdd(retry + (retry_mode == 3), 1)] = env;
+    if (RETRY && pass1 && !big && (ii[ka->lay.misc + 2] & 3)) {
+        if (paired) redo_env = env; else to_list(env);
         GSYNC();      // the record is reused by the wave's next env
         continue;
+    }
+    if (RETRY) {
+        beyond = beyond || ii[ka->lay.misc + 0] > ka_small->lay.maxcon;
+        if (lane == 0 && (big || pass2 || (retry_mode & 8))) bigflag[env] = beyond ? 1 : 0;
     }
 
     // ---- write back ---------------------------------------------------------------------------
@@ -2645,7 +2715,12 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
         o_diag[4 * env] = ncon; o_diag[4 * env + 1] = nefc_last; o_diag[4 * env + 2] = ii[ka->lay.misc + 2]; o_diag[4 * env + 3] = (bad ? 1 : 0) | ((ii[ka->lay.misc + 3] & 0xff) << 8) | ((E.nit_sum & 0xfff) << 16) | ((E.nit_max < 15 ? E.nit_max : 15) << 28);
     }
     GSYNC();      // the record is reused by the wave's next env
+    if (RETRY && big && pass1) {      // give the pair back: the grant first (unless the partner has left), then the claim the partner waits on
+        if (lds_get(&pair_grant[pr]) == 1) lds_put(&pair_grant[pr], 0);
+        lds_put(&pair_want[pr], 0);
+    }
   }
+    if (RETRY && paired) lds_put(&pair_grant[pr], 2);      // this wave is leaving: its record is the partner's for the asking
 }
 
 // Launch order of the envs: by the cost (shader-clock cycles) of their last step, most expensive first.  A block holds its LDS
@@ -2697,6 +2772,7 @@ struct PhysHost {
     DevModel<double> md;
     Layout lay, lay2;               // first pass / second pass (lay2 == lay with one tier)
     bool two_pass() const { return maxcon1 < maxcon || maxefc1 < maxefc; }
+    int pair_waves = 1;             // option "pair_waves": 0 = every env that needs the full capacities waits for the second pass
     int* d_retry = nullptr;         // two counters (used alternately, like d_head) + the list of envs for the second pass
     unsigned long long retry_parity = 0;
     void* d_kargs2 = nullptr;       // KArgs of the second pass
@@ -2964,6 +3040,8 @@ struct PhysHost {
         L.maxcon = maxcon;
         L.maxefc = maxefc;
         L.expcon = this->maxcon;
+        L.gefc = this->maxefc;
+        L.ggrp = this->maxefc / 3 + 8;
         size_t rs = f64 ? 8 : 4;
         L.bytes_per_env = (int)((L.nreal * rs + (size_t)L.nint * 4 + 15) & ~(size_t)15);
         if (getenv("AVSIM_DEBUG_LAYOUT"))
@@ -3011,10 +3089,12 @@ struct PhysHost {
             int ms = f64 ? md.msize : mf.msize;
             // row / contact capacities per task: every box of a compound object resting on the condim-6 table
             // contributes 4 contacts x 6 rows (SewNeedle 24 contacts / 128 rows, TubeTransfer 40 / 248 at rest)
-            // Two tiers where the smaller first one lets more envs share a CU (SewNeedle: 8 instead of 6; TubeTransfer): the second
-            // pass costs a launch and, when its list is not empty, the latency of one env-step, so the other tasks keep one tier.
+            // Two tiers where the smaller first one lets more envs share a CU (SewNeedle: 7 instead of 6 -- the scripted grasp of
+            // BASELINE config 3 reaches 194 rows / 35 contacts in most envs at once, so the first tier must hold that: with 176 rows,
+            // 8 per CU, nearly every env needed the full record during the grasp; TubeTransfer): the second pass costs a launch and,
+            // when its list is not empty, the latency of one env-step, so the other tasks keep one tier.
             static const int cap_efc[5] = {176, 176, 336, 480, 176}, cap_con[5] = {48, 48, 72, 96, 48};
-            static const int cap_efc1[5] = {176, 176, 176, 288, 176}, cap_con1[5] = {48, 48, 48, 64, 48};
+            static const int cap_efc1[5] = {176, 176, 224, 288, 176}, cap_con1[5] = {48, 48, 56, 64, 48};
             maxefc = cap_efc[b.scalar("task_id")];
             maxcon = cap_con[b.scalar("task_id")];
             maxefc1 = cap_efc1[b.scalar("task_id")];
@@ -3028,7 +3108,7 @@ struct PhysHost {
             d_diag = up(std::vector<int>((size_t)N * 4, 0));
             d_cost = up(std::vector<int>((size_t)N, 0));
             d_order = up(std::vector<int>((size_t)N, 0));
-            d_retry = up(std::vector<int>((size_t)N + 2, 0));
+            d_retry = up(std::vector<int>(2 * (size_t)N + 2, 0));      // two counters, the list, one flag per env
             alloc_contacts();
         } catch (const std::exception& e) {
             err = std::string("physics init: ") + e.what();
@@ -3057,6 +3137,7 @@ struct PhysHost {
         if (n == "export_contacts") { export_contacts = v != 0; return true; }
         if (n == "num_joints") { if (v != 14 && v != 21) return false; mf.nj = md.nj = (int)v; return true; }
         if (n == "order_envs") { order_envs = v != 0; return true; }
+        if (n == "pair_waves") { pair_waves = v != 0; return true; }
         if (n == "qcqp_tridiag") { mf.qcqp_tridiag = md.qcqp_tridiag = v < 0 ? 0 : (v > 2 ? 2 : (int)v); return true; }
         if (n == "noslip_per_tree") { mf.noslip_per_tree = md.noslip_per_tree = v != 0; return true; }
         if (n == "persist_blocks") { int x = (int)v; if (x >= 1 && x <= 64) { persist_over = x; return true; } return false; }
@@ -3112,7 +3193,10 @@ struct PhysHost {
         }
         const bool two = two_pass();
         const int wpb = waves_per_block<real, MAXW>(lay), wpb2 = waves_per_block<real, MAXW>(lay2);
-        const size_t shmem = (size_t)lay.bytes_per_env * wpb + tables, shmem2 = (size_t)lay2.bytes_per_env * wpb2 + tables;
+        const size_t pairflags = two ? 2 * (MAXW / 2 > 0 ? MAXW / 2 : 1) * sizeof(int) : 0;
+        const size_t shmem = (size_t)lay.bytes_per_env * wpb + tables + pairflags, shmem2 = (size_t)lay2.bytes_per_env * wpb2 + tables + pairflags;
+        // pairs of waves take the envs that need the full capacities inside the first pass when the full record fits two small ones
+        const int pairing = (two && wpb >= 2 && lay2.bytes_per_env <= 2 * lay.bytes_per_env && pair_waves) ? 8 : 0;
         if (shmem > 160 * 1024 || (two && shmem2 > 160 * 1024)) { err = "per-block LDS exceeds 160 KiB; lower maxefc/maxcon"; return -1; }
         // persistent blocks: as many as the CUs hold at once (LDS bound), never more than the envs need
         const int per_cu = (int)((160 * 1024) / shmem) > 0 ? (int)((160 * 1024) / shmem) : 1;
@@ -3142,7 +3226,7 @@ struct PhysHost {
             hipLaunchKernelGGL(two ? kern2 : kern1, dim3(nblk), dim3(64 * wpb), shmem, st, (KPtr<real>)d_kargs, (const real*)d_img_real, (const int*)d_img_int, N, nsub, pgs_iters, action, want_reward,
                                (real*)qpos, (real*)qvel, (real*)ctrl, (real*)warm, latch, agent, (int*)reward, (unsigned char*)success, d_ncon,
                                d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof, d_xpose, order, order_envs ? d_cost : (int*)nullptr, head, next,
-                               d_retry, two ? 1 + 2 * par : 0);
+                               d_retry, two ? (1 + 2 * par) | pairing : 0, (KPtr<real>)d_kargs2);
         }
         if (two) {
             // second pass: the envs the first one gave up on, with the full capacities; one workgroup per CU is plenty for the few there
@@ -3153,10 +3237,10 @@ struct PhysHost {
             retry_parity++;
             int nblk2 = num_cu;
             if (nblk2 > (N + wpb2 - 1) / wpb2) nblk2 = (N + wpb2 - 1) / wpb2;
-            hipLaunchKernelGGL(kern2, dim3(nblk2), dim3(64 * wpb2), shmem2, st, (KPtr<real>)d_kargs2, (const real*)d_img_real, (const int*)d_img_int, 0, nsub, pgs_iters, action, want_reward,
+            hipLaunchKernelGGL(kern2, dim3(nblk2), dim3(64 * wpb2), shmem2, st, (KPtr<real>)d_kargs2, (const real*)d_img_real, (const int*)d_img_int, N, nsub, pgs_iters, action, want_reward,
                                (real*)qpos, (real*)qvel, (real*)ctrl, (real*)warm, latch, agent, (int*)reward, (unsigned char*)success, d_ncon,
                                d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof, d_xpose, (const int*)rlist, order_envs ? d_cost : (int*)nullptr, head, next,
-                               d_retry, 2 + 2 * par);
+                               d_retry, 2 + 2 * par, (KPtr<real>)d_kargs2);
         }
         if (nsub > 0) have_cost = true;
         hipError_t e = hipGetLastError();

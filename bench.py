@@ -430,6 +430,8 @@ def main():
                        "newton_iters_per_substep": float(((dg[:, 3] >> 16) & 0xfff).mean()) / 20.0, "newton_iters_max": int(((dg[:, 3] >> 28) & 0xf).max()),
                        "mean_ncon": float(w.ncon_sum.mean().item()) / args.steps if args.config == 3 else float(dg[:, 0].mean()),
                        "mean_nefc": float(dg[:, 1].mean()),
+                       "nefc_percentiles_50_90_99_100": [float(x) for x in np.percentile(dg[:, 1], [50, 90, 99, 100])],
+                       "ncon_percentiles_50_90_99_100": [float(x) for x in np.percentile(dg[:, 0], [50, 90, 99, 100])],
                        "envs_with_8_contacts_for_100_steps": float((w.rich >= 100).float().mean().item()) if args.config == 3 else None,
                        "gathered_envs": int(all_ret.numel()), "mean_return": float(all_ret.mean().item()),
                        "success_rate": float(all_succ.to(torch.float32).mean().item())},

@@ -281,23 +281,27 @@ def test_tridiagonal_multiplier_iteration_equals_mujocos():
     assert np.median(dq) < 1e-10 and (dq > 1e-8).sum() <= 3 and dq.max() < 1e-5 and dv.max() < 1e-4
 
 
-def test_two_tier_capacities_second_pass_is_exact():
-    """The contact / row capacities come in two tiers (PhysHost::launch_t): the first pass of a launch runs every env with the small
-    ones (the LDS record that lets the most envs share a CU), an env that runs out of them in some substep is stepped again by a
-    second pass with the full ones, from its untouched state.  HookPackage random walk with a first tier of 16 contacts / 36 rows (the envs need 35 to 41 here) --
-    some envs fit, most do not: states, rewards, contact counts and the contact export equal, bit for bit, those of ONE pass with the
-    full capacities, and no overflow flag is left."""
+def test_two_tier_capacities_are_exact():
+    """The contact / row capacities come in two tiers (PhysHost::launch_t): a launch runs every env with the small ones (the LDS record
+    that lets the most envs share a CU); an env that needs more -- predicted by its flag from the last step, or found out by running
+    out -- is stepped from its untouched state with the full ones: by its wave in the two adjacent records of a wave pair while the
+    partner waits (when the full record fits two small ones), else by a second pass over the list of such envs.  HookPackage random
+    walk, the envs need 35 to 41 rows: with a first tier of 36 rows (some envs fit, others do not) or 16 (none fits), with the pairs
+    (full tier 80 rows) and without (full tier 336 rows: the record is too big for a pair; or option pair_waves = 0), the states,
+    rewards, contact counts and the contact export equal, bit for bit, those of ONE pass with the full capacities, and no overflow
+    flag is left."""
     task, na, n, T = "hook_package", 2, 64, 10
     md = model_dict(task, na)
     gids = np.arange(n)
     acts = walk_actions(md, gids, T, 14, 3000)
-    out = []
-    for first in (None, (36, 16), (16, 16)):
-        opt = {"maxefc": 336, "maxcon": 72}
+
+    def run(full, first=None, **extra):
+        opt = {"maxefc": full[0], "maxcon": full[1]}
         if first:
             opt.update({"maxefc_first": first[0], "maxcon_first": first[1]})
+        opt.update(extra)
         sim = make(task, na, n, **opt)
-        assert sim.maxcon == 72
+        assert sim.maxcon == full[1]
         sim.reset(poses_for(task, gids, 3000))
         rws, ds = [], []
         for t in range(T):
@@ -305,14 +309,16 @@ def test_two_tier_capacities_second_pass_is_exact():
             rws.append(rw.copy())
             ds.append(sim.diag()[:, :3].copy())
         q, v, c, w = sim.get_state()
-        out.append((q, v, w, np.stack(rws), np.stack(ds), ap, sim.contacts()))
+        out = (q, v, w, np.stack(rws), np.stack(ds), ap) + tuple(sim.contacts())
         sim.close()
-    ref = out[0]
-    nefc = ref[4][:, :, 1]
-    assert (nefc > 36).any() and (nefc.max(0) <= 36).any(), "the first tier should hold some envs and not others"
-    assert (ref[4][:, :, 2] == 0).all()
-    for o in out[1:]:
-        for a, b in zip(o[:6], ref[:6]):
-            assert np.array_equal(a, b)
-        for a, b in zip(o[6], ref[6]):
-            assert np.array_equal(a, b)
+        return out
+
+    for full in ((80, 24), (336, 72)):
+        ref = run(full)
+        nefc = ref[4][:, :, 1]
+        assert (nefc > 36).any() and (nefc.max(0) <= 36).any(), "the first tier should hold some envs and not others"
+        assert (ref[4][:, :, 2] == 0).all()
+        for first, extra in (((36, 16), {}), ((16, 16), {}), ((36, 16), {"pair_waves": 0})):
+            o = run(full, first, **extra)
+            for k, (a, b) in enumerate(zip(o, ref)):
+                assert np.array_equal(a, b), (full, first, extra, k)
