@@ -73,7 +73,8 @@ __device__ __forceinline__ void exp_screw(const double w_[3], const double v_[3]
     T w[3] = {(T)w_[0], (T)w_[1], (T)w_[2]}, v[3] = {(T)v_[0], (T)v_[1], (T)v_[2]};
     T S[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0}, S2[9];
     mat3mul(S, S, S2);
-    T s = sin(th), c = cos(th);
+    T s, c;
+    sincos(th, &s, &c);      // (one argument reduction for both)
 #pragma unroll
     for (int i = 0; i < 9; i++) R[i] = ((i % 4 == 0) ? T(1) : T(0)) + s * S[i] + (1 - c) * S2[i];
 #pragma unroll
@@ -132,6 +133,54 @@ __device__ __forceinline__ void jac(const IkArm& A, const T* q, T J[6][NJ]) {
     }
 }
 
+// The same two with the joints' exponentials exp([S_i] q_i) made once and shared (DiffIK evaluates both at the same q every
+// iteration; an exponential is a sine, a cosine and two 3 x 3 products in double): operation for operation the results of fk / jac.
+template <typename T, int NJ>
+__device__ __forceinline__ void joint_exps(const IkArm& A, const T* q, T Re[NJ][9], T pe[NJ][3]) {
+#pragma unroll
+    for (int i = 0; i < NJ; i++) exp_screw<T>(A.w[i], A.v[i], q[i], Re[i], pe[i]);
+}
+template <typename T, int NJ>
+__device__ __forceinline__ void fk_from(const IkArm& A, const T Re[NJ][9], const T pe[NJ][3], T R[9], T p[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) R[3 * i + j] = (T)A.site0[4 * i + j];
+        p[i] = (T)A.site0[4 * i + 3];
+    }
+#pragma unroll
+    for (int i = NJ - 1; i >= 0; i--) {
+        T np[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) np[r] = Re[i][3 * r] * p[0] + Re[i][3 * r + 1] * p[1] + Re[i][3 * r + 2] * p[2] + pe[i][r];
+        mat3mul(Re[i], R, R);
+        p[0] = np[0]; p[1] = np[1]; p[2] = np[2];
+    }
+}
+template <typename T, int NJ>
+__device__ __forceinline__ void jac_from(const IkArm& A, const T Re[NJ][9], const T pe[NJ][3], T J[6][NJ]) {
+    T R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+        T w[3] = {(T)A.w[i][0], (T)A.w[i][1], (T)A.w[i][2]}, v[3] = {(T)A.v[i][0], (T)A.v[i][1], (T)A.v[i][2]};
+        T Rw[3], Rv[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            Rw[r] = R[3 * r] * w[0] + R[3 * r + 1] * w[1] + R[3 * r + 2] * w[2];
+            Rv[r] = R[3 * r] * v[0] + R[3 * r + 1] * v[1] + R[3 * r + 2] * v[2];
+        }
+        J[3][i] = Rw[0]; J[4][i] = Rw[1]; J[5][i] = Rw[2];
+        J[0][i] = p[1] * Rw[2] - p[2] * Rw[1] + Rv[0];
+        J[1][i] = p[2] * Rw[0] - p[0] * Rw[2] + Rv[1];
+        J[2][i] = p[0] * Rw[1] - p[1] * Rw[0] + Rv[2];
+        T np[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) np[r] = R[3 * r] * pe[i][0] + R[3 * r + 1] * pe[i][1] + R[3 * r + 2] * pe[i][2] + p[r];
+        mat3mul(R, Re[i], R);
+        p[0] = np[0]; p[1] = np[1]; p[2] = np[2];
+    }
+}
+
 // in-register Cholesky solve of a 6x6 SPD system A x = b (lower triangle of A used). `guard`: pivots
 // below guard*max_diag are treated as singular directions (their solution component is dropped).
 template <typename T>
@@ -184,14 +233,16 @@ __device__ void diffik(const IkParams& P, int arm, const T* qin, const T pos[3],
     const T k_pos = (T)P.k_pos, k_ori = (T)P.k_ori, dt = (T)P.dt, vmax = (T)P.max_angvel;
     for (int it = 0; it < iters; it++) {
         T Rc[9], pc[3], tw[6], dr[3];
-        fk<T, NJ>(A, q, Rc, pc);
+        T Ee[NJ][9], Ep[NJ][3];
+        joint_exps<T, NJ>(A, q, Ee, Ep);
+        fk_from<T, NJ>(A, Ee, Ep, Rc, pc);
 #pragma unroll
         for (int i = 0; i < 3; i++) tw[i] = k_pos * (pos[i] - pc[i]) / dt;
         angular_error(Rt, Rc, dr);
 #pragma unroll
         for (int i = 0; i < 3; i++) tw[3 + i] = k_ori * dr[i] / dt;
         T J[6][NJ];
-        jac<T, NJ>(A, q, J);
+        jac_from<T, NJ>(A, Ee, Ep, J);
         T JJt[6][6], Ad[6][6];
 #pragma unroll
         for (int i = 0; i < 6; i++)
