@@ -63,6 +63,7 @@ constexpr int RG_W = 8, RVERT_MAX = 32, RFACE_MAX = 64;
 struct RenderModel {
     int ngeom, ncam, nbody, nplane, nedge;   // nplane / nedge: faces / edges summed over the visible polyhedra (one camera's scratch)
     const int *rg, *r_fvadr, *r_fvnum, *r_fvidx, *r_edge;
+    const unsigned* r_fvmask;      // the vertices of a face as a bit set (polyhedra of at most RVERT_MAX = 32 vertices): one word per face
     const float *r_vert, *r_plane;
     const int *geom_type, *geom_body, *geom_visible, *cam_body;
     const float *geom_pos, *geom_mat, *geom_size, *geom_bcen, *geom_rbound, *cam_pos, *cam_mat, *cam_fovy;   // cam_fovy: tan(fovy / 2) per camera
@@ -148,9 +149,13 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
             float c3x = 0, c3y = 0, c3z = 0;
             unsigned behind = 0;                      // vertices nearer than half the near plane distance (or behind the camera)
             const bool big = poly && (nvert > RVERT_MAX || G[3] > RFACE_MAX);      // (no such polyhedron in the models: general path)
+            float hn0 = poly && nvert > 0 ? hv[0] : 0.f, hn1 = poly && nvert > 0 ? hv[1] : 0.f, hn2 = poly && nvert > 0 ? hv[2] : 0.f;      // next vertex, fetched one ahead
             for (int k = 0; k < nvert; k++) {
                 float pl[3];
-                if (poly) { pl[0] = hv[3 * k]; pl[1] = hv[3 * k + 1]; pl[2] = hv[3 * k + 2]; }
+                if (poly) {
+                    pl[0] = hn0; pl[1] = hn1; pl[2] = hn2;
+                    if (k + 1 < nvert) { hn0 = hv[3 * k + 3]; hn1 = hv[3 * k + 4]; hn2 = hv[3 * k + 5]; }
+                }
                 else { pl[0] = (k & 1) ? ex : -ex; pl[1] = (k & 2) ? ey : -ey; pl[2] = (k & 4) ? ez : -ez; }
                 const float d0 = pl[0] - rec[0], d1 = pl[1] - rec[1], d2 = pl[2] - rec[2];
                 // p_c = A^T (p_l - o_l)
@@ -183,8 +188,17 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
                 float4* se = reinterpret_cast<float4*>(sedge) + cbase * m.nedge + eoff;
                 unsigned long long front = 0;
                 const float fpad = 1e-4f;
+                // (plane and vertex set of the NEXT face are fetched while this one is worked on: the loop is one face per round trip
+                // otherwise, the lanes of a wave being at different geoms)
+                const float4* PL = reinterpret_cast<const float4*>(m.r_plane) + G[2];
+                const unsigned* FM = m.r_fvmask + G[2];
+                float4 n_next = np > 0 ? PL[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+                unsigned fm_next = np > 0 ? FM[0] : 0u;
                 for (int p = 0; p < np; p++) {
-                    const float* n = m.r_plane + 4 * (size_t)(G[2] + p);
+                    const float4 n4 = n_next;
+                    unsigned fm = fm_next;
+                    if (p + 1 < np) { n_next = PL[p + 1]; fm_next = FM[p + 1]; }
+                    const float n[4] = {n4.x, n4.y, n4.z, n4.w};
                     float4 q;
                     q.x = n[0] * rec[3] + n[1] * rec[6] + n[2] * rec[9];
                     q.y = n[0] * rec[4] + n[1] * rec[7] + n[2] * rec[10];
@@ -195,11 +209,11 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
                     if (q.w < 0) {
                         if (p < 64) front |= 1ull << p;
                         if (!big) {
-                            const int fa = m.r_fvadr[G[2] + p], fn = m.r_fvnum[G[2] + p];
-                            bool clipped = false;
-                            for (int j = 0; j < fn; j++) {
-                                const int v = m.r_fvidx[fa + j];
-                                clipped = clipped || ((behind >> v) & 1u);
+                            // (the face's vertices from one word, next to the plane: no chain of dependent loads per face)
+                            const bool clipped = (behind & fm) != 0;
+                            while (fm) {
+                                const int v = __builtin_ctz(fm);
+                                fm &= fm - 1;
                                 const float iz = -1.0f / vcz[v][lane];
                                 const float x = vcx[v][lane] * iz, y = vcy[v][lane] * iz;
                                 b.x = fminf(b.x, x); b.y = fmaxf(b.y, x); b.z = fminf(b.z, y); b.w = fmaxf(b.w, y);
@@ -213,8 +227,12 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
                 int nsil = 0;
                 if (!big) {
                     const int ne = G[5];
+                    const int4* ED = reinterpret_cast<const int4*>(m.r_edge) + G[4];
+                    int4 e_next = ne > 0 ? ED[0] : make_int4(0, 0, 0, 0);
                     for (int e = 0; e < ne; e++) {
-                        const int* E = m.r_edge + 4 * (size_t)(G[4] + e);
+                        const int4 e4 = e_next;
+                        if (e + 1 < ne) e_next = ED[e + 1];
+                        const int E[4] = {e4.x, e4.y, e4.z, e4.w};
                         if ((((front >> E[2]) ^ (front >> E[3])) & 1ull) == 0) continue;
                         const float x0 = vcx[E[0]][lane], y0 = vcy[E[0]][lane], z0 = vcz[E[0]][lane], x1 = vcx[E[1]][lane], y1 = vcy[E[1]][lane], z1 = vcz[E[1]][lane];
                         float A = y0 * z1 - z0 * y1, B = z0 * x1 - x0 * z1, Cz = x0 * y1 - y0 * x1;
@@ -785,6 +803,7 @@ struct RenderHost {
         auto gs = b.f("geom_size"), hv = b.f("hull_vert"), hpl = b.f("hull_plane");
         std::vector<float> rvert, rplane;
         std::vector<int> fvadr, fvnum, fvidx, redge, rg((size_t)m.ngeom * RG_W, 0);
+        std::vector<unsigned> fvmask;
         std::map<std::pair<int, int>, std::array<int, 6>> cache;
         m.nplane = 0; m.nedge = 0;
         for (int g = 0; g < m.ngeom; g++) {
@@ -800,7 +819,9 @@ struct RenderHost {
                     for (int f = 0; f < a[3]; f++) {
                         fvadr.push_back((int)fvidx.size());
                         fvnum.push_back(hfn[hp[2 * g] + f]);
-                        for (int j = 0; j < hfn[hp[2 * g] + f]; j++) fvidx.push_back(hfi[hfa[hp[2 * g] + f] + j]);
+                        unsigned msk = 0;
+                        for (int j = 0; j < hfn[hp[2 * g] + f]; j++) { const int v = hfi[hfa[hp[2 * g] + f] + j]; fvidx.push_back(v); if (v < 32) msk |= 1u << v; }
+                        fvmask.push_back(msk);
                     }
                     for (int k = 0; k < 4 * a[5]; k++) redge.push_back(hed[4 * (size_t)he[2 * g] + k]);
                 } else {
@@ -815,7 +836,9 @@ struct RenderHost {
                             for (float x : n) rplane.push_back(x);
                             fvadr.push_back((int)fvidx.size());
                             fvnum.push_back(4);
-                            for (int k = 0; k < 8; k++) if (((k >> c) & 1) == sd) fvidx.push_back(k);
+                            unsigned msk = 0;
+                            for (int k = 0; k < 8; k++) if (((k >> c) & 1) == sd) { fvidx.push_back(k); msk |= 1u << k; }
+                            fvmask.push_back(msk);
                         }
                     for (int u = 0; u < 8; u++)
                         for (int c = 0; c < 3; c++) {
@@ -835,7 +858,7 @@ struct RenderHost {
             G[6] = m.nplane; G[7] = m.nedge;
             m.nplane += a[3]; m.nedge += a[5];
         }
-        m.rg = up(rg); m.r_vert = up(rvert); m.r_plane = up(rplane); m.r_fvadr = up(fvadr); m.r_fvnum = up(fvnum); m.r_fvidx = up(fvidx); m.r_edge = up(redge);
+        m.rg = up(rg); m.r_vert = up(rvert); m.r_plane = up(rplane); m.r_fvadr = up(fvadr); m.r_fvnum = up(fvnum); m.r_fvidx = up(fvidx); m.r_edge = up(redge); m.r_fvmask = up(fvmask);
     }
     void build(const Blob& b, int N_) {
         N = N_;
