@@ -49,8 +49,8 @@ enum {
 };
 
 /* dims[]: 0 nq, 1 nv, 2 nu (actuators, 21), 3 num_joints of the action/agent_pos (14|21), 4 nobj (free objects),
- * 5 max_reward, 6 num_envs, 7 task id, 8 ncon capacity, 9 nefc capacity, 10 LDS bytes per block (one env per
- * wavefront + the hot model tables), 11 blocks that fit one CU's 160 KiB */
+ * 5 max_reward, 6 num_envs, 7 task id, 8 ncon capacity, 9 nefc capacity (the full tier), 10 LDS bytes per block (one env per
+ * wavefront with the first tier's record + the hot model tables), 11 blocks that fit one CU's 160 KiB */
 #define AVSIM_NDIMS 12
 
 /* Build a batched simulation from a compiled model blob (av_aloha_amd/compiler, replaces env.py:53-56).
@@ -63,7 +63,17 @@ int avsim_dims(const avsim_t* h, int32_t dims[AVSIM_NDIMS]);
 /* Solver / capacity / debug knobs (returns AVSIM_EINVAL for an unknown name or a value out of range):
  *   "solver"            0 PGS (BASELINE north_star), 1 Newton (MuJoCo's default, what the reference runs; default)
  *   "pgs_iters"         Gauss-Seidel sweeps of the PGS solver (default 20); "newton_iters" cap (default 100 = MuJoCo), "newton_tol" (1e-8 in f64 = MuJoCo, 1e-6 in f32)
- *   "maxefc", "maxcon"  constraint rows / contacts kept per env (per-task defaults 176-336 / 48-72); re-sizes the records
+ *   "maxefc", "maxcon"  constraint rows / contacts an env can hold (per-task defaults 176-480 / 48-96): the stride of the contact export
+ *                       and of the global row scratch; setting one makes it the capacity of a single tier (one pass)
+ *   "maxefc_first", "maxcon_first"   the FIRST tier of the two-tier capacities (defaults: SewNeedle 224 / 56 of 336 / 72, TubeTransfer
+ *                       288 / 64 of 480 / 96; the other tasks have one tier): a launch steps every env with the LDS record of the first
+ *                       tier -- more envs per CU --, and an env that needs more in some substep is stepped again from its untouched
+ *                       state with the full capacities: by its wave in the two adjacent records of a wave pair ("pair_waves" 1, the
+ *                       default, when the full record fits two small ones), else by a second pass over the list of such envs.
+ *                       Results are those of one pass with the full capacities, bit for bit
+ *   "qcqp_tridiag"      multiplier iteration of a sliding contact's noslip QCQP: 0 MuJoCo's Cholesky per iterate (f64 default), 1 the
+ *                       same iterates on the Householder-tridiagonal form of the friction block, 2 tridiagonal form + secular-equation
+ *                       steps (Newton on 1/r - 1/|y|; f32 default): the same multiplier within the iteration's own thresholds
  *   "num_joints"        14 | 21: width of the action / agent_pos rows, whatever the blob's arm count (a 3-arm env whose camera
  *                       arm was parked by hide_middle_arm, env.py:394-395, keeps its 21-D action on the 2-arm model)
  *   "waves_per_block"   envs per workgroup, 0 = as many as fit in 160 KiB of LDS (<= 8)

@@ -26,20 +26,21 @@ python - <<PY
 import csv, glob, json, collections
 o = "$o"
 def collect(name):
-    acc = collections.defaultdict(list)
+    # the TIMED env-step launches: dispatches in order, without the forward-only launches of reset / FK and the near-empty second
+    # passes of the two-tier capacities (small), the last five of the rest -- the same launches for every counter
+    out = {}
     for f in glob.glob(o + "/%s/**/*counter_collection.csv" % name, recursive=True):
         per = collections.defaultdict(lambda: collections.defaultdict(float))
         for r in csv.DictReader(open(f)):
             if "k_phys" in r["Kernel_Name"]:
-                per[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
-        for d in per.values():
-            for k, v in d.items():
-                acc[k].append(v)
-    # env-step launches are the large half of the k_phys dispatches (forward-only launches of reset / FK are small)
-    out = {}
-    for k, v in acc.items():
-        v = sorted(v); v = v[len(v) // 2:]
-        out[k] = sum(v) / max(1, len(v))
+                per[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        if not per:
+            continue
+        ref = max(next(iter(per.values())).keys(), key=lambda k: max(d.get(k, 0.0) for d in per.values()))
+        top = max(d.get(ref, 0.0) for d in per.values())
+        ids = [i for i in sorted(per) if per[i].get(ref, 0.0) > 0.1 * top][-5:]
+        for k in per[ids[0]]:
+            out[k] = sum(per[i].get(k, 0.0) for i in ids) / len(ids)
     return out
 N = 4096
 res = {"source": "tools/prof_flops.sh $tag: rocprofv3 --pmc passes of bench.py --steps 5 (SQ counters of k_phys, mean over its env-step launches of 4096 envs x 20 substeps); flops = (ADD + MUL + 2 FMA + TRANS) wave-instructions x 64 x lane utilisation (SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)); packed v_pk_* instructions are counted by the SQ as one instruction per wave, so this is a lower bound where they are used"}
