@@ -322,3 +322,31 @@ def test_two_tier_capacities_are_exact():
             o = run(full, first, **extra)
             for k, (a, b) in enumerate(zip(o, ref)):
                 assert np.array_equal(a, b), (full, first, extra, k)
+
+
+def test_sew_needle_default_tiers_equal_one_tier():
+    """SewNeedle-3Arms as shipped (first tier 224 rows / 56 contacts of 336 / 72, wave pairs) and with a first tier that most envs
+    outgrow (128 / 32: at rest the scene needs 128 rows / 24 contacts, the random walk adds to that) against ONE tier of 336 / 72:
+    states, rewards and diagnostics identical bit for bit after 25 env-steps of the random walk with closing grippers."""
+    task, na, n, T = "sew_needle", 3, 96, 25
+    md = model_dict(task, na)
+    gids = np.arange(n)
+    acts = walk_actions(md, gids, T, 21, 2000, close_grippers=True)
+    out = []
+    for opt in ({"maxefc": 336, "maxcon": 72}, {}, {"maxefc_first": 128, "maxcon_first": 32}, {"maxefc_first": 128, "maxcon_first": 32, "pair_waves": 0}):
+        sim = make(task, na, n, **opt)
+        assert sim.maxcon == 72 and sim.maxefc == 336
+        sim.reset(poses_for(task, gids, 2000))
+        rws, ds = [], []
+        for t in range(T):
+            ap, rw, su = sim.step(acts[t])
+            rws.append(rw.copy())
+            ds.append(sim.diag()[:, :3].copy())
+        q, v, c, w = sim.get_state()
+        out.append((q, v, w, np.stack(rws), np.stack(ds), ap))
+        sim.close()
+    ref = out[0]
+    assert (ref[4][:, :, 2] == 0).all() and (ref[4][:, :, 1] > 128).any()
+    for k, o in enumerate(out[1:]):
+        for j, (a, b) in enumerate(zip(o, ref)):
+            assert np.array_equal(a, b), (k, j)
