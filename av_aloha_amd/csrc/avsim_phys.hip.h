@@ -42,6 +42,7 @@ struct DevModel {
     int nq, nv, nu, nbody, njnt, ngeom, npair, ntree, neq, nfloss, nlimited, nment, task_id, nj, msize;
     real timestep, gravity[3], impratio, grip_lo, grip_hi;
     int noslip_iters;
+    int noslip_trees;             // 1 (default): noslip passes whose contacts all touch one kinematic tree run per tree, the trees' chains side by side (option "noslip_trees")
     int qcqp_tridiag;             // sliding contacts' multiplier iteration: 0 MuJoCo's Cholesky per iterate (f64 default), 1 the same iterates through the tridiagonal form, 2 tridiagonal form + secular-equation steps (f32 default); option "qcqp_tridiag"
     int noslip_per_tree;          // 1: the dry-friction rows of the noslip pass go per kinematic tree (needs <= 8 trees); option "noslip_per_tree"
     int solver, newton_iters;     // 0 = PGS (dual), 1 = Newton (primal, the reference's default solver)
@@ -926,6 +927,228 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
             if (lane_get(wave_sum(imp), 0) < noslip_tol_scaled) break;
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// The noslip pass when every contact touches ONE kinematic tree (objects resting on the table, an arm on the table; no contact
+// between two trees -- the scene of the headline workload until a gripper closes on something).  mj_solNoSlip's sweep relaxes the
+// dry-friction rows, then the contacts in order; rows and contacts of different trees share no dof, so the sweep falls apart into
+// one independent chain per tree, and pgs_groups' "one contact per step for the whole wave" (280 instructions a step) leaves that
+// on the table.  Here octet t of the wave owns tree t for the whole pass: lane 8 t + k keeps qacc[dof k of tree t] in a register
+// (as the per-tree dry-friction steps already do) and the octets walk their trees' contacts side by side, one contact per step and
+// octet -- the steps of a sweep are the LONGEST chain, not the number of contacts, and a step needs no LDS round trip for the
+// acceleration, no atomics and no wave-wide broadcasts:
+//   row residuals   lane k holds column k of the contact's J (6 loads, one step ahead): 6 products, 6 octet sums (DPP);
+//   friction block  the multiplier-0 candidate f - A^-1 res of mju_QCQP through the block inverse made with the rows (lane r = row r,
+//                   the residuals come over by octet broadcasts), its cone test and cost change by two octet sums; condim-3 contacts
+//                   run mju_QCQP2's two-by-two multiplier iteration, redundantly on the lanes of the octet;
+//   update          x_k += sum_r B[r][k] dl_r with the contact's J M^-1 column in registers.
+// Same arithmetic per contact as pgs_groups' noslip steps (same octet sums, same candidate, same tests), the order of the contacts
+// of a tree is the reference's, and trees do not interact: the results differ from pgs_groups' by the rounding of the acceleration
+// update (a chain of FMAs here, LDS atomic adds of rounded products there) and of the sweep's improvement sum.
+// A contact with >= 3 friction rows that SLIDES (candidate outside its cone section) needs the multiplier iteration: the function
+// then gives up -- it has written nothing but the rows' spare word -- and the caller runs pgs_groups from the untouched state.
+// Returns 1 when the pass is done, 0 for "use pgs_groups" (two-tree contact, more than 64 contacts, sliding contact, odd layout).
+// ------------------------------------------------------------------------------------------------
+template <typename real>
+__device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const int) cefc, GLB_PTR(const real) rJ,
+                                                      LDS_PTR(real) q, LDS_PTR(const int) gI, GLB_PTR(const real) gA, int ncon, int nefc, int noslip_iters,
+                                                      real noslip_tol_scaled, NoslipLead<real> nl) {
+    rowS = uni_lds(rowS); rowI = uni_lds(rowI); cefc = uni_lds(cefc); q = uni_lds(q); gI = uni_lds(gI);
+    rJ = uni_glb(rJ); gA = uni_glb(gA);
+    ncon = __builtin_amdgcn_readfirstlane(ncon); nefc = __builtin_amdgcn_readfirstlane(nefc); noslip_iters = __builtin_amdgcn_readfirstlane(noslip_iters);
+    noslip_tol_scaled = lane_get(noslip_tol_scaled, 0);
+    nl.Minv = uni_lds(nl.Minv); nl.tadr = uni_lds(nl.tadr); nl.tnum = uni_lds(nl.tnum); nl.floss_dof = uni_lds(nl.floss_dof); nl.dmap = uni_lds(nl.dmap);
+    nl.ntree = __builtin_amdgcn_readfirstlane(nl.ntree); nl.nv = __builtin_amdgcn_readfirstlane(nl.nv); nl.neq = __builtin_amdgcn_readfirstlane(nl.neq);
+    nl.nfloss = __builtin_amdgcn_readfirstlane(nl.nfloss); nl.nlg = __builtin_amdgcn_readfirstlane(nl.nlg); nl.tridiag = __builtin_amdgcn_readfirstlane(nl.tridiag);
+    const int lane = threadIdx.x & 63, ft = lane >> 3, fi = lane & 7;
+    if (noslip_iters <= 0 || nl.nlg < 0 || ncon <= 0 || ncon > 64) return 0;
+    // ---- the contacts' trees; every contact must have its rows, one tree, and the group pgs_groups would give it ----
+    int ctree = -1;
+    bool bad = false;
+    if (lane < ncon) {
+        const int ce = cefc[lane];
+        if (ce < 0) bad = true;
+        else {
+            const int h = ce & 0xffff, ra = rowI[h];
+            ctree = (ra >> 10) & 7;
+            bad = ((ra >> 19) & 15) != 0 || ctree >= nl.ntree || (gI[nl.nlg + lane] & 0xffff) != h || ((gI[nl.nlg + lane] >> 16) & 15) != (ce >> 16) || (ce >> 16) > GRP_MAX || (ce >> 16) == 2;
+        }
+    }
+    if (__any(bad)) return 0;
+    unsigned long long chain = 0;      // this octet's contacts (bit c = contact c), walked in index order
+    int nstep = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const unsigned long long m = __ballot(ctree == t);
+        if (ft == t) chain = m;
+        const int n = __popcll(m);
+        nstep = n > nstep ? n : nstep;
+    }
+    // ---- dry-friction rows, as in pgs_groups: lane 8 t + i = dof i of tree t ----
+    for (int k = lane; k < nl.nv; k += 64) nl.dmap[k] = -1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int r = lane; r < nl.nfloss; r += 64) nl.dmap[nl.floss_dof[r]] = nl.neq + r;
+    // the spare word of every row record takes the forces of the pass; the rows' own word is written when the pass has succeeded
+    for (int i = lane; i < nefc; i += 64) rowS[RS_S * i + 8] = rowS[RS_S * i + 6];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool fm = ft < nl.ntree && fi < nl.tnum[ft < nl.ntree ? ft : 0];
+    const int fdof = fm ? nl.tadr[ft] + fi : 0;
+    const int frow = fm ? nl.dmap[fdof] : -1;
+    real mrow[TREE_W];
+#pragma unroll
+    for (int s = 0; s < TREE_W; s++) mrow[s] = fm ? nl.Minv[64 * ft + 8 * fi + s] : real(0);
+    LDS_PTR(real) FS = rowS + RS_S * (frow >= 0 ? frow : 0);
+    const real faref = FS[0], finv = frow >= 0 ? FS[3] : real(0), flo = FS[4], fhi = FS[5];
+    const real fdiag = finv != 0 ? real(1) / finv : real(0);
+    real ff = frow >= 0 ? FS[6] : real(0);
+    real x = fm ? q[fdof] : real(0);
+    // ---- contact data, one step ahead ----
+    struct CD { int h, dim, g; real J[GRP_MAX], B[GRP_MAX], qc[GA_QW], a1, aref, invn, f0, muinv; };
+    auto fetch = [&](unsigned long long& rem, CD& d) {
+        const bool on = rem != 0;
+        const int c = on ? __builtin_ctzll(rem) : 0;
+        rem &= rem - 1;
+        const int ce = cefc[c];
+        d.h = on ? (ce & 0xffff) : 0; d.dim = on ? (ce >> 16) : 0; d.g = nl.nlg + c;
+#pragma unroll
+        for (int r = 0; r < GRP_MAX; r++) {
+            GLB_PTR(const real) R = rJ + ROW_S * (d.h + (r < d.dim ? r : 0)) + fi;       // (a row of this contact in any case)
+            d.J[r] = R[0];
+            d.B[r] = R[TREE_W];
+        }
+        const int qr = (fi >= 1 && fi <= 5) ? fi - 1 : 0;
+#pragma unroll
+        for (int s = 0; s < GA_QW; s++) d.qc[s] = gA[GA_W * d.g + GA_Q + 8 * s + qr];
+        d.a1 = gA[GA_W * d.g + 2];      // the coupling of the two friction rows of a condim-3 contact (rows 2 and 1)
+        LDS_PTR(const real) S = rowS + RS_S * (d.h + (fi < d.dim ? fi : 0));
+        d.aref = S[0]; d.invn = S[3]; d.f0 = S[8]; d.muinv = S[7];
+    };
+    bool slid = false;
+    for (int sweep = 0; sweep < noslip_iters; sweep++) {
+        real imp = 0;
+        // dry-friction rows of mj_solNoSlip [EXT]: clamped scalar update, undone when it would raise the cost (costChange)
+#pragma unroll
+        for (int s = 0; s < TREE_W; s++) {
+            const real res = x - faref;
+            const real fs = tmin(tmax(ff - res * finv, flo), fhi);
+            const real dl_ = fs - ff, ch = dl_ * (real(0.5) * dl_ * fdiag + res);
+            const bool take = frow >= 0 && fi == s && !(ch > real(1e-10));
+            if (take) { imp -= ch; ff = fs; }
+            const real ds = oct_bcast_n(take ? dl_ : real(0), s);
+            x += mrow[s] * ds;
+        }
+        // the contacts of this octet's tree, in order
+        unsigned long long rem = chain;
+        CD cur, nxt;
+        fetch(rem, cur);
+        for (int step = 0; step < nstep; step++) {
+            fetch(rem, nxt);
+            const int dim = cur.dim, n = dim - 1;
+            const bool row = fi >= 1 && fi < dim;
+            // row residuals J_r . qacc: every lane ends up with all of them
+            real res_r = 0;
+#pragma unroll
+            for (int r = 1; r < GRP_MAX; r++) {
+                const real sr = oct_sum(r < dim ? cur.J[r] * x : real(0));
+                if (fi == r) res_r = sr;
+            }
+            res_r = row ? res_r - cur.aref : real(0);
+            const real fn = oct_bcast<0>(cur.f0), r2 = fn * fn;
+            real f = cur.f0;
+            if (n >= 3) {
+                // multiplier 0 first: the unconstrained minimiser f - A^-1 res (the inverse made with the rows); inside the cone section
+                // this is mju_QCQP's answer, and its cost change is dl . res / 2
+                bool done = false;
+                if (!(fn < real(1e-15)) && oct_bcast<1>(cur.qc[5]) == real(0)) {
+                    const real ra[5] = {oct_bcast<1>(res_r), oct_bcast<2>(res_r), oct_bcast<3>(res_r), oct_bcast<4>(res_r), oct_bcast<5>(res_r)};
+                    real t = 0;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) t += cur.qc[k] * ra[k];
+                    const real dl_ = row ? -t : real(0), vr = cur.f0 + dl_;
+                    const real w = row ? vr * cur.muinv : real(0);
+                    const real val = oct_sum(w * w) - r2;
+                    if (val < QTol<real>::abs + QTol<real>::rel * r2) {
+                        const real change = real(0.5) * oct_sum(dl_ * res_r);
+                        if (!(change > real(1e-10))) {
+                            if (fi == 0) imp -= change;
+                            if (row) f = vr;
+                        }
+                        done = true;
+                    }
+                }
+                if (!done && !(fn < real(1e-15))) slid = true;      // the multiplier iteration: pgs_groups has it
+                // (fn < 1e-15: mju_QCQP is not called, v = 0 ... handled by pgs_groups as well)
+                if (!done && fn < real(1e-15)) slid = true;
+            } else if (n == 2) {
+                // mju_QCQP2 [EXT] as pgs_groups evaluates it, on the lanes of the octet
+                const real resq0 = oct_bcast<1>(res_r), resq1 = oct_bcast<2>(res_r);
+                const real of0 = oct_bcast<1>(cur.f0), of1 = oct_bcast<2>(cur.f0);
+                const real dq0 = real(1) / oct_bcast<1>(cur.muinv), dq1 = real(1) / oct_bcast<2>(cur.muinv);
+                const real A00 = real(1) / oct_bcast<1>(cur.invn), A11 = real(1) / oct_bcast<2>(cur.invn), A10 = oct_bcast<2>(cur.a1);
+                real bq0 = resq0, bq1 = resq1;
+                bq0 -= A00 * of0; bq0 -= A10 * of1;
+                bq1 -= A10 * of0; bq1 -= A11 * of1;
+                real v0 = 0, v1 = 0;
+                if (!(fn < real(1e-15))) {
+                    const real vtol = QTol<real>::abs + QTol<real>::rel * r2;
+                    real la = 0;
+                    const real b1 = bq0 * dq0, b2 = bq1 * dq1;
+                    const real A11s = A00 * dq0 * dq0, A22s = A11 * dq1 * dq1, A12s = A10 * dq0 * dq1;
+                    real y1 = 0, y2 = 0;
+                    bool singular = false;
+                    for (int iter = 0; iter < 20; iter++) {
+                        const real det = (A11s + la) * (A22s + la) - A12s * A12s;
+                        if (det < real(1e-10)) { singular = true; break; }
+                        const real detinv = real(1) / det, P11 = (A22s + la) * detinv, P22 = (A11s + la) * detinv, P12 = -A12s * detinv;
+                        y1 = -P11 * b1 - P12 * b2;
+                        y2 = -P12 * b1 - P22 * b2;
+                        const real val = y1 * y1 + y2 * y2 - r2;
+                        if (val < vtol) break;
+                        const real yw = P11 * y1 * y1 + 2 * P12 * y1 * y2 + P22 * y2 * y2;
+                        const real delta = nl.tridiag == 2 ? secular_step(val, r2, fn, yw) : val / (2 * yw);
+                        if (delta < QTol<real>::abs + QTol<real>::rel * la) break;
+                        la += delta;
+                    }
+                    v0 = singular ? real(0) : y1 * dq0;
+                    v1 = singular ? real(0) : y2 * dq1;
+                    if (!singular && la != 0) {       // exactly onto the ellipsoid
+                        const real sq = v0 * v0 / (dq0 * dq0) + v1 * v1 / (dq1 * dq1);
+                        const real sc = sqrt(r2 / tmax(real(1e-15), sq));
+                        v0 *= sc; v1 *= sc;
+                    }
+                }
+                const real change = (v0 - of0) * (real(0.5) * (A00 * (v0 - of0) + A10 * (v1 - of1)) + resq0) + (v1 - of1) * (real(0.5) * (A10 * (v0 - of0) + A11 * (v1 - of1)) + resq1);
+                if (!(change > real(1e-10)) && dim == 3) {
+                    if (fi == 0) imp -= change;
+                    if (fi == 1) f = v0;
+                    if (fi == 2) f = v1;
+                }
+            }
+            // x += B^T (f - f0); the normal row does not move
+            const real dl = row ? f - cur.f0 : real(0);
+#pragma unroll
+            for (int r = 1; r < GRP_MAX; r++) x += (r < dim ? cur.B[r] : real(0)) * oct_bcast_n(dl, r);
+            if (row) rowS[RS_S * (cur.h + fi) + 8] = f;
+            cur = nxt;
+        }
+        if (__any(slid)) return 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next sweep reads the forces this one has stored
+        __builtin_amdgcn_wave_barrier();
+        if (lane_get(wave_sum(imp), 0) < noslip_tol_scaled) break;
+    }
+    // ---- the pass has succeeded: accelerations and forces to their places ----
+    if (fm) q[fdof] = x;
+    if (frow >= 0) FS[8] = ff;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < nefc; i += 64) rowS[RS_S * i + 6] = rowS[RS_S * i + 8];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return 1;
 }
 
 }  // namespace avs
@@ -2356,6 +2579,13 @@ struct Env {
             nit_sum += used; nit_max = used > nit_max ? used : nit_max;
             GSYNC();
             long long tn0 = profiling ? __builtin_readcyclecounter() : 0;
+            // every contact on one kinematic tree: the trees' chains side by side (noslip_trees); else, or when a contact slides, the
+            // general pass
+            int done_ = 0;
+            if (ka->m.noslip_trees && lead_per_tree())
+                done_ = noslip_trees<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const int))cefc, (GLB_PTR(const real))rJ, (LDS_PTR(real))qacc,
+                                           (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), ncon, nefc, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
+            if (!__builtin_amdgcn_readfirstlane(done_))
             pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (GLB_PTR(const real))rJ, (GLB_PTR(const real))rowsB_(), (LDS_PTR(real))qacc,
                              (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], 0, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
             if (profiling && lane == 0) (ii + ka->lay.nprof)[6] += (int)(__builtin_readcyclecounter() - tn0);
@@ -2831,7 +3061,7 @@ struct PhysHost {
         m.nj = b.scalar("num_arms") == 3 ? 21 : 14;
         auto opt = F("opt");
         m.timestep = (real)opt[0]; m.gravity[0] = (real)opt[1]; m.gravity[1] = (real)opt[2]; m.gravity[2] = (real)opt[3];
-        m.impratio = (real)opt[4]; m.noslip_iters = (int)opt[5]; m.noslip_per_tree = 1; m.qcqp_tridiag = sizeof(real) == 4 ? 2 : 0;
+        m.impratio = (real)opt[4]; m.noslip_iters = (int)opt[5]; m.noslip_per_tree = 1; m.noslip_trees = 1; m.qcqp_tridiag = sizeof(real) == 4 ? 2 : 0;
         m.solver = 1; m.newton_iters = 100; m.newton_tol = sizeof(real) == 8 ? (real)1e-8 : (real)1e-6;     // MuJoCo defaults: iterations 100, tolerance 1e-8
         m.nscale = (real)(1.0 / ((opt.size() > 7 && opt[7] > 0 ? opt[7] : 1.0) * std::max(1, m.nv)));
         auto gr = F("grip_range");
@@ -3140,6 +3370,7 @@ struct PhysHost {
         if (n == "pair_waves") { pair_waves = v != 0; return true; }
         if (n == "qcqp_tridiag") { mf.qcqp_tridiag = md.qcqp_tridiag = v < 0 ? 0 : (v > 2 ? 2 : (int)v); return true; }
         if (n == "noslip_per_tree") { mf.noslip_per_tree = md.noslip_per_tree = v != 0; return true; }
+        if (n == "noslip_trees") { mf.noslip_trees = md.noslip_trees = v != 0; return true; }
         if (n == "persist_blocks") { int x = (int)v; if (x >= 1 && x <= 64) { persist_over = x; return true; } return false; }
         if (n == "waves_per_block") { int x = (int)v; if (x >= 0 && x <= 8) { wpb_override = x; return true; } return false; }
         if (n == "profile_phases") {
