@@ -976,7 +976,8 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
             bad = ((ra >> 19) & 15) != 0 || ctree >= nl.ntree || (gI[nl.nlg + lane] & 0xffff) != h || ((gI[nl.nlg + lane] >> 16) & 15) != (ce >> 16) || (ce >> 16) > GRP_MAX || (ce >> 16) == 2;
         }
     }
-    if (__any(bad)) return 0;
+    LDS_PTR(int) prof = uni_lds(nl.prof);
+    if (__any(bad)) { if (prof && lane == 0) prof[1] += 1; return 0; }
     unsigned long long chain = 0;      // this octet's contacts (bit c = contact c), walked in index order
     int nstep = 0;
 #pragma unroll
@@ -1080,9 +1081,11 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
                         done = true;
                     }
                 }
-                if (!done && !(fn < real(1e-15))) slid = true;      // the multiplier iteration: pgs_groups has it
-                // (fn < 1e-15: mju_QCQP is not called, v = 0 ... handled by pgs_groups as well)
-                if (!done && fn < real(1e-15)) slid = true;
+                // No normal force: mj_solNoSlip takes the friction forces to zero (subject to the cost test).  They are zero already when
+                // the primal solution had no normal force either -- nothing to do; anything else, and the multiplier iteration of a
+                // sliding contact, is pgs_groups' business
+                if (!done && fn < real(1e-15) && oct_sum(row ? fabs(cur.f0) : real(0)) == real(0)) done = true;
+                if (!done) slid = true;
             } else if (n == 2) {
                 // mju_QCQP2 [EXT] as pgs_groups evaluates it, on the lanes of the octet
                 const real resq0 = oct_bcast<1>(res_r), resq1 = oct_bcast<2>(res_r);
@@ -1135,12 +1138,13 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
             if (row) rowS[RS_S * (cur.h + fi) + 8] = f;
             cur = nxt;
         }
-        if (__any(slid)) return 0;
+        if (__any(slid)) { if (prof && lane == 0) prof[2] += 1; return 0; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next sweep reads the forces this one has stored
         __builtin_amdgcn_wave_barrier();
         if (lane_get(wave_sum(imp), 0) < noslip_tol_scaled) break;
     }
     // ---- the pass has succeeded: accelerations and forces to their places ----
+    if (prof && lane == 0) prof[3] += 1;
     if (fm) q[fdof] = x;
     if (frow >= 0) FS[8] = ff;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2581,10 +2585,13 @@ struct Env {
             long long tn0 = profiling ? __builtin_readcyclecounter() : 0;
             // every contact on one kinematic tree: the trees' chains side by side (noslip_trees); else, or when a contact slides, the
             // general pass
+            // (an env whose pass has given up on a sliding contact skips the attempt for the rest of its env-step: contacts that slide
+            // go on sliding for a while)
             int done_ = 0;
-            if (ka->m.noslip_trees && lead_per_tree())
+            if (ka->m.noslip_trees && lead_per_tree() && misc[8] == 0)
                 done_ = noslip_trees<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const int))cefc, (GLB_PTR(const real))rJ, (LDS_PTR(real))qacc,
                                            (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), ncon, nefc, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
+            if (!__builtin_amdgcn_readfirstlane(done_) && lane == 0) misc[8] = 1;
             if (!__builtin_amdgcn_readfirstlane(done_))
             pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (GLB_PTR(const real))rJ, (GLB_PTR(const real))rowsB_(), (LDS_PTR(real))qacc,
                              (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], 0, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
@@ -2846,6 +2853,7 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
     for (int i = lane; i < ka->m.nv; i += G) { r[ka->lay.qvel + i] = g_qvel[(size_t)env * ka->m.nv + i]; r[ka->lay.warm + i] = g_warm[(size_t)env * ka->m.nv + i]; }
     for (int i = lane; i < ka->m.nu; i += G) r[ka->lay.ctrl + i] = g_ctrl[(size_t)env * ka->m.nu + i];
     if (lane == 0) for (int k = 0; k < 8; k++) { ii[ka->lay.misc + k] = 0; ii[ka->lay.nprof + k] = 0; ii[ka->lay.nprof + 8 + k] = 0; }
+    if (lane == 0) ii[ka->lay.misc + 8] = 0;
     E.profiling = o_prof != nullptr;
     GSYNC();
     if (action) {
@@ -3265,7 +3273,7 @@ struct PhysHost {
         L.nreal = (o + 3) & ~3;
         int io = 0;
         auto Iq = [&](int n) { int x = io; io += n; return x; };
-        L.cand = Iq(ANC_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.misc = Iq(8); L.nprof = Iq(16);
+        L.cand = Iq(ANC_MAX); L.cpair = Iq(maxcon); L.cefc = Iq(maxcon); L.rmeta = Iq(maxefc); L.rowI = Iq(maxefc); L.gI = Iq(maxefc / 3 + 8); L.misc = Iq(12); L.nprof = Iq(16);
         L.nint = (io + 3) & ~3;
         L.maxcon = maxcon;
         L.maxefc = maxefc;
