@@ -1085,7 +1085,147 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
                 // the primal solution had no normal force either -- nothing to do; anything else, and the multiplier iteration of a
                 // sliding contact, is pgs_groups' business
                 if (!done && fn < real(1e-15) && oct_sum(row ? fabs(cur.f0) : real(0)) == real(0)) done = true;
-                if (!done) slid = true;
+                if (!done && (nl.tridiag == 0 || fn < real(1e-15))) slid = true;
+                else if (!done) {
+                    // ---- the contact slides: mju_QCQP's multiplier iteration on the Householder-tridiagonal form of the scaled friction
+                    // block, as in pgs_groups (same operations in the same order), the block gathered by octet broadcasts instead of
+                    // wave-wide ones; redundantly on the eight lanes of the octet ----
+                    const int tri = fi <= 5 ? fi * (fi - 1) / 2 : 0;
+                    real acs[GRP_MAX - 1];
+#pragma unroll
+                    for (int k = 0; k < GRP_MAX - 1; k++) acs[k] = gA[GA_W * cur.g + tri + k];
+                    real Aq[5][5], bq[5], dq[5], oldf[5], resq[5], v[5];
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        const bool in = j < n;
+                        resq[j] = in ? oct_bcast_n(res_r, j + 1) : real(0);
+                        oldf[j] = in ? oct_bcast_n(cur.f0, j + 1) : real(0);
+                        const real mi = oct_bcast_n(cur.muinv, j + 1);
+                        dq[j] = in ? real(1) / mi : real(1);
+                        const real di = oct_bcast_n(cur.invn, j + 1);
+                        Aq[j][j] = in ? real(1) / di : real(1);
+#pragma unroll
+                        for (int k = 0; k < j; k++) { const real c = in ? oct_bcast_n(acs[k + 1], j + 1) : real(0); Aq[j][k] = c; Aq[k][j] = c; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        real t = resq[j];
+#pragma unroll
+                        for (int k = 0; k < 5; k++) t -= (j < n && k < n) ? Aq[j][k] * oldf[k] : real(0);
+                        bq[j] = t;
+                        v[j] = 0;
+                    }
+                    const real vtol = QTol<real>::abs + QTol<real>::rel * r2;
+                    real la = 0, y[5];
+                    bool singular = oct_bcast<1>(cur.qc[5]) != real(0);
+                    real As[5][5], cs[5], w[5], hv[3][5], hb[3];
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        cs[j] = j < n ? bq[j] * dq[j] : real(0);
+                        y[j] = 0;
+#pragma unroll
+                        for (int k = 0; k < 5; k++) As[j][k] = (j < n && k < n) ? Aq[j][k] * dq[j] * dq[k] : (j == k ? real(1) : real(0));
+                    }
+                    if (!singular) {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            real sigma = 0;
+#pragma unroll
+                            for (int i = k + 2; i < 5; i++) sigma += As[i][k] * As[i][k];
+                            const real x0 = As[k + 1][k];
+#pragma unroll
+                            for (int i = 0; i < 5; i++) hv[k][i] = 0;
+                            hb[k] = 0;
+                            if (sigma != real(0)) {
+                                const real nrm = sqrt(x0 * x0 + sigma), alpha = x0 > 0 ? -nrm : nrm;
+                                hv[k][k + 1] = x0 - alpha;
+#pragma unroll
+                                for (int i = k + 2; i < 5; i++) hv[k][i] = As[i][k];
+                                const real beta = real(2) / (hv[k][k + 1] * hv[k][k + 1] + sigma);
+                                hb[k] = beta;
+                                real pv[5], vp = 0;
+#pragma unroll
+                                for (int i = k + 1; i < 5; i++) {
+                                    real t = 0;
+#pragma unroll
+                                    for (int j = k + 1; j < 5; j++) t += As[i][j] * hv[k][j];
+                                    pv[i] = beta * t;
+                                    vp += hv[k][i] * pv[i];
+                                }
+                                const real K = real(0.5) * beta * vp;
+#pragma unroll
+                                for (int i = k + 1; i < 5; i++) pv[i] -= K * hv[k][i];
+#pragma unroll
+                                for (int i = k + 1; i < 5; i++)
+#pragma unroll
+                                    for (int j = k + 1; j <= i; j++) { As[i][j] -= hv[k][i] * pv[j] + pv[i] * hv[k][j]; As[j][i] = As[i][j]; }
+                                As[k + 1][k] = alpha; As[k][k + 1] = alpha;
+#pragma unroll
+                                for (int i = k + 2; i < 5; i++) { As[i][k] = 0; As[k][i] = 0; }
+                                real t = 0;
+#pragma unroll
+                                for (int i = k + 1; i < 5; i++) t += hv[k][i] * cs[i];
+                                t *= beta;
+#pragma unroll
+                                for (int i = k + 1; i < 5; i++) cs[i] -= t * hv[k][i];
+                            }
+                        }
+                        const real b0 = As[1][0], b1 = As[2][1], b2 = As[3][2], b3 = As[4][3];
+                        for (int iter = 0; iter < 20; iter++) {
+                            const real d0 = As[0][0] + la, r0 = real(1) / d0, l0 = b0 * r0;
+                            const real d1 = As[1][1] + la - l0 * b0, r1 = real(1) / d1, l1 = b1 * r1;
+                            const real d2 = As[2][2] + la - l1 * b1, r2_ = real(1) / d2, l2 = b2 * r2_;
+                            const real d3 = As[3][3] + (3 < n ? la : real(0)) - l2 * b2, r3 = real(1) / d3, l3 = b3 * r3;
+                            const real d4 = As[4][4] + (4 < n ? la : real(0)) - l3 * b3, r4 = real(1) / d4;
+                            real z0 = -cs[0], z1 = -cs[1] - l0 * z0, z2 = -cs[2] - l1 * z1, z3 = -cs[3] - l2 * z2, z4 = -cs[4] - l3 * z3;
+                            y[4] = z4 * r4; y[3] = z3 * r3 - l3 * y[4]; y[2] = z2 * r2_ - l2 * y[3]; y[1] = z1 * r1 - l1 * y[2]; y[0] = z0 * r0 - l0 * y[1];
+                            real val = -r2;
+#pragma unroll
+                            for (int i = 0; i < 5; i++) val += y[i] * y[i];
+                            if (val < vtol) break;
+                            z0 = y[0]; z1 = y[1] - l0 * z0; z2 = y[2] - l1 * z1; z3 = y[3] - l2 * z2; z4 = y[4] - l3 * z3;
+                            w[4] = z4 * r4; w[3] = z3 * r3 - l3 * w[4]; w[2] = z2 * r2_ - l2 * w[3]; w[1] = z1 * r1 - l1 * w[2]; w[0] = z0 * r0 - l0 * w[1];
+                            real yw = 0;
+#pragma unroll
+                            for (int i = 0; i < 5; i++) yw += y[i] * w[i];
+                            const real delta = nl.tridiag == 2 ? secular_step(val, r2, fn, yw) : val / (2 * yw);
+                            if (delta < QTol<real>::abs + QTol<real>::rel * la) break;
+                            la += delta;
+                        }
+#pragma unroll
+                        for (int k = 2; k >= 0; k--) {
+                            real t = 0;
+#pragma unroll
+                            for (int i = k + 1; i < 5; i++) t += hv[k][i] * y[i];
+                            t *= hb[k];
+#pragma unroll
+                            for (int i = k + 1; i < 5; i++) y[i] -= t * hv[k][i];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 5; j++) v[j] = (singular || !(j < n)) ? real(0) : y[j] * dq[j];
+                    if (!singular && la != 0) {       // exactly onto the ellipsoid
+                        real sq = 0;
+#pragma unroll
+                        for (int j = 0; j < 5; j++) sq += j < n ? v[j] * v[j] / (dq[j] * dq[j]) : real(0);
+                        const real sc = sqrt(r2 / tmax(real(1e-15), sq));
+#pragma unroll
+                        for (int j = 0; j < 5; j++) v[j] *= sc;
+                    }
+                    real change = 0;
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        real t = 0;
+#pragma unroll
+                        for (int k = 0; k < 5; k++) t += (j < n && k < n) ? Aq[j][k] * (v[k] - oldf[k]) : real(0);
+                        change += j < n ? (v[j] - oldf[j]) * (real(0.5) * t + resq[j]) : real(0);
+                    }
+                    if (!(change > real(1e-10))) {
+                        if (fi == 0) imp -= change;
+#pragma unroll
+                        for (int j = 0; j < 5; j++) if (fi == j + 1 && j < n) f = v[j];
+                    }
+                }
             } else if (n == 2) {
                 // mju_QCQP2 [EXT] as pgs_groups evaluates it, on the lanes of the octet
                 const real resq0 = oct_bcast<1>(res_r), resq1 = oct_bcast<2>(res_r);
