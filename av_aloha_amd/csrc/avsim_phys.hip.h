@@ -930,6 +930,153 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
 }
 
 
+// The friction block of a SLIDING contact in noslip_trees: mju_QCQP's multiplier iteration on the Householder-tridiagonal form of the
+// scaled block, as in pgs_groups (same operations in the same order), the block gathered by octet broadcasts instead of wave-wide
+// ones; redundantly on the eight lanes of the octet.  Returns the new force of this lane's row (lanes 1..n), *change = the cost change.
+template <typename real>
+__device__ __attribute__((noinline)) real qcqp_slide_octet(GLB_PTR(const real) gA, int g, int n, int fi, real res_r, real f0, real muinv, real invn, real qc5, real fn,
+                                                          int tridiag, real* change_out) {
+    struct { int tridiag; } nl{tridiag};
+    struct { real f0, muinv, invn; real qc[GA_QW]; int g; } cur;
+    cur.f0 = f0; cur.muinv = muinv; cur.invn = invn; cur.qc[5] = qc5; cur.g = g;
+    const real r2 = fn * fn;
+    const int tri = fi <= 5 ? fi * (fi - 1) / 2 : 0;
+    real acs[GRP_MAX - 1];
+#pragma unroll
+    for (int k = 0; k < GRP_MAX - 1; k++) acs[k] = gA[GA_W * cur.g + tri + k];
+    real Aq[5][5], bq[5], dq[5], oldf[5], resq[5], v[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const bool in = j < n;
+        resq[j] = in ? oct_bcast_n(res_r, j + 1) : real(0);
+        oldf[j] = in ? oct_bcast_n(cur.f0, j + 1) : real(0);
+        const real mi = oct_bcast_n(cur.muinv, j + 1);
+        dq[j] = in ? real(1) / mi : real(1);
+        const real di = oct_bcast_n(cur.invn, j + 1);
+        Aq[j][j] = in ? real(1) / di : real(1);
+#pragma unroll
+        for (int k = 0; k < j; k++) { const real c = in ? oct_bcast_n(acs[k + 1], j + 1) : real(0); Aq[j][k] = c; Aq[k][j] = c; }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        real t = resq[j];
+#pragma unroll
+        for (int k = 0; k < 5; k++) t -= (j < n && k < n) ? Aq[j][k] * oldf[k] : real(0);
+        bq[j] = t;
+        v[j] = 0;
+    }
+    const real vtol = QTol<real>::abs + QTol<real>::rel * r2;
+    real la = 0, y[5];
+    bool singular = oct_bcast<1>(cur.qc[5]) != real(0);
+    real As[5][5], cs[5], w[5], hv[3][5], hb[3];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        cs[j] = j < n ? bq[j] * dq[j] : real(0);
+        y[j] = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) As[j][k] = (j < n && k < n) ? Aq[j][k] * dq[j] * dq[k] : (j == k ? real(1) : real(0));
+    }
+    if (!singular) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            real sigma = 0;
+#pragma unroll
+            for (int i = k + 2; i < 5; i++) sigma += As[i][k] * As[i][k];
+            const real x0 = As[k + 1][k];
+#pragma unroll
+            for (int i = 0; i < 5; i++) hv[k][i] = 0;
+            hb[k] = 0;
+            if (sigma != real(0)) {
+                const real nrm = sqrt(x0 * x0 + sigma), alpha = x0 > 0 ? -nrm : nrm;
+                hv[k][k + 1] = x0 - alpha;
+#pragma unroll
+                for (int i = k + 2; i < 5; i++) hv[k][i] = As[i][k];
+                const real beta = real(2) / (hv[k][k + 1] * hv[k][k + 1] + sigma);
+                hb[k] = beta;
+                real pv[5], vp = 0;
+#pragma unroll
+                for (int i = k + 1; i < 5; i++) {
+                    real t = 0;
+#pragma unroll
+                    for (int j = k + 1; j < 5; j++) t += As[i][j] * hv[k][j];
+                    pv[i] = beta * t;
+                    vp += hv[k][i] * pv[i];
+                }
+                const real K = real(0.5) * beta * vp;
+#pragma unroll
+                for (int i = k + 1; i < 5; i++) pv[i] -= K * hv[k][i];
+#pragma unroll
+                for (int i = k + 1; i < 5; i++)
+#pragma unroll
+                    for (int j = k + 1; j <= i; j++) { As[i][j] -= hv[k][i] * pv[j] + pv[i] * hv[k][j]; As[j][i] = As[i][j]; }
+                As[k + 1][k] = alpha; As[k][k + 1] = alpha;
+#pragma unroll
+                for (int i = k + 2; i < 5; i++) { As[i][k] = 0; As[k][i] = 0; }
+                real t = 0;
+#pragma unroll
+                for (int i = k + 1; i < 5; i++) t += hv[k][i] * cs[i];
+                t *= beta;
+#pragma unroll
+                for (int i = k + 1; i < 5; i++) cs[i] -= t * hv[k][i];
+            }
+        }
+        const real b0 = As[1][0], b1 = As[2][1], b2 = As[3][2], b3 = As[4][3];
+        for (int iter = 0; iter < 20; iter++) {
+            const real d0 = As[0][0] + la, r0 = real(1) / d0, l0 = b0 * r0;
+            const real d1 = As[1][1] + la - l0 * b0, r1 = real(1) / d1, l1 = b1 * r1;
+            const real d2 = As[2][2] + la - l1 * b1, r2_ = real(1) / d2, l2 = b2 * r2_;
+            const real d3 = As[3][3] + (3 < n ? la : real(0)) - l2 * b2, r3 = real(1) / d3, l3 = b3 * r3;
+            const real d4 = As[4][4] + (4 < n ? la : real(0)) - l3 * b3, r4 = real(1) / d4;
+            real z0 = -cs[0], z1 = -cs[1] - l0 * z0, z2 = -cs[2] - l1 * z1, z3 = -cs[3] - l2 * z2, z4 = -cs[4] - l3 * z3;
+            y[4] = z4 * r4; y[3] = z3 * r3 - l3 * y[4]; y[2] = z2 * r2_ - l2 * y[3]; y[1] = z1 * r1 - l1 * y[2]; y[0] = z0 * r0 - l0 * y[1];
+            real val = -r2;
+#pragma unroll
+            for (int i = 0; i < 5; i++) val += y[i] * y[i];
+            if (val < vtol) break;
+            z0 = y[0]; z1 = y[1] - l0 * z0; z2 = y[2] - l1 * z1; z3 = y[3] - l2 * z2; z4 = y[4] - l3 * z3;
+            w[4] = z4 * r4; w[3] = z3 * r3 - l3 * w[4]; w[2] = z2 * r2_ - l2 * w[3]; w[1] = z1 * r1 - l1 * w[2]; w[0] = z0 * r0 - l0 * w[1];
+            real yw = 0;
+#pragma unroll
+            for (int i = 0; i < 5; i++) yw += y[i] * w[i];
+            const real delta = nl.tridiag == 2 ? secular_step(val, r2, fn, yw) : val / (2 * yw);
+            if (delta < QTol<real>::abs + QTol<real>::rel * la) break;
+            la += delta;
+        }
+#pragma unroll
+        for (int k = 2; k >= 0; k--) {
+            real t = 0;
+#pragma unroll
+            for (int i = k + 1; i < 5; i++) t += hv[k][i] * y[i];
+            t *= hb[k];
+#pragma unroll
+            for (int i = k + 1; i < 5; i++) y[i] -= t * hv[k][i];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) v[j] = (singular || !(j < n)) ? real(0) : y[j] * dq[j];
+    if (!singular && la != 0) {       // exactly onto the ellipsoid
+        real sq = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) sq += j < n ? v[j] * v[j] / (dq[j] * dq[j]) : real(0);
+        const real sc = sqrt(r2 / tmax(real(1e-15), sq));
+#pragma unroll
+        for (int j = 0; j < 5; j++) v[j] *= sc;
+    }
+    real change = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        real t = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) t += (j < n && k < n) ? Aq[j][k] * (v[k] - oldf[k]) : real(0);
+        change += j < n ? (v[j] - oldf[j]) * (real(0.5) * t + resq[j]) : real(0);
+    }
+    *change_out = change;
+    real fv = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) if (fi == j + 1 && j < n) fv = v[j];
+    return fv;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The noslip pass when every contact touches ONE kinematic tree (objects resting on the table, an arm on the table; no contact
 // between two trees -- the scene of the headline workload until a gripper closes on something).  mj_solNoSlip's sweep relaxes the
@@ -1008,24 +1155,28 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
     real ff = frow >= 0 ? FS[6] : real(0);
     real x = fm ? q[fdof] : real(0);
     // ---- contact data, one step ahead ----
-    struct CD { int h, dim, g; real J[GRP_MAX], B[GRP_MAX], qc[GA_QW], a1, aref, invn, f0, muinv; };
+    struct CD { int h, dim, g; real J[GRP_MAX], B[GRP_MAX], qc[GA_QW], ar[GRP_MAX], a1, aref, invn, f0, muinv; };
     auto fetch = [&](unsigned long long& rem, CD& d) {
         const bool on = rem != 0;
         const int c = on ? __builtin_ctzll(rem) : 0;
         rem &= rem - 1;
         const int ce = cefc[c];
         d.h = on ? (ce & 0xffff) : 0; d.dim = on ? (ce >> 16) : 0; d.g = nl.nlg + c;
+        // the six records from the contact's first row on, whatever its row count: one address, constant offsets (what lies past
+        // the contact -- the next contact's rows, the env's spare capacity, for the launch's last env the J M^-1 half of the
+        // buffer -- is masked where it is used)
+        GLB_PTR(const real) R = rJ + ROW_S * d.h + fi;
 #pragma unroll
-        for (int r = 0; r < GRP_MAX; r++) {
-            GLB_PTR(const real) R = rJ + ROW_S * (d.h + (r < d.dim ? r : 0)) + fi;       // (a row of this contact in any case)
-            d.J[r] = R[0];
-            d.B[r] = R[TREE_W];
-        }
+        for (int r = 0; r < GRP_MAX; r++) { d.J[r] = R[ROW_S * r]; d.B[r] = R[ROW_S * r + TREE_W]; }
         const int qr = (fi >= 1 && fi <= 5) ? fi - 1 : 0;
+        GLB_PTR(const real) Q = gA + GA_W * d.g + GA_Q + qr;
 #pragma unroll
-        for (int s = 0; s < GA_QW; s++) d.qc[s] = gA[GA_W * d.g + GA_Q + 8 * s + qr];
+        for (int s = 0; s < GA_QW; s++) d.qc[s] = Q[8 * s];
         d.a1 = gA[GA_W * d.g + 2];      // the coupling of the two friction rows of a condim-3 contact (rows 2 and 1)
-        LDS_PTR(const real) S = rowS + RS_S * (d.h + (fi < d.dim ? fi : 0));
+        LDS_PTR(const real) S0 = rowS + RS_S * d.h;
+#pragma unroll
+        for (int r = 1; r < GRP_MAX; r++) d.ar[r] = S0[RS_S * r];       // the rows' reference accelerations, for every lane
+        LDS_PTR(const real) S = S0 + RS_S * (fi < d.dim ? fi : 0);
         d.aref = S[0]; d.invn = S[3]; d.f0 = S[8]; d.muinv = S[7];
     };
     bool slid = false;
@@ -1044,20 +1195,18 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
         }
         // the contacts of this octet's tree, in order
         unsigned long long rem = chain;
-        CD cur, nxt;
-        fetch(rem, cur);
-        for (int step = 0; step < nstep; step++) {
-            fetch(rem, nxt);
+        CD ca, cb;      // two sets, used alternately: the next contact's data lands in one while the other is worked on
+        auto one_step = [&](const CD& cur) {
             const int dim = cur.dim, n = dim - 1;
             const bool row = fi >= 1 && fi < dim;
             // row residuals J_r . qacc: every lane ends up with all of them
-            real res_r = 0;
+            real res_r = 0, ra[5];
 #pragma unroll
             for (int r = 1; r < GRP_MAX; r++) {
                 const real sr = oct_sum(r < dim ? cur.J[r] * x : real(0));
-                if (fi == r) res_r = sr;
+                ra[r - 1] = r < dim ? sr - cur.ar[r] : real(0);
+                if (fi == r) res_r = ra[r - 1];
             }
-            res_r = row ? res_r - cur.aref : real(0);
             const real fn = oct_bcast<0>(cur.f0), r2 = fn * fn;
             real f = cur.f0;
             if (n >= 3) {
@@ -1065,7 +1214,6 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
                 // this is mju_QCQP's answer, and its cost change is dl . res / 2
                 bool done = false;
                 if (!(fn < real(1e-15)) && oct_bcast<1>(cur.qc[5]) == real(0)) {
-                    const real ra[5] = {oct_bcast<1>(res_r), oct_bcast<2>(res_r), oct_bcast<3>(res_r), oct_bcast<4>(res_r), oct_bcast<5>(res_r)};
                     real t = 0;
 #pragma unroll
                     for (int k = 0; k < 5; k++) t += cur.qc[k] * ra[k];
@@ -1086,149 +1234,19 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
                 // sliding contact, is pgs_groups' business
                 if (!done && fn < real(1e-15) && oct_sum(row ? fabs(cur.f0) : real(0)) == real(0)) done = true;
                 if (!done && (nl.tridiag == 0 || fn < real(1e-15))) slid = true;
-                else if (!done) {
-                    // ---- the contact slides: mju_QCQP's multiplier iteration on the Householder-tridiagonal form of the scaled friction
-                    // block, as in pgs_groups (same operations in the same order), the block gathered by octet broadcasts instead of
-                    // wave-wide ones; redundantly on the eight lanes of the octet ----
-                    const int tri = fi <= 5 ? fi * (fi - 1) / 2 : 0;
-                    real acs[GRP_MAX - 1];
-#pragma unroll
-                    for (int k = 0; k < GRP_MAX - 1; k++) acs[k] = gA[GA_W * cur.g + tri + k];
-                    real Aq[5][5], bq[5], dq[5], oldf[5], resq[5], v[5];
-#pragma unroll
-                    for (int j = 0; j < 5; j++) {
-                        const bool in = j < n;
-                        resq[j] = in ? oct_bcast_n(res_r, j + 1) : real(0);
-                        oldf[j] = in ? oct_bcast_n(cur.f0, j + 1) : real(0);
-                        const real mi = oct_bcast_n(cur.muinv, j + 1);
-                        dq[j] = in ? real(1) / mi : real(1);
-                        const real di = oct_bcast_n(cur.invn, j + 1);
-                        Aq[j][j] = in ? real(1) / di : real(1);
-#pragma unroll
-                        for (int k = 0; k < j; k++) { const real c = in ? oct_bcast_n(acs[k + 1], j + 1) : real(0); Aq[j][k] = c; Aq[k][j] = c; }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 5; j++) {
-                        real t = resq[j];
-#pragma unroll
-                        for (int k = 0; k < 5; k++) t -= (j < n && k < n) ? Aq[j][k] * oldf[k] : real(0);
-                        bq[j] = t;
-                        v[j] = 0;
-                    }
-                    const real vtol = QTol<real>::abs + QTol<real>::rel * r2;
-                    real la = 0, y[5];
-                    bool singular = oct_bcast<1>(cur.qc[5]) != real(0);
-                    real As[5][5], cs[5], w[5], hv[3][5], hb[3];
-#pragma unroll
-                    for (int j = 0; j < 5; j++) {
-                        cs[j] = j < n ? bq[j] * dq[j] : real(0);
-                        y[j] = 0;
-#pragma unroll
-                        for (int k = 0; k < 5; k++) As[j][k] = (j < n && k < n) ? Aq[j][k] * dq[j] * dq[k] : (j == k ? real(1) : real(0));
-                    }
-                    if (!singular) {
-#pragma unroll
-                        for (int k = 0; k < 3; k++) {
-                            real sigma = 0;
-#pragma unroll
-                            for (int i = k + 2; i < 5; i++) sigma += As[i][k] * As[i][k];
-                            const real x0 = As[k + 1][k];
-#pragma unroll
-                            for (int i = 0; i < 5; i++) hv[k][i] = 0;
-                            hb[k] = 0;
-                            if (sigma != real(0)) {
-                                const real nrm = sqrt(x0 * x0 + sigma), alpha = x0 > 0 ? -nrm : nrm;
-                                hv[k][k + 1] = x0 - alpha;
-#pragma unroll
-                                for (int i = k + 2; i < 5; i++) hv[k][i] = As[i][k];
-                                const real beta = real(2) / (hv[k][k + 1] * hv[k][k + 1] + sigma);
-                                hb[k] = beta;
-                                real pv[5], vp = 0;
-#pragma unroll
-                                for (int i = k + 1; i < 5; i++) {
-                                    real t = 0;
-#pragma unroll
-                                    for (int j = k + 1; j < 5; j++) t += As[i][j] * hv[k][j];
-                                    pv[i] = beta * t;
-                                    vp += hv[k][i] * pv[i];
-                                }
-                                const real K = real(0.5) * beta * vp;
-#pragma unroll
-                                for (int i = k + 1; i < 5; i++) pv[i] -= K * hv[k][i];
-#pragma unroll
-                                for (int i = k + 1; i < 5; i++)
-#pragma unroll
-                                    for (int j = k + 1; j <= i; j++) { As[i][j] -= hv[k][i] * pv[j] + pv[i] * hv[k][j]; As[j][i] = As[i][j]; }
-                                As[k + 1][k] = alpha; As[k][k + 1] = alpha;
-#pragma unroll
-                                for (int i = k + 2; i < 5; i++) { As[i][k] = 0; As[k][i] = 0; }
-                                real t = 0;
-#pragma unroll
-                                for (int i = k + 1; i < 5; i++) t += hv[k][i] * cs[i];
-                                t *= beta;
-#pragma unroll
-                                for (int i = k + 1; i < 5; i++) cs[i] -= t * hv[k][i];
-                            }
-                        }
-                        const real b0 = As[1][0], b1 = As[2][1], b2 = As[3][2], b3 = As[4][3];
-                        for (int iter = 0; iter < 20; iter++) {
-                            const real d0 = As[0][0] + la, r0 = real(1) / d0, l0 = b0 * r0;
-                            const real d1 = As[1][1] + la - l0 * b0, r1 = real(1) / d1, l1 = b1 * r1;
-                            const real d2 = As[2][2] + la - l1 * b1, r2_ = real(1) / d2, l2 = b2 * r2_;
-                            const real d3 = As[3][3] + (3 < n ? la : real(0)) - l2 * b2, r3 = real(1) / d3, l3 = b3 * r3;
-                            const real d4 = As[4][4] + (4 < n ? la : real(0)) - l3 * b3, r4 = real(1) / d4;
-                            real z0 = -cs[0], z1 = -cs[1] - l0 * z0, z2 = -cs[2] - l1 * z1, z3 = -cs[3] - l2 * z2, z4 = -cs[4] - l3 * z3;
-                            y[4] = z4 * r4; y[3] = z3 * r3 - l3 * y[4]; y[2] = z2 * r2_ - l2 * y[3]; y[1] = z1 * r1 - l1 * y[2]; y[0] = z0 * r0 - l0 * y[1];
-                            real val = -r2;
-#pragma unroll
-                            for (int i = 0; i < 5; i++) val += y[i] * y[i];
-                            if (val < vtol) break;
-                            z0 = y[0]; z1 = y[1] - l0 * z0; z2 = y[2] - l1 * z1; z3 = y[3] - l2 * z2; z4 = y[4] - l3 * z3;
-                            w[4] = z4 * r4; w[3] = z3 * r3 - l3 * w[4]; w[2] = z2 * r2_ - l2 * w[3]; w[1] = z1 * r1 - l1 * w[2]; w[0] = z0 * r0 - l0 * w[1];
-                            real yw = 0;
-#pragma unroll
-                            for (int i = 0; i < 5; i++) yw += y[i] * w[i];
-                            const real delta = nl.tridiag == 2 ? secular_step(val, r2, fn, yw) : val / (2 * yw);
-                            if (delta < QTol<real>::abs + QTol<real>::rel * la) break;
-                            la += delta;
-                        }
-#pragma unroll
-                        for (int k = 2; k >= 0; k--) {
-                            real t = 0;
-#pragma unroll
-                            for (int i = k + 1; i < 5; i++) t += hv[k][i] * y[i];
-                            t *= hb[k];
-#pragma unroll
-                            for (int i = k + 1; i < 5; i++) y[i] -= t * hv[k][i];
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 5; j++) v[j] = (singular || !(j < n)) ? real(0) : y[j] * dq[j];
-                    if (!singular && la != 0) {       // exactly onto the ellipsoid
-                        real sq = 0;
-#pragma unroll
-                        for (int j = 0; j < 5; j++) sq += j < n ? v[j] * v[j] / (dq[j] * dq[j]) : real(0);
-                        const real sc = sqrt(r2 / tmax(real(1e-15), sq));
-#pragma unroll
-                        for (int j = 0; j < 5; j++) v[j] *= sc;
-                    }
-                    real change = 0;
-#pragma unroll
-                    for (int j = 0; j < 5; j++) {
-                        real t = 0;
-#pragma unroll
-                        for (int k = 0; k < 5; k++) t += (j < n && k < n) ? Aq[j][k] * (v[k] - oldf[k]) : real(0);
-                        change += j < n ? (v[j] - oldf[j]) * (real(0.5) * t + resq[j]) : real(0);
-                    }
+                else if (__builtin_expect(!done, 0)) {
+                    // the contact slides: the multiplier iteration, out of line (rare; its forty-odd live values would otherwise sit in
+                    // the registers of every step)
+                    real change;
+                    const real fv = qcqp_slide_octet<real>(gA, cur.g, n, fi, res_r, cur.f0, cur.muinv, cur.invn, cur.qc[5], fn, nl.tridiag, &change);
                     if (!(change > real(1e-10))) {
                         if (fi == 0) imp -= change;
-#pragma unroll
-                        for (int j = 0; j < 5; j++) if (fi == j + 1 && j < n) f = v[j];
+                        if (row) f = fv;
                     }
                 }
             } else if (n == 2) {
                 // mju_QCQP2 [EXT] as pgs_groups evaluates it, on the lanes of the octet
-                const real resq0 = oct_bcast<1>(res_r), resq1 = oct_bcast<2>(res_r);
+                const real resq0 = ra[0], resq1 = ra[1];
                 const real of0 = oct_bcast<1>(cur.f0), of1 = oct_bcast<2>(cur.f0);
                 const real dq0 = real(1) / oct_bcast<1>(cur.muinv), dq1 = real(1) / oct_bcast<2>(cur.muinv);
                 const real A00 = real(1) / oct_bcast<1>(cur.invn), A11 = real(1) / oct_bcast<2>(cur.invn), A10 = oct_bcast<2>(cur.a1);
@@ -1276,7 +1294,15 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
 #pragma unroll
             for (int r = 1; r < GRP_MAX; r++) x += (r < dim ? cur.B[r] : real(0)) * oct_bcast_n(dl, r);
             if (row) rowS[RS_S * (cur.h + fi) + 8] = f;
-            cur = nxt;
+        };
+        fetch(rem, ca);
+        for (int step = 0; step < nstep; step += 2) {
+            fetch(rem, cb);
+            one_step(ca);
+            if (step + 1 < nstep) {
+                fetch(rem, ca);
+                one_step(cb);
+            }
         }
         if (__any(slid)) { if (prof && lane == 0) prof[2] += 1; return 0; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next sweep reads the forces this one has stored
@@ -2728,7 +2754,7 @@ struct Env {
             // (an env whose pass has given up on a sliding contact skips the attempt for the rest of its env-step: contacts that slide
             // go on sliding for a while)
             int done_ = 0;
-            if (ka->m.noslip_trees && lead_per_tree() && misc[8] == 0)
+            if (ka->m.noslip_trees && lead_per_tree() && __builtin_amdgcn_readfirstlane(misc[8]) == 0)
                 done_ = noslip_trees<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const int))cefc, (GLB_PTR(const real))rJ, (LDS_PTR(real))qacc,
                                            (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), ncon, nefc, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
             if (!__builtin_amdgcn_readfirstlane(done_) && lane == 0) misc[8] = 1;
