@@ -80,6 +80,8 @@ int avsim_dims(const avsim_t* h, int32_t dims[AVSIM_NDIMS]);
  *   "noslip_per_tree"   1 (default): the dry-friction rows of the noslip pass are relaxed per kinematic tree, all trees at once
  *                       (models with <= 8 trees); 0 = six rows at a time through the Gauss-Seidel groups (what models with more
  *                       trees get); same results to rounding
+ *   "noslip_trees"      1 (default): a noslip pass whose contacts all touch one kinematic tree runs per tree, octet t of the wave on tree t,
+ *                       the trees' contact chains side by side; 0 = always the wave-wide Gauss-Seidel groups (same results to rounding)
  *   "order_envs"        1 (default): workgroups take the envs in the order of their cost in the previous step, most expensive
  *                       first (results do not depend on it); 0 = in index order
  *   "export_contacts"   0 skips the per-step contact export (avsim_get_contacts); "kernel_timing" 1 brackets every physics
