@@ -1099,11 +1099,11 @@ __device__ __attribute__((noinline)) real qcqp_slide_octet(GLB_PTR(const real) g
 // Returns 1 when the pass is done, 0 for "use pgs_groups" (two-tree contact, more than 64 contacts, sliding contact, odd layout).
 // ------------------------------------------------------------------------------------------------
 template <typename real>
-__device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const int) cefc, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
+__device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const int) cefc, GLB_PTR(const real) rJ,
                                                       LDS_PTR(real) q, LDS_PTR(const int) gI, GLB_PTR(const real) gA, int ncon, int nefc, int noslip_iters,
                                                       real noslip_tol_scaled, NoslipLead<real> nl) {
     rowS = uni_lds(rowS); rowI = uni_lds(rowI); cefc = uni_lds(cefc); q = uni_lds(q); gI = uni_lds(gI);
-    rJ = uni_glb(rJ); rB = uni_glb(rB); gA = uni_glb(gA);
+    rJ = uni_glb(rJ); gA = uni_glb(gA);
     ncon = __builtin_amdgcn_readfirstlane(ncon); nefc = __builtin_amdgcn_readfirstlane(nefc); noslip_iters = __builtin_amdgcn_readfirstlane(noslip_iters);
     noslip_tol_scaled = lane_get(noslip_tol_scaled, 0);
     nl.Minv = uni_lds(nl.Minv); nl.tadr = uni_lds(nl.tadr); nl.tnum = uni_lds(nl.tnum); nl.floss_dof = uni_lds(nl.floss_dof); nl.dmap = uni_lds(nl.dmap);
@@ -1111,48 +1111,28 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
     nl.nfloss = __builtin_amdgcn_readfirstlane(nl.nfloss); nl.nlg = __builtin_amdgcn_readfirstlane(nl.nlg); nl.tridiag = __builtin_amdgcn_readfirstlane(nl.tridiag);
     const int lane = threadIdx.x & 63, ft = lane >> 3, fi = lane & 7;
     if (noslip_iters <= 0 || nl.nlg < 0 || ncon <= 0 || ncon > 64) return 0;
-    // ---- the contacts' trees (one, or two for a contact between two trees); every contact must have its rows and the group
-    // pgs_groups would give it ----
-    int tA = -1, tB = -1;
+    // ---- the contacts' trees; every contact must have its rows, one tree, and the group pgs_groups would give it ----
+    int ctree = -1;
     bool bad = false;
     if (lane < ncon) {
         const int ce = cefc[lane];
         if (ce < 0) bad = true;
         else {
             const int h = ce & 0xffff, ra = rowI[h];
-            tA = (ra >> 10) & 7;
-            tB = ((ra >> 19) & 15) != 0 ? (ra >> 23) & 7 : -1;
-            bad = tA >= nl.ntree || tB >= nl.ntree || tB == tA || (gI[nl.nlg + lane] & 0xffff) != h || ((gI[nl.nlg + lane] >> 16) & 15) != (ce >> 16) || (ce >> 16) > GRP_MAX || (ce >> 16) == 2;
+            ctree = (ra >> 10) & 7;
+            bad = ((ra >> 19) & 15) != 0 || ctree >= nl.ntree || (gI[nl.nlg + lane] & 0xffff) != h || ((gI[nl.nlg + lane] >> 16) & 15) != (ce >> 16) || (ce >> 16) > GRP_MAX || (ce >> 16) == 2;
         }
     }
     LDS_PTR(int) prof = uni_lds(nl.prof);
     if (__any(bad)) { if (prof && lane == 0) prof[1] += 1; return 0; }
-    // The order: a tree's contacts in index order (its chain); a contact between two trees sits in both chains and is relaxed by both
-    // octets in the same step, so it waits for its predecessors in BOTH.  Level of a contact = the step it is relaxed in = 1 + the
-    // larger of its two predecessors' levels; a tree has at most one contact per level.
-    unsigned long long chain = 0, mA = 0, mB = 0;      // this octet's chain; the chains of this lane's contact's trees
+    unsigned long long chain = 0;      // this octet's contacts (bit c = contact c), walked in index order
     int nstep = 0;
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-        const unsigned long long m = __ballot(tA == t || tB == t);
+        const unsigned long long m = __ballot(ctree == t);
         if (ft == t) chain = m;
-        if (tA == t) mA = m;
-        if (tB == t) mB = m;
         const int n = __popcll(m);
         nstep = n > nstep ? n : nstep;
-    }
-    const unsigned long long below = (1ull << lane) - 1ull;
-    int lev = lane < ncon ? __popcll(mA & below) : 1 << 20;       // no contact between two trees: the position in the chain
-    if (__any(tB >= 0)) {
-        const int pA = (mA & below) ? 63 - __builtin_clzll(mA & below) : -1, pB = (tB >= 0 && (mB & below)) ? 63 - __builtin_clzll(mB & below) : -1;
-        lev = lane < ncon ? -1 : 1 << 20;
-        nstep = 0;
-        for (int L = 0; L < 64; L++) {
-            const int la = __shfl(lev, pA >= 0 ? pA : 0, 64), lb = __shfl(lev, pB >= 0 ? pB : 0, 64);
-            if (lev < 0 && (pA < 0 || la >= 0) && (pB < 0 || lb >= 0)) lev = L;
-            nstep = L + 1;
-            if (!__any(lev < 0)) break;
-        }
     }
     // ---- dry-friction rows, as in pgs_groups: lane 8 t + i = dof i of tree t ----
     for (int k = lane; k < nl.nv; k += 64) nl.dmap[k] = -1;
@@ -1175,26 +1155,19 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
     real ff = frow >= 0 ? FS[6] : real(0);
     real x = fm ? q[fdof] : real(0);
     // ---- contact data, one step ahead ----
-    struct CD { int h, dim, g, side, partner; bool two; real J[GRP_MAX], B[GRP_MAX], qc[GA_QW], ar[GRP_MAX], a1, aref, invn, f0, muinv; };
-    auto fetch = [&](int L, CD& d) {
-        const unsigned long long m = __ballot(lev == L) & chain;      // this octet's contact of level L, if it has one
-        const bool on = m != 0;
-        const int c = on ? __builtin_ctzll(m) : 0;
+    struct CD { int h, dim, g; real J[GRP_MAX], B[GRP_MAX], qc[GA_QW], ar[GRP_MAX], a1, aref, invn, f0, muinv; };
+    auto fetch = [&](unsigned long long& rem, CD& d) {
+        const bool on = rem != 0;
+        const int c = on ? __builtin_ctzll(rem) : 0;
+        rem &= rem - 1;
         const int ce = cefc[c];
         d.h = on ? (ce & 0xffff) : 0; d.dim = on ? (ce >> 16) : 0; d.g = nl.nlg + c;
-        // a contact between two trees: this octet's tree is its first (side 0: words 0..7 of the row records) or its second (side 1:
-        // words 8..15); its J M^-1 rows are in the second buffer (a one-tree contact keeps them in words 8..15 of the J record)
-        const int ra_ = rowI[d.h];
-        d.two = on && ((ra_ >> 19) & 15) != 0;
-        d.side = (d.two && ((ra_ >> 10) & 7) != ft) ? 1 : 0;
-        d.partner = d.two ? (d.side ? (ra_ >> 10) & 7 : (ra_ >> 23) & 7) : ft;
         // the six records from the contact's first row on, whatever its row count: one address, constant offsets (what lies past
         // the contact -- the next contact's rows, the env's spare capacity, for the launch's last env the J M^-1 half of the
         // buffer -- is masked where it is used)
-        GLB_PTR(const real) R = rJ + ROW_S * d.h + TREE_W * d.side + fi;
-        GLB_PTR(const real) RB = d.two ? rB + ROW_S * d.h + TREE_W * d.side + fi : R + TREE_W;
+        GLB_PTR(const real) R = rJ + ROW_S * d.h + fi;
 #pragma unroll
-        for (int r = 0; r < GRP_MAX; r++) { d.J[r] = R[ROW_S * r]; d.B[r] = RB[ROW_S * r]; }
+        for (int r = 0; r < GRP_MAX; r++) { d.J[r] = R[ROW_S * r]; d.B[r] = R[ROW_S * r + TREE_W]; }
         const int qr = (fi >= 1 && fi <= 5) ? fi - 1 : 0;
         GLB_PTR(const real) Q = gA + GA_W * d.g + GA_Q + qr;
 #pragma unroll
@@ -1221,26 +1194,17 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
             x += mrow[s] * ds;
         }
         // the contacts of this octet's tree, in order
+        unsigned long long rem = chain;
         CD ca, cb;      // two sets, used alternately: the next contact's data lands in one while the other is worked on
         auto one_step = [&](const CD& cur) {
             const int dim = cur.dim, n = dim - 1;
             const bool row = fi >= 1 && fi < dim;
             // row residuals J_r . qacc: every lane ends up with all of them
-            real res_r = 0, ra[5], sr[GRP_MAX];
-#pragma unroll
-            for (int r = 1; r < GRP_MAX; r++) sr[r] = oct_sum(r < dim ? cur.J[r] * x : real(0));
-            if (__any(cur.two)) {
-                // a contact between two trees: the other tree's octet has the other half of every sum (first tree's part + second tree's
-                // part, in that order on both sides, so that the two octets go on with identical numbers)
-#pragma unroll
-                for (int r = 1; r < GRP_MAX; r++) {
-                    const real other = __shfl(sr[r], 8 * cur.partner + fi, 64);
-                    if (cur.two) sr[r] = cur.side == 0 ? sr[r] + other : other + sr[r];
-                }
-            }
+            real res_r = 0, ra[5];
 #pragma unroll
             for (int r = 1; r < GRP_MAX; r++) {
-                ra[r - 1] = r < dim ? sr[r] - cur.ar[r] : real(0);
+                const real sr = oct_sum(r < dim ? cur.J[r] * x : real(0));
+                ra[r - 1] = r < dim ? sr - cur.ar[r] : real(0);
                 if (fi == r) res_r = ra[r - 1];
             }
             const real fn = oct_bcast<0>(cur.f0), r2 = fn * fn;
@@ -1259,7 +1223,7 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
                     if (val < QTol<real>::abs + QTol<real>::rel * r2) {
                         const real change = real(0.5) * oct_sum(dl_ * res_r);
                         if (!(change > real(1e-10))) {
-                            if (fi == 0 && cur.side == 0) imp -= change;
+                            if (fi == 0) imp -= change;
                             if (row) f = vr;
                         }
                         done = true;
@@ -1276,7 +1240,7 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
                     real change;
                     const real fv = qcqp_slide_octet<real>(gA, cur.g, n, fi, res_r, cur.f0, cur.muinv, cur.invn, cur.qc[5], fn, nl.tridiag, &change);
                     if (!(change > real(1e-10))) {
-                        if (fi == 0 && cur.side == 0) imp -= change;
+                        if (fi == 0) imp -= change;
                         if (row) f = fv;
                     }
                 }
@@ -1320,7 +1284,7 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
                 }
                 const real change = (v0 - of0) * (real(0.5) * (A00 * (v0 - of0) + A10 * (v1 - of1)) + resq0) + (v1 - of1) * (real(0.5) * (A10 * (v0 - of0) + A11 * (v1 - of1)) + resq1);
                 if (!(change > real(1e-10)) && dim == 3) {
-                    if (fi == 0 && cur.side == 0) imp -= change;
+                    if (fi == 0) imp -= change;
                     if (fi == 1) f = v0;
                     if (fi == 2) f = v1;
                 }
@@ -1329,14 +1293,14 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
             const real dl = row ? f - cur.f0 : real(0);
 #pragma unroll
             for (int r = 1; r < GRP_MAX; r++) x += (r < dim ? cur.B[r] : real(0)) * oct_bcast_n(dl, r);
-            if (row && cur.side == 0) rowS[RS_S * (cur.h + fi) + 8] = f;
+            if (row) rowS[RS_S * (cur.h + fi) + 8] = f;
         };
-        fetch(0, ca);
+        fetch(rem, ca);
         for (int step = 0; step < nstep; step += 2) {
-            fetch(step + 1, cb);
+            fetch(rem, cb);
             one_step(ca);
             if (step + 1 < nstep) {
-                fetch(step + 2, ca);
+                fetch(rem, ca);
                 one_step(cb);
             }
         }
@@ -2791,7 +2755,7 @@ struct Env {
             // go on sliding for a while)
             int done_ = 0;
             if (ka->m.noslip_trees && lead_per_tree() && __builtin_amdgcn_readfirstlane(misc[8]) == 0)
-                done_ = noslip_trees<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const int))cefc, (GLB_PTR(const real))rJ, (GLB_PTR(const real))rowsB_(), (LDS_PTR(real))qacc,
+                done_ = noslip_trees<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const int))cefc, (GLB_PTR(const real))rJ, (LDS_PTR(real))qacc,
                                            (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), ncon, nefc, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
             if (!__builtin_amdgcn_readfirstlane(done_) && lane == 0) misc[8] = 1;
             if (!__builtin_amdgcn_readfirstlane(done_))
