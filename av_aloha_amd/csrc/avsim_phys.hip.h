@@ -274,10 +274,10 @@ using KPtr = const KArgs<real> __attribute__((address_space(4)))*;
 
 // all-reduce over the 16 lanes of a DPP row
 AVS_DEV float row16_sum(float x) {
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));  // row_ror:8
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));  // row_ror:4
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false));  // row_ror:2
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false));  // row_ror:1
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x128, 0xf, 0xf, true));  // row_ror:8
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x124, 0xf, 0xf, true));  // row_ror:4
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x122, 0xf, 0xf, true));  // row_ror:2
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x121, 0xf, 0xf, true));  // row_ror:1
     return x;
 }
 AVS_DEV double row16_sum(double x) {
@@ -318,9 +318,9 @@ struct RowS {
 };
 
 AVS_DEV float oct_sum(float x) {   // sum over each aligned group of 8 lanes
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));  // row_half_mirror
     return x;
 }
 AVS_DEV double oct_sum(double x) {
@@ -334,8 +334,8 @@ AVS_DEV double oct_sum(double x) {
 template <int J>
 AVS_DEV int oct_bcast_i(int x) {
     constexpr int q = J & 3, ctrl = q | (q << 2) | (q << 4) | (q << 6);
-    const int a = __builtin_amdgcn_update_dpp(0, x, ctrl, 0xf, 0xf, false);      // quad_perm:[q,q,q,q]
-    const int b = __builtin_amdgcn_update_dpp(0, a, 0x141, 0xf, 0xf, false);     // row_half_mirror: lane i <- lane 7 - i of its 8
+    const int a = __builtin_amdgcn_mov_dpp(x, ctrl, 0xf, 0xf, true);      // quad_perm:[q,q,q,q] (every lane has a source: the destination needs no initial value)
+    const int b = __builtin_amdgcn_mov_dpp(a, 0x141, 0xf, 0xf, true);     // row_half_mirror: lane i <- lane 7 - i of its 8
     const bool hi = (threadIdx.x & 4) != 0;
     return hi == (J >= 4) ? a : b;
 }

@@ -282,7 +282,7 @@ __device__ __forceinline__ float vmax1(float a, float b) { float r; asm("v_max_f
 __device__ __forceinline__ float vmin1(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 __device__ inline float wave_max(float x) {
-#define AVS_DPP_MAX(ctrl) x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false)))
+#define AVS_DPP_MAX(ctrl) x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true)))
     AVS_DPP_MAX(0xB1);    // quad_perm [1,0,3,2]
     AVS_DPP_MAX(0x4E);    // quad_perm [2,3,0,1]
     AVS_DPP_MAX(0x141);   // row_half_mirror
