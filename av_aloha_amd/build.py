@@ -33,7 +33,7 @@ def build_hip(force=False, verbose=False):
 
 def _build_hip_locked(verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-c"]
+    common = [hipcc, "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-c"]
     units = [
         # f32 divide / sqrt through v_rcp / v_rsq (~1 ulp) instead of the correctly rounded 10-instruction sequences; the f64
         # parity mode is unaffected and the f32 tolerances of tests/test_gpu_physics.py are stated against the f64 oracle
@@ -41,8 +41,11 @@ def _build_hip_locked(verbose):
         # instead of v_rcp + multiply); nothing in the physics lives below 1e-38
         # no SLP vectoriser: packing pairs of scalar operations into v_pk_* costs register shuffles and keeps the DPP moves of the
         # cross-lane sums from folding into their adds (config 2: 972 k -> 1009 k env-steps/s, private segment 592 -> 464 B)
-        ("avsim_api", ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero", "-fno-slp-vectorize"] + (["-DAVSIM_RENDER_STATS"] if os.environ.get("AVSIM_RENDER_STATS") else []) + os.environ.get("AVSIM_EXTRA_FLAGS", "").split()),
-        ("avsim_phys_f64", ["-ffp-contract=off"]),
+        # -O2, no loop vectoriser, no atomic optimiser (the LDS atomics of a wave go to distinct addresses by construction): measured
+        # together 1006 k -> 1023 k (tools/exp_flags_multi.sh, profiles/r03_experiments.txt); -O3 was the setting until then
+        ("avsim_api", ["-O2", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero", "-fno-slp-vectorize", "-fno-vectorize",
+                       "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"] + (["-DAVSIM_RENDER_STATS"] if os.environ.get("AVSIM_RENDER_STATS") else []) + os.environ.get("AVSIM_EXTRA_FLAGS", "").split()),
+        ("avsim_phys_f64", ["-O3", "-ffp-contract=off"] + os.environ.get("AVSIM_EXTRA_FLAGS_F64", "").split()),
     ]
     procs = []
     for name, extra in units:
