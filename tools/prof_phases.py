@@ -40,6 +40,8 @@ print("inside solve (Newton):", "  ".join(f"{n} {v:.0f}" for n, v in zip(nn, mn)
 tot = out[:, :8].sum(1) / 20
 print("per-env total cycles/substep percentiles 50/90/99/max:", np.percentile(tot, [50, 90, 99, 100]).round(0), " noslip 50/90/99/max:", np.percentile(out[:, 16] / 20, [50, 90, 99, 100]).round(0),
       " narrow 50/90/99/max:", np.percentile(out[:, 9] / 21, [50, 90, 99, 100]).round(0))
+# (when the noslip pass runs per tree -- noslip_trees, the default where every contact touches one tree -- slots 1 / 2 / 3 count passes refused at
+# entry / given up on a sliding contact / done instead: tools/prof_noslip_trees.py; pass noslip_trees=0 on the command line for pgs_groups' probes)
 # noslip probes (pgs_groups): group steps, cycles gathering a sliding contact's block, cycles in sliding-contact branches, sliding steps,
 # multiplier iterations, cycles in the pass; then box-box and other narrow-phase cycles (collide)
 print("probe slots per substep [nstep, gather cyc, sliding cyc, sliding steps, multiplier its, noslip cyc, boxbox cyc, narrow cyc]:", (out[:, 18:26].mean(0) / 20).round(1))
