@@ -1,0 +1,30 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import episode_util as U
+from av_aloha_amd import workloads as W
+from av_aloha_amd.sim_env import make_sim_env
+task, n = "slot_insertion", 32
+envA = make_sim_env("sim_" + task, cameras=[], num_envs=n, f64=False); envA.sim.set_option("noslip_trees", 0)
+envB = make_sim_env("sim_" + task, cameras=[], num_envs=n, f64=False); envB.sim.set_option("noslip_trees", 1)
+poses = W.object_poses(task, np.arange(n), 1000)
+envA.sim.reset(poses); envB.sim.reset(poses)
+obs = envA.get_obs(); q = obs["qpos"].reshape(n, -1)
+home = {k: obs["poses"][k].reshape(n, 7).copy() for k in ("left", "right", "middle")}
+script = U.make_script(task, home, q)
+worst = []
+for t in range(script.steps()):
+    qa, va, ca, wa = envA.sim.get_state()
+    envB.sim.set_state(qa, va, ca, wa)
+    a = script.action(q)
+    envA.sim.step_cartesian(a); envB.sim.step_cartesian(a)
+    q, v, _, _ = envA.sim.get_state()
+    qb, vb, _, _ = envB.sim.get_state()
+    dA, dB = envA.sim.diag(), envB.sim.diag()
+    dq = np.abs(qb - q).max(1); dv = np.abs(vb - v).max(1)
+    k = int(np.argmax(dv))
+    if dv[k] > 1e-2 or (dB[:, 3] & 1).any():
+        print(f"step {t}: env {k} |dq| {dq[k]:.3e} |dv| {dv[k]:.3e} ncon A/B {dA[k,0]}/{dB[k,0]} nefc {dA[k,1]}/{dB[k,1]} diverged B {int((dB[:,3]&1).sum())} A {int((dA[:,3]&1).sum())}; envs with |dv|>1e-2: {int((dv>1e-2).sum())}")
+    worst.append(dv.max())
+print("max |dv| over the episode:", max(worst), "at step", int(np.argmax(worst)))
