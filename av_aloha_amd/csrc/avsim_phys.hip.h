@@ -1112,16 +1112,18 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
     const int lane = threadIdx.x & 63, ft = lane >> 3, fi = lane & 7;
     if (noslip_iters <= 0 || nl.nlg < 0 || ncon <= 0 || ncon > 64) return 0;
     // ---- the contacts' trees; every contact must have its rows, one tree, and the group pgs_groups would give it ----
+    // (a contact without rows -- the reward-only pins of the needle and of the hook -- is in no chain and has no group: the groups
+    // count the contacts WITH rows)
     int ctree = -1;
     bool bad = false;
-    if (lane < ncon) {
-        const int ce = cefc[lane];
-        if (ce < 0) bad = true;
-        else {
-            const int h = ce & 0xffff, ra = rowI[h];
-            ctree = (ra >> 10) & 7;
-            bad = ((ra >> 19) & 15) != 0 || ctree >= nl.ntree || (gI[nl.nlg + lane] & 0xffff) != h || ((gI[nl.nlg + lane] >> 16) & 15) != (ce >> 16) || (ce >> 16) > GRP_MAX || (ce >> 16) == 2;
-        }
+    const int ce_l = lane < ncon ? cefc[lane] : -1;
+    const unsigned long long hasrows = __ballot(ce_l >= 0);
+    const int g_lane = nl.nlg + __popcll(hasrows & ((1ull << lane) - 1ull));      // the group of this lane's contact
+    if (ce_l >= 0) {
+        const int ce = ce_l, g = g_lane;
+        const int h = ce & 0xffff, ra = rowI[h];
+        ctree = (ra >> 10) & 7;
+        bad = ((ra >> 19) & 15) != 0 || ctree >= nl.ntree || (gI[g] & 0xffff) != h || ((gI[g] >> 16) & 15) != (ce >> 16) || (ce >> 16) > GRP_MAX || (ce >> 16) == 2;
     }
     LDS_PTR(int) prof = uni_lds(nl.prof);
     if (__any(bad)) { if (prof && lane == 0) prof[1] += 1; return 0; }
@@ -1161,7 +1163,7 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
         const int c = on ? __builtin_ctzll(rem) : 0;
         rem &= rem - 1;
         const int ce = cefc[c];
-        d.h = on ? (ce & 0xffff) : 0; d.dim = on ? (ce >> 16) : 0; d.g = nl.nlg + c;
+        d.h = on ? (ce & 0xffff) : 0; d.dim = on ? (ce >> 16) : 0; d.g = __shfl(g_lane, c, 64);
         // the six records from the contact's first row on, whatever its row count: one address, constant offsets (what lies past
         // the contact -- the next contact's rows, the env's spare capacity, for the launch's last env the J M^-1 half of the
         // buffer -- is masked where it is used)
