@@ -350,3 +350,32 @@ def test_sew_needle_default_tiers_equal_one_tier():
     for k, o in enumerate(out[1:]):
         for j, (a, b) in enumerate(zip(o, ref)):
             assert np.array_equal(a, b), (k, j)
+
+
+def test_noslip_per_tree_equals_the_wave_wide_pass():
+    """The noslip pass per kinematic tree (noslip_trees: octet t of the wave on tree t, the trees' contact chains side by side; the
+    default where every contact touches one tree) against the wave-wide Gauss-Seidel groups (option noslip_trees = 0), both in f64 on
+    the device: the same contacts in the same order per tree, so the states agree to 1e-9 after 10 env-steps (200 substeps) of the
+    HookPackage random walk and of resting SlotInsertion scenes with moving arms, contact counts identical.  (Differences: the
+    acceleration update is a chain of FMAs instead of LDS atomic adds of rounded products, the sweep's improvement is summed per tree.)"""
+    for task, na, seed in (("hook_package", 2, 3000), ("slot_insertion", 3, 1000)):
+        n, T = 48, 10
+        md = model_dict(task, na)
+        gids = np.arange(n)
+        acts = walk_actions(md, gids, T, 14 if na == 2 else 21, seed)
+        out = []
+        for flag in (0, 1):
+            from av_aloha_amd.sim import BatchedSim
+            sim = BatchedSim(task, na, n, f64=True, options={"noslip_trees": flag})
+            sim.reset(poses_for(task, gids, seed))
+            nc = []
+            for t in range(T):
+                sim.step(acts[t])
+                nc.append(sim.diag()[:, 0].copy())
+            q, v, _, _ = sim.get_state()
+            out.append((q, v, np.stack(nc)))
+            sim.close()
+        assert np.array_equal(out[0][2], out[1][2]), task
+        assert out[0][2].max() >= 6
+        np.testing.assert_allclose(out[1][0], out[0][0], atol=1e-9, err_msg=task)
+        np.testing.assert_allclose(out[1][1], out[0][1], atol=1e-7, err_msg=task)
