@@ -1115,7 +1115,7 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
     // (a contact without rows -- the reward-only pins of the needle and of the hook -- is in no chain and has no group: the groups
     // count the contacts WITH rows)
     int ctree = -1;
-    bool bad = false;
+    bool bad = false, two_ = false;
     const int ce_l = lane < ncon ? cefc[lane] : -1;
     const unsigned long long hasrows = __ballot(ce_l >= 0);
     const int g_lane = nl.nlg + __popcll(hasrows & ((1ull << lane) - 1ull));      // the group of this lane's contact
@@ -1123,10 +1123,11 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
         const int ce = ce_l, g = g_lane;
         const int h = ce & 0xffff, ra = rowI[h];
         ctree = (ra >> 10) & 7;
-        bad = ((ra >> 19) & 15) != 0 || ctree >= nl.ntree || (gI[g] & 0xffff) != h || ((gI[g] >> 16) & 15) != (ce >> 16) || (ce >> 16) > GRP_MAX || (ce >> 16) == 2;
+        two_ = ((ra >> 19) & 15) != 0;
+        bad = two_ || ctree >= nl.ntree || (gI[g] & 0xffff) != h || ((gI[g] >> 16) & 15) != (ce >> 16) || (ce >> 16) > GRP_MAX || (ce >> 16) == 2;
     }
     LDS_PTR(int) prof = uni_lds(nl.prof);
-    if (__any(bad)) { if (prof && lane == 0) prof[1] += 1; return 0; }
+    if (__any(bad)) { if (prof && lane == 0) prof[1] += 1; return __any(two_) ? 2 : 0; }      // 2: a contact between two trees (noslip_trees2)
     unsigned long long chain = 0;      // this octet's contacts (bit c = contact c), walked in index order
     int nstep = 0;
 #pragma unroll
@@ -1322,6 +1323,287 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
     __builtin_amdgcn_wave_barrier();
     return 1;
 }
+
+// noslip_trees for passes with a contact BETWEEN TWO kinematic trees (a gripper holding something, an object lying on another): such a
+// contact sits in both trees' chains and is relaxed by both octets in the same step -- its level is one more than the larger of its
+// two predecessors' levels, a tree has at most one contact per level --, each octet sums its tree's half of the row residuals and gets
+// the other half from its partner (ds_bpermute; first tree's part + second tree's part on both sides, so that the two octets go on
+// with identical numbers), both run the friction block, each moves its own tree's accelerations, the first tree's octet stores the
+// forces.  A SLIDING contact between two trees hands the pass to pgs_groups (the multiplier iteration inside the pass made the f32
+// whole-episode test diverge; one-tree sliding contacts stay inside).  A function of its own, entered when noslip_trees returns 2: with
+// the two-tree bookkeeping in noslip_trees the headline workload, which has no such contact, lost 1.6 %; this way 0.5 %.
+template <typename real>
+__device__ __attribute__((noinline)) int noslip_trees2(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const int) cefc, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
+                                                      LDS_PTR(real) q, LDS_PTR(const int) gI, GLB_PTR(const real) gA, int ncon, int nefc, int noslip_iters,
+                                                      real noslip_tol_scaled, NoslipLead<real> nl) {
+    rowS = uni_lds(rowS); rowI = uni_lds(rowI); cefc = uni_lds(cefc); q = uni_lds(q); gI = uni_lds(gI);
+    rJ = uni_glb(rJ); rB = uni_glb(rB); gA = uni_glb(gA);
+    ncon = __builtin_amdgcn_readfirstlane(ncon); nefc = __builtin_amdgcn_readfirstlane(nefc); noslip_iters = __builtin_amdgcn_readfirstlane(noslip_iters);
+    noslip_tol_scaled = lane_get(noslip_tol_scaled, 0);
+    nl.Minv = uni_lds(nl.Minv); nl.tadr = uni_lds(nl.tadr); nl.tnum = uni_lds(nl.tnum); nl.floss_dof = uni_lds(nl.floss_dof); nl.dmap = uni_lds(nl.dmap);
+    nl.ntree = __builtin_amdgcn_readfirstlane(nl.ntree); nl.nv = __builtin_amdgcn_readfirstlane(nl.nv); nl.neq = __builtin_amdgcn_readfirstlane(nl.neq);
+    nl.nfloss = __builtin_amdgcn_readfirstlane(nl.nfloss); nl.nlg = __builtin_amdgcn_readfirstlane(nl.nlg); nl.tridiag = __builtin_amdgcn_readfirstlane(nl.tridiag);
+    const int lane = threadIdx.x & 63, ft = lane >> 3, fi = lane & 7;
+    if (noslip_iters <= 0 || nl.nlg < 0 || ncon <= 0 || ncon > 64) return 0;
+    // ---- the contacts' trees (one, or two for a contact between two trees); every contact must have its rows and the group
+    // pgs_groups would give it ----
+    int tA = -1, tB = -1;
+    bool bad = false;
+    const int ce_l = lane < ncon ? cefc[lane] : -1;
+    const unsigned long long hasrows = __ballot(ce_l >= 0);      // (contacts without rows -- reward-only pins -- are in no chain and have no group)
+    const int g_lane = nl.nlg + __popcll(hasrows & ((1ull << lane) - 1ull));
+    if (ce_l >= 0) {
+        const int ce = ce_l, h = ce & 0xffff, ra = rowI[h];
+        tA = (ra >> 10) & 7;
+        tB = ((ra >> 19) & 15) != 0 ? (ra >> 23) & 7 : -1;
+        bad = tA >= nl.ntree || tB >= nl.ntree || tB == tA || (gI[g_lane] & 0xffff) != h || ((gI[g_lane] >> 16) & 15) != (ce >> 16) || (ce >> 16) > GRP_MAX || (ce >> 16) == 2;
+    }
+    LDS_PTR(int) prof = uni_lds(nl.prof);
+    if (__any(bad)) { if (prof && lane == 0) prof[1] += 1; return 0; }
+    // The order: a tree's contacts in index order (its chain); a contact between two trees sits in both chains and is relaxed by both
+    // octets in the same step, so it waits for its predecessors in BOTH.  Level of a contact = the step it is relaxed in = 1 + the
+    // larger of its two predecessors' levels; a tree has at most one contact per level.
+    unsigned long long chain = 0, mA = 0, mB = 0;      // this octet's chain; the chains of this lane's contact's trees
+    int nstep = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const unsigned long long m = __ballot(tA == t || tB == t);
+        if (ft == t) chain = m;
+        if (tA == t) mA = m;
+        if (tB == t) mB = m;
+        const int n = __popcll(m);
+        nstep = n > nstep ? n : nstep;
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int lev = ce_l >= 0 ? __popcll(mA & below) : 1 << 20;       // no contact between two trees: the position in the chain
+    if (__any(tB >= 0)) {
+        const int pA = (mA & below) ? 63 - __builtin_clzll(mA & below) : -1, pB = (tB >= 0 && (mB & below)) ? 63 - __builtin_clzll(mB & below) : -1;
+        lev = ce_l >= 0 ? -1 : 1 << 20;
+        nstep = 0;
+        for (int L = 0; L < 64; L++) {
+            const int la = __shfl(lev, pA >= 0 ? pA : 0, 64), lb = __shfl(lev, pB >= 0 ? pB : 0, 64);
+            if (lev < 0 && (pA < 0 || la >= 0) && (pB < 0 || lb >= 0)) lev = L;
+            nstep = L + 1;
+            if (!__any(lev < 0)) break;
+        }
+    }
+    // ---- dry-friction rows, as in pgs_groups: lane 8 t + i = dof i of tree t ----
+    for (int k = lane; k < nl.nv; k += 64) nl.dmap[k] = -1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int r = lane; r < nl.nfloss; r += 64) nl.dmap[nl.floss_dof[r]] = nl.neq + r;
+    // the spare word of every row record takes the forces of the pass; the rows' own word is written when the pass has succeeded
+    for (int i = lane; i < nefc; i += 64) rowS[RS_S * i + 8] = rowS[RS_S * i + 6];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool fm = ft < nl.ntree && fi < nl.tnum[ft < nl.ntree ? ft : 0];
+    const int fdof = fm ? nl.tadr[ft] + fi : 0;
+    const int frow = fm ? nl.dmap[fdof] : -1;
+    real mrow[TREE_W];
+#pragma unroll
+    for (int s = 0; s < TREE_W; s++) mrow[s] = fm ? nl.Minv[64 * ft + 8 * fi + s] : real(0);
+    LDS_PTR(real) FS = rowS + RS_S * (frow >= 0 ? frow : 0);
+    const real faref = FS[0], finv = frow >= 0 ? FS[3] : real(0), flo = FS[4], fhi = FS[5];
+    const real fdiag = finv != 0 ? real(1) / finv : real(0);
+    real ff = frow >= 0 ? FS[6] : real(0);
+    real x = fm ? q[fdof] : real(0);
+    // ---- contact data, one step ahead ----
+    // the sweeps, compiled twice: for passes whose contacts all touch one tree (nothing of the two-tree bookkeeping in the steps) and for
+    // passes with a contact between two trees
+    auto sweeps = [&](auto two_tag) -> int {
+    constexpr bool TWO = decltype(two_tag)::value;
+    struct CD { int h, dim, g, side, partner; bool two; real J[GRP_MAX], B[GRP_MAX], qc[GA_QW], ar[GRP_MAX], a1, aref, invn, f0, muinv; };
+    unsigned long long rem = 0;      // (one-tree passes: what is left of this octet's chain in the current sweep)
+    auto fetch = [&](int L, CD& d) {
+        // this octet's contact of level L, if it has one; without contacts between two trees the levels are the positions in the chain
+        const unsigned long long m = TWO ? __ballot(lev == L) & chain : rem;
+        const bool on = m != 0;
+        const int c = on ? __builtin_ctzll(m) : 0;
+        if (!TWO) rem &= rem - 1;
+        const int ce = cefc[c];
+        d.h = on ? (ce & 0xffff) : 0; d.dim = on ? (ce >> 16) : 0; d.g = __shfl(g_lane, c, 64);
+        // a contact between two trees: this octet's tree is its first (side 0: words 0..7 of the row records) or its second (side 1:
+        // words 8..15); its J M^-1 rows are in the second buffer (a one-tree contact keeps them in words 8..15 of the J record)
+        d.two = false; d.side = 0; d.partner = ft;
+        if (TWO) {
+            const int ra_ = rowI[d.h];
+            d.two = on && ((ra_ >> 19) & 15) != 0;
+            d.side = (d.two && ((ra_ >> 10) & 7) != ft) ? 1 : 0;
+            d.partner = d.two ? (d.side ? (ra_ >> 10) & 7 : (ra_ >> 23) & 7) : ft;
+        }
+        // the six records from the contact's first row on, whatever its row count: one address, constant offsets (what lies past
+        // the contact -- the next contact's rows, the env's spare capacity, for the launch's last env the J M^-1 half of the
+        // buffer -- is masked where it is used)
+        GLB_PTR(const real) R = rJ + ROW_S * d.h + TREE_W * d.side + fi;
+        GLB_PTR(const real) RB = (TWO && d.two) ? rB + ROW_S * d.h + TREE_W * d.side + fi : R + TREE_W;
+#pragma unroll
+        for (int r = 0; r < GRP_MAX; r++) { d.J[r] = R[ROW_S * r]; d.B[r] = RB[ROW_S * r]; }
+        const int qr = (fi >= 1 && fi <= 5) ? fi - 1 : 0;
+        GLB_PTR(const real) Q = gA + GA_W * d.g + GA_Q + qr;
+#pragma unroll
+        for (int s = 0; s < GA_QW; s++) d.qc[s] = Q[8 * s];
+        d.a1 = gA[GA_W * d.g + 2];      // the coupling of the two friction rows of a condim-3 contact (rows 2 and 1)
+        LDS_PTR(const real) S0 = rowS + RS_S * d.h;
+#pragma unroll
+        for (int r = 1; r < GRP_MAX; r++) d.ar[r] = S0[RS_S * r];       // the rows' reference accelerations, for every lane
+        LDS_PTR(const real) S = S0 + RS_S * (fi < d.dim ? fi : 0);
+        d.aref = S[0]; d.invn = S[3]; d.f0 = S[8]; d.muinv = S[7];
+    };
+    bool slid = false;
+    for (int sweep = 0; sweep < noslip_iters; sweep++) {
+        real imp = 0;
+        // dry-friction rows of mj_solNoSlip [EXT]: clamped scalar update, undone when it would raise the cost (costChange)
+#pragma unroll
+        for (int s = 0; s < TREE_W; s++) {
+            const real res = x - faref;
+            const real fs = tmin(tmax(ff - res * finv, flo), fhi);
+            const real dl_ = fs - ff, ch = dl_ * (real(0.5) * dl_ * fdiag + res);
+            const bool take = frow >= 0 && fi == s && !(ch > real(1e-10));
+            if (take) { imp -= ch; ff = fs; }
+            const real ds = oct_bcast_n(take ? dl_ : real(0), s);
+            x += mrow[s] * ds;
+        }
+        // the contacts of this octet's tree, in order
+        CD ca, cb;      // two sets, used alternately: the next contact's data lands in one while the other is worked on
+        auto one_step = [&](const CD& cur) {
+            const int dim = cur.dim, n = dim - 1;
+            const bool row = fi >= 1 && fi < dim;
+            // row residuals J_r . qacc: every lane ends up with all of them
+            real res_r = 0, ra[5], sr[GRP_MAX];
+#pragma unroll
+            for (int r = 1; r < GRP_MAX; r++) sr[r] = oct_sum(r < dim ? cur.J[r] * x : real(0));
+            if (TWO && __any(cur.two)) {
+                // a contact between two trees: the other tree's octet has the other half of every sum (first tree's part + second tree's
+                // part, in that order on both sides, so that the two octets go on with identical numbers)
+#pragma unroll
+                for (int r = 1; r < GRP_MAX; r++) {
+                    const real other = __shfl(sr[r], 8 * cur.partner + fi, 64);
+                    if (cur.two) sr[r] = cur.side == 0 ? sr[r] + other : other + sr[r];
+                }
+            }
+#pragma unroll
+            for (int r = 1; r < GRP_MAX; r++) {
+                ra[r - 1] = r < dim ? sr[r] - cur.ar[r] : real(0);
+                if (fi == r) res_r = ra[r - 1];
+            }
+            const real fn = oct_bcast<0>(cur.f0), r2 = fn * fn;
+            real f = cur.f0;
+            if (n >= 3) {
+                // multiplier 0 first: the unconstrained minimiser f - A^-1 res (the inverse made with the rows); inside the cone section
+                // this is mju_QCQP's answer, and its cost change is dl . res / 2
+                bool done = false;
+                if (!(fn < real(1e-15)) && oct_bcast<1>(cur.qc[5]) == real(0)) {
+                    real t = 0;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) t += cur.qc[k] * ra[k];
+                    const real dl_ = row ? -t : real(0), vr = cur.f0 + dl_;
+                    const real w = row ? vr * cur.muinv : real(0);
+                    const real val = oct_sum(w * w) - r2;
+                    if (val < QTol<real>::abs + QTol<real>::rel * r2) {
+                        const real change = real(0.5) * oct_sum(dl_ * res_r);
+                        if (!(change > real(1e-10))) {
+                            if (fi == 0 && cur.side == 0) imp -= change;
+                            if (row) f = vr;
+                        }
+                        done = true;
+                    }
+                }
+                // No normal force: mj_solNoSlip takes the friction forces to zero (subject to the cost test).  They are zero already when
+                // the primal solution had no normal force either -- nothing to do; anything else, and the multiplier iteration of a
+                // sliding contact, is pgs_groups' business
+                if (!done && fn < real(1e-15) && oct_sum(row ? fabs(cur.f0) : real(0)) == real(0)) done = true;
+                if (!done && (nl.tridiag == 0 || fn < real(1e-15) || cur.two)) slid = true;
+                else if (__builtin_expect(!done, 0)) {
+                    // the contact slides: the multiplier iteration, out of line (rare; its forty-odd live values would otherwise sit in
+                    // the registers of every step)
+                    real change;
+                    const real fv = qcqp_slide_octet<real>(gA, cur.g, n, fi, res_r, cur.f0, cur.muinv, cur.invn, cur.qc[5], fn, nl.tridiag, &change);
+                    if (!(change > real(1e-10))) {
+                        if (fi == 0 && cur.side == 0) imp -= change;
+                        if (row) f = fv;
+                    }
+                }
+            } else if (n == 2) {
+                // mju_QCQP2 [EXT] as pgs_groups evaluates it, on the lanes of the octet
+                const real resq0 = ra[0], resq1 = ra[1];
+                const real of0 = oct_bcast<1>(cur.f0), of1 = oct_bcast<2>(cur.f0);
+                const real dq0 = real(1) / oct_bcast<1>(cur.muinv), dq1 = real(1) / oct_bcast<2>(cur.muinv);
+                const real A00 = real(1) / oct_bcast<1>(cur.invn), A11 = real(1) / oct_bcast<2>(cur.invn), A10 = oct_bcast<2>(cur.a1);
+                real bq0 = resq0, bq1 = resq1;
+                bq0 -= A00 * of0; bq0 -= A10 * of1;
+                bq1 -= A10 * of0; bq1 -= A11 * of1;
+                real v0 = 0, v1 = 0;
+                if (!(fn < real(1e-15))) {
+                    const real vtol = QTol<real>::abs + QTol<real>::rel * r2;
+                    real la = 0;
+                    const real b1 = bq0 * dq0, b2 = bq1 * dq1;
+                    const real A11s = A00 * dq0 * dq0, A22s = A11 * dq1 * dq1, A12s = A10 * dq0 * dq1;
+                    real y1 = 0, y2 = 0;
+                    bool singular = false;
+                    for (int iter = 0; iter < 20; iter++) {
+                        const real det = (A11s + la) * (A22s + la) - A12s * A12s;
+                        if (det < real(1e-10)) { singular = true; break; }
+                        const real detinv = real(1) / det, P11 = (A22s + la) * detinv, P22 = (A11s + la) * detinv, P12 = -A12s * detinv;
+                        y1 = -P11 * b1 - P12 * b2;
+                        y2 = -P12 * b1 - P22 * b2;
+                        const real val = y1 * y1 + y2 * y2 - r2;
+                        if (val < vtol) break;
+                        const real yw = P11 * y1 * y1 + 2 * P12 * y1 * y2 + P22 * y2 * y2;
+                        const real delta = nl.tridiag == 2 ? secular_step(val, r2, fn, yw) : val / (2 * yw);
+                        if (delta < QTol<real>::abs + QTol<real>::rel * la) break;
+                        la += delta;
+                    }
+                    v0 = singular ? real(0) : y1 * dq0;
+                    v1 = singular ? real(0) : y2 * dq1;
+                    if (!singular && la != 0) {       // exactly onto the ellipsoid
+                        const real sq = v0 * v0 / (dq0 * dq0) + v1 * v1 / (dq1 * dq1);
+                        const real sc = sqrt(r2 / tmax(real(1e-15), sq));
+                        v0 *= sc; v1 *= sc;
+                    }
+                }
+                const real change = (v0 - of0) * (real(0.5) * (A00 * (v0 - of0) + A10 * (v1 - of1)) + resq0) + (v1 - of1) * (real(0.5) * (A10 * (v0 - of0) + A11 * (v1 - of1)) + resq1);
+                if (!(change > real(1e-10)) && dim == 3) {
+                    if (fi == 0 && cur.side == 0) imp -= change;
+                    if (fi == 1) f = v0;
+                    if (fi == 2) f = v1;
+                }
+            }
+            // x += B^T (f - f0); the normal row does not move
+            const real dl = row ? f - cur.f0 : real(0);
+#pragma unroll
+            for (int r = 1; r < GRP_MAX; r++) x += (r < dim ? cur.B[r] : real(0)) * oct_bcast_n(dl, r);
+            if (row && cur.side == 0) rowS[RS_S * (cur.h + fi) + 8] = f;
+        };
+        rem = chain;
+        fetch(0, ca);
+        for (int step = 0; step < nstep; step += 2) {
+            fetch(step + 1, cb);
+            one_step(ca);
+            if (step + 1 < nstep) {
+                fetch(step + 2, ca);
+                one_step(cb);
+            }
+        }
+        if (__any(slid)) { if (prof && lane == 0) prof[2] += 1; return 0; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next sweep reads the forces this one has stored
+        __builtin_amdgcn_wave_barrier();
+        if (lane_get(wave_sum(imp), 0) < noslip_tol_scaled) break;
+    }
+    return 1;
+    };
+    if (!(__any(tB >= 0) ? sweeps(BoolTag<true>{}) : sweeps(BoolTag<false>{}))) return 0;
+    // ---- the pass has succeeded: accelerations and forces to their places ----
+    if (prof && lane == 0) prof[3] += 1;
+    if (fm) q[fdof] = x;
+    if (frow >= 0) FS[8] = ff;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < nefc; i += 64) rowS[RS_S * i + 6] = rowS[RS_S * i + 8];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return 1;
+}
+
 
 }  // namespace avs
 #include "avsim_newton.hip.h"
@@ -2759,8 +3041,11 @@ struct Env {
             if (ka->m.noslip_trees && lead_per_tree() && __builtin_amdgcn_readfirstlane(misc[8]) == 0)
                 done_ = noslip_trees<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const int))cefc, (GLB_PTR(const real))rJ, (LDS_PTR(real))qacc,
                                            (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), ncon, nefc, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
-            if (!__builtin_amdgcn_readfirstlane(done_) && lane == 0) misc[8] = 1;
-            if (!__builtin_amdgcn_readfirstlane(done_))
+            if (__builtin_amdgcn_readfirstlane(done_) == 2)
+                done_ = noslip_trees2<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const int))cefc, (GLB_PTR(const real))rJ, (GLB_PTR(const real))rowsB_(), (LDS_PTR(real))qacc,
+                                            (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), ncon, nefc, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
+            if (__builtin_amdgcn_readfirstlane(done_) != 1 && lane == 0) misc[8] = 1;
+            if (__builtin_amdgcn_readfirstlane(done_) != 1)
             pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (GLB_PTR(const real))rJ, (GLB_PTR(const real))rowsB_(), (LDS_PTR(real))qacc,
                              (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], 0, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
             if (profiling && lane == 0) (ii + ka->lay.nprof)[6] += (int)(__builtin_readcyclecounter() - tn0);
