@@ -6,8 +6,9 @@ import episode_util as U
 from av_aloha_amd import workloads as W
 from av_aloha_amd.sim_env import make_sim_env
 task, n = "slot_insertion", 32
-envA = make_sim_env("sim_" + task, cameras=[], num_envs=n, f64=False); envA.sim.set_option("noslip_trees", 0)
-envB = make_sim_env("sim_" + task, cameras=[], num_envs=n, f64=False); envB.sim.set_option("noslip_trees", 1)
+F64 = len(sys.argv) > 1
+envA = make_sim_env("sim_" + task, cameras=[], num_envs=n, f64=F64); envA.sim.set_option("noslip_trees", 0); envA.sim.set_option("qcqp_tridiag", 2)
+envB = make_sim_env("sim_" + task, cameras=[], num_envs=n, f64=F64); envB.sim.set_option("noslip_trees", 1); envB.sim.set_option("qcqp_tridiag", 2)
 poses = W.object_poses(task, np.arange(n), 1000)
 envA.sim.reset(poses); envB.sim.reset(poses)
 obs = envA.get_obs(); q = obs["qpos"].reshape(n, -1)
@@ -24,7 +25,7 @@ for t in range(script.steps()):
     dA, dB = envA.sim.diag(), envB.sim.diag()
     dq = np.abs(qb - q).max(1); dv = np.abs(vb - v).max(1)
     k = int(np.argmax(dv))
-    if dv[k] > 1e-2 or (dB[:, 3] & 1).any():
+    if dv[k] > (1e-6 if F64 else 1e-2) or (dB[:, 3] & 1).any():
         print(f"step {t}: env {k} |dq| {dq[k]:.3e} |dv| {dv[k]:.3e} ncon A/B {dA[k,0]}/{dB[k,0]} nefc {dA[k,1]}/{dB[k,1]} diverged B {int((dB[:,3]&1).sum())} A {int((dA[:,3]&1).sum())}; envs with |dv|>1e-2: {int((dv>1e-2).sum())}")
     worst.append(dv.max())
 print("max |dv| over the episode:", max(worst), "at step", int(np.argmax(worst)))
