@@ -1,3 +1,7 @@
+"""Lock-step comparison of the noslip pass per tree (noslip_trees = 1) with the wave-wide groups (0) on the scripted SlotInsertion episode:
+every env-step both variants start from the SAME state (the reference's), so a deviation is that step's own and not an earlier one's
+amplified.  f32 by default, any argument: f64 (with qcqp_tridiag = 2 on both sides).  Prints the steps whose largest |dv| exceeds 1e-2
+(1e-6 in f64) or that reset an env.  Run on the GPU box: python tools/exp_lockstep_noslip.py [f64]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
