@@ -274,6 +274,7 @@ using KPtr = const KArgs<real> __attribute__((address_space(4)))*;
 
 // all-reduce over the 16 lanes of a DPP row
 AVS_DEV float row16_sum(float x) {
+    asm volatile("" : "+v"(x));      // (as in oct_sum: every lane of the row gets the same sum to the last bit)
     x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x128, 0xf, 0xf, true));  // row_ror:8
     x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x124, 0xf, 0xf, true));  // row_ror:4
     x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x122, 0xf, 0xf, true));  // row_ror:2
@@ -317,7 +318,12 @@ struct RowS {
     real aref, R, inv, invn, lo, hi, f, muinv;
 };
 
+// (The argument goes through an empty asm: were it visibly a product a * b, the f32 build -- FMA contraction on -- would turn the
+// first step into fma(a, b, neighbour's ROUNDED product), a different number in the two lanes of a pair, and the eight lanes of an octet
+// would no longer hold the same sum to the last bit.  noslip_trees takes decisions on such sums in every lane of the octet: with the
+// contraction the lanes of an octet disagreed about a sliding contact that sits on its cone, |w|^2 - r^2 ~ 0.)
 AVS_DEV float oct_sum(float x) {   // sum over each aligned group of 8 lanes
+    asm volatile("" : "+v"(x));
     x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
     x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
     x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));  // row_half_mirror
@@ -1329,9 +1335,9 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
 // two predecessors' levels, a tree has at most one contact per level --, each octet sums its tree's half of the row residuals and gets
 // the other half from its partner (ds_bpermute; first tree's part + second tree's part on both sides, so that the two octets go on
 // with identical numbers), both run the friction block, each moves its own tree's accelerations, the first tree's octet stores the
-// forces.  A SLIDING contact between two trees hands the pass to pgs_groups (the multiplier iteration inside the pass made the f32
-// whole-episode test diverge; one-tree sliding contacts stay inside).  A function of its own, entered when noslip_trees returns 2: with
-// the two-tree bookkeeping in noslip_trees the headline workload, which has no such contact, lost 1.6 %; this way 0.5 %.
+// forces; a sliding contact runs the multiplier iteration on both octets (identical inputs, identical results: oct_sum keeps FMA
+// contraction out of the sums).  A function of its own, entered when noslip_trees returns 2: with the two-tree bookkeeping in
+// noslip_trees the headline workload, which has no such contact, lost 1.6 %; this way 0.3 %.
 template <typename real>
 __device__ __attribute__((noinline)) int noslip_trees2(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const int) cefc, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
                                                       LDS_PTR(real) q, LDS_PTR(const int) gI, GLB_PTR(const real) gA, int ncon, int nefc, int noslip_iters,
@@ -1512,7 +1518,7 @@ __device__ __attribute__((noinline)) int noslip_trees2(LDS_PTR(real) rowS, LDS_P
                 // the primal solution had no normal force either -- nothing to do; anything else, and the multiplier iteration of a
                 // sliding contact, is pgs_groups' business
                 if (!done && fn < real(1e-15) && oct_sum(row ? fabs(cur.f0) : real(0)) == real(0)) done = true;
-                if (!done && (nl.tridiag == 0 || fn < real(1e-15) || cur.two)) slid = true;
+                if (!done && (nl.tridiag == 0 || fn < real(1e-15))) slid = true;
                 else if (__builtin_expect(!done, 0)) {
                     // the contact slides: the multiplier iteration, out of line (rare; its forty-odd live values would otherwise sit in
                     // the registers of every step)
