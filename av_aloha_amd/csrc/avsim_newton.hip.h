@@ -428,6 +428,48 @@ AVS_DEV void nblock_chol(const NewtonArgs<real>& A, int lane) {
             if (k <= i) A.H[rbase + k] = row[k];
     }
 }
+// The trees that no row couples to another one, in a scene where some rows do (`tmask`: the trees of the coupled component): their
+// blocks of H factor as above, inside their octets, while the dense factorisation below takes the coupled dofs only.  The forward
+// substitution comes with it in the dense path's arithmetic -- there lane nv carries -g through the columns as one more row:
+// y_j = g'_j rsq(pivot_j), g'_k -= y_j L_kj -- so L and y are entry for entry what ndense_chol over all nv columns leaves in H and g.
+template <typename real>
+AVS_DEV void nblock_chol_fwd(LDS_PTR(real) H, LDS_PTR(real) g, int a0_, int n_, bool act, int lane) {
+    // (a0_, n_: first dof and size of the tree of this lane's octet; act: the octet has a tree and it lies outside the component)
+    struct { LDS_PTR(real) H; LDS_PTR(real) g; } A = {H, g};
+    const int i = lane & 7;
+    const int n = act ? n_ : 0, a0 = act ? a0_ : 0;
+    const int rbase = (a0 + i) * (a0 + i + 1) / 2 + a0;
+    real row[TREE_W];
+#pragma unroll
+    for (int k = 0; k < TREE_W; k++) {
+        const bool in = i < n && k <= i;
+        const real v = A.H[in ? rbase + k : 0];
+        row[k] = in ? v : (k == i ? real(1) : real(0));
+    }
+    const real gi = A.g[i < n ? a0 + i : 0];
+    real x = i < n ? -gi : real(0), y = 0;
+#pragma unroll
+    for (int j = 0; j < TREE_W; j++) {
+        const real piv = tmax(oct_bcast_n(row[j], j), real(1e-30));
+        real d, rinv;
+        if (sizeof(real) == 4) { rinv = (real)__builtin_amdgcn_rsqf((float)piv); d = piv * rinv; }
+        else { d = sqrt(piv); rinv = real(1) / d; }
+        const real lij = i == j ? d : row[j] * rinv;
+        row[j] = lij;
+        const real mul = i > j ? lij : real(0);
+#pragma unroll
+        for (int k = j + 1; k < TREE_W; k++) row[k] -= mul * oct_bcast_n(lij, k);
+        const real yj = oct_bcast_n(x, j) * rinv;
+        y = i == j ? yj : y;
+        x = x - yj * mul;
+    }
+    if (i < n) {
+#pragma unroll
+        for (int k = 0; k < TREE_W; k++)
+            if (k <= i) A.H[rbase + k] = row[k];
+        A.g[a0 + i] = y;
+    }
+}
 // dl = (L L^T)^-1 (-g) with the block factor stored in the packed triangle: both substitutions inside the octets
 template <typename real>
 AVS_DEV void nblock_solve(const NewtonArgs<real>& A, int lane) {
@@ -462,48 +504,94 @@ AVS_DEV void nblock_solve(const NewtonArgs<real>& A, int lane) {
 
 // Dense factorisation for scenes where a contact couples two trees.  Out of line on purpose: its 48-entry register row would
 // otherwise push the Newton loop's per-contact state out to scratch memory in every solve, coupled or not.
+// It runs over the `nc` dofs of the coupled component only (lane p < nc holds the row of dof `mydof`, ascending; lane nc the row
+// "nv" = -g; the trees outside the component go through nblock_chol_fwd): a column is a serial step of ~570 cycles whatever it
+// holds, and the entries between the component and the other trees are zeros that stay zeros -- the same L and y, entry for entry,
+// as the factorisation over all nv columns.
 template <typename real>
-__device__ __attribute__((noinline)) void ndense_chol(LDS_PTR(real) H_, int nv_) {
+__device__ __attribute__((noinline)) void ndense_chol(LDS_PTR(real) H_, int nv_, LDS_PTR(const int) rowI_, int ne_, int k_a0, int k_n) {
+    // (arguments: only what the caller has live at the call anyway -- the rows' dof windows, and per lane the first dof and the size
+    // of its dof's tree; every further uniform value kept for this call is an SGPR the Newton loop of the uncoupled scenes spills
+    // around: 1 - 2 % of the headline configuration.  The trees are numbered by ascending dof address, so the lanes that hold a
+    // tree's first dof give the tree table back.)
     const int lane = threadIdx.x & 63;
-    LDS_PTR(real) H = (LDS_PTR(real))(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)H_);
-    const int nv = __builtin_amdgcn_readfirstlane(nv_);
-    struct { LDS_PTR(real) H; } A = {H};
-
-                // g sits right behind the packed triangle (NewtonArgs contract), i.e. it is "row nv" of the same array
-                real row[NVMAX];
-                const int rbase = lane * (lane + 1) / 2;
-                const real sgn = lane == nv ? real(-1) : real(1);
-    #pragma unroll
-                for (int k = 0; k < NVMAX; k++) {
-                    const bool ok = lane <= nv && k <= lane && k < nv;
-                    const real v = A.H[ok ? rbase + k : 0];
-                    row[k] = ok ? sgn * v : real(0);
-                }
-                for (int j = 0; j < nv; j++) {
-                    // pivot: d = sqrt(H_jj), column j = row[0] / d.  f32 takes the hardware rsq (1 ulp), f64 the exact pair
-                    const real piv = tmax(lane_get(row[0], j), real(1e-30));
-                    real d, rinv;
-                    if (sizeof(real) == 4) { rinv = (real)__builtin_amdgcn_rsqf((float)piv); d = piv * rinv; }
-                    else { d = sqrt(piv); rinv = real(1) / d; }
-                    const real lij = row[0] * rinv;
-                    // L_ij for the rows below, d on the diagonal, y_j = (L^-1 (-g))_j from lane nv ("row nv" is g's storage)
-                    if (lane >= j && lane <= nv) A.H[rbase + j] = lane == j ? d : lij;
-    #pragma unroll
-                    for (int mb = 1; mb < NVMAX; mb += 8) {
-                        if (j + mb <= nv - 1) {          // wave-uniform: the rest of the row is past the matrix
-    #pragma unroll
-                            for (int mm = 0; mm < 8; mm++) {
-                                const int m = mb + mm;
-                                if (m < NVMAX) row[m - 1] = row[m] - lij * lane_get(lij, (j + m) & 63);
-                            }
-                        }
-                    }
+    LDS_PTR(real) H = uni_lds(H_);
+    LDS_PTR(const int) rowI = uni_lds(rowI_);
+    const int nv = __builtin_amdgcn_readfirstlane(nv_), ne = __builtin_amdgcn_readfirstlane(ne_);
+    LDS_PTR(int) tmp = (LDS_PTR(int))(H + nv * (nv + 1) / 2 + nv);      // the search direction's words (behind H and g: NewtonArgs contract), idle here
+    const unsigned long long firsts = __ballot(lane < nv && lane == k_a0);
+    const int ntree = __popcll(firsts);
+    // the coupled component: the trees that some row couples to another tree (by the rows present, active or not), its dofs in
+    // ascending order one per lane; everything when there are more than eight trees
+    int mydof = lane < nv ? lane : nv, nc = nv;
+    if (ntree <= 8) {
+        unsigned mine = 0;
+        for (int i = lane; i < ne; i += 64) {
+            const int ra = rowI[i];
+            if (((ra >> 19) & 15) != 0) mine |= (1u << ((ra >> 10) & 7)) | (1u << ((ra >> 23) & 7));
+        }
+        unsigned tmask = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) tmask |= __any((mine >> t) & 1u) ? (1u << t) : 0u;
+        const int mytree = __popcll(firsts & ((2ull << lane) - 1ull)) - 1;
+        const bool isc = lane < nv && ((tmask >> mytree) & 1u);
+        const unsigned long long cm = __ballot(isc);
+        nc = __popcll(cm);
+        if (nc < nv) {
+            if (isc) tmp[__popcll(cm & ((1ull << lane) - 1ull))] = lane;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            mydof = lane < nc ? tmp[lane] : nv;
+            // tree t of this lane's octet: the t-th lane that holds a first dof
+            const int t = lane >> 3;
+            unsigned long long m = firsts;
+#pragma unroll
+            for (int q = 0; q < 7; q++) m = q < t ? (m & (m - 1)) : m;
+            const bool act = t < ntree && !((tmask >> t) & 1u);
+            const int a0 = m != 0 ? __builtin_ctzll(m) : 0;
+            const int n = __shfl(k_n, a0, 64);
+            nblock_chol_fwd<real>(H, H + nv * (nv + 1) / 2, a0, n, act, lane);
+        }
+    }
+    // g sits right behind the packed triangle (NewtonArgs contract), i.e. it is "row nv" of the same array
+    real row[NVMAX];
+    const int rbase = mydof * (mydof + 1) / 2;
+    const real sgn = lane == nc ? real(-1) : real(1);
+#pragma unroll
+    for (int k = 0; k < NVMAX; k++) {
+        const bool ok = lane <= nc && k <= lane && k < nc;
+        const int ck = __builtin_amdgcn_readlane(mydof, k);
+        const real v = H[ok ? rbase + ck : 0];
+        row[k] = ok ? sgn * v : real(0);
+    }
+    for (int j = 0; j < nc; j++) {
+        // pivot: d = sqrt(H_jj), column j = row[0] / d.  f32 takes the hardware rsq (1 ulp), f64 the exact pair
+        const real piv = tmax(lane_get(row[0], j), real(1e-30));
+        real d, rinv;
+        if (sizeof(real) == 4) { rinv = (real)__builtin_amdgcn_rsqf((float)piv); d = piv * rinv; }
+        else { d = sqrt(piv); rinv = real(1) / d; }
+        const real lij = row[0] * rinv;
+        // L_ij for the rows below, d on the diagonal, y_j = (L^-1 (-g))_j from lane nc ("row nv" is g's storage)
+        const int cj = __builtin_amdgcn_readlane(mydof, j);
+        if (lane >= j && lane <= nc) H[rbase + cj] = lane == j ? d : lij;
+#pragma unroll
+        for (int mb = 1; mb < NVMAX; mb += 8) {
+            if (j + mb <= nc - 1) {          // wave-uniform: the rest of the row is past the matrix
+#pragma unroll
+                for (int mm = 0; mm < 8; mm++) {
+                    const int m = mb + mm;
+                    if (m < NVMAX) row[m - 1] = row[m] - lij * lane_get(lij, (j + m) & 63);
                 }
             }
+        }
+    }
+}
 
 // r / ii: the env's real and int LDS regions, li: the block's hot-table image; everything else comes from the layout
 // NCH = contact chunks of 64 (one contact per lane and chunk): 1 when the model's contact cap is <= 64
-template <typename real, int NCH>
+// COUPLED: some row reaches into two kinematic trees (the caller looks: solve_i) -- two instances, so that the solves of scenes
+// without such rows carry nothing of the dense path (its call alone costs the Newton loop SGPRs: 1 % of the headline configuration)
+template <typename real, int NCH, bool COUPLED>
 __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PTR(const real) rows, LDS_PTR(real) r_, LDS_PTR(int) ii_, LDS_PTR(const int) li_, int nefc, int ncon, int nlead,
                                                       int iters, real tol, real scale, int profiling) {
     const int lane = threadIdx.x & 63;
@@ -537,13 +625,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         A.k_a0 = A.tree_dofadr[t]; A.k_n = A.tree_dofnum[t]; A.k_mb = A.tree_madr[t] + (k - A.k_a0) * A.k_n;
     }
     int used = 0;
-    // does any row reach into two kinematic trees?  (second dof window non-empty; wave-uniform)
-    bool coupled = false;
-    {
-        bool two = false;
-        for (int i = lane; i < ne; i += 64) two = two || ((A.rowI[i] >> 19) & 15) != 0;
-        coupled = __any(two) != 0 || A.ntree > 8;
-    }
+    constexpr bool coupled = COUPLED;
     long long tp0 = A.prof ? __builtin_readcyclecounter() : 0;
     // ---- per-contact constants ----
     NCon<real> con[NCH];
@@ -654,7 +736,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         if (!(same && !middle)) {
             // ---- Hessian: packed lower triangle ----
             // (block-diagonal case: only entries inside the tree blocks are read, and the M blocks below overwrite all of them)
-            if (coupled) {
+            if constexpr (coupled) {
                 for (int e = lane; e < nv * (nv + 1) / 2; e += 64) A.H[e] = 0;
                 NSYNC();
             }
@@ -697,13 +779,13 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
             NSYNC();
             NPROF(2);
             // ---- Cholesky + forward substitution in registers: lane i = row i, lane nv = -g ----
-            if (!coupled) nblock_chol<real>(A, lane);
-            else ndense_chol<real>(A.H, nv);
+            if constexpr (!coupled) nblock_chol<real>(A, lane);
+            else ndense_chol<real>(A.H, nv, A.rowI, ne, A.k_a0, A.k_n);
             have_L = !middle && A.nlead <= 64;
             sig_lead = cur_lead;
 #pragma unroll
             for (int ch = 0; ch < NCH; ch++) sig_z1[ch] = cur_z1[ch];
-        } else if (coupled) {
+        } else if constexpr (coupled) {
             // same Hessian as last time: forward substitution L y = -g with the stored factor (lane i holds y_i)
             real x = lane < nv ? -A.g[lane] : real(0);
             const real dinv = lane < nv ? real(1) / A.H[lane * (lane + 1) / 2 + lane] : real(0);
@@ -721,7 +803,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         NSYNC();
         NPROF(3);
         // ---- backward substitution L^T x = y, lane j holds x_j; column entries prefetched one step ahead ----
-        if (!coupled) {
+        if constexpr (!coupled) {
             nblock_solve<real>(A, lane);
         } else {
             real x = lane < nv ? A.g[lane] : real(0);

@@ -3033,9 +3033,14 @@ struct Env {
             GSYNC();
             // (one or two contacts per lane by the env's own contact count, not by the capacity: the sums then run in the same order
             // whatever LDS layout the env is stepped with -- the two capacity tiers of PhysHost::launch_t give identical results)
-            int used = __builtin_amdgcn_readfirstlane(ncon) <= 64
-                ? newton_solve<real, 1>(ka, (GLB_PTR(const real))rJ, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0)
-                : newton_solve<real, 2>(ka, (GLB_PTR(const real))rJ, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0);
+            // does any row reach into two kinematic trees?  (second dof window non-empty; wave-uniform)  Then the Hessian is not block
+            // diagonal: the instance with the dense factorisation of the coupled component
+            bool two_ = false;
+            for (int i = lane; i < nefc; i += G) two_ = two_ || ((rowI[i] >> 19) & 15) != 0;
+            const bool coupled = __any(two_) != 0 || ka->m.ntree > 8;
+#define AVS_NEWTON(NCH_, CPL_) newton_solve<real, NCH_, CPL_>(ka, (GLB_PTR(const real))rJ, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0)
+            int used = __builtin_amdgcn_readfirstlane(ncon) <= 64 ? (coupled ? AVS_NEWTON(1, true) : AVS_NEWTON(1, false)) : (coupled ? AVS_NEWTON(2, true) : AVS_NEWTON(2, false));
+#undef AVS_NEWTON
             nit_sum += used; nit_max = used > nit_max ? used : nit_max;
             GSYNC();
             long long tn0 = profiling ? __builtin_readcyclecounter() : 0;
