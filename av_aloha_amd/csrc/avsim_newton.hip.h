@@ -509,50 +509,11 @@ AVS_DEV void nblock_solve(const NewtonArgs<real>& A, int lane) {
 // holds, and the entries between the component and the other trees are zeros that stay zeros -- the same L and y, entry for entry,
 // as the factorisation over all nv columns.
 template <typename real>
-__device__ __attribute__((noinline)) void ndense_chol(LDS_PTR(real) H_, int nv_, LDS_PTR(const int) rowI_, int ne_, int k_a0, int k_n) {
-    // (arguments: only what the caller has live at the call anyway -- the rows' dof windows, and per lane the first dof and the size
-    // of its dof's tree; every further uniform value kept for this call is an SGPR the Newton loop of the uncoupled scenes spills
-    // around: 1 - 2 % of the headline configuration.  The trees are numbered by ascending dof address, so the lanes that hold a
-    // tree's first dof give the tree table back.)
+__device__ __attribute__((noinline)) void ndense_chol(LDS_PTR(real) H_, int nv_, int mydof, int nc_, int oa0, int on, bool oact) {
     const int lane = threadIdx.x & 63;
     LDS_PTR(real) H = uni_lds(H_);
-    LDS_PTR(const int) rowI = uni_lds(rowI_);
-    const int nv = __builtin_amdgcn_readfirstlane(nv_), ne = __builtin_amdgcn_readfirstlane(ne_);
-    LDS_PTR(int) tmp = (LDS_PTR(int))(H + nv * (nv + 1) / 2 + nv);      // the search direction's words (behind H and g: NewtonArgs contract), idle here
-    const unsigned long long firsts = __ballot(lane < nv && lane == k_a0);
-    const int ntree = __popcll(firsts);
-    // the coupled component: the trees that some row couples to another tree (by the rows present, active or not), its dofs in
-    // ascending order one per lane; everything when there are more than eight trees
-    int mydof = lane < nv ? lane : nv, nc = nv;
-    if (ntree <= 8) {
-        unsigned mine = 0;
-        for (int i = lane; i < ne; i += 64) {
-            const int ra = rowI[i];
-            if (((ra >> 19) & 15) != 0) mine |= (1u << ((ra >> 10) & 7)) | (1u << ((ra >> 23) & 7));
-        }
-        unsigned tmask = 0;
-#pragma unroll
-        for (int t = 0; t < 8; t++) tmask |= __any((mine >> t) & 1u) ? (1u << t) : 0u;
-        const int mytree = __popcll(firsts & ((2ull << lane) - 1ull)) - 1;
-        const bool isc = lane < nv && ((tmask >> mytree) & 1u);
-        const unsigned long long cm = __ballot(isc);
-        nc = __popcll(cm);
-        if (nc < nv) {
-            if (isc) tmp[__popcll(cm & ((1ull << lane) - 1ull))] = lane;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            mydof = lane < nc ? tmp[lane] : nv;
-            // tree t of this lane's octet: the t-th lane that holds a first dof
-            const int t = lane >> 3;
-            unsigned long long m = firsts;
-#pragma unroll
-            for (int q = 0; q < 7; q++) m = q < t ? (m & (m - 1)) : m;
-            const bool act = t < ntree && !((tmask >> t) & 1u);
-            const int a0 = m != 0 ? __builtin_ctzll(m) : 0;
-            const int n = __shfl(k_n, a0, 64);
-            nblock_chol_fwd<real>(H, H + nv * (nv + 1) / 2, a0, n, act, lane);
-        }
-    }
+    const int nv = __builtin_amdgcn_readfirstlane(nv_), nc = __builtin_amdgcn_readfirstlane(nc_);
+    if (nc < nv) nblock_chol_fwd<real>(H, H + nv * (nv + 1) / 2, oa0, on, oact, lane);
     // g sits right behind the packed triangle (NewtonArgs contract), i.e. it is "row nv" of the same array
     real row[NVMAX];
     const int rbase = mydof * (mydof + 1) / 2;
@@ -585,6 +546,101 @@ __device__ __attribute__((noinline)) void ndense_chol(LDS_PTR(real) H_, int nv_,
             }
         }
     }
+}
+
+// The coupled component of a solve: the trees that some row couples to another tree (by the rows present, active or not), its
+// dofs in ascending order one per lane (lane p < nc: dof `mydof`; nv on the other lanes); everything when there are more than eight
+// trees.  The trees outside it keep their octets: lane 8 t + i = dof i of tree t (oa0, on; oact: the octet has such a tree).
+struct NComp { int mydof, nc, oa0, on; bool oact; };
+template <typename real>
+AVS_DEV NComp ncomponent(const NewtonArgs<real>& A, int lane, int ne, LDS_PTR(int) tmp) {
+    const int nv = A.nv;
+    NComp c;
+    c.mydof = lane < nv ? lane : nv; c.nc = nv; c.oa0 = 0; c.on = 0; c.oact = false;
+    if (A.ntree > 8) return c;
+    unsigned mine = 0;
+    for (int i = lane; i < ne; i += 64) {
+        const int ra = A.rowI[i];
+        if (((ra >> 19) & 15) != 0) mine |= (1u << ((ra >> 10) & 7)) | (1u << ((ra >> 23) & 7));
+    }
+    unsigned tmask = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) tmask |= __any((mine >> t) & 1u) ? (1u << t) : 0u;
+    const bool isc = lane < nv && ((tmask >> A.dof_tree[lane < nv ? lane : 0]) & 1u);
+    const unsigned long long cm = __ballot(isc);
+    c.nc = __popcll(cm);
+    if (c.nc == nv) return c;
+    if (isc) tmp[__popcll(cm & ((1ull << lane) - 1ull))] = lane;
+    NSYNC();
+    c.mydof = lane < c.nc ? tmp[lane] : nv;
+    NSYNC();
+    const int t = lane >> 3;
+    c.oact = t < A.ntree && !((tmask >> t) & 1u);
+    c.oa0 = c.oact ? A.tree_dofadr[t] : 0;
+    c.on = c.oact ? A.tree_dofnum[t] : 0;
+    return c;
+}
+
+// Substitutions with the stored factor in a coupled scene, the same split: the trees outside the component inside their octets
+// (nblock_solve's steps), the component's dofs one per lane over its nc columns (the dense loops' steps) -- the products with the
+// zeros between the two are left out, every other operation is the one the loop over all nv columns did.
+//   fwd: L y = -g (y -> g), for an iteration that keeps the last factor;  bwd: L^T x = y (g -> dl)
+template <typename real, bool FWD>
+AVS_DEV void ncomp_subst(const NewtonArgs<real>& A, const NComp& c, int lane) {
+    const int nv = A.nv, nc = c.nc, i8 = lane & 7;
+    // ---- octets ----
+    const bool omine = c.oact && i8 < c.on;
+    const int a0 = c.oa0, obase = (a0 + i8) * (a0 + i8 + 1) / 2 + a0;
+    real ocf[TREE_W];
+#pragma unroll
+    for (int k = 0; k < TREE_W; k++) {
+        const bool in = FWD ? (omine && k < i8) : (omine && k < c.on && k > i8);
+        const real v = A.H[in ? (FWD ? obase + k : (a0 + k) * (a0 + k + 1) / 2 + a0 + i8) : 0];
+        ocf[k] = in ? v : real(0);
+    }
+    const real odg = A.H[omine ? obase + i8 : 0];
+    const real odinv = omine ? real(1) / odg : real(1);
+    const real og = A.g[omine ? a0 + i8 : 0];
+    real ox = omine ? (FWD ? -og : og) : real(0);
+    // ---- the component ----
+    const int md = c.mydof, rb = md * (md + 1) / 2;
+    const bool cm = lane < nc;
+    const real cg = A.g[cm ? md : 0];
+    real x = cm ? (FWD ? -cg : cg) : real(0);
+    const real dinv = cm ? real(1) / A.H[rb + md] : real(0);
+    if (nc < nv) {
+#pragma unroll
+        for (int jj = 0; jj < TREE_W; jj++) {
+            const int j = FWD ? jj : TREE_W - 1 - jj;
+            const real xj = oct_bcast_n(ox * odinv, j);
+            ox = i8 == j ? xj : ox - ocf[j] * xj;
+        }
+    }
+    if (FWD) {
+        int cn = __builtin_amdgcn_readlane(md, 0);
+        real Lnext = (lane > 0 && cm) ? A.H[rb + cn] : real(0);
+        for (int j = 0; j < nc; j++) {
+            const real Lc = Lnext;
+            if (j + 1 < nc) { cn = __builtin_amdgcn_readlane(md, j + 1); Lnext = (lane > j + 1 && cm) ? A.H[rb + cn] : real(0); }
+            const real yj = lane_get(x * dinv, j);
+            if (lane == j) x = yj;
+            else if (lane > j) x -= Lc * yj;
+        }
+    } else {
+        int cn = __builtin_amdgcn_readlane(md, nc - 1);
+        real Lnext = lane < nc - 1 ? A.H[cn * (cn + 1) / 2 + md] : real(0);
+        for (int i = nc - 1; i >= 0; i--) {
+            const real Lc = Lnext;
+            if (i > 0) { cn = __builtin_amdgcn_readlane(md, i - 1); Lnext = lane < i - 1 ? A.H[cn * (cn + 1) / 2 + md] : real(0); }
+            const real xi = lane_get(x * dinv, i);
+            if (lane == i) x = xi;
+            else if (lane < i) x -= Lc * xi;
+        }
+    }
+    NSYNC();
+    LDS_PTR(real) out = FWD ? A.g : A.dl;
+    if (cm) out[md] = x;
+    if (nc < nv && omine) out[a0 + i8] = ox;
 }
 
 // r / ii: the env's real and int LDS regions, li: the block's hot-table image; everything else comes from the layout
@@ -626,6 +682,8 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
     }
     int used = 0;
     constexpr bool coupled = COUPLED;
+    NComp comp;
+    if constexpr (coupled) comp = ncomponent<real>(A, lane, ne, (LDS_PTR(int))A.dl);      // (the search direction's words are idle until the first back substitution)
     long long tp0 = A.prof ? __builtin_readcyclecounter() : 0;
     // ---- per-contact constants ----
     NCon<real> con[NCH];
@@ -780,25 +838,14 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
             NPROF(2);
             // ---- Cholesky + forward substitution in registers: lane i = row i, lane nv = -g ----
             if constexpr (!coupled) nblock_chol<real>(A, lane);
-            else ndense_chol<real>(A.H, nv, A.rowI, ne, A.k_a0, A.k_n);
+            else ndense_chol<real>(A.H, nv, comp.mydof, comp.nc, comp.oa0, comp.on, comp.oact);
             have_L = !middle && A.nlead <= 64;
             sig_lead = cur_lead;
 #pragma unroll
             for (int ch = 0; ch < NCH; ch++) sig_z1[ch] = cur_z1[ch];
         } else if constexpr (coupled) {
-            // same Hessian as last time: forward substitution L y = -g with the stored factor (lane i holds y_i)
-            real x = lane < nv ? -A.g[lane] : real(0);
-            const real dinv = lane < nv ? real(1) / A.H[lane * (lane + 1) / 2 + lane] : real(0);
-            real Lnext = (lane > 0 && lane < nv) ? A.H[lane * (lane + 1) / 2] : real(0);
-            for (int j = 0; j < nv; j++) {
-                const real Lc = Lnext;
-                if (j + 1 < nv) Lnext = (lane > j + 1 && lane < nv) ? A.H[lane * (lane + 1) / 2 + j + 1] : real(0);
-                const real yj = lane_get(x * dinv, j);
-                if (lane == j) x = yj;
-                else if (lane > j) x -= Lc * yj;
-            }
-            NSYNC();
-            if (lane < nv) A.g[lane] = x;
+            // same Hessian as last time: forward substitution L y = -g with the stored factor
+            ncomp_subst<real, true>(A, comp, lane);
         }
         NSYNC();
         NPROF(3);
@@ -806,18 +853,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         if constexpr (!coupled) {
             nblock_solve<real>(A, lane);
         } else {
-            real x = lane < nv ? A.g[lane] : real(0);
-            const real dinv = lane < nv ? real(1) / A.H[lane * (lane + 1) / 2 + lane] : real(0);
-            real Lnext = lane < nv - 1 ? A.H[(nv - 1) * nv / 2 + lane] : real(0);
-            for (int i = nv - 1; i >= 0; i--) {
-                const real Lc = Lnext;
-                if (i > 0) Lnext = lane < i - 1 ? A.H[(i - 1) * i / 2 + lane] : real(0);
-                const real xi = lane_get(x * dinv, i);
-                if (lane == i) x = xi;
-                else if (lane < i) x -= Lc * xi;
-            }
-            NSYNC();
-            if (lane < nv) A.dl[lane] = x;
+            ncomp_subst<real, false>(A, comp, lane);
         }
         NSYNC();
         NPROF(7);
