@@ -553,11 +553,11 @@ __device__ __attribute__((noinline)) void ndense_chol(LDS_PTR(real) H_, int nv_,
 // trees.  The trees outside it keep their octets: lane 8 t + i = dof i of tree t (oa0, on; oact: the octet has such a tree).
 struct NComp { int mydof, nc, oa0, on; bool oact; };
 template <typename real>
-AVS_DEV NComp ncomponent(const NewtonArgs<real>& A, int lane, int ne, LDS_PTR(int) tmp) {
+AVS_DEV NComp ncomponent(const NewtonArgs<real>& A, int lane, int ne, LDS_PTR(int) tmp, bool whole) {
     const int nv = A.nv;
     NComp c;
     c.mydof = lane < nv ? lane : nv; c.nc = nv; c.oa0 = 0; c.on = 0; c.oact = false;
-    if (A.ntree > 8) return c;
+    if (A.ntree > 8 || whole) return c;
     unsigned mine = 0;
     for (int i = lane; i < ne; i += 64) {
         const int ra = A.rowI[i];
@@ -683,7 +683,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
     int used = 0;
     constexpr bool coupled = COUPLED;
     NComp comp;
-    if constexpr (coupled) comp = ncomponent<real>(A, lane, ne, (LDS_PTR(int))A.dl);      // (the search direction's words are idle until the first back substitution)
+    if constexpr (coupled) comp = ncomponent<real>(A, lane, ne, (LDS_PTR(int))A.dl, __builtin_amdgcn_readfirstlane(ka->m.newton_component) == 0);      // (the search direction's words are idle until the first back substitution)
     long long tp0 = A.prof ? __builtin_readcyclecounter() : 0;
     // ---- per-contact constants ----
     NCon<real> con[NCH];

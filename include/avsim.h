@@ -82,6 +82,9 @@ int avsim_dims(const avsim_t* h, int32_t dims[AVSIM_NDIMS]);
  *                       trees get); same results to rounding
  *   "noslip_trees"      1 (default): a noslip pass whose contacts all touch one kinematic tree runs per tree, octet t of the wave on tree t,
  *                       the trees' contact chains side by side; 0 = always the wave-wide Gauss-Seidel groups (same results to rounding)
+ *   "newton_component"  1 (default): in a scene where some contact couples two kinematic trees (a needle in a gripper) Newton's dense
+ *                       factorisation and substitutions run over the dofs of the coupled trees only, the other trees in their lane
+ *                       octets; 0 = over all nv columns (the same bits: the entries in between are zeros)
  *   "order_envs"        1 (default): workgroups take the envs in the order of their cost in the previous step, most expensive
  *                       first (results do not depend on it); 0 = in index order
  *   "export_contacts"   0 skips the per-step contact export (avsim_get_contacts); "kernel_timing" 1 brackets every physics

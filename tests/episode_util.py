@@ -116,7 +116,7 @@ def pool_map(fn, jobs, procs=None):
 
 
 # ---- device side -------------------------------------------------------------------------------------------------------
-def device_episode(task, n, f64, seed0=None, record_qpos=True):
+def device_episode(task, n, f64, seed0=None, record_qpos=True, options=None):
     """The scripted policy closed loop on the device (23-D action -> GradIK x2 + DiffIK on the measured joints -> 20 substeps,
     sim_env.py:277-312), n envs with the poses of seeds seed0 + i.  Records what the physics was driven with: ctrl [T, n, nu] in
     actuator units (double copies of the device's values, exact in both precisions).
@@ -125,6 +125,8 @@ def device_episode(task, n, f64, seed0=None, record_qpos=True):
     seed0 = TASK_SEED[task] if seed0 is None else seed0
     env = make_sim_env("sim_" + task, cameras=[], num_envs=n, f64=f64)
     poses = W.object_poses(task, np.arange(n), seed0)
+    for k, v in (options or {}).items():
+        env.sim.set_option(k, v)
     env.sim.reset(poses)
     obs = env.get_obs()
     q0 = obs["qpos"].reshape(n, -1)

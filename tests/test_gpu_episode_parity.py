@@ -56,3 +56,17 @@ def test_f32_product_mode_success_flags_vs_f64_oracle_128_seeds():
           f"oracle {np.mean([r['orc_success'] for r in rows]):.3f}")
     assert np.mean([r["dev_success"] for r in rows]) >= 0.9
     assert len(mism) <= max(2, n // 50), mism
+
+
+@pytest.mark.parametrize("f64", [False, True])
+def test_coupled_component_factorisation_is_bit_identical(f64):
+    """Newton in a scene where a contact couples two kinematic trees (the needle in the gripper: right arm + needle, 14 of 35 dofs): the
+    dense factorisation and the two substitutions over the coupled component only, the other trees inside their lane octets (the default),
+    against the same over all nv columns (option newton_component = 0).  The entries between the component and the other trees are zeros
+    that stay zeros and every other operation is the same one: whole closed-loop episodes (250 env-steps = 5000 substeps; GradIK amplifies a
+    rounding-level difference to 1e-5 within a step) agree BIT FOR BIT -- ctrl, joint and object positions, rewards, contact counts."""
+    a = U.device_episode("sew_needle", 8, f64=f64)
+    b = U.device_episode("sew_needle", 8, f64=f64, options={"newton_component": 0})
+    assert a["ncon"].max() >= 30 and (a["reward"].max(axis=0) >= 2).sum() >= 7          # the needle is grasped and lifted: coupled scenes
+    for k in ("ctrl", "qpos", "reward", "ncon"):
+        assert np.array_equal(a[k], b[k]), k
