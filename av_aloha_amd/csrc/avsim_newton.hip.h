@@ -269,7 +269,7 @@ AVS_DEV void nblock4_load(const NewtonArgs<real>& A, int lane, int r0, int dim, 
 #pragma unroll
     for (int p = 0; p < 6; p++) Jraw[p] = J[ROW_S * (p < dim ? p : 0) + t];
 }
-template <typename real>
+template <typename real, bool BATCH>
 AVS_DEV void nblock4(const NewtonArgs<real>& A, int lane, int r0, int dim, bool on, bool full, const real* w, int c, const real* cc1, const real* cc2, real cs1, real cs2,
                      const real* Jraw) {
     const int ra = A.rowI[on ? r0 : 0], t = lane & 15, gq = on ? nslot_dof(ra, t) : -1;
@@ -305,6 +305,25 @@ AVS_DEV void nblock4(const NewtonArgs<real>& A, int lane, int r0, int dim, bool 
             }
             return;
         }
+        if constexpr (BATCH) {
+            // (the coupled instance: eight rows' entries fetched from the other lanes at once instead of one row per round trip)
+            for (int s0 = 0; s0 < smax; s0 += 8) {
+                real js[8][6];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+#pragma unroll
+                    for (int p = 0; p < 6; p++) js[u][p] = __shfl(Jt[p], (lane & 48) | (s0 + u), 64);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int gp = nslot_dof(ra, s0 + u);
+                    real acc = 0;
+#pragma unroll
+                    for (int p = 0; p < 6; p++) acc += w[p] * js[u][p] * Jt[p];
+                    if (on && gp >= 0 && gq >= 0 && gq <= gp) __hip_atomic_fetch_add(A.H + gp * (gp + 1) / 2 + gq, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            return;
+        }
         for (int s = 0; s < smax; s++) {
             const int gp = nslot_dof(ra, s);
             real acc = 0;
@@ -322,6 +341,30 @@ AVS_DEV void nblock4(const NewtonArgs<real>& A, int lane, int r0, int dim, bool 
     const real s1 = __shfl(cs1, c & 63, 64), s2 = __shfl(cs2, c & 63, 64);
 #pragma unroll
     for (int p = 0; p < 6; p++) { y1t += c1[p] * Jt[p]; y2t += c2[p] * Jt[p]; }
+    if constexpr (BATCH) {
+        for (int s0 = 0; s0 < smax; s0 += 8) {
+            real jsb[8][6];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int p = 0; p < 6; p++) jsb[u][p] = __shfl(Jt[p], (lane & 48) | (s0 + u), 64);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int gp = nslot_dof(ra, s0 + u);
+                real acc = 0, y1s = 0, y2s = 0;
+#pragma unroll
+                for (int p = 0; p < 6; p++) {
+                    const real js = jsb[u][p];
+                    acc += w[p] * js * Jt[p];
+                    y1s += c1[p] * js;
+                    y2s += c2[p] * js;
+                }
+                if (full) acc += s1 * y1s * y1t - s2 * y2s * y2t;
+                if (on && gp >= 0 && gq >= 0 && gq <= gp) __hip_atomic_fetch_add(A.H + gp * (gp + 1) / 2 + gq, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        return;
+    }
     for (int s = 0; s < smax; s++) {
         const int gp = nslot_dof(ra, s);
         real acc = 0, y1s = 0, y2s = 0;
@@ -827,7 +870,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
                         real w[6];
     #pragma unroll
                         for (int p = 0; p < 6; p++) w[p] = __shfl(cw[ch][p], c & 63, 64);
-                        nblock4<real>(A, lane, head, dim, zn != 0, zn == 2, w, c, cc1[ch], cc2[ch], cs1[ch], cs2[ch], Jraw);
+                        nblock4<real, COUPLED>(A, lane, head, dim, zn != 0, zn == 2, w, c, cc1[ch], cc2[ch], cs1[ch], cs2[ch], Jraw);
                     }
                     c = cn; zn = znn; head = headn; dim = dimn;
     #pragma unroll
@@ -954,6 +997,14 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
     NSYNC();
     NPROF(5);
     return used;
+}
+
+// The coupled instances as functions of their own: what they keep in registers (the component, the batched Hessian rows) then
+// does not weigh on the register allocation of Env::solve, where the uncoupled instance of the headline scene is inlined.
+template <typename real, int NCH>
+__device__ __attribute__((noinline)) int newton_solve_coupled(KPtr<real> ka, GLB_PTR(const real) rows, LDS_PTR(real) r_, LDS_PTR(int) ii_, LDS_PTR(const int) li_, int nefc, int ncon, int nlead,
+                                                              int iters, real tol, real scale, int profiling) {
+    return newton_solve<real, NCH, true>(ka, rows, r_, ii_, li_, nefc, ncon, nlead, iters, tol, scale, profiling);
 }
 
 }  // namespace avs

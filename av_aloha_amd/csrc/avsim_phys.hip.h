@@ -3039,9 +3039,10 @@ struct Env {
             bool two_ = false;
             for (int i = lane; i < nefc; i += G) two_ = two_ || ((rowI[i] >> 19) & 15) != 0;
             const bool coupled = __any(two_) != 0 || ka->m.ntree > 8;
-#define AVS_NEWTON(NCH_, CPL_) newton_solve<real, NCH_, CPL_>(ka, (GLB_PTR(const real))rJ, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0)
-            int used = __builtin_amdgcn_readfirstlane(ncon) <= 64 ? (coupled ? AVS_NEWTON(1, true) : AVS_NEWTON(1, false)) : (coupled ? AVS_NEWTON(2, true) : AVS_NEWTON(2, false));
-#undef AVS_NEWTON
+#define AVS_NEWTON_ARGS ka, (GLB_PTR(const real))rJ, (LDS_PTR(real))r, (LDS_PTR(int))ii, (LDS_PTR(const int))li, nefc, ncon, misc[4], newton_iters, newton_tol, scale, profiling ? 1 : 0
+            int used = __builtin_amdgcn_readfirstlane(ncon) <= 64 ? (coupled ? newton_solve_coupled<real, 1>(AVS_NEWTON_ARGS) : newton_solve<real, 1, false>(AVS_NEWTON_ARGS))
+                                                                  : (coupled ? newton_solve_coupled<real, 2>(AVS_NEWTON_ARGS) : newton_solve<real, 2, false>(AVS_NEWTON_ARGS));
+#undef AVS_NEWTON_ARGS
             nit_sum += used; nit_max = used > nit_max ? used : nit_max;
             GSYNC();
             long long tn0 = profiling ? __builtin_readcyclecounter() : 0;

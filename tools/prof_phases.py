@@ -51,3 +51,4 @@ print("ncon percentiles", np.percentile(d[:, 0], [50, 90, 99, 100]), "newton max
 top = np.argsort(-tot)[: max(1, N // 100)]
 print("slowest 1 % of the envs: total", tot[top].mean().round(0), " phases", (out[top, :8].mean(0) / 20).round(0), " noslip", (out[top, 16].mean() / 20).round(0),
       " narrow", (out[top, 9].mean() / 21).round(0), " ncon", d[top, 0].mean().round(1), " probe slots", (out[top, 18:26].mean(0) / 20).round(1))
+print("   their Newton split:", "  ".join(f"{n} {v:.0f}" for n, v in zip(nn, out[top, 10:18].mean(0) / 20)), f"  iterations/substep {((d[top, 3] >> 16) & 0xfff).mean() / 20:.2f}")
