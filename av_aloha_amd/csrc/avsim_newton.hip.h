@@ -22,7 +22,10 @@
 //             multipliers travel by v_readlane.  Lane nv carries -g as an extra row, so the forward substitution
 //             comes out of the factorisation; the backward substitution reads L's columns back from LDS.  When no row
 //             couples two kinematic trees H is block diagonal: lane 8 t + i then factors / solves tree t's block inside
-//             its octet (nblock_chol / nblock_solve), eight steps instead of nv columns.
+//             its octet (nblock_chol / nblock_solve), eight steps instead of nv columns.  When rows do couple trees (a needle in a
+//             gripper) the dense loops take the dofs of the coupled trees only, one per lane, and the other trees keep their octets
+//             (ncomponent / ndense_chol / nblock_chol_fwd / ncomp_subst; the solver instance for such scenes is a function of its
+//             own, newton_solve_coupled, so that Env::solve carries only the uncoupled one).
 //   search    exact line search: safeguarded 1-D Newton on phi'(alpha); J a and J dl are fixed per iteration, so an
 //             evaluation is a handful of FMAs per lane and two wave-wide DPP sums.
 #pragma once
