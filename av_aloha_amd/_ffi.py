@@ -61,6 +61,7 @@ def lib():
         L.avsim_event_record.argtypes = [vp, i32]
         L.avsim_event_elapsed_ms.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
         L.avsim_kernel_time.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(C.c_int64)]
+        L.avsim_render_kernel_time.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 

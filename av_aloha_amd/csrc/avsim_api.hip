@@ -438,7 +438,7 @@ int avsim_dims(const avsim_t* h, int32_t d[AVSIM_NDIMS]) {
 int avsim_set_option(avsim_t* h, const char* name, double value) {
     if (!h || !name) return AVSIM_EINVAL;
     AVS_ON_DEVICE(h);               // "maxefc" / "maxcon" / "profile_phases" allocate on the handle's device
-    if (!std::strcmp(name, "kernel_timing")) { h->ktiming = value != 0; return AVSIM_OK; }
+    if (!std::strcmp(name, "kernel_timing")) { h->ktiming = value != 0; h->render.timing = value != 0; return AVSIM_OK; }
     if (!std::strcmp(name, "render_proxies")) { h->render_proxies = value != 0; return AVSIM_OK; }
     if (!std::strcmp(name, "diffik_iters")) { h->ik.diff_iters = (int)value; return AVSIM_OK; }
     if (!std::strcmp(name, "gradik_iters")) { h->ik.grad_iters = (int)value; return AVSIM_OK; }
@@ -500,6 +500,22 @@ int avsim_kernel_time(avsim_t* h, int reset, double* total_ms, int64_t* launches
     if (total_ms) *total_ms = tot;
     if (launches) *launches = (int64_t)(h->kev_used / 2);
     if (reset) h->kev_used = 0;
+    return AVSIM_OK;
+}
+
+int avsim_render_kernel_time(avsim_t* h, int reset, double* total_ms, int64_t* launches) {
+    if (!h) return AVSIM_EINVAL;
+    AVS_ON_DEVICE(h);
+    double tot = 0;
+    for (size_t i = 0; i + 1 < h->render.tev_used; i += 2) {
+        float ms = 0;
+        HIPCHK(h, hipEventSynchronize(h->render.tev[i + 1]));
+        HIPCHK(h, hipEventElapsedTime(&ms, h->render.tev[i], h->render.tev[i + 1]));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int64_t)(h->render.tev_used / 2);
+    if (reset) h->render.tev_used = 0;
     return AVSIM_OK;
 }
 
@@ -822,9 +838,9 @@ int avsim_visual_info(avsim_t* h, int32_t info[4]) {
     if (!h || !info) return AVSIM_EINVAL;
     AVS_ON_DEVICE(h);
     info[0] = h->vis.loaded ? h->vis.S.ntri : 0; info[1] = h->vis.loaded ? h->vis.S.nvert : 0; info[2] = 0; info[3] = h->vis.have_inst ? (int)h->vis.inst_mesh.size() : 0;
-    if (h->vis.loaded && h->vis.X.flags && h->vis.nviews_cap > 0) {
+    if (h->vis.loaded && h->vis.X.flags && h->vis.last_nviews > 0) {      // the views of the LAST launch only: rows beyond them hold an earlier, larger call's flags
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        std::vector<int> f((size_t)h->vis.nviews_cap * 8);
+        std::vector<int> f((size_t)h->vis.last_nviews * 8);
         HIPCHK(h, hipMemcpy(f.data(), h->vis.X.flags, f.size() * sizeof(int), hipMemcpyDeviceToHost));
         for (size_t v = 0; v < f.size(); v += 8) info[2] |= f[v];
     }

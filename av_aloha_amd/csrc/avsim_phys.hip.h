@@ -3861,7 +3861,7 @@ struct PhysHost {
             if (n == "maxefc") maxefc = maxefc1 = x; else if (n == "maxcon") maxcon = maxcon1 = x;
             else if (n == "maxefc_first") maxefc1 = x < maxefc ? x : maxefc; else maxcon1 = x < maxcon ? x : maxcon;
             make_layout(dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], dims[6]);
-            try { alloc_contacts(); } catch (...) { return false; }
+            alloc_contacts();           // a failed hipMalloc throws: avsim_set_option reports it as AVSIM_EHIP, not as an unknown option
             return true;
         }
         return false;

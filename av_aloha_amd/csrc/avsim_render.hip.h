@@ -778,6 +778,10 @@ struct RenderHost {
     int* d_cam_ids = nullptr;
     size_t recs_cap = 0;
     int N = 0;
+    // option "kernel_timing": HIP events around every k_render_depth launch on the launch stream (avsim_render_kernel_time)
+    bool timing = false;
+    std::vector<hipEvent_t> tev;
+    size_t tev_used = 0;
 
     template <typename T>
     T* up(const std::vector<T>& v) {
@@ -890,6 +894,8 @@ struct RenderHost {
     void destroy() {
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
+        for (auto& ev : tev) (void)hipEventDestroy(ev);
+        tev.clear(); tev_used = 0;
         if (d_recs) (void)hipFree(d_recs);
         if (d_counts) (void)hipFree(d_counts);
         if (d_order) (void)hipFree(d_order);
@@ -928,6 +934,10 @@ struct RenderHost {
         hipLaunchKernelGGL(k_render_geoms, dim3(ncam_sel, N), dim3(64), 0, st, m, (const float*)d_xpose, (const int*)d_cam_ids, ncam_sel, H, W, d_recs, d_counts, d_order, d_tplanes, d_camaux, d_fbox, d_sedge);
         const int bin_tx = bin_width((W + TILE_W - 1) / TILE_W);
         const int tiles = (((W + TILE_W - 1) / TILE_W + bin_tx - 1) / bin_tx) * (((H + TILE_H - 1) / TILE_H + BIN_TY - 1) / BIN_TY);     // bins
+        if (timing) {
+            while (tev.size() < tev_used + 2) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) { err = "hipEventCreate failed"; return -3; } tev.push_back(ev); }
+            (void)hipEventRecord(tev[tev_used], st);
+        }
         if (rgb)
             hipLaunchKernelGGL(k_render_depth<true>, dim3(tiles, ncam_sel, N), dim3(256), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, (const float4*)d_fbox, (const float4*)d_sedge, m.nplane, m.nedge,
                                m.cam_fovy, (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, (float*)nullptr, m.geom_rgba, m.light, (const float*)d_camaux, (unsigned char*)d_out, bin_tx);
@@ -936,6 +946,7 @@ struct RenderHost {
                                m.cam_fovy, (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, (float*)d_out, m.geom_rgba, m.light, (const float*)d_camaux, (unsigned char*)nullptr, bin_tx);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("render kernel launch: ") + hipGetErrorString(e); return -3; }
+        if (timing) { (void)hipEventRecord(tev[tev_used + 1], st); tev_used += 2; }
 #ifdef AVSIM_RENDER_STATS
         {
             unsigned long long hst[8];

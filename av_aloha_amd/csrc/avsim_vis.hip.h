@@ -388,7 +388,7 @@ struct VisHost {
     VisScene S{};
     VisScratch X{};
     std::vector<void*> allocs;
-    int slots = 0, nviews_cap = 0;
+    int slots = 0, max_slots = 0, nviews_cap = 0, last_nviews = 0;     // scratch slots allocated / the most a launch uses (4 x CUs); flag rows allocated / written by the last launch
     bool attr_done = false;
     int* d_cam_ids = nullptr;
 
@@ -450,7 +450,7 @@ struct VisHost {
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
         for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.flags, (void*)d_cam_ids}) if (p) (void)hipFree(p);
-        X = VisScratch{}; d_cam_ids = nullptr; loaded = false; slots = 0; nviews_cap = 0;
+        X = VisScratch{}; d_cam_ids = nullptr; loaded = false; slots = 0; max_slots = 0; nviews_cap = 0; last_nviews = 0;
     }
     // overflow flags of the last launch, OR over the views (bit 0: triangle records, bit 1: tile lists); synchronises the stream
     int launch(hipStream_t st, int N, const float* d_xpose, const int* cam_ids_host, int ncam_sel, int ncam_model, int H, int W, void* d_out, std::string& err) {
@@ -461,16 +461,30 @@ struct VisHost {
         for (int c = 0; c < ncam_sel; c++)
             if (cam_ids_host[c] < 0 || cam_ids_host[c] >= ncam_model) { err = "avsim_render_rgb: camera index out of range"; return -1; }
         const int nviews = N * ncam_sel;
-        if (!slots) {
+        if (!max_slots) {
             int dev = 0, cus = 256;
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-            slots = 4 * cus;
+            max_slots = 4 * cus;
             X.reccap = S.ntri + 2048;                  // near-plane clipping can split a triangle in two
             X.listcap = 8 * S.ntri + 4 * VIS_MAXTILES;
-            if (hipMalloc((void**)&X.vcam, (size_t)slots * S.nvert * sizeof(float4)) != hipSuccess || hipMalloc((void**)&X.rec, (size_t)slots * X.reccap * 4 * sizeof(float4)) != hipSuccess ||
-                hipMalloc((void**)&X.bbox, (size_t)slots * X.reccap * 4 * sizeof(int)) != hipSuccess || hipMalloc((void**)&X.list, (size_t)slots * X.listcap * sizeof(int)) != hipSuccess ||
-                hipMalloc((void**)&d_cam_ids, 16 * sizeof(int)) != hipSuccess) { err = "hipMalloc(visual render scratch) failed"; slots = 0; return -3; }
+            if (hipMalloc((void**)&d_cam_ids, 16 * sizeof(int)) != hipSuccess) { err = "hipMalloc(visual render camera ids) failed"; max_slots = 0; return -3; }
+        }
+        // per-slot scratch (camera-frame vertices, triangle records, their boxes, tile lists: ~2.8 MB a slot for the 20 k-triangle
+        // scenes) for as many workgroups as this call can use -- a single env with one camera holds one slot, not 4 x CUs of them
+        // (2.9 GB per handle: a vector env of single-env handles ran out of HBM); regrown when a later call has more views
+        const int want = nviews < max_slots ? nviews : max_slots;
+        if (want > slots) {
+            if (hipStreamSynchronize(st) != hipSuccess) { err = "visual render: stream synchronisation failed"; return -3; }
+            for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list}) if (p) (void)hipFree(p);
+            X.vcam = nullptr; X.rec = nullptr; X.bbox = nullptr; X.list = nullptr; slots = 0;
+            if (hipMalloc((void**)&X.vcam, (size_t)want * S.nvert * sizeof(float4)) != hipSuccess || hipMalloc((void**)&X.rec, (size_t)want * X.reccap * 4 * sizeof(float4)) != hipSuccess ||
+                hipMalloc((void**)&X.bbox, (size_t)want * X.reccap * 4 * sizeof(int)) != hipSuccess || hipMalloc((void**)&X.list, (size_t)want * X.listcap * sizeof(int)) != hipSuccess) {
+                for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list}) if (p) (void)hipFree(p);
+                X.vcam = nullptr; X.rec = nullptr; X.bbox = nullptr; X.list = nullptr;
+                err = "hipMalloc(visual render scratch) failed"; return -3;
+            }
+            slots = want;
         }
         if (nviews > nviews_cap) {
             if (X.flags) (void)hipFree(X.flags);
@@ -478,6 +492,7 @@ struct VisHost {
             if (hipMalloc((void**)&X.flags, (size_t)nviews * 8 * sizeof(int)) != hipSuccess) { err = "hipMalloc(visual render flags) failed"; nviews_cap = 0; return -3; }
             nviews_cap = nviews;
         }
+        last_nviews = nviews;
         if (hipMemsetAsync(X.flags, 0, (size_t)nviews * 8 * sizeof(int), st) != hipSuccess || hipMemcpyAsync(d_cam_ids, cam_ids_host, ncam_sel * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { err = "visual render set-up copy failed"; return -3; }
         const int grid = nviews < slots ? nviews : slots;
         const size_t shmem = (size_t)(2 * ntile + 1) * sizeof(int);

@@ -136,6 +136,12 @@ class BatchedSim:
         ids = np.array([names.index(c) if isinstance(c, str) else int(c) for c in cameras], dtype=np.int32)
         out = np.empty((self.N, len(ids), height, width, 3), dtype=np.uint8)
         self.h.check(self.h.L.avsim_render_rgb(self.h.h, ids.ctypes.data, len(ids), height, width, out.ctypes.data))
+        if visual:
+            ov = self.visual_info()["overflow"]
+            if ov:          # the image lacks triangles: say so instead of handing a policy a silently incomplete observation
+                import warnings
+                warnings.warn(f"avsim_render_rgb: a view ran out of {'triangle records' if ov & 1 else ''}{' and ' if ov == 3 else ''}{'tile-list entries' if ov & 2 else ''} "
+                              f"at {height}x{width}: triangles were dropped from the image", RuntimeWarning, stacklevel=2)
         return out
 
     def reward_from_pairs(self, geom_pairs, latch=None):

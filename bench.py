@@ -15,6 +15,7 @@ generators live in av_aloha_amd/workloads.py):
 Inputs (the action tensors) and all state are resident in HBM before the timed region starts; nothing crosses PCIe inside it.
 
     python bench.py --gpus 1 --steps 100 --warmup 10
+    python bench.py --gpus 8 ...            (no launcher: starts the 8 ranks itself through torch.distributed.run, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit/..., plus
@@ -259,17 +260,19 @@ class Workload:
         self.h.close()
 
 
-def side_run(args, torch, cfg_id, N, local, f64, warmup, steps):
+def side_run(args, torch, cfg_id, N, local, f64, warmup, steps, render=""):
     """A short run of another configuration / precision on this GPU, for the extra fields of the bench line (single rank):
-    -> (env-steps/s, ms per step, mean k_phys launch ms, diagnostics)."""
-    w = Workload(args, cfg_id, N, 0, 1, local, f64, warmup + steps, torch)
+    -> (env-steps/s, ms per step, mean k_phys launch ms, diagnostics; with `render` the depth images' time and write rate too)."""
+    w = Workload(args, cfg_id, N, 0, 1, local, f64, warmup + steps, torch, render)
     for t in range(warmup):
         w.step(t)
+        w.render(False)
     w.begin_timed()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(warmup, warmup + steps):
         w.step(t)
+        w.render(True)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     k_ms, k_n = w.kernel_time()
@@ -277,8 +280,39 @@ def side_run(args, torch, cfg_id, N, local, f64, warmup, steps):
     info = {"value": N * steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warmup, "kernel_avg_ms": k_ms / max(1, k_n),
             "mean_ncon": float(dg[:, 0].mean()), "mean_nefc": float(dg[:, 1].mean()), "nan_envs": int((w.diverged & 1).sum().item()),
             "resets_in_timed_region": w.resets, "mean_return": float(w.ret.mean().item()), "success_rate": float(w.succ_any.float().mean().item())}
+    if w.depth is not None:
+        r_ms = sum(a.elapsed_time(b) for a, b in w.r_events) / max(1, len(w.r_events))
+        r_bytes = w.depth.numel() * 4
+        k_rd_ms, k_rd_n = C.c_double(0), C.c_int64(0)
+        w.h.check(w.L.avsim_render_kernel_time(w.h.h, 1, C.byref(k_rd_ms), C.byref(k_rd_n)))
+        info.update({"render": f"{w.rH}x{w.rW} f32 x 4 cameras", "render_call_ms": r_ms, "render_bytes_per_step": r_bytes,
+                     "render_call_frac_of_hbm_write_roof": r_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "k_render_depth_ms": k_rd_ms.value / max(1, k_rd_n.value) if k_rd_n.value else None,
+                     "k_render_depth_frac_of_hbm_write_roof": (r_bytes / (k_rd_ms.value / k_rd_n.value * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_rd_n.value else None,
+                     "hit_fraction": float((w.depth < 29.9).float().mean().item())})
     w.close()
     return info
+
+
+def launch_ranks(n, share_gpu):
+    """Re-run this command line as n ranks of one node through torch.distributed.run (rendezvous on 127.0.0.1, a free port), the
+    form the driver itself uses for N > 1.  Fails loudly when the node has fewer GPUs than ranks (unless --share-gpu)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and not share_gpu:
+        print(f"bench.py: --gpus {n} needs {n} GPUs on this node, {have} visible (--share-gpu runs every rank on cuda:0: a testing aid, not a measurement)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -303,14 +337,23 @@ def main():
     ap.add_argument("--dump", default="", help="testing aid: rank 0 saves the gathered per-env returns / successes to this .npz")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU) and pass their
+        # exit code on; rank 0 of the child world prints the line
+        raise SystemExit(launch_ranks(args.gpus, args.share_gpu))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the simulation path has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if args.share_gpu:
         local = 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} (LOCAL_RANK {local}) has no GPU: {torch.cuda.device_count()} visible; --share-gpu puts every rank on cuda:0 (testing aid)")
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or args.dist_always:
@@ -376,6 +419,7 @@ def main():
         elapsed = float(tt.item())
         n_ranks_seen = dist.get_world_size()
 
+    assert n_ranks_seen == world == args.gpus, (n_ranks_seen, world, args.gpus)
     if rank == 0:
         if args.dump:
             np.savez(args.dump, ret=all_ret.cpu().numpy(), succ=all_succ.cpu().numpy(), agent_sum=all_agent.cpu().numpy())
@@ -407,6 +451,7 @@ def main():
         except Exception:
             pass
         kflops_step = kf.get("flops_per_env_step")
+        valu_k_tflops = kflops_step * N / k_avg_s / 1e12 if (kflops_step and k_avg_s > 0) else None
         headline = args.config == 2
         workload = {
             2: f"{cfg['gym_id']} (BASELINE configs[1] at the metric's 4096 envs): 23-D Cartesian action -> DLS IK on 3 arms -> 20 substeps (dt 0.002) + agent_pos + reward/success, no render",
@@ -418,7 +463,7 @@ def main():
             "metric": "env-steps/sec (whole node) at 4096 parallel envs, SlotInsertion-3Arms" if headline else
                       f"env-steps/sec (whole node), {cfg['gym_id'].split('/')[1]} workload of SURVEY 8(d) config {args.config} (not the headline metric)",
             "is_headline_metric": headline,
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "value_per_gpu": value / world, "unit": "env-steps/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": workload,
@@ -435,8 +480,13 @@ def main():
                        "envs_with_8_contacts_for_100_steps": float((w.rich >= 100).float().mean().item()) if args.config == 3 else None,
                        "gathered_envs": int(all_ret.numel()), "mean_return": float(all_ret.mean().item()),
                        "success_rate": float(all_succ.to(torch.float32).mean().item())},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            # what bounds k_phys is the issue rate and latency of one wave's dependent VALU / LDS chain (neither HBM nor
+            # MFMA): `frac` is the kernel's own floating-point work against the vector peak; the HBM view the contract asks for
+            # (algorithmic bytes per launch / launch time against 8 TB/s) is kept next to it as hbm_*
+            "roofline": {"bound": "valu+latency", "achieved": valu_k_tflops, "peak": VALU_PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                         "frac": valu_k_tflops / VALU_PEAK_TFLOPS[dtype] if valu_k_tflops is not None else None,
+                         "hbm_achieved": achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_over_algorithmic": traffic / (abytes * N) if traffic else None,
                          "kernel": f"k_phys<{'double' if args.f64 else 'float'}>", "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": int(k_n),
                          "algorithmic_bytes_per_launch": abytes * N,
@@ -447,11 +497,11 @@ def main():
                          # the kernel's OWN arithmetic (its sparse row windows and per-tree solves, not the oracle's dense rows):
                          # floating-point VALU instructions the SQ counted for k_phys x lanes active, per env-step
                          "valu_flops_per_env_step_kernel": kflops_step,
-                         "valu_frac_kernel": kflops_step * N / k_avg_s / 1e12 / VALU_PEAK_TFLOPS[dtype] if (kflops_step and k_avg_s > 0) else None,
+                         "valu_frac_kernel": valu_k_tflops / VALU_PEAK_TFLOPS[dtype] if valu_k_tflops is not None else None,
                          "valu_lane_utilisation": kf.get("lane_utilisation"),
                          "kernel_flops_source": kf.get("source"),
                          "note": "state stays in LDS across the 20 substeps, so HBM sees ~1 KB per env-step; the kernel is "
-                                 "VALU/LDS-latency bound (SURVEY 8d), the HBM fraction is reported because the contract asks for it; "
+                                 "VALU/LDS-latency bound (SURVEY 8d): frac = valu_frac_kernel; hbm_frac is reported because the contract asks for it; "
                                  "valu_frac uses the flops counted in the oracle's instrumented dense build (profiles/flop_counts.json), "
                                  "valu_frac_kernel the kernel's own floating-point instruction counts (profiles/kernel_flops.json)"},
         }
@@ -483,6 +533,9 @@ def main():
             c4 = side_run(args, torch, 4, N, local, False, 10, 100)
             out["config4_value"] = c4["value"]
             out["config4"] = {**c4, "note": "HookPackage-2Arms 14-D joint random walk, this GPU's 4096-env shard (BASELINE configs[3])"}
+            c5 = side_run(args, torch, 5, N, local, False, 2, 10, RENDER_DEFAULT)
+            out["config5_value"] = c5["value"]
+            out["config5"] = {**c5, "note": "config 2 + depth images of zed_cam_left/right + wrist_cam_left/right at 480x640 f32 every step (BASELINE configs[4]); 4.9 MB of depth per env-step: HBM-write bound by construction (SURVEY 8d)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, n_total, home, 1 if args.solver == "newton" else 0)
         elif world > 1:

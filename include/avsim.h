@@ -149,11 +149,14 @@ int avsim_get_phase_cycles(avsim_t* h, int64_t* out);
 int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, float* out);
 
 /* The same cameras as colour images, the layout of the reference's "pixels" observation and of render()
- * (env.py:180-188, :195-200): out = uint8[N][ncam][height][width][3] (RGB).  Drawn are the collision proxies in their flat
- * material colours (rgba / material of the MJCF; the textured table in one colour; robot links in the colour of the
- * visual meshes they stand in for), lit by the scene's headlight (scene.xml:9) and directional light (scene.xml:48) with
- * Lambert terms, over the skybox gradient (scene.xml:34); no textures, shadows, specular terms or transparency, so the
- * images are a stand-in for MuJoCo's OpenGL output, not a pixel match.  Pointer conventions as avsim_render_depth. */
+ * (env.py:180-188, :195-200): out = uint8[N][ncam][height][width][3] (RGB).  Once avsim_load_visual has run (the Python facades
+ * do that on first use) the VISUAL scene is rasterised: the decimated visual meshes of the robots, the frame and camera mounts,
+ * the textured table, the task objects (k_vis_render; flat Lambert shading under the scene's headlight scene.xml:9 and directional
+ * light :48, table texture, skybox gradient :34).  Without a loaded visual scene, or with option "render_proxies" 1, the collision
+ * proxies are drawn in their flat material colours instead (the depth rasteriser's colour variant).  Neither has shadows, specular
+ * terms, anti-aliasing or transparency: a stand-in for MuJoCo's OpenGL output, not a pixel match.  A view that runs out of triangle
+ * records or tile-list entries sets the overflow flags of avsim_visual_info (the image then lacks triangles).  Pointer conventions
+ * as avsim_render_depth. */
 int avsim_render_rgb(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, uint8_t* out);
 /* The visual scene of avsim_render_rgb (env.py:180-188, :195-200 draw the visual meshes of aloha_sim.xml class
  * "visual", the frame and the textured table of scene.xml, the task objects): library_blob = models/visual_meshes.avv, the decimated
@@ -185,6 +188,9 @@ int avsim_event_elapsed_ms(avsim_t* h, int slot_a, int slot_b, float* ms); /* sy
  * HIP events around every launch (on the launch stream, no per-launch synchronisation) when enabled via
  * avsim_set_option("kernel_timing", 1); this call synchronises on the recorded events */
 int avsim_kernel_time(avsim_t* h, int reset, double* total_ms, int64_t* launches);
+/* the same for the image kernel of avsim_render_depth / the proxy mode of avsim_render_rgb (k_render_depth alone: the pose pass
+ * and the per-view set-up kernel in front of it are not in the figure) */
+int avsim_render_kernel_time(avsim_t* h, int reset, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -77,3 +77,25 @@ def test_rccl_collectives_execute_for_a_world_of_one_rank(tmp_path):
     a, b = np.load(dn), np.load(d1)
     for k in ("ret", "succ", "agent_sum"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2` with no torch.distributed.run in front (the shape of the driver's N = 1 command): bench.py starts the
+    two ranks itself, one process per GPU (here --share-gpu / gloo: both on the one GPU of the test box), and the line says so."""
+    d2 = str(tmp_path / "self.npz")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--config", "4", "--steps", "4", "--warmup", "1",
+           "--no-cpu-baseline", "--envs-per-gpu", "256", "--dump", d2]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == r["n_ranks_seen"] == 2 and r["config"]["envs_total"] == 512 and r["config"]["gathered_envs"] == 512
+    assert abs(r["value_per_gpu"] * 2 - r["value"]) < 1e-6 * r["value"]
+    # without --share-gpu the one-GPU box must refuse, loudly, instead of printing n_gpus: 1
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert out.returncode != 0 and "needs 2 GPUs" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -142,3 +142,18 @@ def test_data_collection_model_variant():
             assert a["geom_solref"].reshape(-1, 2)[g, 0] == 0.01 and b["geom_solref"].reshape(-1, 2)[g, 0] == 0.02       # MuJoCo default 0.02 1
             changed = np.nonzero(np.any(a["pair_solref"].reshape(-1, 2) != b["pair_solref"].reshape(-1, 2), axis=1))[0]
             assert len(changed) > 0 and all(g in a["pair_geom"].reshape(-1, 2)[p] for p in changed)                      # only pairs of that geom
+
+
+def test_bench_gpus_flag_refuses_a_node_with_fewer_gpus():
+    """bench.py --gpus N starts N ranks itself (one process per GPU); on a node with fewer GPUs it must fail loudly and
+    print no line (it used to ignore the flag and report n_gpus: 1)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        return
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "needs 2 GPUs" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
