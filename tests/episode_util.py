@@ -13,14 +13,16 @@ from av_aloha_amd import workloads as W
 from orc_env import OrcEnv
 from orc_ffi import dp
 
-TASK_SEED = {"slot_insertion": 1000, "sew_needle": 2000}
+TASK_SEED = {"slot_insertion": 1000, "sew_needle": 2000, "insert_peg": 4000, "hook_package": 3000, "sew_needle_thread": 2000}
+SCRIPT_KW = {}                    # development aid (tools/dev_script.py): keyword overrides of the script's parameters
+MODEL_OF = {"sew_needle_thread": "sew_needle"}      # script name -> task model (SewNeedle has two scripts: config 3's lift, the whole threading)
 GRIP_RANGE = (0.002, 0.037)
 VARIANT = "data_collection"        # the model av_aloha_amd.sim_env runs (data_collection_scripts/assets, as the reference's sim_env.py)
 
 
 def oracle_home(task="slot_insertion"):
     """{'left','right','middle'} -> [7] eef poses (xyz + quat wxyz) at the home ctrl, through the oracle's FK (kinematics.py:17-24)."""
-    e = OrcEnv(task, 3, VARIANT)
+    e = OrcEnv(MODEL_OF.get(task, task), 3, VARIANT)
     ch = np.array(e.ctrl, dtype=np.float64)
     Ts = []
     for arm, sl in ((0, slice(0, 6)), (1, slice(7, 13)), (2, slice(14, 21))):
@@ -39,6 +41,11 @@ def make_script(task, home, qpos0):
     if task == "slot_insertion":
         from scripted import SlotInsertionScript
         return SlotInsertionScript(home, qpos0)
+    if task in ("insert_peg", "hook_package", "sew_needle_thread"):
+        import scripted
+        cls = {"insert_peg": scripted.InsertPegScript, "hook_package": getattr(scripted, "HookPackageScript", None),
+               "sew_needle_thread": getattr(scripted, "SewNeedleThreadScript", None)}[task]
+        return cls(home, qpos0, **SCRIPT_KW)
 
     class Lift:
         def __init__(self):
@@ -55,7 +62,7 @@ def make_script(task, home, qpos0):
 
 
 def _new_env(task, pose):
-    e = OrcEnv(task, 3, VARIANT)
+    e = OrcEnv(MODEL_OF.get(task, task), 3, VARIANT)
     e.d.solver = 1                  # Newton, the reference's solver (MuJoCo default; aloha_sim.xml:4 does not change it)
     e.reset(pose)
     return e
@@ -123,8 +130,8 @@ def device_episode(task, n, f64, seed0=None, record_qpos=True, options=None):
     -> dict(poses, home, ctrl, reward [T, n], success [T, n], qpos [T, n, nq], ncon [T, n], diverged [n], capped [n])"""
     from av_aloha_amd.sim_env import make_sim_env
     seed0 = TASK_SEED[task] if seed0 is None else seed0
-    env = make_sim_env("sim_" + task, cameras=[], num_envs=n, f64=f64)
-    poses = W.object_poses(task, np.arange(n), seed0)
+    env = make_sim_env("sim_" + MODEL_OF.get(task, task), cameras=[], num_envs=n, f64=f64)
+    poses = W.object_poses(MODEL_OF.get(task, task), np.arange(n), seed0)
     for k, v in (options or {}).items():
         env.sim.set_option(k, v)
     env.sim.reset(poses)

@@ -85,3 +85,113 @@ class SlotInsertionScript:
         a[:, 16:23] = self.home["middle"]
         self.t += 1
         return a
+
+
+# ---- the other task families (north_star: success flags for InsertPeg, SewNeedle, HookPackage as well) -----------------------------
+def quat_rot(q, v):
+    """Rotate v [n, 3] by unit quaternions q [n, 4] (w x y z)."""
+    w, u = q[:, :1], q[:, 1:]
+    t = 2.0 * np.cross(u, v)
+    return v + w * t + np.cross(u, t)
+
+
+def yaw_quat(yaw):
+    n = len(yaw)
+    return np.stack([np.cos(yaw / 2), np.zeros(n), np.zeros(n), np.sin(yaw / 2)], axis=1)
+
+
+class _Phases:
+    """Phase clock shared by the scripts: T = step counts; phase() -> (index, fraction done in (0, 1])."""
+    T = ()
+
+    def phase(self):
+        t = self.t
+        for k, d in enumerate(self.T):
+            if t < d:
+                return k, (t + 1) / d
+            t -= d
+        return len(self.T) - 1, 1.0
+
+    def steps(self):
+        return sum(self.T)
+
+    def _down(self, home):
+        n = self.n
+        c, s = np.cos(np.pi / 4), np.sin(np.pi / 4)
+        self.down_r = np.stack([qmul(np.array([c, 0.0, -s, 0.0]), home["right"][i, 3:]) for i in range(n)])
+        self.down_l = np.stack([qmul(np.array([c, 0.0, s, 0.0]), home["left"][i, 3:]) for i in range(n)])
+
+    def _assemble(self, lpos, lquat, lgrip, rpos, rquat, rgrip):
+        a = np.zeros((self.n, 23))
+        a[:, 0:3], a[:, 3:7], a[:, 7] = lpos, lquat, lgrip
+        a[:, 8:11], a[:, 11:15], a[:, 15] = rpos, rquat, rgrip
+        a[:, 16:23] = self.home["middle"]
+        self.t += 1
+        return a
+
+
+def ramp(f, frac=0.8):
+    return min(1.0, f / frac)
+
+
+PINCH = 0.135          # control site (wrist, aloha_sim.xml:249) -> pinch point between the finger pads (:248: 0.13 along the gripper)
+
+
+class InsertPegScript(_Phases):
+    """InsertPeg (task_insert_peg.xml; reward stages env.py:453-462): the right arm grasps the peg (12 x 2 x 2 cm, lying along x)
+    `side` metres off its centre towards its own base, the left arm the square tube (`hole`, 12 cm long, 3.6 cm clear inside) as far off
+    its centre, both with the gripper pitched `pitch` radians below the horizontal (pointing straight down, the wrist-camera mounts on
+    the grippers' backs face each other and meet 18 cm apart); both lift (reward 2), the tube is carried to a fixed place above the
+    table, the peg in front of its mouth, and the peg's free end is pushed `depth` metres into it (peg touches the tube: 3; peg overlaps
+    the `pin` box that fills the tube's middle 8 cm: 4 = success).  Closed loop on the measured poses (qpos[23:30] peg, [30:37] hole):
+    while aligning and inserting, the right hand's target integrates the error between the peg's free end and the point on the tube's
+    axis it should be at, so that the sag of the off-centre grasps and the IK's residual do not matter."""
+    T = (50, 40, 25, 45, 70, 40, 60, 20)
+
+    def __init__(self, home, qpos, side=0.03, carry=0.12, depth=0.05, gain=0.15, clip=0.06, pitch=0.85):
+        self.n = n = qpos.shape[0]
+        self.home = home
+        c, s = np.cos(pitch / 2), np.sin(pitch / 2)
+        self.quat_r = np.stack([qmul(np.array([c, 0.0, -s, 0.0]), home["right"][i, 3:]) for i in range(n)])
+        self.quat_l = np.stack([qmul(np.array([c, 0.0, s, 0.0]), home["left"][i, 3:]) for i in range(n)])
+        # control site relative to the pinch point: back along the gripper's axis (the left arm faces +x, the right arm -x)
+        self.site_l = PINCH * np.array([-np.cos(pitch), 0.0, np.sin(pitch)])
+        self.site_r = PINCH * np.array([np.cos(pitch), 0.0, np.sin(pitch)])
+        self.peg0, self.hole0 = qpos[:, 23:26].copy(), qpos[:, 30:33].copy()
+        self.side, self.carry, self.depth, self.gain, self.clip = side, carry, depth, gain, clip
+        self.corr = np.zeros((n, 3))
+        self.t = 0
+
+    def action(self, qpos):
+        n = self.n
+        k, f = self.phase()
+        peg, pegq, hole, holeq = qpos[:, 23:26], qpos[:, 26:30], qpos[:, 30:33], qpos[:, 33:37]
+        ex = np.tile([1.0, 0.0, 0.0], (n, 1))
+        # pinch points: the peg a little above mid height, the tube above its axis (finger tips clear of the table)
+        pr = self.peg0 + np.array([self.side, 0.0, 0.004])
+        pl = self.hole0 + np.array([-self.side, 0.0, 0.008])
+        up = np.array([0.0, 0.0, 1.0])
+        meet = np.array([-0.06, 0.0])                               # where the tube is held: xy of its centre
+        if k == 0:
+            pr, pl, g = pr + 0.10 * up, pl + 0.10 * up, 0.0
+        elif k == 1:
+            pr, pl, g = pr + 0.10 * (1 - ramp(f)) * up, pl + 0.10 * (1 - ramp(f)) * up, 0.0
+        elif k == 2:
+            g = ramp(f, 0.6)
+        elif k == 3:
+            pr, pl, g = pr + self.carry * ramp(f) * up, pl + self.carry * ramp(f) * up, 1.0
+        else:
+            g = 1.0
+            s = ramp(f) if k == 4 else 1.0
+            # the peg's free end `gap` metres in front of the tube's mouth, then `depth` inside
+            gap = 0.02 if k <= 5 else (0.02 - (0.02 + self.depth) * ramp(f) if k == 6 else -self.depth)
+            dl = np.concatenate([meet - self.hole0[:, :2], np.zeros((n, 1))], axis=1)
+            dr = np.concatenate([meet + np.array([0.12 + gap, 0.0]) - self.peg0[:, :2], np.reshape(self.hole0[:, 2] - self.peg0[:, 2], (n, 1))], axis=1)
+            pl = pl + self.carry * up + s * dl
+            pr = pr + self.carry * up + s * dr
+            if k >= 5:
+                tip = peg - 0.06 * quat_rot(pegq, ex)
+                goal = hole + (0.06 + gap) * quat_rot(holeq, ex)      # where the peg's free end should be on the tube's axis
+                self.corr = np.clip(self.corr + self.gain * (goal - tip), -self.clip, self.clip)
+            pr = pr + self.corr
+        return self._assemble(pl + self.site_l, self.quat_l, g, pr + self.site_r, self.quat_r, g)
