@@ -195,3 +195,72 @@ class InsertPegScript(_Phases):
                 self.corr = np.clip(self.corr + self.gain * (goal - tip), -self.clip, self.clip)
             pr = pr + self.corr
         return self._assemble(pl + self.site_l, self.quat_l, g, pr + self.site_r, self.quat_r, g)
+
+
+class HookPackageScript(_Phases):
+    """HookPackage (task_hook_package.xml; reward stages env.py:851-862): both arms take the package from its sides, grippers horizontal
+    (the home orientation: the left arm faces +x, the right arm -x, fingers open along y) pinching the 3 cm thick body 1.5 cm in from its
+    edges at mid height; both lift (reward 2), carry it in front of the hook's tip with the loop on top of the package (2 x 2 cm clear)
+    on the hook's axis, and push it `along` metres up the hook towards the wall (package touches the hook: 3; the pin box in the loop
+    overlaps the pin cylinder inside the hook: 4 = success); then both let go and back off, and the package hangs on the hook.
+    Closed loop on the measured poses (qpos[23:30] hook, [30:37] package): from the approach on, both hands' targets integrate the
+    error between the loop's centre and the point of the hook's axis it should be at."""
+    T = (30, 35, 40, 25, 50, 60, 50, 60, 20, 40)
+    AXIS = np.array([0.0, -np.sin(1.3), np.cos(1.3)])     # hook cylinder's axis in the hook body's frame (euler="1.3 0 0"), towards the tip
+    LOOP = np.array([0.0, 0.0, 0.11])                      # centre of the loop's opening in the package frame
+
+    def __init__(self, home, qpos, inset=0.015, along=0.05, gain=0.15, clip=0.06, lift=0.04):
+        self.n = n = qpos.shape[0]
+        self.home = home
+        self.pkg0 = qpos[:, 30:33].copy()
+        self.inset, self.along, self.gain, self.clip, self.lift = inset, along, gain, clip, lift
+        self.corr = np.zeros((n, 3))
+        self.t = 0
+
+    def action(self, qpos):
+        n = self.n
+        k, f = self.phase()
+        hook, hookq, pkg, pkgq = qpos[:, 23:26], qpos[:, 26:30], qpos[:, 30:33], qpos[:, 33:37]
+        ax = quat_rot(hookq, np.tile(self.AXIS, (n, 1)))
+        loop = pkg + quat_rot(pkgq, np.tile(self.LOOP, (n, 1)))
+        ex = np.array([1.0, 0.0, 0.0])
+        body = self.pkg0 + np.array([0.0, -0.01, 0.05])             # centre of the package's body (package-1) at reset
+        pl, pr = body - (0.05 - self.inset) * ex, body + (0.05 - self.inset) * ex
+        g = 0.0
+        k -= 1
+        if k < 0:         # at the height of the home pose to the sides of the package (the home pose's pinch points can be right above it)
+            pl, pr = pl - 0.05 * ex, pr + 0.05 * ex
+            pl[:, 2] = pr[:, 2] = self.home["left"][:, 2]
+        elif k == 0:      # down beside the package, clear of its edges
+            pl, pr = pl - 0.05 * ex, pr + 0.05 * ex
+            pl[:, 2] = pr[:, 2] = self.home["left"][:, 2] + ramp(f) * (pl[:, 2] - self.home["left"][:, 2])
+        elif k == 1:      # move in
+            pl, pr = pl - 0.05 * (1 - ramp(f)) * ex, pr + 0.05 * (1 - ramp(f)) * ex
+        elif k == 2:
+            g = ramp(f, 0.6)
+        elif k <= 6:
+            g = 1.0
+            # where the loop's centre should be: s metres from the hook's centre along its axis (tip at 0.1), `lift` above it until it is in front of the tip
+            if k == 3:      # straight up to the height of the hook's tip
+                want = self.pkg0 + self.LOOP
+                want[:, 2] = want[:, 2] + ramp(f) * (hook[:, 2] + 0.13 * ax[:, 2] + self.lift - want[:, 2])
+                goal = None
+            else:
+                s = 0.13 if k == 4 else (0.13 if k == 5 else 0.13 - (0.13 - self.along) * ramp(f))
+                goal = hook + s * ax
+                if k == 4:
+                    goal = goal + np.array([0.0, 0.0, self.lift])
+                start = self.pkg0 + self.LOOP
+                start[:, 2] = hook[:, 2] + 0.13 * ax[:, 2] + self.lift
+                want = start + (ramp(f) if k == 4 else 1.0) * (goal - start)
+                if k >= 5 or f > 0.8:
+                    self.corr = np.clip(self.corr + self.gain * (goal - loop), -self.clip, self.clip)
+            d = want - (self.pkg0 + self.LOOP) + self.corr
+            pl, pr = pl + d, pr + d
+            self.last = (pl.copy(), pr.copy())
+        else:             # let go (7), back off sideways (8)
+            pl, pr = self.last
+            if k == 8:
+                pl, pr = pl - 0.06 * ramp(f) * ex, pr + 0.06 * ramp(f) * ex
+        site = PINCH * ex
+        return self._assemble(pl - site, self.home["left"][:, 3:], g, pr + site, self.home["right"][:, 3:], g)
