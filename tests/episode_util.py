@@ -23,6 +23,7 @@ VARIANT = "data_collection"        # the model av_aloha_amd.sim_env runs (data_c
 def oracle_home(task="slot_insertion"):
     """{'left','right','middle'} -> [7] eef poses (xyz + quat wxyz) at the home ctrl, through the oracle's FK (kinematics.py:17-24)."""
     e = OrcEnv(MODEL_OF.get(task, task), 3, VARIANT)
+    e.reset(np.tile([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], (e.nq - 23) // 7))        # ctrl := the home pose (zeros before the first reset)
     ch = np.array(e.ctrl, dtype=np.float64)
     Ts = []
     for arm, sl in ((0, slice(0, 6)), (1, slice(7, 13)), (2, slice(14, 21))):

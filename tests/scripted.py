@@ -100,6 +100,48 @@ def yaw_quat(yaw):
     return np.stack([np.cos(yaw / 2), np.zeros(n), np.zeros(n), np.sin(yaw / 2)], axis=1)
 
 
+def make_fk(task):
+    """-> fk(qpos [n, nq], arm) -> 4x4 [n, 4, 4]: pose of the arm's control site (product of exponentials over the model's joint screws,
+    kinematics.py:7-26; ik_* tables of the compiled data-collection model)."""
+    import os
+    from av_aloha_amd.compiler.compile import read_blob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = read_blob(os.path.join(root, "models", f"dc_{task}_3arms.avm"))
+    w0, p0, site0, qadr, nj = (np.asarray(md[k]) for k in ("ik_w0", "ik_p0", "ik_site0", "ik_qadr", "ik_n"))
+
+    def fk(qpos, arm):
+        n = qpos.shape[0]
+        T = np.tile(np.eye(4), (n, 1, 1))
+        for i in range(int(nj[arm])):
+            th = qpos[:, int(qadr[arm, i])]
+            w, p = w0[arm, i], p0[arm, i]
+            K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+            R = np.eye(3)[None] + np.sin(th)[:, None, None] * K[None] + (1 - np.cos(th))[:, None, None] * (K @ K)[None]
+            Ti = np.tile(np.eye(4), (n, 1, 1))
+            Ti[:, :3, :3] = R
+            Ti[:, :3, 3] = p[None] - R @ p
+            T = T @ Ti
+        return T @ site0[arm][None]
+    return fk
+
+
+class HandServo:
+    """Integral correction of a hand's position target: GradIK settles a few millimetres (centimetres at the edge of the workspace) off
+    the commanded point because its cost trades the pose against joint-centring terms (grad_ik.py:168-198); the command becomes target +
+    the accumulated (target - measured control-site position), measured through `fk` on the joints.  It accumulates only while the hand is
+    within `near` of its target (not while it is still travelling)."""
+
+    def __init__(self, fk, arm, n, gain=0.3, clip=0.04, near=0.03):
+        self.fk, self.arm, self.gain, self.clip, self.near = fk, arm, gain, clip, near
+        self.acc = np.zeros((n, 3))
+
+    def __call__(self, target, qpos):
+        err = target - self.fk(qpos, self.arm)[:, :3, 3]
+        close = np.linalg.norm(err, axis=1) < self.near
+        self.acc[close] = np.clip(self.acc[close] + self.gain * err[close], -self.clip, self.clip)
+        return target + self.acc
+
+
 class _Phases:
     """Phase clock shared by the scripts: T = step counts; phase() -> (index, fraction done in (0, 1])."""
     T = ()
@@ -135,31 +177,50 @@ def ramp(f, frac=0.8):
 
 
 PINCH = 0.135          # control site (wrist, aloha_sim.xml:249) -> pinch point between the finger pads (:248: 0.13 along the gripper)
+BASE_X, BASE_Y = 0.469, 0.032     # the manipulators' bases (aloha_sim.xml:119, :208): left at -BASE_X facing +x, right at +BASE_X facing -x
+
+
+def radial_hand(P, pitch, home_quat, right):
+    """Wrist target for a gripper whose pinch point is at P [n, 3], pitched `pitch` radians below the horizontal and heading along the
+    line from its arm's base through P (the heading a 6-dof arm gives for free: the waist turns, nothing else has to; a heading held
+    parallel to x costs forearm roll, which GradIK's joint-centring terms trade against the position: 3-4 cm off at |y| = 8 cm).
+    -> (site position [n, 3], quaternion wxyz [n, 4], heading angle [n])"""
+    n = P.shape[0]
+    if right:
+        psi = np.arctan2(BASE_Y - P[:, 1], BASE_X - P[:, 0])
+        a = np.stack([-np.cos(pitch) * np.cos(psi), -np.cos(pitch) * np.sin(psi), -np.sin(pitch) * np.ones(n)], axis=1)
+        qp = np.array([np.cos(pitch / 2), 0.0, -np.sin(pitch / 2), 0.0])
+    else:
+        psi = np.arctan2(P[:, 1] - BASE_Y, P[:, 0] + BASE_X)
+        a = np.stack([np.cos(pitch) * np.cos(psi), np.cos(pitch) * np.sin(psi), -np.sin(pitch) * np.ones(n)], axis=1)
+        qp = np.array([np.cos(pitch / 2), 0.0, np.sin(pitch / 2), 0.0])
+    qz = yaw_quat(psi)
+    quat = np.stack([qmul(qz[i], qmul(qp, home_quat[i])) for i in range(n)])
+    return P - PINCH * a, quat, psi
 
 
 class InsertPegScript(_Phases):
     """InsertPeg (task_insert_peg.xml; reward stages env.py:453-462): the right arm grasps the peg (12 x 2 x 2 cm, lying along x)
     `side` metres off its centre towards its own base, the left arm the square tube (`hole`, 12 cm long, 3.6 cm clear inside) as far off
     its centre, both with the gripper pitched `pitch` radians below the horizontal (pointing straight down, the wrist-camera mounts on
-    the grippers' backs face each other and meet 18 cm apart); both lift (reward 2), the tube is carried to a fixed place above the
-    table, the peg in front of its mouth, and the peg's free end is pushed `depth` metres into it (peg touches the tube: 3; peg overlaps
-    the `pin` box that fills the tube's middle 8 cm: 4 = success).  Closed loop on the measured poses (qpos[23:30] peg, [30:37] hole):
-    while aligning and inserting, the right hand's target integrates the error between the peg's free end and the point on the tube's
-    axis it should be at, so that the sag of the off-centre grasps and the IK's residual do not matter."""
+    the grippers' backs face each other and meet 18 cm apart) and heading radially from the arm's base (`radial_hand`: the objects turn
+    into the pads when the fingers close and turn back as they are carried to the line between the bases); both lift (reward 2), the
+    tube is carried to a fixed place above the table on that line, the peg in front of its mouth, and the peg's free end is pushed
+    `depth` metres into it (peg touches the tube: 3; peg overlaps the `pin` box that fills the tube's middle 8 cm: 4 = success).
+    Closed loop on the measured poses (qpos[23:30] peg, [30:37] hole): while aligning and inserting, the right hand's target integrates
+    the error between the peg's free end and the point on the tube's axis it should be at, so that the sag of the off-centre grasps and
+    the IK's residual do not matter."""
     T = (50, 40, 25, 45, 70, 40, 60, 20)
 
     def __init__(self, home, qpos, side=0.03, carry=0.12, depth=0.05, gain=0.15, clip=0.06, pitch=0.85):
         self.n = n = qpos.shape[0]
         self.home = home
-        c, s = np.cos(pitch / 2), np.sin(pitch / 2)
-        self.quat_r = np.stack([qmul(np.array([c, 0.0, -s, 0.0]), home["right"][i, 3:]) for i in range(n)])
-        self.quat_l = np.stack([qmul(np.array([c, 0.0, s, 0.0]), home["left"][i, 3:]) for i in range(n)])
-        # control site relative to the pinch point: back along the gripper's axis (the left arm faces +x, the right arm -x)
-        self.site_l = PINCH * np.array([-np.cos(pitch), 0.0, np.sin(pitch)])
-        self.site_r = PINCH * np.array([np.cos(pitch), 0.0, np.sin(pitch)])
+        self.pitch = pitch
         self.peg0, self.hole0 = qpos[:, 23:26].copy(), qpos[:, 30:33].copy()
         self.side, self.carry, self.depth, self.gain, self.clip = side, carry, depth, gain, clip
         self.corr = np.zeros((n, 3))
+        fk = make_fk("insert_peg")
+        self.servo_l, self.servo_r = HandServo(fk, 0, n), HandServo(fk, 1, n)
         self.t = 0
 
     def action(self, qpos):
@@ -171,7 +232,7 @@ class InsertPegScript(_Phases):
         pr = self.peg0 + np.array([self.side, 0.0, 0.004])
         pl = self.hole0 + np.array([-self.side, 0.0, 0.008])
         up = np.array([0.0, 0.0, 1.0])
-        meet = np.array([-0.06, 0.0])                               # where the tube is held: xy of its centre
+        meet = np.array([-0.06, BASE_Y])                            # where the tube is held: xy of its centre, on the line between the bases
         if k == 0:
             pr, pl, g = pr + 0.10 * up, pl + 0.10 * up, 0.0
         elif k == 1:
@@ -194,7 +255,9 @@ class InsertPegScript(_Phases):
                 goal = hole + (0.06 + gap) * quat_rot(holeq, ex)      # where the peg's free end should be on the tube's axis
                 self.corr = np.clip(self.corr + self.gain * (goal - tip), -self.clip, self.clip)
             pr = pr + self.corr
-        return self._assemble(pl + self.site_l, self.quat_l, g, pr + self.site_r, self.quat_r, g)
+        sl, ql, _ = radial_hand(pl, self.pitch, self.home["left"][:, 3:], False)
+        sr, qr, _ = radial_hand(pr, self.pitch, self.home["right"][:, 3:], True)
+        return self._assemble(self.servo_l(sl, qpos), ql, g, self.servo_r(sr, qpos), qr, g)
 
 
 class HookPackageScript(_Phases):
@@ -264,3 +327,94 @@ class HookPackageScript(_Phases):
                 pl, pr = pl - 0.06 * ramp(f) * ex, pr + 0.06 * ramp(f) * ex
         site = PINCH * ex
         return self._assemble(pl - site, self.home["left"][:, 3:], g, pr + site, self.home["right"][:, 3:], g)
+
+
+class SewNeedleThreadScript(_Phases):
+    """SewNeedle through all its reward stages (task_sew_needle.xml; env.py:676-689).  The right arm grasps the needle (10 x 2 x 2 cm, along
+    x) top-down `side` metres off its centre towards its own base and lifts it (1, 2), holds it in front of the wall's window (3 x 3 cm
+    clear, 2 cm deep, centre 5 cm above the wall body's origin) and pushes it through until the needle's centre is `past` metres beyond
+    the wall's mid-plane (needle touches the wall: 3; pin-needle meets pin-wall: the threading latch env.py:673, reward 4 from then on);
+    it lets go -- the needle rests in the window, its centre of mass over the sill -- and backs off upwards; only then does the left
+    arm come down on the end that sticks out on the other side (top-down both: with the two hands at the wall together the wrist-camera
+    mounts on the grippers' backs would meet), closes and pulls the needle `pull` metres out of the window: held by the left gripper
+    alone, clear of the table and of pin-wall, latch set = 5 = success (env.py:686-689).  Closed loop on the measured poses
+    (qpos[23:30] wall, [30:37] needle): in front of the window and while pushing, the right hand's target integrates the error of the
+    needle's leading end against the window's axis; the left hand is placed on the measured needle."""
+    T = (50, 40, 25, 40, 60, 30, 60, 15, 70, 40, 25, 60, 20)
+
+    def __init__(self, home, qpos, side=0.035, past=0.005, pull=0.08, gain=0.15, clip=0.05):
+        self.n = n = qpos.shape[0]
+        self.home = home
+        self._down(home)
+        self.needle0 = qpos[:, 30:33].copy()
+        self.side, self.past, self.pull, self.gain, self.clip = side, past, pull, gain, clip
+        self.corr = np.zeros((n, 3))
+        self.lgrasp = None
+        fk = make_fk("sew_needle")
+        self.servo_l, self.servo_r = HandServo(fk, 0, n), HandServo(fk, 1, n)
+        self.t = 0
+
+    def action(self, qpos):
+        n = self.n
+        k, f = self.phase()
+        wall, wallq, ndl, ndlq = qpos[:, 23:26], qpos[:, 26:30], qpos[:, 30:33], qpos[:, 33:37]
+        ex, up = np.array([1.0, 0.0, 0.0]), np.array([0.0, 0.0, 1.0])
+        exn = np.tile(ex, (n, 1))
+        window = wall + quat_rot(wallq, np.tile([0.0, 0.0, 0.05], (n, 1)))          # centre of the window
+        wax = quat_rot(wallq, exn)                                                     # its axis (the wall's x)
+        c0 = self.needle0 + np.array([0.0, 0.0, 0.01])                                 # needle's centre at reset (the body's origin is its underside)
+        site = np.array([0.0, 0.0, PINCH + 0.005])                                     # top-down: the wrist above the pinch point, the pads a little above the needle's axis
+        pr = c0 + self.side * ex
+        gr, gl = 0.0, 0.0
+        # the left hand waits further out than its home pose (there its fingers are 6 cm from the centre line, where the right
+        # gripper's camera mount arrives when the needle goes through the wall)
+        park_l = self.home["left"][:, :3] + np.array([-0.10, 0.0, 0.04])
+        pl_site = park_l.copy()
+        lquat = self.home["left"][:, 3:]
+        if k == 0:
+            pr = pr + 0.10 * up
+        elif k == 1:
+            pr = pr + 0.10 * (1 - ramp(f)) * up
+        elif k == 2:
+            gr = ramp(f, 0.6)
+        elif k == 3:
+            gr = 1.0
+            pr = pr + ramp(f) * (window[:, 2:3] - c0[:, 2:3]) * up
+        elif k <= 7:
+            gr = 1.0 if k < 7 else max(0.0, 1.0 - f / 0.6)
+            # the needle's centre on the window's axis: its leading end `gap` in front of the wall's face, then through until the centre is `past` beyond the mid-plane
+            gap = 0.02
+            x_front = 0.01 + gap + 0.05
+            s = x_front if k <= 5 else (x_front - (x_front + self.past) * ramp(f) if k == 6 else -self.past)
+            goal_c = window + s * wax
+            start = c0.copy(); start[:, 2] = window[:, 2]
+            want = start + (ramp(f) if k == 4 else 1.0) * (goal_c - start)
+            if k in (5, 6):
+                lead = ndl + quat_rot(ndlq, np.tile([-0.05, 0.0, 0.01], (n, 1)))      # the needle's leading end (its -x face's centre)
+                self.corr = np.clip(self.corr + self.gain * ((goal_c - 0.05 * wax) - lead), -self.clip, self.clip)
+            pr = want + self.side * ex + self.corr
+            self.rlast = pr.copy()
+        else:
+            # the right hand straight up and back to its side; the left hand above the end that sticks out, down, close, pull
+            r8 = ramp(f, 0.5) if k == 8 else 1.0
+            back = np.maximum(0.0, 0.30 - (self.rlast[:, :1] + 0.0))                      # ... until its wrist is 30 cm from the centre line
+            pr = self.rlast + 0.07 * min(1.0, 2 * r8) * up + r8 * back * ex
+            if self.lgrasp is None or k == 8:
+                cn = ndl + quat_rot(ndlq, np.tile([0.0, 0.0, 0.01], (n, 1)))
+                self.lgrasp = cn - self.side * quat_rot(ndlq, exn)
+            pl = self.lgrasp.copy()
+            lquat = self.down_l
+            if k == 8:
+                h = park_l - site
+                fl = max(0.0, (f - 0.4) / 0.6)                                             # once the right hand is out of the way
+                pl = h + ramp(fl) * (pl + 0.10 * up - h)
+                lquat = self.down_l if fl > 0.2 else self.home["left"][:, 3:]
+            elif k == 9:
+                pl = pl + 0.10 * (1 - ramp(f)) * up
+            elif k == 10:
+                gl = ramp(f, 0.6)
+            else:
+                gl = 1.0
+                pl = pl - self.pull * (ramp(f) if k == 11 else 1.0) * ex
+            pl_site = pl + site
+        return self._assemble(self.servo_l(pl_site, qpos), lquat, gl, self.servo_r(pr + site, qpos), self.down_r, gr)
