@@ -25,7 +25,7 @@ def ip(a):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(ROOT, "oracle", "liborc.so")
+        so = os.environ.get("ORC_LIB") or os.path.join(ROOT, "oracle", "liborc.so")      # ORC_LIB: the sanitizer build (tests/test_oracle_sanitizers.py)
         if not os.path.exists(so):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
         _LIB = C.CDLL(so)

@@ -129,3 +129,59 @@ def test_crosses_h5py_both_ways_where_it_is_installed(tmp_path):
     assert bool(attrs["sim"]) is True
     for k, v in data.items():
         assert np.array_equal(back[k], v)
+
+
+def _libhdf5():
+    """The C library itself, where the image has one (no h5py needed): /opt/conda/lib/libhdf5.so* through ctypes."""
+    import ctypes as C
+    import glob
+    for pat in ("/opt/conda/lib/libhdf5.so*", "/usr/lib/x86_64-linux-gnu/libhdf5*.so*", "/usr/lib/x86_64-linux-gnu/hdf5/serial/libhdf5.so*"):
+        for p in sorted(glob.glob(pat)):
+            try:
+                L = C.CDLL(p)
+                if hasattr(L, "H5Fopen") and hasattr(L, "H5Dread"):
+                    return L
+            except OSError:
+                continue
+    return None
+
+
+def test_real_libhdf5_reads_what_hdf5min_writes(tmp_path):
+    """An episode file of the home-made writer opened by the real HDF5 library (H5Fopen / H5Dopen2 / H5Dget_space / H5Dread /
+    H5Aexists): every dataset -- the chunked u8 image stacks and the contiguous f32 tables -- comes back identical and the root
+    carries the attribute `sim` (record_sim_episodes.py:186-206).  Skipped where no libhdf5 is installed."""
+    import ctypes as C
+    L = _libhdf5()
+    if L is None:
+        pytest.skip("no libhdf5 shared library in this image")
+    hid = C.c_int64
+    L.H5open.restype = C.c_int
+    L.H5Fopen.restype = hid; L.H5Fopen.argtypes = [C.c_char_p, C.c_uint, hid]
+    L.H5Dopen2.restype = hid; L.H5Dopen2.argtypes = [hid, C.c_char_p, hid]
+    L.H5Dget_space.restype = hid; L.H5Dget_space.argtypes = [hid]
+    L.H5Sget_simple_extent_ndims.restype = C.c_int; L.H5Sget_simple_extent_ndims.argtypes = [hid]
+    L.H5Sget_simple_extent_dims.restype = C.c_int; L.H5Sget_simple_extent_dims.argtypes = [hid, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.H5Dread.restype = C.c_int; L.H5Dread.argtypes = [hid, hid, hid, hid, hid, C.c_void_p]
+    L.H5Aexists.restype = C.c_int; L.H5Aexists.argtypes = [hid, C.c_char_p]
+    for fn in ("H5Dclose", "H5Sclose", "H5Fclose"):
+        getattr(L, fn).restype = C.c_int; getattr(L, fn).argtypes = [hid]
+    assert L.H5open() >= 0
+    native = {np.dtype(np.float32): hid.in_dll(L, "H5T_NATIVE_FLOAT_g").value, np.dtype(np.uint8): hid.in_dll(L, "H5T_NATIVE_UCHAR_g").value}
+    data = episode(T=5, H=24, W=32)
+    path = harness.save_episode(data, str(tmp_path), 0, use_h5py=False)
+    f = L.H5Fopen(path.encode(), 0, 0)                                     # H5F_ACC_RDONLY, H5P_DEFAULT
+    assert f >= 0, "libhdf5 does not accept the file"
+    assert L.H5Aexists(f, b"sim") > 0
+    for name, want in data.items():
+        d = L.H5Dopen2(f, name.encode(), 0)
+        assert d >= 0, name
+        sp = L.H5Dget_space(d)
+        nd = L.H5Sget_simple_extent_ndims(sp)
+        dims = (C.c_uint64 * nd)()
+        L.H5Sget_simple_extent_dims(sp, dims, None)
+        assert tuple(dims) == want.shape, name
+        got = np.empty(want.shape, dtype=want.dtype)
+        assert L.H5Dread(d, native[want.dtype], 0, 0, 0, got.ctypes.data) >= 0, name      # H5S_ALL, H5S_ALL, H5P_DEFAULT
+        assert np.array_equal(got, want), name
+        L.H5Sclose(sp); L.H5Dclose(d)
+    L.H5Fclose(f)

@@ -1,0 +1,65 @@
+"""The CPU oracle under AddressSanitizer + UndefinedBehaviorSanitizer: `make -C oracle san` builds the same sources
+with -fsanitize=address,undefined; a child process with libasan preloaded and ORC_LIB pointing at that build runs the oracle's
+physics / constraint / collision / reward / IK paths (a contact-rich SewNeedle stretch, a HookPackage random walk, the Cartesian IK
+composite, the depth ray caster); any sanitizer report aborts the child.  Skipped where gcc's libasan is not installed."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["AVS_ROOT"]); sys.path.insert(0, os.path.join(os.environ["AVS_ROOT"], "tests"))
+import episode_util as U
+from av_aloha_amd import workloads as W
+from orc_env import OrcEnv
+from orc_ffi import dp
+# scripted SewNeedle threading: grasp, contact-rich push through the window (MPR, multiccd, Newton with coupled trees, noslip, latch)
+task = "sew_needle_thread"
+home = U.oracle_home(task)
+pose = W.object_poses("sew_needle", np.arange(1), U.TASK_SEED[task])[0]
+e = U._new_env(task, pose)
+script = U.make_script(task, home, np.array(e.qpos)[None])
+a21 = np.zeros(21); lo, hi = U.GRIP_RANGE
+best = 0
+for t in range(int(os.environ.get("AVS_SAN_STEPS", "300"))):
+    a = np.ascontiguousarray(script.action(np.array(e.qpos)[None])[0])
+    e.L.orc_cart_to_ctrl(e.dptr, dp(a), 0, dp(a21))
+    c = a21.copy()
+    for j in (6, 13):
+        c[j] = a21[j] * (hi - lo) + lo
+    rw, su = U._step_ctrl(e, c)
+    best = max(best, rw)
+assert best >= 2 and np.isfinite(np.array(e.qpos)).all()
+e.close()
+# HookPackage-2Arms under the joint random walk, PGS solver (the other solver path), depth ray caster
+e = OrcEnv("hook_package", 2)
+e.d.solver = 0; e.d.pgs_iters = 20
+e.reset(W.object_poses("hook_package", np.arange(1), 3000)[0])
+from av_aloha_amd.compiler.compile import read_blob
+md = read_blob(os.path.join(os.environ["AVS_ROOT"], "models", "hook_package_2arms.avm"))
+acts = W.walk_actions(md["qpos_home"], md["act_ctrlrange"], [0], 20, 14, 3000).astype(np.float64)
+for t in range(20):
+    e.env_step(acts[t, 0])
+img = e.render_depth("overhead_cam", 12, 16)
+assert np.isfinite(img).all()
+e.close()
+print("sanitized run ok")
+'''
+
+
+def test_oracle_runs_clean_under_asan_ubsan():
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("gcc's libasan is not installed")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "san"], stdout=subprocess.DEVNULL)
+    so = os.path.join(ROOT, "oracle", "_san", "liborc.so")
+    env = dict(os.environ, LD_PRELOAD=os.path.realpath(asan), ORC_LIB=so, AVS_ROOT=ROOT,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and "sanitized run ok" in out.stdout, out.stdout[-1500:] + out.stderr[-4000:]
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-4000:]

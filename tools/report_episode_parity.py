@@ -1,7 +1,9 @@
 """Whole-episode parity table, device vs CPU oracle (tests/episode_util.py; run on the MI355X box):
     python tools/report_episode_parity.py [out.json]
-f64 device mode and the f32 product mode of the scripted SlotInsertion (grasp - carry - insert, 350 env-steps) and SewNeedle (reach -
-grasp - lift, 250 env-steps) episodes against the oracle stepping the same ctrl sequences: per-step reward agreement, final
+f64 device mode and the f32 product mode of the scripted episodes of the four task families north_star names -- SlotInsertion (grasp -
+carry - insert, 350 env-steps), InsertPeg (two pitched grasps, peg into the tube, 350), SewNeedle (all five reward stages: grasp,
+thread through the wall's window, hand over to the left gripper, 535; and BASELINE config 3's reach - grasp - lift, 250), HookPackage
+(two-arm carry onto the hook, release, 410) -- against the oracle stepping the same ctrl sequences: per-step reward agreement, final
 is_success (env.py:224) on both sides, position distance over the episode."""
 import json
 import os
@@ -15,7 +17,10 @@ import numpy as np
 import episode_util as U
 
 out = {}
-for task, n64, n32 in (("slot_insertion", 16, 128), ("sew_needle", 16, 128)):
+only = [a for a in sys.argv[2:]]
+for task, n64, n32 in (("slot_insertion", 16, 128), ("insert_peg", 16, 128), ("sew_needle_thread", 16, 128), ("hook_package", 16, 128), ("sew_needle", 16, 128)):
+    if only and task not in only:
+        continue
     for mode, n in (("f64", n64), ("f32", n32)):
         dev = U.device_episode(task, n, f64=mode == "f64")
         rows = U.compare_with_replay(task, dev)
@@ -29,13 +34,15 @@ for task, n64, n32 in (("slot_insertion", 16, 128), ("sew_needle", 16, 128)):
             "oracle_final_reward_hist": np.bincount([r["orc_final_reward"] for r in rows], minlength=6).tolist(),
             "success_flag_mismatches": len(mism), "final_reward_mismatches": len(fin),
             "envs_with_identical_reward_sequence": int(sum(r["first_reward_diff"] == -1 for r in rows)),
+            "reward_steps_differing_p50_p90_max": [float(x) for x in np.percentile([r["n_reward_diff"] for r in rows], [50, 90, 100])],
+            "device_max_reward_hist": np.bincount([r["dev_max_reward"] for r in rows], minlength=6).tolist(),
             "envs_with_identical_contact_counts": int(sum(r["ncon_diff_steps"] == 0 for r in rows)),
             "max_qpos_err_p50_p90_max": [float(np.percentile(e, 50)), float(np.percentile(e, 90)), float(e.max())],
             "diverged_envs": int(dev["diverged"].sum()), "capped_envs": int(dev["capped"].sum()),
             "mismatching_envs": mism[:16], "reward_diff_envs": [r for r in rows if r["first_reward_diff"] != -1][:16],
         }
         print(task, mode, json.dumps({k: v for k, v in out[f"{task}_{mode}"].items() if not k.endswith("_envs") or k in ("diverged_envs", "capped_envs")}), flush=True)
-path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r03_episode_parity.json")
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r04_episode_parity.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
 print("wrote", path)
