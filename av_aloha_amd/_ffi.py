@@ -44,6 +44,8 @@ def lib():
         L.avsim_set_qpos.argtypes = [vp, vp]
         L.avsim_get_state.argtypes = [vp, vp, vp, vp, vp]
         L.avsim_set_state.argtypes = [vp, vp, vp, vp, vp]
+        L.avsim_get_reset_poses.argtypes = [vp, vp]
+        L.avsim_set_reset_poses.argtypes = [vp, vp]
         L.avsim_get_latch.argtypes = [vp, vp]
         L.avsim_set_latch.argtypes = [vp, vp]
         L.avsim_get_contacts.argtypes = [vp, vp, vp, vp]

@@ -740,6 +740,22 @@ int avsim_set_latch(avsim_t* h, const int32_t* latch) {
     return h->finish();
 }
 
+// The object poses a diverged env falls back to (mj_checkPos-style reset): written by avsim_reset; state next to the
+// latch for a handle that continues another one's episode (hide / show_middle_arm, checkpoints): double[N][nobj][7]
+int avsim_get_reset_poses(avsim_t* h, double* obj_qpos) {
+    if (!h || !obj_qpos) return AVSIM_EINVAL;
+    AVS_ON_DEVICE(h);
+    HIPCHK(h, hipMemcpyAsync(obj_qpos, h->phys.d_obj_reset, sizeof(double) * (size_t)h->N * h->nobj * 7, h->io_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    return h->finish();
+}
+
+int avsim_set_reset_poses(avsim_t* h, const double* obj_qpos) {
+    if (!h || !obj_qpos) return AVSIM_EINVAL;
+    AVS_ON_DEVICE(h);
+    HIPCHK(h, hipMemcpyAsync(h->phys.d_obj_reset, obj_qpos, sizeof(double) * (size_t)h->N * h->nobj * 7, h->io_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    return h->finish();
+}
+
 int avsim_set_qpos(avsim_t* h, const double* qpos) {
     if (!h || !qpos) return AVSIM_EINVAL;
     return avsim_set_state(h, qpos, nullptr, nullptr, nullptr);

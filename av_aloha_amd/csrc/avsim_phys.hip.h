@@ -3235,6 +3235,10 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
         if (nwork <= 0) return;
     }
     int* const bigflag = retry + 2 + N;
+    // the first tier's capacities: the small layout's in the first pass; the second pass runs with ka_small == ka_big and gets them in the
+    // upper bits of retry_mode (measured against the full ones, `beyond` was always false there and the pass cleared the prediction
+    // flag of exactly the envs that need the full record: they were stepped twice in every step)
+    const int cap1_con = pass2 ? (retry_mode >> 8) & 0x3ff : ka_small->lay.maxcon, cap1_efc = pass2 ? (retry_mode >> 18) & 0x3ff : ka_small->lay.maxefc;
     // (the pairs' flags: 2 x MAXW / 2 ints behind the tables in the dynamic LDS of a RETRY launch)
     int* const pair_want = reinterpret_cast<int*>(smem + (size_t)(blockDim.x >> 6) * ka_small->lay.bytes_per_env + (size_t)ka_small->mo.nreal * sizeof(real) + (size_t)ka_small->mo.nint * 4);
     int* const pair_grant = pair_want + MAXW / 2;
@@ -3259,12 +3263,26 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
     auto lds_put = [&](int* p, int v) { if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto to_list = [&](int e) { if (lane == 0) retry[2 + atomicAdd(retry + ((retry_mode & 7) == 3), 1)] = e; };
     // the partner wants both records: wait here (this wave's record is dead between two envs) until it is done
+    // A claim is (generation << 8) | (wave + 1), the grant is the claim it answers (PAIR_LEFT once a wave of the pair has left the
+    // kernel): a grant left over from an earlier claim never matches a later one, and a claim renewed before the parked partner has
+    // polled is granted like the first (the grant used to be a bare 1 set once per park: the renewed claim then waited out its
+    // time-out, and a stale 1 could hand both records to a claimant whose partner was in the middle of an env).
+    constexpr int PAIR_LEFT = -1;
+    int claim_gen = 0, my_claim = 0;
     auto park = [&]() {
-        const int w = lds_get(&pair_want[pr]);
-        if (w != 0 && w != wave + 1) {
-            lds_put(&pair_grant[pr], 1);
-            while (lds_get(&pair_want[pr]) != 0) __builtin_amdgcn_s_sleep(32);
+        for (;;) {
+            const int w = lds_get(&pair_want[pr]);
+            if (w == 0 || (w & 0xff) == wave + 1) break;
+            lds_put(&pair_grant[pr], w);
+            __builtin_amdgcn_s_sleep(32);
         }
+    };
+    auto claim = [&]() {
+        int got = 0;
+        const int c = (++claim_gen << 8) | (wave + 1);
+        if (lane == 0) { int expect = 0; got = __hip_atomic_compare_exchange_strong(&pair_want[pr], &expect, c, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0; }
+        my_claim = c;
+        return __builtin_amdgcn_readfirstlane(got) != 0;
     };
     int redo_env = -1;      // the env this wave has just abandoned with the small record
   for (;;) {
@@ -3285,26 +3303,24 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
     if (RETRY && big) {
         // take the pair: the claim is an LDS compare-and-swap, the partner answers at its next env boundary (or has left: grant 2)
         bool mine = false;
-        if (paired) {
-            int got = 0;
-            if (lane == 0) { int expect = 0; got = __hip_atomic_compare_exchange_strong(&pair_want[pr], &expect, wave + 1, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0; }
-            mine = __builtin_amdgcn_readfirstlane(got) != 0;
-        }
+        if (paired) mine = claim();
         if (!mine && paired) {
             // the partner has claimed the pair for an env of its own: let it (this wave's record is dead), then claim in turn -- the
             // partner answers at its next env boundary.  (The most expensive envs come first in a launch's order, and those are the
             // ones that need the full capacities: at the start of a launch both waves of a pair usually hold one.)
             for (int tries = 0; tries < 64 && !mine; tries++) {
                 park();
-                int got = 0;
-                if (lane == 0) { int expect = 0; got = __hip_atomic_compare_exchange_strong(&pair_want[pr], &expect, wave + 1, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0; }
-                mine = __builtin_amdgcn_readfirstlane(got) != 0;
+                mine = claim();
             }
         }
         if (!mine) { to_list(env); continue; }      // (an unpaired wave; the partner's claim, if any, is answered by park() at the top)
         int polls = 0;
-        while (lds_get(&pair_grant[pr]) == 0 && polls < (1 << 18)) { __builtin_amdgcn_s_sleep(32); polls++; }
-        if (polls >= (1 << 18)) { to_list(env); lds_put(&pair_want[pr], 0); continue; }      // (never seen: a partner's env-step is ~2000 polls)
+        for (;; polls++) {
+            const int g = lds_get(&pair_grant[pr]);
+            if (g == my_claim || g == PAIR_LEFT || polls >= (1 << 15)) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if (polls >= (1 << 15)) { lds_put(&pair_want[pr], 0); to_list(env); continue; }      // (never seen: a partner's env-step is ~2000 polls; the claim is withdrawn first, its grant can never match another)
     }
     KPtr<real> ka = (RETRY && big) ? ka_big : ka_small;
     const long long t_launch = __builtin_readcyclecounter();
@@ -3346,7 +3362,7 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
         }
         PROF(4, E.collide());
         PROF(5, E.make_constraints());
-        if (RETRY) beyond = beyond || ii[ka->lay.misc + 0] > ka_small->lay.maxcon || ii[ka->lay.misc + 1] > ka_small->lay.maxefc;
+        if (RETRY) beyond = beyond || ii[ka->lay.misc + 0] > cap1_con || ii[ka->lay.misc + 1] > cap1_efc;
         PROF(6, E.solve(pgs_iters, ka->m.solver, ka->m.newton_iters, ka->m.newton_tol, ka->m.nscale));
         {
             Env<real, G> e(E);
@@ -3379,7 +3395,7 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
         continue;
     }
     if (RETRY) {
-        beyond = beyond || ii[ka->lay.misc + 0] > ka_small->lay.maxcon;
+        beyond = beyond || ii[ka->lay.misc + 0] > cap1_con;
         if (lane == 0 && (big || pass2 || (retry_mode & 8))) bigflag[env] = beyond ? 1 : 0;
     }
 
@@ -3420,11 +3436,10 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
     }
     GSYNC();      // the record is reused by the wave's next env
     if (RETRY && big && pass1) {      // give the pair back: the grant first (unless the partner has left), then the claim the partner waits on
-        if (lds_get(&pair_grant[pr]) == 1) lds_put(&pair_grant[pr], 0);
-        lds_put(&pair_want[pr], 0);
+        lds_put(&pair_want[pr], 0);           // (the grant stays: it is keyed to this claim)
     }
   }
-    if (RETRY && paired) lds_put(&pair_grant[pr], 2);      // this wave is leaving: its record is the partner's for the asking
+    if (RETRY && paired) lds_put(&pair_grant[pr], PAIR_LEFT);      // this wave is leaving: its record is the partner's for the asking
 }
 
 // Launch order of the envs: by the cost (shader-clock cycles) of their last step, most expensive first.  A block holds its LDS
@@ -3946,7 +3961,7 @@ struct PhysHost {
             hipLaunchKernelGGL(kern2, dim3(nblk2), dim3(64 * wpb2), shmem2, st, (KPtr<real>)d_kargs2, (const real*)d_img_real, (const int*)d_img_int, N, nsub, pgs_iters, action, want_reward,
                                (real*)qpos, (real*)qvel, (real*)ctrl, (real*)warm, latch, agent, (int*)reward, (unsigned char*)success, d_ncon,
                                d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof, d_xpose, (const int*)rlist, order_envs ? d_cost : (int*)nullptr, head, next,
-                               d_retry, 2 + 2 * par, (KPtr<real>)d_kargs2);
+                               d_retry, (2 + 2 * par) | (maxcon1 << 8) | (maxefc1 << 18), (KPtr<real>)d_kargs2);      // (+ the FIRST tier's capacities: what "needed the full record" is measured against)
         }
         if (nsub > 0) have_cost = true;
         hipError_t e = hipGetLastError();

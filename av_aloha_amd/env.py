@@ -225,12 +225,14 @@ class GuidedVisionEnv(_EnvBase):
             return
         q, v, c, w = self.sim.get_state()
         latch = self.sim.get_latch()                 # SewNeedle's threaded_needle stage carries over (env.py:596, :686-689)
+        fallback = self.sim.get_reset_poses()        # ... and so do the object poses a diverged env is put back to
         old = self.sim
         self.sim = BatchedSim(self.task, arms, self.num_envs, device=self._device, f64=self._f64, options=self._options)
         self.sim.set_option("num_joints", self.num_joints)
         self.sim.nj = self.sim.h.nj = self.num_joints
         self.sim.set_state(q, v, c, w)
         self.sim.set_latch(latch)
+        self.sim.set_reset_poses(fallback)
         old.close()
         self._model_arms = arms
         self._refresh_agent_pos()

@@ -89,6 +89,16 @@ class BatchedSim:
         l = np.ascontiguousarray(latch, dtype=np.int32).reshape(self.N)
         self.h.check(self.h.L.avsim_set_latch(self.h.h, l.ctypes.data))
 
+    def get_reset_poses(self):
+        """[N, nobj, 7] object poses a diverged env is put back to (those of the episode's reset)."""
+        o = np.empty((self.N, self.nobj, 7))
+        self.h.check(self.h.L.avsim_get_reset_poses(self.h.h, o.ctypes.data))
+        return o
+
+    def set_reset_poses(self, poses):
+        o = np.ascontiguousarray(poses, dtype=np.float64).reshape(self.N, self.nobj, 7)
+        self.h.check(self.h.L.avsim_set_reset_poses(self.h.h, o.ctypes.data))
+
     def set_qpos(self, qpos):
         q = np.ascontiguousarray(qpos, dtype=np.float64).reshape(self.N, self.nq)
         self.h.check(self.h.L.avsim_set_qpos(self.h.h, q.ctypes.data))

@@ -122,6 +122,11 @@ int avsim_set_qpos(avsim_t* h, const double* qpos);
 /* full state for checkpoint / tests: qpos[N][nq], qvel[N][nv], ctrl[N][nu], warmstart[N][nv]; NULL = skip */
 int avsim_get_state(avsim_t* h, double* qpos, double* qvel, double* ctrl, double* warmstart);
 int avsim_set_state(avsim_t* h, const double* qpos, const double* qvel, const double* ctrl, const double* warmstart);
+/* the object poses an env whose state diverged is put back to (what avsim_reset was given; the model's default poses before the
+ * first reset): double[N][nobj][7].  Not touched by avsim_set_state / avsim_set_qpos -- a handle that continues another handle's
+ * episode carries them over with this pair, next to avsim_get_latch / avsim_set_latch */
+int avsim_get_reset_poses(avsim_t* h, double* obj_qpos);
+int avsim_set_reset_poses(avsim_t* h, const double* obj_qpos);
 /* the per-env reward latch int32[N] (SewNeedle's _threaded_needle, env.py:602, :631, :673, :686-689; 0 for the other tasks): part
  * of an env's state next to qpos / qvel / ctrl -- a checkpoint or a move of the env to another handle carries it along */
 int avsim_get_latch(avsim_t* h, int32_t* latch);

@@ -92,6 +92,27 @@ def replay_worker(args):
     return rw, su, qs, nc
 
 
+def lockstep_worker(args):
+    """Teacher-forced: at every env-step the oracle is put into the DEVICE's state at the start of that step (joint and object positions,
+    velocities, solver warm start, reward latch -- f32 values are exact doubles) and steps the device's ctrl once.  The f32 product
+    path's whole episodes are thus checked step by step against the f64 oracle without the divergence of two chaotic trajectories in
+    between: a reward / success flag that differs needs a contact within f32 rounding of its margin IN THAT STEP.
+    -> rewards [T], success [T], largest |qpos difference| after the step [T], ncon [T]"""
+    task, pose, q0, v0, w0, l0, ctrls, q1 = args
+    e = _new_env(task, pose)
+    T = ctrls.shape[0]
+    rw, su, er, nc = np.zeros(T, np.int32), np.zeros(T, bool), np.zeros(T), np.zeros(T, np.int32)
+    warm = e.arr("qacc_warmstart", e.nv)
+    for t in range(T):
+        e.qpos[:] = q0[t]; e.qvel[:] = v0[t]; warm[:] = w0[t]
+        e.d.threaded = int(l0[t])
+        rw[t], su[t] = _step_ctrl(e, ctrls[t])
+        er[t] = np.abs(np.array(e.qpos) - q1[t]).max()
+        nc[t] = e.d.ncon
+    e.close()
+    return rw, su, er, nc
+
+
 def closed_loop_worker(args):
     """Closed loop: the script reads the oracle's own qpos, the oracle's GradIK / DiffIK (sim_env.py:277-301) make ctrl.
     -> rewards [T], success [T], final qpos, ctrl [T, nu]"""
@@ -124,7 +145,7 @@ def pool_map(fn, jobs, procs=None):
 
 
 # ---- device side -------------------------------------------------------------------------------------------------------
-def device_episode(task, n, f64, seed0=None, record_qpos=True, options=None):
+def device_episode(task, n, f64, seed0=None, record_qpos=True, options=None, record_state=False):
     """The scripted policy closed loop on the device (23-D action -> GradIK x2 + DiffIK on the measured joints -> 20 substeps,
     sim_env.py:277-312), n envs with the poses of seeds seed0 + i.  Records what the physics was driven with: ctrl [T, n, nu] in
     actuator units (double copies of the device's values, exact in both precisions).
@@ -144,8 +165,13 @@ def device_episode(task, n, f64, seed0=None, record_qpos=True, options=None):
     out = dict(poses=poses, home=home, ctrl=np.zeros((T, n, env.sim.nu)), reward=np.zeros((T, n), np.int32), success=np.zeros((T, n), bool),
                qpos=np.zeros((T, n, env.sim.nq)) if record_qpos else None, ncon=np.zeros((T, n), np.int32),
                diverged=np.zeros(n, bool), capped=np.zeros(n, bool))
+    if record_state:      # the state at the START of every step (lockstep_worker)
+        out.update(q0=np.zeros((T, n, env.sim.nq)), v0=np.zeros((T, n, env.sim.nv)), w0=np.zeros((T, n, env.sim.nv)), l0=np.zeros((T, n), np.int32))
     q = q0
     for t in range(T):
+        if record_state:
+            out["q0"][t], out["v0"][t], _, out["w0"][t] = env.sim.get_state()
+            out["l0"][t] = env.sim.get_latch()
         _, rw, su = env.sim.step_cartesian(script.action(q))
         q, _, c, _ = env.sim.get_state()
         d = env.sim.diag()
@@ -173,4 +199,20 @@ def compare_with_replay(task, dev, envs=None):
                          orc_max_reward=int(rw.max()), dev_final_reward=int(dev["reward"][-1, k]), orc_final_reward=int(rw[-1]),
                          max_qpos_err=float(err.max()), final_qpos_err=float(err[-1].max()),
                          ncon_diff_steps=int((nc != dev["ncon"][:, k]).sum())))
+    return rows
+
+
+def compare_lockstep(task, dev, envs=None):
+    """Per env: number of steps whose reward / success flag differs between the device and the oracle stepped from the device's state
+    (lockstep_worker), final success on both sides, largest one-step position difference.  -> list of dicts"""
+    n = dev["ctrl"].shape[1]
+    envs = list(range(n)) if envs is None else list(envs)
+    c = np.ascontiguousarray
+    res = pool_map(lockstep_worker, [(task, dev["poses"][k], c(dev["q0"][:, k]), c(dev["v0"][:, k]), c(dev["w0"][:, k]), c(dev["l0"][:, k]), c(dev["ctrl"][:, k]),
+                                      c(dev["qpos"][:, k])) for k in envs])
+    rows = []
+    for k, (rw, su, er, nc) in zip(envs, res):
+        rows.append(dict(env=k, reward_diff_steps=int((rw != dev["reward"][:, k]).sum()), success_diff_steps=int((su != dev["success"][:, k]).sum()),
+                         dev_success=bool(dev["success"][-1, k]), orc_success=bool(su[-1]), dev_max_reward=int(dev["reward"][:, k].max()),
+                         max_step_err=float(er.max()), ncon_diff_steps=int((nc != dev["ncon"][:, k]).sum()), steps=int(len(rw))))
     return rows

@@ -278,6 +278,8 @@ class HookPackageScript(_Phases):
         self.pkg0 = qpos[:, 30:33].copy()
         self.inset, self.along, self.gain, self.clip, self.lift = inset, along, gain, clip, lift
         self.corr = np.zeros((n, 3))
+        fk = make_fk("hook_package")
+        self.servo_l, self.servo_r = HandServo(fk, 0, n), HandServo(fk, 1, n)
         self.t = 0
 
     def action(self, qpos):
@@ -326,7 +328,7 @@ class HookPackageScript(_Phases):
             if k == 8:
                 pl, pr = pl - 0.06 * ramp(f) * ex, pr + 0.06 * ramp(f) * ex
         site = PINCH * ex
-        return self._assemble(pl - site, self.home["left"][:, 3:], g, pr + site, self.home["right"][:, 3:], g)
+        return self._assemble(self.servo_l(pl - site, qpos), self.home["left"][:, 3:], g, self.servo_r(pr + site, qpos), self.home["right"][:, 3:], g)
 
 
 class SewNeedleThreadScript(_Phases):

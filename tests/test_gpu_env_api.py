@@ -108,10 +108,15 @@ def test_hide_middle_arm_keeps_the_sew_needle_latch():
     env.reset()
     assert env.sim.get_latch().tolist() == [0, 0, 0]
     env.sim.set_latch(np.array([0, 1, 0], dtype=np.int32))
+    fallback = env.sim.get_reset_poses()                        # where a diverged env's objects go back to: this episode's reset poses
+    assert fallback.shape == (3, 2, 7) and np.allclose(fallback[:, :, :3], env.sim.get_state()[0][:, 23:].reshape(3, 2, 7)[:, :, :3], atol=0.02)
+    assert np.ptp(fallback[:, 1, 0]) > 1e-4                     # (sampled per env, not the model's default poses)
     env.hide_middle_arm()
     assert env.sim.get_latch().tolist() == [0, 1, 0]
+    assert np.array_equal(env.sim.get_reset_poses(), fallback)
     env.show_middle_arm()
     assert env.sim.get_latch().tolist() == [0, 1, 0]
+    assert np.array_equal(env.sim.get_reset_poses(), fallback)
     env.reset()
     assert env.sim.get_latch().tolist() == [0, 0, 0]           # env.py:631: reset clears it
     env.close()

@@ -1,16 +1,29 @@
-"""Episode-length parity of the device against the CPU oracle, success flags included (north_star: "task-success flags match
-bit-exact"; env.py:224 is_success, :546-589 SlotInsertion and :640-690 SewNeedle reward stages).
+"""Episode-length parity of the device against the CPU oracle, success flags included, for the four task families north_star names
+(north_star: "task-success flags match bit-exact"; env.py:224 is_success; reward stages env.py:425-472 InsertPeg, :546-589
+SlotInsertion, :640-690 SewNeedle, :820-863 HookPackage).
 
-The scripted policies (tests/scripted.py, av_aloha_amd/workloads.py) run closed loop on the device for whole episodes - grasp,
-carry, insert (350 env-steps = 7000 substeps) and reach, grasp, lift (250 env-steps) -; the ctrl vector the device's IK produced at
-every step is recorded and the oracle steps the SAME ctrl sequence from the same reset state (tests/episode_util.py).
+The scripted policies (tests/scripted.py, av_aloha_amd/workloads.py) run closed loop on the device for whole episodes that REACH
+max_reward: grasp - carry - insert (SlotInsertion, 350 env-steps = 7000 substeps), two pitched grasps and the peg into the tube
+(InsertPeg, 350), grasp - thread through the wall's window - hand over to the left gripper (SewNeedle, all five stages, 535), two-arm
+carry onto the hook and release (HookPackage, 410); plus BASELINE config 3's reach - grasp - lift (SewNeedle, 250).  The ctrl vector
+the device's IK produced at every step is recorded and the oracle steps the SAME ctrl sequence from the same reset state
+(tests/episode_util.py).
 
-  * f64 device mode vs the oracle: the reward of every step and the final is_success are identical; joint and object positions stay
-    within 1e-3 rad / m over the whole episode with a median over the envs below 1e-6 (observed on 16 seeds, profiles/
-    r03_episode_parity.json: SlotInsertion median 1.5e-11, max 9e-6; SewNeedle median 2e-8, max 3e-4); the contact count differs in
-    at most a handful of steps of an env (a contact at the edge of its margin).
-  * f32 product mode vs the f64 oracle, 128 seeds: the number of envs whose final is_success differs is counted and bounded; the
-    table goes to profiles/r03_episode_parity.json (tools/report_episode_parity.py writes it).
+  * f64 device mode vs the oracle, open-loop replay: the reward of every step and the final is_success are identical (HookPackage: in
+    all envs but at most one, whose released package swings on the nearly frictionless hook, friction 0.01 -- a handful of steps);
+    the median over the envs of the largest position difference stays below 1e-6 (observed 1e-11 ... 5e-8: the two sides multiply
+    their kinematic chains out in a different order, 1e-16 per substep, a grasp held by friction amplifies that by about e per 170
+    substeps, a released object that falls or swings by much more: single envs reach centimetres there, with the same rewards).
+  * f32 product mode vs the f64 oracle, 128 seeds per task, two comparisons:
+      - teacher-forced (`lockstep`): at every env-step the oracle is put into the device's f32 state and steps the device's ctrl once.
+        Per-step reward and success flags without the divergence of two chaotic trajectories in between: a differing flag needs a
+        contact within f32 rounding of its margin in that step.  Observed (profiles/r04_episode_parity.json): 0 differing success
+        flags in 158 080 env-steps of SlotInsertion / InsertPeg / SewNeedle and 5 - 11 differing rewards per task (0.02 %);
+        HookPackage 0.15 % while the released package is knocked about in 4 of the 128 envs.
+      - open-loop replay of the whole ctrl sequence: the final is_success per env.  The f64 replay of controls that were computed
+        in closed loop on the f32 trajectory has no feedback: a millimetre of difference in how the object sits in the gripper, and
+        the replayed peg meets the tube's rim (clearance 8 mm).  The mismatch count is stated and bounded per task
+        (observed 0 / 6 / 4 / 0 of 128).
 """
 import numpy as np
 import pytest
@@ -19,43 +32,65 @@ import episode_util as U
 
 pytestmark = pytest.mark.gpu
 
-# f64 device vs oracle over a whole episode: the two differ in the order of the kinematic chain products (pointer jumping vs parent
-# to child), i.e. by 1e-16 per substep, and a grasp held by friction amplifies that by about e per 170 substeps (measured: 1e-16 ->
-# 1e-11 typical, 3e-4 in the worst of 32 episodes): stated bounds on the positions over the 5000 / 7000 substeps of an episode
-F64_POS_TOL_MAX, F64_POS_TOL_MEDIAN = 1e-3, 1e-6
+F64_POS_TOL_MEDIAN = 1e-6
+# (script, envs, max_reward the episode reaches, tasks whose bodies never fall or swing freely: max position difference bounded too)
+F64_CASES = [("slot_insertion", 8, 4, 1e-3), ("insert_peg", 8, 4, None), ("sew_needle_thread", 8, 5, None), ("hook_package", 8, 4, None), ("sew_needle", 8, None, 1e-3)]
 
 
-@pytest.mark.parametrize("task,n", [("slot_insertion", 8), ("sew_needle", 8)])
-def test_f64_full_episode_rewards_and_success_identical(task, n):
+@pytest.mark.parametrize("task,n,max_reward,pos_tol", F64_CASES)
+def test_f64_full_episode_rewards_and_success_identical(task, n, max_reward, pos_tol):
     dev = U.device_episode(task, n, f64=True)
     assert not dev["diverged"].any() and not dev["capped"].any()
     rows = U.compare_with_replay(task, dev)
+    differing = [r for r in rows if r["first_reward_diff"] != -1]
+    if task == "hook_package":           # the released package swings on the hook (friction 0.01): a few steps of one env may differ
+        assert len(differing) <= 1 and all(r["n_reward_diff"] <= 4 for r in differing), differing
+    else:
+        assert not differing, f"{task}: reward sequences differ: {differing}"
     for r in rows:
-        assert r["first_reward_diff"] == -1, f"{task} env {r['env']}: reward sequences differ from step {r['first_reward_diff']} ({r})"
         assert r["dev_success"] == r["orc_success"], r
-        assert r["ncon_diff_steps"] <= 5, r
-        assert r["max_qpos_err"] < F64_POS_TOL_MAX, r
+        assert r["dev_final_reward"] == r["orc_final_reward"], r
+        if pos_tol is not None:
+            assert r["ncon_diff_steps"] <= 5 and r["max_qpos_err"] < pos_tol, r
     assert np.median([r["max_qpos_err"] for r in rows]) < F64_POS_TOL_MEDIAN
-    if task == "slot_insertion":          # the episodes are real ones: the stick ends up in the slot (reward 4 = success)
-        assert sum(r["dev_success"] for r in rows) >= n - 1, rows
-    else:                                   # the needle is held off the table by the gripper (reward 2, env.py:666-671)
+    if max_reward is not None:            # the episodes are real ones: they end at max_reward = success (env.py:224) on both sides
+        assert sum(r["dev_success"] and r["dev_final_reward"] == max_reward for r in rows) >= n - 1, rows
+        assert sum(r["orc_success"] for r in rows) >= n - 1, rows
+    else:                                  # config 3's lift: the needle is held off the table by the gripper (reward 2, env.py:666-671)
         assert sum(r["dev_final_reward"] >= 2 for r in rows) >= n - 1, rows
 
 
-def test_f32_product_mode_success_flags_vs_f64_oracle_128_seeds():
-    """The f32 product path's whole episodes against the f64 oracle stepping the same ctrl sequences, 128 seeds of SlotInsertion:
-    final is_success per env.  A mismatch needs a contact event within the f32 rounding of a decision (the pin boxes touching,
-    env.py:584-587, or the stick leaving the gripper a step earlier): the count is bounded at 2 % and written down
-    (profiles/r03_episode_parity.json; DESIGN.md 4 states the number of the round)."""
-    n = 128
-    dev = U.device_episode("slot_insertion", n, f64=False)
+# task: (open-loop replay: bound on final-flag mismatches of 128; lockstep: bounds on differing success-flag steps, differing reward
+# steps (fraction of all env-steps), final-flag mismatches).  Observed at the end of round 4 in the comments.
+F32_CASES = {
+    "slot_insertion":    dict(replay_mismatch=2, ls_success_steps=2, ls_reward_frac=1e-3, ls_final=0, min_success=0.9),     # 0; 0, 1.1e-4, 0
+    "insert_peg":        dict(replay_mismatch=10, ls_success_steps=2, ls_reward_frac=1e-3, ls_final=0, min_success=0.9),    # 6; 0, 2.2e-4, 0
+    "sew_needle_thread": dict(replay_mismatch=8, ls_success_steps=2, ls_reward_frac=1e-3, ls_final=0, min_success=0.9),     # 4; 0, 1.6e-4, 0
+    "hook_package":      dict(replay_mismatch=2, ls_success_steps=160, ls_reward_frac=4e-3, ls_final=4, min_success=0.9),   # 0; 77, 1.5e-3, 3
+}
+
+
+@pytest.mark.parametrize("task", list(F32_CASES))
+def test_f32_product_mode_success_flags_vs_f64_oracle_128_seeds(task):
+    """The f32 product path's whole episodes against the f64 oracle, 128 seeds: per-step flags teacher-forced from the device's own
+    states, and the final is_success of the open-loop replay (see the module docstring for what each can and cannot show)."""
+    n, B = 128, F32_CASES[task]
+    dev = U.device_episode(task, n, f64=False, record_state=True)
     assert dev["diverged"].mean() <= 0.01 and dev["capped"].mean() <= 0.01
-    rows = U.compare_with_replay("slot_insertion", dev)
+    assert dev["success"][-1].mean() >= B["min_success"], f"{task}: the scripted episodes succeed on the device in {dev['success'][-1].mean():.2f} of the envs"
+    ls = U.compare_lockstep(task, dev)
+    steps = sum(r["steps"] for r in ls)
+    succ_steps, rew_steps = sum(r["success_diff_steps"] for r in ls), sum(r["reward_diff_steps"] for r in ls)
+    ls_final = sum(r["dev_success"] != r["orc_success"] for r in ls)
+    rows = U.compare_with_replay(task, dev)
     mism = [r for r in rows if r["dev_success"] != r["orc_success"]]
-    print(f"f32 vs f64 oracle: {len(mism)} / {n} success-flag mismatches; device success {np.mean([r['dev_success'] for r in rows]):.3f}, "
-          f"oracle {np.mean([r['orc_success'] for r in rows]):.3f}")
-    assert np.mean([r["dev_success"] for r in rows]) >= 0.9
-    assert len(mism) <= max(2, n // 50), mism
+    print(f"{task} f32 vs f64 oracle, {n} seeds: teacher-forced {succ_steps} success-flag / {rew_steps} reward differences in {steps} env-steps, {ls_final} final flags; "
+          f"open-loop replay {len(mism)} final-flag mismatches; device success {np.mean([r['dev_success'] for r in rows]):.3f}, oracle replay {np.mean([r['orc_success'] for r in rows]):.3f}")
+    assert succ_steps <= B["ls_success_steps"], (succ_steps, [r for r in ls if r["success_diff_steps"]][:8])
+    assert rew_steps <= B["ls_reward_frac"] * steps, (rew_steps, steps)
+    assert ls_final <= B["ls_final"], [r for r in ls if r["dev_success"] != r["orc_success"]]
+    assert len(mism) <= B["replay_mismatch"], mism
+    assert np.mean([r["orc_success"] for r in rows]) >= 0.85
 
 
 @pytest.mark.parametrize("f64", [False, True])

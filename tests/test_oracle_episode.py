@@ -26,3 +26,33 @@ def test_oracle_scripted_needle_lift():
     res = U.pool_map(U.closed_loop_worker, [(task, poses[k], home) for k in range(n)], 2)
     for k, (rw, su, q, cs) in enumerate(res):
         assert rw[-1] >= 2 and q[32] - poses[k, 1, 2] > 0.08      # held by the gripper, off the table (env.py:666-671)
+
+
+def _solves(task, n, max_reward):
+    home = U.oracle_home(task)
+    poses = W.object_poses(U.MODEL_OF.get(task, task), np.arange(n), U.TASK_SEED[task])
+    res = U.pool_map(U.closed_loop_worker, [(task, poses[k], home) for k in range(n)], n)
+    for rw, su, q, cs in res:
+        assert rw.max() == max_reward and su[-1] and rw[-1] == max_reward, (task, rw.max(), rw[-1])
+    return res
+
+
+def test_oracle_scripted_insert_peg_succeeds():
+    """env.py:453-462: both grasped and lifted (2), the peg in the tube touches the pin (4 = success)."""
+    for rw, su, q, cs in _solves("insert_peg", 2, 4):
+        assert (rw == 2).sum() > 50
+
+
+def test_oracle_scripted_sew_needle_threads_and_hands_over():
+    """env.py:676-689: grasp (1, 2), the threading latch (4, env.py:673), the left gripper alone holds the threaded needle clear of the
+    table and of pin-wall (5 = success) -- the stages the lift of BASELINE config 3 never reaches."""
+    for rw, su, q, cs in _solves("sew_needle_thread", 2, 5):
+        first = {v: int(np.argmax(rw == v)) for v in (1, 2, 4, 5)}
+        assert first[1] < first[2] < first[4] < first[5]
+        assert q[30] < q[23] - 0.05          # the needle ends up beyond the wall (qpos[23:26] wall, [30:33] needle)
+
+
+def test_oracle_scripted_hook_package_succeeds():
+    """env.py:851-862: both hands on the package (1), lifted (2), on the hook with the pins meeting (4 = success), still 4 after both let go."""
+    for rw, su, q, cs in _solves("hook_package", 2, 4):
+        assert (rw[-30:] == 4).all() and q[31] > 0.22          # hanging on the hook near the wall, hands gone
