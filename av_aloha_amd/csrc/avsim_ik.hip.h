@@ -6,6 +6,13 @@
 
 #include "avsim_model.h"
 
+// No FMA contraction in the IK (the whole header; restored at its end).  The reference's GradIK is a secant descent that amplifies a
+// rounding-level difference by 1.5 - 2 per iteration: with the default contraction the compiler fuses differently
+// whenever the surrounding code changes, and every closed-loop episode becomes another trajectory.  Without it the device evaluates
+// the expressions with the roundings of the oracle (oracle/Makefile: -ffp-contract=off) and of the reference's plain NumPy, and a
+// restructured kernel with the same operations gives the same bits (round 4: the row-parallel exponentials of gradik).
+#pragma clang fp contract(off)
+
 namespace avs {
 
 template <typename T>
@@ -386,9 +393,8 @@ __device__ __forceinline__ void limit_pose(const T cp[3], const T cR[9], const T
 
 // cost of grad_ik.py:168-198 at q; also hands back the position / rotation error norms of the pose (solution_fn, :200-220)
 template <typename T>
-__device__ __forceinline__ T gik_cost(const IkParams& P, const IkArm& A, const T* q, const T* qs, const T* tp, const T* tR, T* perr, T* rerr) {
-    T Rc[9], pc[3], e[3];
-    fk<T, 6>(A, q, Rc, pc);
+__device__ __forceinline__ T gik_cost_at(const IkParams& P, const IkArm& A, const T* Rc, const T* pc, const T* q, const T* qs, const T* tp, const T* tR, T* perr, T* rerr) {
+    T e[3];
     T d0 = tp[0] - pc[0], d1 = tp[1] - pc[1], d2 = tp[2] - pc[2];
     const T pn = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
     T t = (T)P.g_pw * pn;
@@ -415,13 +421,54 @@ __device__ __forceinline__ T gik_cost(const IkParams& P, const IkArm& A, const T
     *rerr = rn;
     return c + s;
 }
+template <typename T>
+__device__ __forceinline__ T gik_cost(const IkParams& P, const IkArm& A, const T* q, const T* qs, const T* tp, const T* tR, T* perr, T* rerr) {
+    T Rc[9], pc[3];
+    fk<T, 6>(A, q, Rc, pc);
+    return gik_cost_at(P, A, Rc, pc, q, qs, tp, tR, perr, rerr);
+}
+
+// Forward kinematics with the six joints' exponentials spread over the lanes of a row: `joint(i, Re, pe)` hands this lane joint i's
+// exp([S_i] q_i) (from the lane that made it, or its own); the products are fk()'s, in fk()'s order, so the pose is fk()'s bit for bit.
+template <typename T, typename F>
+__device__ __forceinline__ void fk_spread(const IkArm& A, F&& joint, T R[9], T p[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) R[3 * i + j] = (T)A.site0[4 * i + j];
+        p[i] = (T)A.site0[4 * i + 3];
+    }
+    // (one joint's exponential in flight while the one before it is multiplied in: fetching all six at once costs 144 registers)
+    T Rn[9], pn[3];
+    joint(5, Rn, pn);
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        T Re[9], pe[3], np[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Re[k] = Rn[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) pe[k] = pn[k];
+        if (i > 0) joint(i - 1, Rn, pn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 3; r++) np[r] = Re[3 * r] * p[0] + Re[3 * r + 1] * p[1] + Re[3 * r + 2] * p[2] + pe[r];
+        mat3mul(Re, R, R);
+        p[0] = np[0]; p[1] = np[1]; p[2] = np[2];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
 // grad_ik.py:8-99 (6-DoF manipulators), one problem per 16-lane row: the reference's loop evaluates its cost function 15 times per
 // iteration one after the other -- 12 central-difference points, the two secant points, the new iterate (+ a forward kinematics for
 // the solution test, which the last evaluation already contains).  The 12 difference points are independent: lane t < 12 of the row
 // takes joint t / 2, sign t & 1; the secant points go to the even / odd lanes; so an iteration is three evaluations deep instead of
-// sixteen.  Every evaluation is the same arithmetic as in the one-lane form and the gradient is gathered in joint order, so the result
-// is bit-identical to it.  All 16 lanes of a row must call this with the same arguments; every lane returns the answer.
+// sixteen.  An evaluation's forward kinematics is six exponentials exp([S_i] q_i) (a sine, a cosine and two 3 x 3 products each, in
+// double) and six pose products; the exponentials are made ONE per lane and handed round the row (fk_spread): a difference point
+// differs from the iterate in one joint, so its lane makes that joint's exponential and takes the other five from the lanes 0..5 that
+// keep the iterate's; the two secant points' twelve are made by lanes 0..11; the new iterate's six by lanes 0..5, which keep them for
+// the next iteration.  Every exponential and every product is the arithmetic of the one-lane form on the same operands and the gradient
+// is gathered in joint order, so the result is bit-identical to it.  All 16 lanes of a row must call this with the same arguments;
+// every lane returns the answer.
 template <typename T>
 // (inlined into its kernels: an out-of-line device function is compiled for the full 512-register budget, which caps its callers
 // at one wave per SIMD whatever they ask for)
@@ -429,24 +476,51 @@ __device__ __forceinline__ void gradik(const IkParams& P, int arm, const T* qs, 
     const IkArm& A = P.arm[arm];
     const int lane = threadIdx.x & 63, t = lane & 15, row0 = lane & ~15;
     const T step = (T)P.g_step;
+    const int jt = t < 6 ? t : (t < 12 ? t - 6 : t - 12);      // the joint whose exponential this lane makes for a point shared by the row
+    const int gi = t < 12 ? (t >> 1) : 0;                       // joint of this lane's difference point (t < 12)
+    const T gs = (t & 1) ? step : -step;                // odd lanes +step (p3), even lanes -step (p1)
+    T BR[9], Bp[3], ER[9], Ep[3];                       // exponentials: of the iterate (lanes 0..5: joint t), of this lane's point
+    auto sel = [](const T* v, int k) -> T { T x = v[0];
+#pragma unroll
+        for (int i = 1; i < 6; i++) x = (k == i) ? v[i] : x;
+        return x; };
+    // the row's own point: lane i < 6 makes joint i's exponential
+    auto from_row = [&](int i, T* Re, T* pe) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) Re[k] = __shfl(ER[k], row0 + i, 64);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pe[k] = __shfl(Ep[k], row0 + i, 64);
+    };
     T cR[9], cp[3], tp[3], tR[9], pe, re;
-    fk<T, 6>(A, qs, cR, cp);
+    exp_screw<T>(A.w[jt], A.v[jt], sel(qs, jt), ER, Ep);
+    fk_spread<T>(A, from_row, cR, cp);
+#pragma unroll
+    for (int k = 0; k < 9; k++) BR[k] = ER[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) Bp[k] = Ep[k];
     limit_pose(cp, cR, pos, tR0, (T)P.g_maxp, (T)P.g_maxr, tp, tR);
-    const T init = gik_cost(P, A, qs, qs, tp, tR, &pe, &re);
+    const T init = gik_cost_at(P, A, cR, cp, qs, qs, tp, tR, &pe, &re);
     T grad[6], work[6], local[6], best[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) { work[i] = local[i] = best[i] = qs[i]; grad[i] = 0; }
     T best_cost = init, prev = 0;
     bool done = false;
-    const int gi = t >> 1;                              // joint of this lane's difference point (t < 12)
-    const T gs = (t & 1) ? step : -step;                // odd lanes +step (p3), even lanes -step (p1)
     for (int it = 0; it < max_it; it++) {
         if (!__any(!done)) break;
+        T Rc[9], pc[3];
         // ---- 12 difference points ----
 #pragma unroll
         for (int i = 0; i < 6; i++) work[i] = local[i] + ((t < 12 && i == gi) ? gs : T(0));
         // (local[i] - step and local[i] + step exactly as the reference forms them: x + (-step) == x - step)
-        const T cd1 = gik_cost(P, A, work, qs, tp, tR, &pe, &re);
+        exp_screw<T>(A.w[gi], A.v[gi], sel(work, gi), ER, Ep);
+        fk_spread<T>(A, [&](int i, T* Re, T* pe_) {
+            const bool own = t < 12 && i == gi;
+#pragma unroll
+            for (int k = 0; k < 9; k++) { const T b = __shfl(BR[k], row0 + i, 64); Re[k] = own ? ER[k] : b; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const T b = __shfl(Bp[k], row0 + i, 64); pe_[k] = own ? Ep[k] : b; }
+        }, Rc, pc);
+        const T cd1 = gik_cost_at(P, A, Rc, pc, work, qs, tp, tR, &pe, &re);
 #pragma unroll
         for (int i = 0; i < 6; i++) grad[i] = __shfl(cd1, row0 + 2 * i + 1, 64) - __shfl(cd1, row0 + 2 * i, 64);
         T sum = 0;
@@ -454,10 +528,18 @@ __device__ __forceinline__ void gradik(const IkParams& P, int arm, const T* qs, 
         for (int i = 0; i < 6; i++) sum += fabs(grad[i]);
         sum += step;
         const T f = step / sum;
-        // ---- secant points: even lanes local - g, odd lanes local + g ----
+        // ---- secant points: even lanes local - g, odd lanes local + g; lane 2 i + parity makes joint i's exponential of that point ----
 #pragma unroll
         for (int i = 0; i < 6; i++) { grad[i] *= f; work[i] = (t & 1) ? local[i] + grad[i] : local[i] - grad[i]; }
-        const T cd2 = gik_cost(P, A, work, qs, tp, tR, &pe, &re);
+        exp_screw<T>(A.w[gi], A.v[gi], sel(work, gi), ER, Ep);
+        fk_spread<T>(A, [&](int i, T* Re, T* pe_) {
+            const int src = row0 + 2 * i + (t & 1);
+#pragma unroll
+            for (int k = 0; k < 9; k++) Re[k] = __shfl(ER[k], src, 64);
+#pragma unroll
+            for (int k = 0; k < 3; k++) pe_[k] = __shfl(Ep[k], src, 64);
+        }, Rc, pc);
+        const T cd2 = gik_cost_at(P, A, Rc, pc, work, qs, tp, tR, &pe, &re);
         const T p1 = __shfl(cd2, row0, 64), p3 = __shfl(cd2, row0 + 1, 64);
         const T p2 = T(0.5) * (p1 + p3), cd = T(0.5) * (p3 - p1);
         const T jd = (isfinite(cd) && cd != T(0)) ? p2 / cd : T(0);
@@ -469,10 +551,16 @@ __device__ __forceinline__ void gradik(const IkParams& P, int arm, const T* qs, 
             nl[i] = x;
         }
         // ---- the new iterate: cost and pose errors in one evaluation ----
-        const T lc = gik_cost(P, A, nl, qs, tp, tR, &pe, &re);
+        exp_screw<T>(A.w[jt], A.v[jt], sel(nl, jt), ER, Ep);
+        fk_spread<T>(A, from_row, Rc, pc);
+        const T lc = gik_cost_at(P, A, Rc, pc, nl, qs, tp, tR, &pe, &re);
         if (!done) {
 #pragma unroll
             for (int i = 0; i < 6; i++) local[i] = nl[i];
+#pragma unroll
+            for (int k = 0; k < 9; k++) BR[k] = ER[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) Bp[k] = Ep[k];
             if (lc < best_cost) {
 #pragma unroll
                 for (int i = 0; i < 6; i++) best[i] = local[i];
@@ -488,3 +576,5 @@ __device__ __forceinline__ void gradik(const IkParams& P, int arm, const T* qs, 
 }
 
 }  // namespace avs
+
+#pragma clang fp contract(fast)
