@@ -6,13 +6,6 @@
 
 #include "avsim_model.h"
 
-// No FMA contraction in the IK (the whole header; restored at its end).  The reference's GradIK is a secant descent that amplifies a
-// rounding-level difference by 1.5 - 2 per iteration: with the default contraction the compiler fuses differently
-// whenever the surrounding code changes, and every closed-loop episode becomes another trajectory.  Without it the device evaluates
-// the expressions with the roundings of the oracle (oracle/Makefile: -ffp-contract=off) and of the reference's plain NumPy, and a
-// restructured kernel with the same operations gives the same bits (round 4: the row-parallel exponentials of gradik).
-#pragma clang fp contract(off)
-
 namespace avs {
 
 template <typename T>
@@ -576,5 +569,3 @@ __device__ __forceinline__ void gradik(const IkParams& P, int arm, const T* qs, 
 }
 
 }  // namespace avs
-
-#pragma clang fp contract(fast)

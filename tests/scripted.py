@@ -344,7 +344,7 @@ class SewNeedleThreadScript(_Phases):
     needle's leading end against the window's axis; the left hand is placed on the measured needle."""
     T = (50, 40, 25, 40, 60, 30, 60, 15, 70, 40, 25, 60, 20)
 
-    def __init__(self, home, qpos, side=0.035, past=0.005, pull=0.08, gain=0.15, clip=0.05):
+    def __init__(self, home, qpos, side=0.035, past=0.005, pull=0.11, gain=0.15, clip=0.05):
         self.n = n = qpos.shape[0]
         self.home = home
         self._down(home)
@@ -415,8 +415,8 @@ class SewNeedleThreadScript(_Phases):
                 pl = pl + 0.10 * (1 - ramp(f)) * up
             elif k == 10:
                 gl = ramp(f, 0.6)
-            else:
+            else:           # pull it out along the window's axis, then a little up: clear of the sill, of pin-wall and of the base plate
                 gl = 1.0
-                pl = pl - self.pull * (ramp(f) if k == 11 else 1.0) * ex
+                pl = pl - self.pull * (ramp(f, 0.7) if k == 11 else 1.0) * ex + 0.02 * (max(0.0, (f - 0.7) / 0.3) if k == 11 else 1.0) * up
             pl_site = pl + site
         return self._assemble(self.servo_l(pl_site, qpos), lquat, gl, self.servo_r(pr + site, qpos), self.down_r, gr)
