@@ -13,7 +13,7 @@ from av_aloha_amd import workloads as W
 from orc_env import OrcEnv
 from orc_ffi import dp
 
-TASK_SEED = {"slot_insertion": 1000, "sew_needle": 2000, "insert_peg": 4000, "hook_package": 3000, "sew_needle_thread": 2000}
+TASK_SEED = {"slot_insertion": 1000, "sew_needle": 2000, "insert_peg": 4000, "hook_package": 3000, "sew_needle_thread": 2000, "tube_transfer": 5000}
 SCRIPT_KW = {}                    # development aid (tools/dev_script.py): keyword overrides of the script's parameters
 MODEL_OF = {"sew_needle_thread": "sew_needle"}      # script name -> task model (SewNeedle has two scripts: config 3's lift, the whole threading)
 GRIP_RANGE = (0.002, 0.037)
@@ -42,10 +42,10 @@ def make_script(task, home, qpos0):
     if task == "slot_insertion":
         from scripted import SlotInsertionScript
         return SlotInsertionScript(home, qpos0)
-    if task in ("insert_peg", "hook_package", "sew_needle_thread"):
+    if task in ("insert_peg", "hook_package", "sew_needle_thread", "tube_transfer"):
         import scripted
-        cls = {"insert_peg": scripted.InsertPegScript, "hook_package": getattr(scripted, "HookPackageScript", None),
-               "sew_needle_thread": getattr(scripted, "SewNeedleThreadScript", None)}[task]
+        cls = {"insert_peg": scripted.InsertPegScript, "hook_package": scripted.HookPackageScript, "sew_needle_thread": scripted.SewNeedleThreadScript,
+               "tube_transfer": scripted.TubeTransferScript}[task]
         return cls(home, qpos0, **SCRIPT_KW)
 
     class Lift:

@@ -420,3 +420,82 @@ class SewNeedleThreadScript(_Phases):
                 pl = pl - self.pull * (ramp(f, 0.7) if k == 11 else 1.0) * ex + 0.02 * (max(0.0, (f - 0.7) / 0.3) if k == 11 else 1.0) * up
             pl_site = pl + site
         return self._assemble(self.servo_l(pl_site, qpos), lquat, gl, self.servo_r(pr + site, qpos), self.down_r, gr)
+
+
+def rot_x(th, v):
+    c, s = np.cos(th), np.sin(th)
+    return np.array([v[0], c * v[1] - s * v[2], s * v[1] + c * v[2]])
+
+
+class TubeTransferScript(_Phases):
+    """TubeTransfer (task_tube_transfer.xml; reward stages env.py:771-778): the right arm takes tube1 (square tube, 10 cm tall, 2.3 cm
+    clear, the 1 cm ball inside, friction 1e-5) from its side, the left arm tube2, grippers horizontal (home orientation) pinching the
+    tubes at mid height; both lift (reward 2); the hands roll about their own axes (the world's x: wrist_rotate) until the tubes lie
+    along y mouth to mouth on one line that slopes `slope` radians down from tube1 to tube2 -- tube1 first stops `slope` short of the
+    horizontal (mouth up, the ball stays at its bottom) and is tipped over, about its mouth, only when the mouths are `gap` metres
+    apart: the ball rolls along the aligned inner walls into tube2 and meets the `pin` box inside it (3 = success).  Closed loop on the
+    measured tube poses (qpos[30:37] tube1, [37:44] tube2): the right hand's target integrates the error of tube1's mouth against the
+    point in front of tube2's mouth."""
+    T = (40, 40, 40, 25, 40, 90, 50, 60, 130)
+
+    def __init__(self, home, qpos, slope=0.5, gap=0.006, height=0.20, gain=0.15, clip=0.05):
+        self.n = n = qpos.shape[0]
+        self.home = home
+        self.t1, self.t2 = qpos[:, 30:33].copy(), qpos[:, 37:40].copy()
+        self.slope, self.gap, self.height, self.gain, self.clip = slope, gap, height, gain, clip
+        self.corr = np.zeros((n, 3))
+        fk = make_fk("tube_transfer")
+        self.servo_l, self.servo_r = HandServo(fk, 0, n), HandServo(fk, 1, n)
+        self.t = 0
+
+    def action(self, qpos):
+        n = self.n
+        k, f = self.phase()
+        tube1, q1, tube2, q2 = qpos[:, 30:33], qpos[:, 33:37], qpos[:, 37:40], qpos[:, 40:44]
+        ex, up = np.array([1.0, 0.0, 0.0]), np.array([0.0, 0.0, 1.0])
+        mid = np.array([0.0, 0.0, 0.05])
+        pr, pl = self.t1 + mid, self.t2 + mid                       # pinch points: the tubes' centres
+        th1 = th2 = 0.0
+        g = 0.0
+        hz = self.home["left"][:, 2]
+        if k == 0:
+            pr, pl = pr + 0.07 * ex, pl - 0.07 * ex
+            pr[:, 2] = pl[:, 2] = hz
+        elif k == 1:
+            pr, pl = pr + 0.07 * ex, pl - 0.07 * ex
+            pr[:, 2] = pl[:, 2] = hz + ramp(f) * (0.05 - hz)
+        elif k == 2:
+            pr, pl = pr + 0.07 * (1 - ramp(f)) * ex, pl - 0.07 * (1 - ramp(f)) * ex
+        elif k == 3:
+            g = ramp(f, 0.6)
+        elif k == 4:
+            g = 1.0
+            pr, pl = pr + ramp(f) * (self.height - 0.05) * up, pl + ramp(f) * (self.height - 0.05) * up
+        else:
+            g = 1.0
+            s = ramp(f) if k == 5 else 1.0
+            half = np.pi / 2
+            th2 = -s * (half - self.slope)                          # tube2: mouth towards +y, `slope` above the horizontal
+            tip = ramp(f) if k == 7 else (1.0 if k == 8 else 0.0)
+            th1 = s * (half - self.slope) + tip * 2 * self.slope    # tube1: mouth towards -y, first above, then `slope` below the horizontal
+            a1, a2 = rot_x(th1, up), rot_x(th2, up)                 # the tubes' axes, bottom -> mouth
+            gp = 0.03 if k == 5 else (0.03 + (self.gap - 0.03) * ramp(f) if k == 6 else self.gap)
+            J = np.array([0.0, BASE_Y, self.height])
+            u = rot_x(-(half - self.slope), up)                     # final direction of the common line, from tube2's bottom up to tube1's bottom: tube2's axis reversed ... (0, cos(slope), sin(slope))
+            u = np.array([0.0, np.cos(self.slope), np.sin(self.slope)])
+            m2 = J - 0.5 * gp * u                                   # tube2's mouth, tube1's mouth
+            m1 = J + 0.5 * gp * u
+            c2, c1 = m2 - 0.05 * a2, m1 - 0.05 * a1                 # their centres = the pinch points
+            start_r, start_l = self.t1 + mid + (self.height - 0.05) * up, self.t2 + mid + (self.height - 0.05) * up
+            pr, pl = start_r + s * (c1 - start_r), start_l + s * (c2 - start_l)
+            if k >= 6:
+                mouth1 = tube1 + quat_rot(q1, np.tile([0.0, 0.0, 0.10], (n, 1)))
+                mouth2 = tube2 + quat_rot(q2, np.tile([0.0, 0.0, 0.10], (n, 1)))
+                ax2 = quat_rot(q2, np.tile(up, (n, 1)))
+                goal = mouth2 + gp * ax2                              # tube1's mouth in front of tube2's, on tube2's axis
+                self.corr = np.clip(self.corr + self.gain * (goal - mouth1), -self.clip, self.clip)
+            pr = pr + self.corr
+        qr = np.stack([qmul(np.array([np.cos(th1 / 2), np.sin(th1 / 2), 0.0, 0.0]), self.home["right"][i, 3:]) for i in range(n)])
+        ql = np.stack([qmul(np.array([np.cos(th2 / 2), np.sin(th2 / 2), 0.0, 0.0]), self.home["left"][i, 3:]) for i in range(n)])
+        site = PINCH * ex
+        return self._assemble(self.servo_l(pl - site, qpos), ql, g, self.servo_r(pr + site, qpos), qr, g)

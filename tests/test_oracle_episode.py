@@ -56,3 +56,9 @@ def test_oracle_scripted_hook_package_succeeds():
     """env.py:851-862: both hands on the package (1), lifted (2), on the hook with the pins meeting (4 = success), still 4 after both let go."""
     for rw, su, q, cs in _solves("hook_package", 2, 4):
         assert (rw[-30:] == 4).all() and q[31] > 0.22          # hanging on the hook near the wall, hands gone
+
+
+def test_oracle_scripted_tube_transfer_succeeds():
+    """env.py:771-778: both tubes grasped (1) and lifted (2), the ball poured from tube1 into tube2 meets the pin (3 = success)."""
+    for rw, su, q, cs in _solves("tube_transfer", 2, 3):
+        assert (rw == 2).sum() > 100

@@ -18,7 +18,7 @@ import episode_util as U
 
 out = {}
 only = [a for a in sys.argv[2:]]
-for task, n64, n32 in (("slot_insertion", 16, 128), ("insert_peg", 16, 128), ("sew_needle_thread", 16, 128), ("hook_package", 16, 128), ("sew_needle", 16, 128)):
+for task, n64, n32 in (("slot_insertion", 16, 128), ("insert_peg", 16, 128), ("sew_needle_thread", 16, 128), ("hook_package", 16, 128), ("tube_transfer", 16, 128), ("sew_needle", 16, 128)):
     if only and task not in only:
         continue
     for mode, n in (("f64", n64), ("f32", n32)):
