@@ -19,12 +19,12 @@ the device's IK produced at every step is recorded and the oracle steps the SAME
       - teacher-forced (`lockstep`): at every env-step the oracle is put into the device's f32 state and steps the device's ctrl once.
         Per-step reward and success flags without the divergence of two chaotic trajectories in between: a differing flag needs a
         contact within f32 rounding of its margin in that step.  Observed (profiles/r04_episode_parity.json): 0 differing success
-        flags in 158 080 env-steps of SlotInsertion / InsertPeg / SewNeedle and 5 - 11 differing rewards per task (0.02 %);
-        HookPackage 0.15 % while the released package is knocked about in 4 of the 128 envs.
+        flags in 224 000 env-steps of SlotInsertion / InsertPeg / SewNeedle / TubeTransfer and 0 - 11 differing rewards per task
+        (< 0.02 %); HookPackage 0.15 % while the released package is knocked about in 4 of the 128 envs.
       - open-loop replay of the whole ctrl sequence: the final is_success per env.  The f64 replay of controls that were computed
         in closed loop on the f32 trajectory has no feedback: a millimetre of difference in how the object sits in the gripper, and
         the replayed peg meets the tube's rim (clearance 8 mm).  The mismatch count is stated and bounded per task
-        (observed 0 / 6 / 4 / 0 of 128).
+        (observed 0 / 4 - 6 / 1 - 4 / 0 / 8 of 128 for SlotInsertion / InsertPeg / SewNeedle / HookPackage / TubeTransfer).
 """
 import numpy as np
 import pytest
@@ -49,6 +49,12 @@ def test_f64_full_episode_rewards_and_success_identical(task, n, max_reward, pos
     differing = [r for r in rows if r["first_reward_diff"] != -1]
     if task == "hook_package":           # the released package swings on the hook (friction 0.01): a few steps of one env may differ
         assert len(differing) <= 1 and all(r["n_reward_diff"] <= 40 for r in differing), differing
+    elif task == "tube_transfer":
+        # the 0.5 g ball rattles in a tube with 2.3 cm of clearance while the arm carries and rolls it: a billiard, chaotic from the lift
+        # on.  The 1e-16 between the two sides becomes a different bounce within the episode, the ball meets the pin a few steps earlier
+        # or later (observed: 4 of 16 envs, at most 9 steps), its orientation is another one altogether -- flags and final rewards are
+        # asserted below for every env; teacher-forced (f32 test below) not one of 65 920 env-steps differs
+        assert len(differing) <= n // 2 and all(r["n_reward_diff"] <= 20 for r in differing), differing
     else:
         assert not differing, f"{task}: reward sequences differ: {differing}"
     for r in rows:
@@ -56,7 +62,8 @@ def test_f64_full_episode_rewards_and_success_identical(task, n, max_reward, pos
         assert r["dev_final_reward"] == r["orc_final_reward"], r
         if pos_tol is not None:
             assert r["ncon_diff_steps"] <= 25 and r["max_qpos_err"] < pos_tol, r      # (a contact at the edge of its margin: a handful of steps; 20 observed in one env)
-    assert np.median([r["max_qpos_err"] for r in rows]) < F64_POS_TOL_MEDIAN
+    if task != "tube_transfer":
+        assert np.median([r["max_qpos_err"] for r in rows]) < F64_POS_TOL_MEDIAN
     if max_reward is not None:            # the episodes are real ones: they end at max_reward = success (env.py:224) on both sides
         assert sum(r["dev_success"] and r["dev_final_reward"] == max_reward for r in rows) >= n - 1, rows
         assert sum(r["orc_success"] for r in rows) >= n - 1, rows
@@ -71,7 +78,7 @@ F32_CASES = {
     "insert_peg":        dict(replay_mismatch=10, ls_success_steps=2, ls_reward_frac=1e-3, ls_final=0, min_success=0.9),    # 6; 0, 2.2e-4, 0
     "sew_needle_thread": dict(replay_mismatch=8, ls_success_steps=2, ls_reward_frac=1e-3, ls_final=0, min_success=0.9),     # 4; 0, 1.6e-4, 0
     "hook_package":      dict(replay_mismatch=2, ls_success_steps=160, ls_reward_frac=4e-3, ls_final=4, min_success=0.9),   # 0; 77, 1.5e-3, 3
-    "tube_transfer":     dict(replay_mismatch=8, ls_success_steps=40, ls_reward_frac=2e-3, ls_final=2, min_success=0.85),   # (set after the first run)
+    "tube_transfer":     dict(replay_mismatch=14, ls_success_steps=2, ls_reward_frac=1e-3, ls_final=0, min_success=0.85),   # 8 (the ball's billiard in the carried tube); 0, 0, 0
 }
 
 
