@@ -12,7 +12,7 @@ the device's IK produced at every step is recorded and the oracle steps the SAME
 
   * f64 device mode vs the oracle, open-loop replay: the reward of every step and the final is_success are identical (HookPackage: in
     all envs but at most one, whose released package swings on the nearly frictionless hook, friction 0.01 -- a handful of steps);
-    the median over the envs of the largest position difference stays below 1e-6 (observed 1e-11 ... 5e-8: the two sides multiply
+    the median over the envs of the largest position difference stays below 1e-6 (observed 7e-10 ... 2e-7: the two sides multiply
     their kinematic chains out in a different order, 1e-16 per substep, a grasp held by friction amplifies that by about e per 170
     substeps, a released object that falls or swings by much more: single envs reach centimetres there, with the same rewards).
   * f32 product mode vs the f64 oracle, 128 seeds per task, two comparisons:
