@@ -89,6 +89,48 @@ def record_episode(env, actions23) -> dict:
     return data
 
 
+def record_scripted(task_name: str, num_episodes: int, cameras=(), seed: int | None = None, device: int = 0, only_success: bool = False, **script_kw):
+    """The counterpart of record_sim_episodes.py:68-212 with a scripted teleoperator in the headset's place (av_aloha_amd/scripted.py):
+    `num_episodes` episodes of `task_name` ("sim_insert_peg", ...) are run SIDE BY SIDE on the device -- one env each, object poses from the
+    task's own reset sampling (global numpy RNG, `seed` seeds it) -- through the Cartesian-action env (sim_env.py:277-312), and come back as
+    a list of episode dicts in the layout of record_sim_episodes.py:155-212 (`/observations/{qpos,qvel,all_qpos}`, `/action` = the joint-space
+    control with normalised grippers, `/observations/images/<cam>` u8 (T, H, W, 3); T = steps + 1, float32) next to per-episode
+    {"max_reward_reached", "success", "rewards"}.  only_success: keep the episodes that end at max_reward (check_dataset_reward.py's criterion)."""
+    from . import scripted
+    from .sim_env import make_sim_env, _TASK_OF_SUBSTRING
+    task = next(key for sub, key in _TASK_OF_SUBSTRING if sub in task_name)
+    n = int(num_episodes)
+    if seed is not None:
+        np.random.seed(seed)
+    env = make_sim_env(task_name, cameras=list(cameras), num_envs=n, device=device)
+    obs, _ = env.reset()
+    b = (lambda a: np.asarray(a)[None]) if n == 1 else np.asarray          # batch axis for a single env
+    home = {k: b(obs["poses"][k]).copy() for k in ("left", "right", "middle")}
+    script = scripted.make_script(scripted.SCRIPT_OF_TASK[task], home, b(obs["qpos"]), **script_kw)
+    steps, rewards = [obs], []
+    max_reward = env.sim.max_reward
+    for _ in range(script.steps()):
+        _, rw, _ = env.sim.step_cartesian(script.action(b(steps[-1]["qpos"])))
+        rewards.append(rw.copy())
+        steps.append(env.get_obs())
+    env.close()
+    rewards = np.stack(rewards)                                           # [T - 1, n]
+    stack = lambda f: np.stack([b(f(s)) for s in steps]).astype(np.float32)   # [T, n, ...]
+    arrays = {"/observations/qpos": stack(lambda s: s["joints"]["position"]), "/observations/qvel": stack(lambda s: s["joints"]["velocity"]),
+              "/observations/all_qpos": stack(lambda s: s["qpos"]), "/action": stack(lambda s: s["control"])}
+    images = {cam: np.stack([b(s["images"][cam]) for s in steps]) for cam in steps[0].get("images", {})}
+    episodes = []
+    for k in range(n):
+        ok = bool(rewards[-1, k] == max_reward)
+        if only_success and not ok:
+            continue
+        data = {name: np.ascontiguousarray(a[:, k]) for name, a in arrays.items()}
+        for cam, img in images.items():
+            data[f"/observations/images/{cam}"] = np.ascontiguousarray(img[:, k])
+        episodes.append({"data": data, "success": ok, "max_reward_reached": int(rewards[:, k].max()), "rewards": rewards[:, k].copy(), "max_reward": int(max_reward)})
+    return episodes
+
+
 def save_episode(data: dict, dataset_dir: str, episode_idx: int, use_h5py: bool | None = None) -> str:
     """episode_<idx>.hdf5 with the reference's layout (record_sim_episodes.py:186-206): through h5py when it is importable
     (use_h5py None / True), else through av_aloha_amd.hdf5min."""

@@ -38,15 +38,10 @@ def oracle_home(task="slot_insertion"):
 def make_script(task, home, qpos0):
     """Per-step 23-D action source for n envs: .steps(), .action(qpos [n, nq]) -> [n, 23]."""
     n = qpos0.shape[0]
+    from av_aloha_amd import scripted
+    if task in scripted.SCRIPTS:
+        return scripted.make_script(task, home, qpos0, **SCRIPT_KW)
     home = {k: np.broadcast_to(np.asarray(v, dtype=np.float64), (n, 7)).copy() for k, v in home.items()}
-    if task == "slot_insertion":
-        from scripted import SlotInsertionScript
-        return SlotInsertionScript(home, qpos0)
-    if task in ("insert_peg", "hook_package", "sew_needle_thread", "tube_transfer"):
-        import scripted
-        cls = {"insert_peg": scripted.InsertPegScript, "hook_package": scripted.HookPackageScript, "sew_needle_thread": scripted.SewNeedleThreadScript,
-               "tube_transfer": scripted.TubeTransferScript}[task]
-        return cls(home, qpos0, **SCRIPT_KW)
 
     class Lift:
         def __init__(self):

@@ -137,3 +137,30 @@ def test_rollout_record_and_replay_on_the_device():
     assert agent.shape == (6, 21) and rewards.shape == (6,)
     assert np.abs(agent - ep["/observations/qpos"]).max() < 1e-6                                  # same joints, same normalisation
     genv.close()
+
+
+@pytest.mark.gpu
+def test_scripted_recording_writes_the_reference_layout_and_replays_to_max_reward(tmp_path):
+    """record_sim_episodes.py's counterpart with a scripted teleoperator (harness.record_scripted, av_aloha_amd/scripted.py): InsertPeg
+    episodes run side by side on the device, saved as episode_<i>.hdf5 in the reference's layout (record_sim_episodes.py:155-212) with one
+    camera, read back, and replayed through set_qpos on the gym env to max_reward (check_dataset_reward.py's criterion)."""
+    from av_aloha_amd import harness
+    from av_aloha_amd.env import make
+    eps = harness.record_scripted("sim_insert_peg", 4, cameras=["wrist_cam_right"], seed=11)
+    assert len(eps) == 4 and sum(e["success"] for e in eps) >= 3
+    T = eps[0]["data"]["/action"].shape[0]
+    assert T == 351 and eps[0]["rewards"].shape == (T - 1,)
+    e = next(e for e in eps if e["success"])
+    d = e["data"]
+    assert d["/observations/qpos"].shape == (T, 21) and d["/observations/qvel"].shape == (T, 21) and d["/observations/all_qpos"].shape == (T, 37)
+    assert d["/action"].shape == (T, 21) and d["/action"].dtype == np.float32
+    img = d["/observations/images/wrist_cam_right"]
+    assert img.shape == (T, 480, 640, 3) and img.dtype == np.uint8 and img[0].std() > 5 and np.abs(img[0].astype(int) - img[-1].astype(int)).mean() > 1
+    assert 0.0 <= d["/action"][:, 6].min() and d["/action"][:, 6].max() <= 1.0            # grippers normalised in the recorded control (sim_env.py:205-218)
+    path = harness.save_episode(d, str(tmp_path), 0)
+    back = harness.load_episode(path)
+    assert set(back) == set(d) and all(np.array_equal(back[k], d[k]) for k in d)
+    genv = make("gym_guided_vision/InsertPeg-3Arms-v0", cameras=[])
+    _, rewards = harness.replay_episode(genv, back)
+    assert rewards.max() == genv.max_reward == 4
+    genv.close()
