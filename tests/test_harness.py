@@ -146,7 +146,7 @@ def test_scripted_recording_writes_the_reference_layout_and_replays_to_max_rewar
     camera, read back, and replayed through set_qpos on the gym env to max_reward (check_dataset_reward.py's criterion)."""
     from av_aloha_amd import harness
     from av_aloha_amd.env import make
-    eps = harness.record_scripted("sim_insert_peg", 4, cameras=["wrist_cam_right"], seed=11)
+    eps = harness.record_scripted("sim_insert_peg", 4, cameras=["cam_right_wrist"], seed=11)
     assert len(eps) == 4 and sum(e["success"] for e in eps) >= 3
     T = eps[0]["data"]["/action"].shape[0]
     assert T == 351 and eps[0]["rewards"].shape == (T - 1,)
@@ -154,7 +154,7 @@ def test_scripted_recording_writes_the_reference_layout_and_replays_to_max_rewar
     d = e["data"]
     assert d["/observations/qpos"].shape == (T, 21) and d["/observations/qvel"].shape == (T, 21) and d["/observations/all_qpos"].shape == (T, 37)
     assert d["/action"].shape == (T, 21) and d["/action"].dtype == np.float32
-    img = d["/observations/images/wrist_cam_right"]
+    img = d["/observations/images/cam_right_wrist"]
     assert img.shape == (T, 480, 640, 3) and img.dtype == np.uint8 and img[0].std() > 5 and np.abs(img[0].astype(int) - img[-1].astype(int)).mean() > 1
     assert 0.0 <= d["/action"][:, 6].min() and d["/action"][:, 6].max() <= 1.0            # grippers normalised in the recorded control (sim_env.py:205-218)
     path = harness.save_episode(d, str(tmp_path), 0)

@@ -3,7 +3,7 @@
 drives the sim with a VR headset and writes episode_<i>.hdf5, :155-212).  All episodes run side by side on the device.
 
     python tools/record_scripted_episodes.py --task_name sim_insert_peg --num_episodes 64 --dataset_dir data/sim_insert_peg \
-        [--cameras zed_cam,wrist_cam_left] [--seed 0] [--only_success] [--check]
+        [--cameras zed_cam,cam_left_wrist] [--seed 0] [--only_success] [--check]
 
 --check replays every saved episode's recorded full states through set_qpos on the task's gym env, as replay_sim_episode.py:221-262
 and gym_guided_vision/scripts/check_dataset_reward.py do, and reports how many reach max_reward."""
@@ -26,7 +26,7 @@ if __name__ == "__main__":
     ap.add_argument("--task_name", required=True, help="sim_insert_peg | sim_slot_insertion | sim_sew_needle | sim_tube_transfer | sim_hook_package (record_sim_episodes.py:33)")
     ap.add_argument("--num_episodes", type=int, default=16)
     ap.add_argument("--dataset_dir", required=True)
-    ap.add_argument("--cameras", default="", help="comma-separated camera names of the Cartesian env (zed_cam = the stereo pair 720 x 1440; others 480 x 640); none by default")
+    ap.add_argument("--cameras", default="", help="comma-separated camera names of the Cartesian env (sim_env.py:22: zed_cam = the stereo pair 720 x 1440; cam_left_wrist, cam_right_wrist, cam_high, cam_low 480 x 640); none by default")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--only_success", action="store_true")
     ap.add_argument("--check", action="store_true")
