@@ -29,6 +29,10 @@ The default line (one GPU, config 2, f32) also carries short side runs on the sa
   "f64_value"         the same workload with AVSIM_F64_PHYSICS (the reference's arithmetic: MuJoCo computes in double)
   "value_episode300"  reset + one whole 300-step episode of config 2
   "config3_value", "config4_value"   the contact-rich configurations (whole 250-step grasp script; 100 steps of the random walk)
+  "config5_value" / "config5"        config 2 + depth images of four cameras at 480x640 every step (BASELINE configs[4]): env-steps/s, the
+                                     image kernel's ms per launch (HIP events, avsim_render_kernel_time) and its fraction of the HBM write roof
+`roofline.bound` is "valu+latency" for the physics kernel: `frac` = its own floating-point work (profiles/kernel_flops.json) per launch time against
+the f32 vector peak; the HBM view of the contract (algorithmic bytes per launch / launch time against 8 TB/s) is kept as hbm_achieved / hbm_frac.
 `scaling` is "weak" with --envs-per-gpu (default 4096 on every GPU) and "strong" with --envs-total; `n_ranks_seen` is
 torch.distributed's world size as the process group reports it.
 """
