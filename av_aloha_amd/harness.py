@@ -131,6 +131,28 @@ def record_scripted(task_name: str, num_episodes: int, cameras=(), seed: int | N
     return episodes
 
 
+def check_dataset_reward(gym_id: str, episodes: list, device: int = 0):
+    """gym_guided_vision/scripts/check_dataset_reward.py:15-63 for a list of episode dicts (or loaded files): the gym env of the task is put
+    into the episode's first recorded state (`set_qpos(all_qpos[0])`) and steps the recorded `/action` sequence OPEN LOOP through `step_action`
+    -- on the gym assets' model, whose peg / needle contacts are stiffer than those of the data-collection assets the episode was recorded on
+    (task_insert_peg.xml:7 "HACK: modified solref different from data collection") --, `get_reward()` after every step; an episode passes when
+    its largest reward is `max_reward`.  All episodes are replayed side by side in one batched env.  -> (passed bool [n], rewards int [T, n])"""
+    from .env import make
+    n = len(episodes)
+    q0 = np.stack([np.asarray(e["/observations/all_qpos"][0], dtype=np.float64) for e in episodes])
+    acts = np.stack([np.asarray(e["/action"], dtype=np.float32) for e in episodes], axis=1)          # [T, n, 21]
+    env = make(gym_id, cameras=[], num_envs=n, device=device)
+    env.reset()
+    env.set_qpos(q0)
+    rewards = np.zeros((acts.shape[0], n), dtype=np.int32)
+    for t in range(acts.shape[0]):
+        env.step_action(acts[t][:, :env.num_joints])
+        rewards[t] = np.asarray(env.get_reward()).reshape(n)
+    ok = rewards.max(axis=0) == env.max_reward
+    env.close()
+    return ok, rewards
+
+
 def save_episode(data: dict, dataset_dir: str, episode_idx: int, use_h5py: bool | None = None) -> str:
     """episode_<idx>.hdf5 with the reference's layout (record_sim_episodes.py:186-206): through h5py when it is importable
     (use_h5py None / True), else through av_aloha_amd.hdf5min."""

@@ -5,8 +5,9 @@ drives the sim with a VR headset and writes episode_<i>.hdf5, :155-212).  All ep
     python tools/record_scripted_episodes.py --task_name sim_insert_peg --num_episodes 64 --dataset_dir data/sim_insert_peg \
         [--cameras zed_cam,cam_left_wrist] [--seed 0] [--only_success] [--check]
 
---check replays every saved episode's recorded full states through set_qpos on the task's gym env, as replay_sim_episode.py:221-262
-and gym_guided_vision/scripts/check_dataset_reward.py do, and reports how many reach max_reward."""
+--check replays every saved episode on the task's gym env both ways the reference has: its recorded full states through set_qpos
+(replay_sim_episode.py:221-262) and its recorded actions open loop through step_action from the first state
+(gym_guided_vision/scripts/check_dataset_reward.py), and reports how many reach max_reward."""
 import argparse
 import os
 import sys
@@ -48,4 +49,7 @@ if __name__ == "__main__":
             _, rewards = harness.replay_episode(env, harness.load_episode(p))
             ok += int(rewards.max() == env.max_reward)
         env.close()
-        print(f"check: {ok} / {len(paths)} replayed episodes reach max_reward {env.max_reward} (check_dataset_reward.py's criterion)")
+        print(f"state replay: {ok} / {len(paths)} episodes reach max_reward {env.max_reward} when their recorded states are replayed through set_qpos (replay_sim_episode.py)")
+        passed, _ = harness.check_dataset_reward(f"gym_guided_vision/{key}-3Arms-v0", [harness.load_episode(p) for p in paths])
+        print(f"check_dataset_reward: {int(passed.sum())} / {len(paths)} episodes reach max_reward when their recorded ACTIONS are stepped open loop on the gym env "
+              f"(gym_guided_vision/scripts/check_dataset_reward.py)")
