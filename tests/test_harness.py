@@ -164,3 +164,20 @@ def test_scripted_recording_writes_the_reference_layout_and_replays_to_max_rewar
     _, rewards = harness.replay_episode(genv, back)
     assert rewards.max() == genv.max_reward == 4
     genv.close()
+
+
+@pytest.mark.gpu
+def test_check_dataset_reward_steps_the_recorded_actions_open_loop():
+    """gym_guided_vision/scripts/check_dataset_reward.py: an episode of a data set passes when the gym env, put into the episode's first
+    recorded state, reaches max_reward while the recorded ACTIONS (joint-space control, normalised grippers, float32) are stepped open loop
+    through step_action.  HookPackage episodes recorded with the scripted teleoperator on the data-collection assets pass it on the gym
+    assets' model (harness.check_dataset_reward, all episodes side by side); an episode whose actions are the home pose throughout does not."""
+    from av_aloha_amd import harness
+    eps = harness.record_scripted("sim_hook_package", 8, seed=3)
+    data = [e["data"] for e in eps]
+    ok, rewards = harness.check_dataset_reward("gym_guided_vision/HookPackage-3Arms-v0", data)
+    assert rewards.shape == (411, 8) and ok.sum() >= 7 and sum(e["success"] for e in eps) >= 7
+    idle = {k: v.copy() for k, v in data[0].items()}
+    idle["/action"][:] = idle["/action"][0]
+    ok2, r2 = harness.check_dataset_reward("gym_guided_vision/HookPackage-3Arms-v0", [idle])
+    assert not ok2[0] and r2.max() == 0
