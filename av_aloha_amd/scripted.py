@@ -217,7 +217,7 @@ class InsertPegScript(_Phases):
     the IK's residual do not matter."""
     T = (50, 40, 25, 45, 70, 40, 60, 20)
 
-    def __init__(self, home, qpos, side=0.03, carry=0.12, depth=0.05, gain=0.15, clip=0.06, pitch=0.85):
+    def __init__(self, home, qpos, side=0.02, carry=0.08, depth=0.035, gain=0.15, clip=0.06, pitch=1.0):
         self.n = n = qpos.shape[0]
         self.home = home
         self.pitch = pitch
@@ -443,7 +443,7 @@ class TubeTransferScript(_Phases):
     point in front of tube2's mouth."""
     T = (40, 40, 40, 25, 40, 90, 50, 60, 130)
 
-    def __init__(self, home, qpos, slope=0.5, gap=0.006, height=0.20, gain=0.15, clip=0.05):
+    def __init__(self, home, qpos, slope=0.5, gap=0.006, height=0.20, gain=0.08, clip=0.05):
         self.n = n = qpos.shape[0]
         self.home = home
         self.t1, self.t2 = qpos[:, 30:33].copy(), qpos[:, 37:40].copy()
