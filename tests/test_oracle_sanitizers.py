@@ -1,7 +1,7 @@
 """The CPU oracle under AddressSanitizer + UndefinedBehaviorSanitizer: `make -C oracle san` builds the same sources
 with -fsanitize=address,undefined; a child process with libasan preloaded and ORC_LIB pointing at that build runs the oracle's
-physics / constraint / collision / reward / IK paths (a contact-rich SewNeedle stretch, a HookPackage random walk, the Cartesian IK
-composite, the depth ray caster); any sanitizer report aborts the child.  Skipped where gcc's libasan is not installed."""
+physics / constraint / collision / reward / IK paths (contact-rich stretches of the scripted SewNeedle, InsertPeg and TubeTransfer episodes,
+a HookPackage random walk under PGS, the Cartesian IK composite, the depth ray caster); any sanitizer report aborts the child.  Skipped where gcc's libasan is not installed."""
 import os
 import subprocess
 import sys
@@ -18,24 +18,25 @@ import episode_util as U
 from av_aloha_amd import workloads as W
 from orc_env import OrcEnv
 from orc_ffi import dp
-# scripted SewNeedle threading: grasp, contact-rich push through the window (MPR, multiccd, Newton with coupled trees, noslip, latch)
-task = "sew_needle_thread"
-home = U.oracle_home(task)
-pose = W.object_poses("sew_needle", np.arange(1), U.TASK_SEED[task])[0]
-e = U._new_env(task, pose)
-script = U.make_script(task, home, np.array(e.qpos)[None])
+# scripted episodes, closed loop: SewNeedle threading (MPR, multiccd, Newton with coupled trees, noslip, the latch), InsertPeg (pitched grasps,
+# box-box of the peg in the tube), TubeTransfer (three free bodies, the sphere in the tubes)
 a21 = np.zeros(21); lo, hi = U.GRIP_RANGE
-best = 0
-for t in range(int(os.environ.get("AVS_SAN_STEPS", "300"))):
-    a = np.ascontiguousarray(script.action(np.array(e.qpos)[None])[0])
-    e.L.orc_cart_to_ctrl(e.dptr, dp(a), 0, dp(a21))
-    c = a21.copy()
-    for j in (6, 13):
-        c[j] = a21[j] * (hi - lo) + lo
-    rw, su = U._step_ctrl(e, c)
-    best = max(best, rw)
-assert best >= 2 and np.isfinite(np.array(e.qpos)).all()
-e.close()
+for task, steps, want in (("sew_needle_thread", 300, 2), ("insert_peg", 200, 2), ("tube_transfer", 160, 2)):
+    home = U.oracle_home(task)
+    pose = W.object_poses(U.MODEL_OF.get(task, task), np.arange(1), U.TASK_SEED[task])[0]
+    e = U._new_env(task, pose)
+    script = U.make_script(task, home, np.array(e.qpos)[None])
+    best = 0
+    for t in range(int(os.environ.get("AVS_SAN_STEPS", steps))):
+        a = np.ascontiguousarray(script.action(np.array(e.qpos)[None])[0])
+        e.L.orc_cart_to_ctrl(e.dptr, dp(a), 0, dp(a21))
+        c = a21.copy()
+        for j in (6, 13):
+            c[j] = a21[j] * (hi - lo) + lo
+        rw, su = U._step_ctrl(e, c)
+        best = max(best, rw)
+    assert best >= want and np.isfinite(np.array(e.qpos)).all(), (task, best)
+    e.close()
 # HookPackage-2Arms under the joint random walk, PGS solver (the other solver path), depth ray caster
 e = OrcEnv("hook_package", 2)
 e.d.solver = 0; e.d.pgs_iters = 20
