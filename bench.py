@@ -82,6 +82,37 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
+
+def kernel_flops(cfg_id, f64):
+    """The kernel's own floating-point work per env-step (SQ instruction counters, tools/prof_flops.sh -> profiles/kernel_flops.json)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "kernel_flops.json"))).get(f"config{2 if cfg_id == 5 else cfg_id}" + ("_f64" if f64 else ""), {})
+    except Exception:
+        return {}
+
+
+def valu_roofline(cfg_id, f64, N, k_avg_ms, k_n, abytes):
+    """roofline block of a k_phys run: the kernel's own flops per launch / mean launch time against the vector peak of the dtype, the
+    HBM view next to it; `frac` stays numeric (the HBM fraction) when profiles/kernel_flops.json lacks the configuration."""
+    dtype = "f64" if f64 else "f32"
+    kf = kernel_flops(cfg_id, f64)
+    k_s = k_avg_ms * 1e-3
+    kflops = kf.get("flops_per_env_step")
+    tf = kflops * N / k_s / 1e12 if (kflops and k_s > 0) else None
+    hbm = abytes * N / k_s / 1e9 if k_s > 0 else 0.0
+    peak = VALU_PEAK_TFLOPS[dtype]
+    if tf is None:
+        return {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS, "traffic": None,
+                "kernel": f"k_phys<{'double' if f64 else 'float'}>", "kernel_avg_ms": k_avg_ms, "kernel_launches": int(k_n),
+                "algorithmic_bytes_per_launch": abytes * N, "note": "no kernel flop count for this configuration in profiles/kernel_flops.json: HBM view only"}
+    return {"bound": "valu+latency", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+            "hbm_achieved": hbm, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": hbm / HBM_PEAK_GBS,
+            "kernel": f"k_phys<{'double' if f64 else 'float'}>", "kernel_avg_ms": k_avg_ms, "kernel_launches": int(k_n),
+            "algorithmic_bytes_per_launch": abytes * N, "valu_flops_per_env_step_kernel": kflops,
+            "valu_lane_utilisation": kf.get("lane_utilisation"), "kernel_flops_source": kf.get("source"),
+            "peak_source": "FP64 vector 78.6 TF / FP32 vector 157.3 TF (AMD MI355X specification; MI355X_MICROARCH.md lists the matrix peaks only)"}
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline (oracle, kind "port"): every core steps its own envs of the same workload
 # ------------------------------------------------------------------------------------------------------------------
@@ -122,21 +153,34 @@ def cpu_baseline_worker(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(cfg_id, n_total, home, solver=1):
+def cpu_baseline(cfg_id, n_total, home, solver=1, budget_s=None):
+    """The oracle on all host cores (kind "port").  Sample: SURVEY 8(d)'s CPU-baseline size -- min(N, 1024) envs x one whole 300-step
+    episode -- when the host finishes it within `budget_s` (default 120 s of wall clock, AVSIM_CPU_BUDGET_S; estimated from the
+    oracle's measured ~60 env-steps/s per core on config 2), otherwise the largest whole number of envs per core x 300 steps that does;
+    the line says which."""
     import multiprocessing as mp
     from av_aloha_amd.build import build_oracle
     build_oracle()
     cores = max(1, min(os.cpu_count() or 1, 64))
-    # ~10-25 s per core: 4 envs x 150 env-steps at ~40-60 env-steps/s/core (the grasp script's GradIK and contacts are slower)
-    per, steps = (4, 150) if cfg_id != 3 else (2, 120)
-    jobs = [(cfg_id, list(range(c * per, (c + 1) * per)), n_total, steps, solver, home) for c in range(cores)]
+    budget_s = float(os.environ.get("AVSIM_CPU_BUDGET_S", "120")) if budget_s is None else budget_s
+    rate_core = {2: 55.0, 5: 55.0, 3: 14.0, 4: 45.0}.get(cfg_id, 40.0)        # env-steps/s per core observed in rounds 2-4 (EPYC 9575F)
+    steps = 300 if cfg_id != 3 else 250                                       # one whole episode / config 3's whole script
+    want = min(n_total, 1024)
+    per = max(1, min((want + cores - 1) // cores, int(budget_s * rate_core / steps)))
+    envs = min(want, per * cores)
+    # contiguous global env ids, the GPU run's first `envs`
+    jobs = [(cfg_id, list(range(c * per, min(envs, (c + 1) * per))), n_total, steps, solver, home) for c in range(cores) if c * per < envs]
     t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
-        pool.map(cpu_baseline_worker, jobs)
+    with mp.get_context("fork").Pool(len(jobs)) as pool:
+        busy = pool.map(cpu_baseline_worker, jobs)
     wall = time.perf_counter() - t0
-    return {"value": cores * per * steps / wall, "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "sample": f"{cores * per} envs x {steps} env-steps of the same workload (config {cfg_id}; oracle/liborc.so, scalar f64 C, "
-                      f"one process per core, solver={'newton' if solver else 'pgs-20'}), wall {wall:.1f} s incl. process start"}
+    full = envs == want
+    return {"value": envs * steps / wall, "unit": "env-steps/s", "cores": len(jobs), "kind": "port", "cpu_model": cpu_model(),
+            "value_per_core": envs * steps / sum(busy) if sum(busy) > 0 else None,
+            "sample": f"{envs} envs x {steps} env-steps of the same workload (config {cfg_id}: global env ids 0..{envs - 1}, the GPU run's seeds and actions; "
+                      f"{'SURVEY 8(d) size min(N, 1024) x one whole episode' if full else f'bounded below SURVEY 8(d) min(N, 1024) = {want} envs by the {budget_s:.0f} s budget'}; "
+                      f"oracle/liborc.so, scalar f64 C, one process per core on {len(jobs)} cores, solver={'newton' if solver else 'pgs-20'}), wall {wall:.1f} s incl. process start",
+            "note": "a straightforward scalar restatement (dense rows, no sparsity, no SIMD): a reported baseline, not a tuned engine; the GPU / CPU ratio says nothing about kernel quality"}
 
 
 class Workload:
@@ -284,6 +328,8 @@ def side_run(args, torch, cfg_id, N, local, f64, warmup, steps, render=""):
     info = {"value": N * steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warmup, "kernel_avg_ms": k_ms / max(1, k_n),
             "mean_ncon": float(dg[:, 0].mean()), "mean_nefc": float(dg[:, 1].mean()), "nan_envs": int((w.diverged & 1).sum().item()),
             "resets_in_timed_region": w.resets, "mean_return": float(w.ret.mean().item()), "success_rate": float(w.succ_any.float().mean().item())}
+    info["roofline"] = valu_roofline(cfg_id, f64, N, k_ms / max(1, k_n), k_n,
+                                     algorithmic_bytes(w.h.nq, w.h.nv, w.nj, 23 if w.ik_mode is not None else 14, f64))
     if w.depth is not None:
         r_ms = sum(a.elapsed_time(b) for a, b in w.r_events) / max(1, len(w.r_events))
         r_bytes = w.depth.numel() * 4
@@ -401,12 +447,21 @@ def main():
     for t in range(args.warmup, total):
         w.step(t)
         w.render(True)
-    # end-of-rollout exchange: one all-gather (RCCL) of (return f32, success i32) per env
+    # end-of-rollout exchange: one all-gather (RCCL) of (return f32, success i32) per env; events around it on the
+    # current stream (the collective is enqueued there), and this rank's own time up to it (before the barrier evens the ranks out)
+    ev_g0, ev_g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev_g0.record()
+    t_g0 = time.perf_counter()
     all_ret, all_succ = gather_episode_stats(w.ret, w.succ_any, dist, always=args.dist_always)
+    ev_g1.record()
+    torch.cuda.synchronize()
+    t_own = time.perf_counter() - t0
+    allgather_host_ms = (time.perf_counter() - t_g0) * 1e3
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    allgather_ms = ev_g0.elapsed_time(ev_g1)
     all_agent = None
     if args.dump:               # testing aid, outside the timed region: a per-env checksum of the final joint positions
         from av_aloha_amd.dist import _all_gather
@@ -417,11 +472,20 @@ def main():
     torch.cuda.synchronize()
     dg = w.diag.cpu().numpy()
     n_ranks_seen = 1
+    rank_ms = [t_own / args.steps * 1e3]
+    rank_kernel_ms = [k_ms / max(1, k_n)]
+    rank_allgather_ms = [allgather_ms]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         n_ranks_seen = dist.get_world_size()
+        # per-rank figures so that a multi-GPU line explains itself: each rank's own ms per step (without the final barrier), its mean
+        # k_phys launch, and the time of the all-gather as its events saw it
+        from av_aloha_amd.dist import _all_gather
+        pr = _all_gather(torch.tensor([[t_own / args.steps * 1e3, k_ms / max(1, k_n), allgather_ms]], dtype=torch.float64,
+                                      device=dev if args.backend == "nccl" else "cpu"), dist).cpu().numpy()
+        rank_ms, rank_kernel_ms, rank_allgather_ms = pr[:, 0].tolist(), pr[:, 1].tolist(), pr[:, 2].tolist()
 
     assert n_ranks_seen == world == args.gpus, (n_ranks_seen, world, args.gpus)
     if rank == 0:
@@ -470,7 +534,18 @@ def main():
             "value": value, "value_per_gpu": value / world, "unit": "env-steps/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
+            "multi_rank": {"allgather_ms": max(rank_allgather_ms), "allgather_ms_per_rank": rank_allgather_ms, "allgather_host_ms_rank0": allgather_host_ms,
+                           "allgather_bytes_per_rank": int(N * 8), "backend": (args.backend if dist is not None else None),
+                           "ms_per_step_rank_min": min(rank_ms), "ms_per_step_rank_max": max(rank_ms), "ms_per_step_per_rank": rank_ms,
+                           "k_phys_ms_per_rank": rank_kernel_ms,
+                           "note": "per-rank wall clock per step up to the end of the rank's own all-gather (before the closing barrier); allgather_ms = HIP "
+                                   "events around gather_episode_stats on the rank's stream (two collectives: f32 returns, i32 successes); world of one rank: a device copy"},
             "config": {"workload": workload,
+                       # the f32 product mode is admissible through north_star's "stated FP tolerance": per-step joint trajectories against the f64
+                       # oracle (the reference's arithmetic: MuJoCo mjtNum = double), asserted in tests/test_gpu_physics.py / test_gpu_bench_path.py
+                       "fp_tolerance": ("f64 device mode: 1e-10 rad per env-step vs the f64 oracle (tests/test_gpu_physics.py)" if args.f64 else
+                                        "f32 state and arithmetic: joint positions within 2e-5 rad of the f64 oracle over 25-30 env-steps (600 substeps) of this workload at 4096 envs "
+                                        "(tests/test_gpu_physics.py, tests/test_gpu_bench_path.py); rewards and success flags exact there; the like-for-like f64 figure is f64_value"),
                        "survey_config": args.config, "envs_per_gpu": N, "envs_total": n_total, "substeps_per_step": 20, "solver": args.solver,
                        "pgs_iters": args.pgs_iters, "noslip_iters": 3, "lanes_per_env": 64, "episode_len": EPISODE_LEN,
                        "resets_in_timed_region": w.resets,
@@ -488,7 +563,7 @@ def main():
             # MFMA): `frac` is the kernel's own floating-point work against the vector peak; the HBM view the contract asks for
             # (algorithmic bytes per launch / launch time against 8 TB/s) is kept next to it as hbm_*
             "roofline": {"bound": "valu+latency", "achieved": valu_k_tflops, "peak": VALU_PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-                         "frac": valu_k_tflops / VALU_PEAK_TFLOPS[dtype] if valu_k_tflops is not None else None,
+                         "frac": valu_k_tflops / VALU_PEAK_TFLOPS[dtype] if valu_k_tflops is not None else achieved / HBM_PEAK_GBS,
                          "hbm_achieved": achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_over_algorithmic": traffic / (abytes * N) if traffic else None,
@@ -527,7 +602,17 @@ def main():
         if headline and world == 1 and not args.f64 and not args.no_extras:
             f = side_run(args, torch, 2, N, local, True, 5, 20)
             out["f64_value"] = f["value"]
-            out["f64"] = {**f, "note": "AVSIM_F64_PHYSICS: the arithmetic of the reference (MuJoCo mjtNum = double), same workload"}
+            out["f64"] = {**f, "dtype": "f64", "note": "AVSIM_F64_PHYSICS: the arithmetic of the reference (MuJoCo mjtNum = double), same workload, same flags; "
+                                                       "its own roofline block (k_phys<double> against the FP64 vector peak)"}
+            out["roofline_f64"] = f["roofline"]
+            # small-N behaviour: BASELINE configs[1] as written (1024 envs: half a round of the 2048 resident wave slots) and the latency of
+            # ONE env-step of ONE env (the reference's documented use is 1 - 10 envs, README.md:163-169: below ~2048 envs throughput is N / latency)
+            v1k = side_run(args, torch, 2, 1024, local, False, 5, 20)
+            out["value_1024"] = v1k["value"]
+            out["config2_1024"] = {**v1k, "note": "BASELINE configs[1] as written: 1024 parallel SlotInsertion-3Arms envs, physics + diff-IK, no render"}
+            one = side_run(args, torch, 2, 1, local, False, 5, 40)
+            out["latency_ms_1env"] = one["ms_per_step"]
+            out["config2_1env"] = {**one, "note": "ONE env: wall clock of one env-step (IK launch + 20 substeps in one k_phys launch + outputs), the latency floor of the design"}
             e = side_run(args, torch, 2, N, local, False, 0, 300)
             out["value_episode300"] = e["value"]
             out["episode300"] = {**e, "note": "steps 0..299 of config 2: reset + one whole 300-step episode (data_collection_scripts/constants.py:23-58)"}
