@@ -14,6 +14,11 @@
   package's own minimal writer (av_aloha_amd/hdf5min.py: same groups, names, dtypes, image chunking (1, H, W, 3) and attribute, in
   the structures libhdf5 writes by default); `load_episode` reads both, and the older .npz files.
 * `replay_episode` (gym_guided_vision/scripts/replay_sim_episode.py:221-262): set_qpos through `/observations/all_qpos`.
+* `rerender_episode` / `rerender_dataset` (gym_guided_vision/scripts/replay_sim_episode.py:47-113): how the reference makes its
+  per-camera-configuration training sets -- a recorded episode's full states are put back frame by frame (`set_qpos`), the gym env
+  of the wanted camera configuration renders its registered cameras (`get_obs()["pixels"]`), and a new HDF5 is written with those
+  images next to the recorded qpos / qvel / action (the first 14 columns for a 2-arm env).  Here the T frames of an episode are T
+  envs of ONE batched handle: one set_qpos, one render call per chunk of frames.
 """
 from __future__ import annotations
 
@@ -89,45 +94,91 @@ def record_episode(env, actions23) -> dict:
     return data
 
 
-def record_scripted(task_name: str, num_episodes: int, cameras=(), seed: int | None = None, device: int = 0, only_success: bool = False, **script_kw):
+def _image_bytes_per_step(cameras) -> int:
+    """u8 bytes of one env's images per time step in the Cartesian env's sizes (sim_env.py:187-203)."""
+    return sum(720 * 1440 * 3 if c == "zed_cam" else 480 * 640 * 3 for c in cameras)
+
+
+def record_scripted(task_name: str, num_episodes: int, cameras=(), seed: int | None = None, device: int = 0, only_success: bool = False,
+                    image_budget_bytes: int = 8 << 30, keep_diverged: bool = False, sink=None, **script_kw):
     """The counterpart of record_sim_episodes.py:68-212 with a scripted teleoperator in the headset's place (av_aloha_amd/scripted.py):
     `num_episodes` episodes of `task_name` ("sim_insert_peg", ...) are run SIDE BY SIDE on the device -- one env each, object poses from the
     task's own reset sampling (global numpy RNG, `seed` seeds it) -- through the Cartesian-action env (sim_env.py:277-312), and come back as
     a list of episode dicts in the layout of record_sim_episodes.py:155-212 (`/observations/{qpos,qvel,all_qpos}`, `/action` = the joint-space
     control with normalised grippers, `/observations/images/<cam>` u8 (T, H, W, 3); T = steps + 1, float32) next to per-episode
-    {"max_reward_reached", "success", "rewards"}.  only_success: keep the episodes that end at max_reward (check_dataset_reward.py's criterion)."""
+    {"max_reward_reached", "success", "rewards", "diverged"}.
+
+    With cameras the episodes are run in batches sized so that one batch's images stay below `image_budget_bytes` of host memory (every
+    step's images are written straight into the per-episode arrays: one copy, not three); the object poses are drawn for ALL episodes first,
+    in episode order, so the data set does not depend on the batching.  An env whose state diverged during some step (avsim_get_diag, the
+    flag the env facades turn into PhysicsError / `truncated`) was put back to its reset state mid-episode: such an episode is dropped, as the
+    reference drops an episode whose physics raised (unless keep_diverged; it is flagged either way).  only_success: keep the episodes whose
+    LARGEST reward over time is max_reward -- check_dataset_reward.py:52-58's criterion; "success" is that flag, "final_success" says
+    whether the episode also ENDS at max_reward.  sink(episode): called for every kept episode as its batch finishes INSTEAD of collecting
+    them (a recorder that writes and forgets keeps one batch in memory; the function then returns the episodes' summaries without "data")."""
     from . import scripted
+    from .env import sample_object_poses
     from .sim_env import make_sim_env, _TASK_OF_SUBSTRING
     task = next(key for sub, key in _TASK_OF_SUBSTRING if sub in task_name)
-    n = int(num_episodes)
+    n_all = int(num_episodes)
     if seed is not None:
         np.random.seed(seed)
-    env = make_sim_env(task_name, cameras=list(cameras), num_envs=n, device=device)
-    obs, _ = env.reset()
-    b = (lambda a: np.asarray(a)[None]) if n == 1 else np.asarray          # batch axis for a single env
-    home = {k: b(obs["poses"][k]).copy() for k in ("left", "right", "middle")}
-    script = scripted.make_script(scripted.SCRIPT_OF_TASK[task], home, b(obs["qpos"]), **script_kw)
-    steps, rewards = [obs], []
-    max_reward = env.sim.max_reward
-    for _ in range(script.steps()):
-        _, rw, _ = env.sim.step_cartesian(script.action(b(steps[-1]["qpos"])))
-        rewards.append(rw.copy())
-        steps.append(env.get_obs())
-    env.close()
-    rewards = np.stack(rewards)                                           # [T - 1, n]
-    stack = lambda f: np.stack([b(f(s)) for s in steps]).astype(np.float32)   # [T, n, ...]
-    arrays = {"/observations/qpos": stack(lambda s: s["joints"]["position"]), "/observations/qvel": stack(lambda s: s["joints"]["velocity"]),
-              "/observations/all_qpos": stack(lambda s: s["qpos"]), "/action": stack(lambda s: s["control"])}
-    images = {cam: np.stack([b(s["images"][cam]) for s in steps]) for cam in steps[0].get("images", {})}
+    poses_all = np.stack([sample_object_poses(task) for _ in range(n_all)])           # the draws of n_all sequential env.reset() calls
+    cameras = list(cameras)
+    b = lambda a, n: np.asarray(a)[None] if n == 1 else np.asarray(a)                 # batch axis for a single env
     episodes = []
-    for k in range(n):
-        ok = bool(rewards[-1, k] == max_reward)
-        if only_success and not ok:
-            continue
-        data = {name: np.ascontiguousarray(a[:, k]) for name, a in arrays.items()}
-        for cam, img in images.items():
-            data[f"/observations/images/{cam}"] = np.ascontiguousarray(img[:, k])
-        episodes.append({"data": data, "success": ok, "max_reward_reached": int(rewards[:, k].max()), "rewards": rewards[:, k].copy(), "max_reward": int(max_reward)})
+    start = 0
+    while start < n_all:
+        # batch size from the image budget: T is only known once the script exists, so size it with the longest script (600 steps)
+        per_ep = _image_bytes_per_step(cameras) * 601
+        n = n_all - start if per_ep == 0 else max(1, min(n_all - start, int(image_budget_bytes // per_ep)))
+        env = make_sim_env(task_name, cameras=cameras, num_envs=n, device=device)
+        env.sim.reset(poses_all[start:start + n])
+        obs = env.get_obs()
+        home = {k: b(obs["poses"][k], n).copy() for k in ("left", "right", "middle")}
+        script = scripted.make_script(scripted.SCRIPT_OF_TASK[task], home, b(obs["qpos"], n), **script_kw)
+        T = script.steps() + 1
+        max_reward = env.sim.max_reward
+        fields = {"/observations/qpos": lambda s: s["joints"]["position"], "/observations/qvel": lambda s: s["joints"]["velocity"],
+                  "/observations/all_qpos": lambda s: s["qpos"], "/action": lambda s: s["control"]}
+        # per-episode arrays, written step by step
+        data = [{name: np.empty((T,) + b(f(obs), n).shape[1:], dtype=np.float32) for name, f in fields.items()} for _ in range(n)]
+        for k in range(n):
+            for cam in obs.get("images", {}):
+                data[k][f"/observations/images/{cam}"] = np.empty((T,) + b(obs["images"][cam], n).shape[1:], dtype=np.uint8)
+        rewards = np.zeros((T - 1, n), dtype=np.int32)
+        diverged = np.zeros(n, dtype=bool)
+
+        def put(t, o):
+            for name, f in fields.items():
+                v = b(f(o), n)
+                for k in range(n):
+                    data[k][name][t] = v[k]
+            for cam, img in o.get("images", {}).items():
+                img = b(img, n)
+                for k in range(n):
+                    data[k][f"/observations/images/{cam}"][t] = img[k]
+        put(0, obs)
+        for t in range(1, T):
+            _, rw, _ = env.sim.step_cartesian(script.action(b(obs["qpos"], n)))
+            diverged |= (env.sim.diag()[:, 3] & 1).astype(bool)
+            rewards[t - 1] = rw
+            obs = env.get_obs()
+            put(t, obs)
+        env.close()
+        for k in range(n):
+            reached = int(rewards[:, k].max())
+            ok = reached == max_reward
+            if (only_success and not ok) or (diverged[k] and not keep_diverged):
+                continue
+            ep = {"data": data[k], "success": bool(ok), "final_success": bool(rewards[-1, k] == max_reward), "max_reward_reached": reached,
+                             "rewards": rewards[:, k].copy(), "max_reward": int(max_reward), "diverged": bool(diverged[k]), "episode_index": start + k}
+            if sink is not None:
+                sink(ep)
+                ep = {k2: v for k2, v in ep.items() if k2 != "data"}
+                data[k] = None
+            episodes.append(ep)
+        start += n
     return episodes
 
 
@@ -203,3 +254,74 @@ def replay_episode(env, data: dict):
         obs.append(env.get_obs()["agent_pos"][..., :na])
         rewards.append(env.get_reward())
     return np.stack(obs), np.asarray(rewards)
+
+
+def rerender_episode(data, env_id: str, save_path: str | None = None, device: int = 0, frames_per_batch: int = 128, env=None, use_h5py: bool | None = None):
+    """gym_guided_vision/scripts/replay_sim_episode.py:47-89 `replay_episode`: `data` is an episode (a path or a loaded dict with
+    `/observations/{qpos,qvel,all_qpos}` and `/action`); `env_id` names the gym env whose camera configuration the new data set is for
+    (`gym_guided_vision/<Task>-{2,3}Arms-v0`: 6 cameras for 3 arms, 4 for 2, 480 x 640, __init__.py:6-19).  Every recorded full state
+    `all_qpos[t]` is put back (`set_qpos`, env.py:251-253) and the env's cameras are rendered (`get_obs()["pixels"]`, env.py:180-188); the
+    result holds `/observations/qpos`, `/observations/qvel`, `/action` -- the first 14 columns for a 2-arm env, all 21 otherwise (:62-73) --
+    and `/observations/images/<cam>` u8 (T, H, W, 3) per camera; `all_qpos` is not carried over (the reference's data_dict does not have it).
+    The frames are independent, so they are T envs of one batched handle, `frames_per_batch` at a time (one set_qpos + one render call each).
+    save_path: also written there in the reference's layout (replay_sim_episode.py:11-44).  env: a batched gym env of `env_id` with
+    num_envs == frames_per_batch to reuse (rerender_dataset passes one)."""
+    from .env import ENVS, make
+    if isinstance(data, str):
+        data = load_episode(data)
+    spec = ENVS[env_id]
+    all_qpos = np.asarray(data["/observations/all_qpos"], dtype=np.float64)
+    T = all_qpos.shape[0]
+    na = 14 if spec["num_arms"] == 2 else 21
+    out = {"/observations/qpos": np.ascontiguousarray(np.asarray(data["/observations/qpos"])[:, :na]),
+           "/observations/qvel": np.ascontiguousarray(np.asarray(data["/observations/qvel"])[:, :na]),
+           "/action": np.ascontiguousarray(np.asarray(data["/action"])[:, :na])}
+    own = env is None
+    B = max(1, min(int(frames_per_batch), T)) if own else env.num_envs
+    if own:
+        env = make(env_id, num_envs=B, device=device)
+    assert env.num_arms == spec["num_arms"] and list(env.cameras) == list(spec["cameras"]), "env does not have the camera configuration of env_id"
+    H, W = env.observation_height, env.observation_width
+    for cam in env.cameras:
+        out[f"/observations/images/{cam}"] = np.empty((T, H, W, 3), dtype=np.uint8)
+    nq = env.sim.nq
+    assert all_qpos.shape[1] == nq, f"the episode's all_qpos has {all_qpos.shape[1]} columns, the model of {env_id} {nq}"
+    for t0 in range(0, T, B):
+        q = all_qpos[t0:t0 + B]
+        n = q.shape[0]
+        if n < B:                                   # the last chunk: the spare envs repeat its last frame
+            q = np.concatenate([q, np.repeat(q[-1:], B - n, 0)])
+        env.sim.set_qpos(q)
+        img = env.sim.render_rgb(env.cameras, H, W)                   # [B, ncam, H, W, 3]
+        for ci, cam in enumerate(env.cameras):
+            out[f"/observations/images/{cam}"][t0:t0 + n] = img[:n, ci]
+    if own:
+        env.close()
+    if save_path is not None:
+        os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
+        d, f = os.path.split(os.path.abspath(save_path))
+        assert f.startswith("episode_") and f.endswith(".hdf5"), "save_path is <dir>/episode_<i>.hdf5 (replay_sim_episode.py:104-107)"
+        save_episode(out, d, int(f[len("episode_"):-len(".hdf5")]), use_h5py=use_h5py)
+    return out
+
+
+def rerender_dataset(dataset_dir: str, env_id: str, episode_idx: int | None = None, device: int = 0, frames_per_batch: int = 128):
+    """replay_sim_episode.py:92-113 `main`: every `episode_*.hdf5` of `dataset_dir` (or the one with `episode_idx`) re-rendered for
+    `env_id` into `<dataset_dir>/<EnvName>/episode_<i>.hdf5` (EnvName = the id without its namespace).  Returns the written paths and
+    the frames per second over the whole run."""
+    import glob
+    import time
+    from .env import make
+    pat = "episode_*.hdf5" if episode_idx is None else f"episode_{episode_idx}.hdf5"
+    paths = sorted(glob.glob(os.path.join(dataset_dir, pat)))
+    env = make(env_id, num_envs=frames_per_batch, device=device) if paths else None
+    written, frames, t0 = [], 0, time.time()
+    for p in paths:
+        save_path = os.path.join(dataset_dir, env_id.split("/")[-1], os.path.basename(p))
+        out = rerender_episode(p, env_id, save_path, env=env)
+        frames += out["/action"].shape[0]
+        written.append(save_path)
+    if env is not None:
+        env.close()
+    dt = time.time() - t0
+    return written, (frames / dt if dt > 0 else 0.0)

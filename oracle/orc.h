@@ -127,6 +127,7 @@ void orc_data_free(orc_data* d);
 /* depth image of camera `cam` at the current state (positions must be fresh: orc_forward / orc_step): float32 metres along
  * the optical axis, out[H][W] row 0 = top; returns the number of pixels that hit a geom */
 int orc_render_depth(const orc_data* d, int cam, int H, int W, float* out);
+int orc_render_depth_rows(const orc_data* d, int cam, int H, int W, int row0, int row_step, int nrows, float* out);
 int orc_render_rgb(const orc_data* d, int cam, int H, int W, unsigned char* out, float* depth);
 /* colour image of the visual meshes (orc_vis.c): brute-force ray caster over the expanded scene of compiler/vismesh.py */
 int orc_vis_render(const orc_data* d, int cam, int nvert, const double* vert, const int* vbody, int ntri, const int* tri, const double* rgb,

@@ -64,6 +64,10 @@ class OrcEnv:
         o = np.ascontiguousarray(obj_qpos, dtype=np.float64).reshape(-1)
         self.L.orc_reset(self.dptr, dp(o))
 
+    def set_qpos(self, qpos):
+        q = np.ascontiguousarray(qpos, dtype=np.float64).reshape(self.nq)
+        self.L.orc_set_qpos(self.dptr, dp(q))
+
     def step(self, nsub=20):
         self.L.orc_step(self.dptr, nsub)
 
@@ -84,6 +88,15 @@ class OrcEnv:
         out = np.empty((H, W), dtype=np.float32)
         self.L.orc_render_depth.restype = C.c_int
         hits = self.L.orc_render_depth(self.dptr, ci, H, W, out.ctypes.data_as(C.c_void_p))
+        assert hits >= 0
+        return out
+
+    def render_depth_rows(self, cam, H, W, row0, row_step, nrows):
+        """rows row0, row0 + row_step, ... of the H x W depth image: float32 [nrows, W] (the same rays as render_depth)."""
+        ci = self.man["camera_names"].index(cam) if isinstance(cam, str) else int(cam)
+        out = np.empty((nrows, W), dtype=np.float32)
+        self.L.orc_render_depth_rows.restype = C.c_int
+        hits = self.L.orc_render_depth_rows(self.dptr, ci, H, W, row0, row_step, nrows, out.ctypes.data_as(C.c_void_p))
         assert hits >= 0
         return out
 

@@ -56,6 +56,12 @@ def test_depth_full_size_properties_and_ragged_width():
     H, W = 480, 640
     img = sim.render_depth(["zed_cam_left", "wrist_cam_right"], H, W)
     assert img.shape == (2, 2, H, W) and np.isfinite(img).all() and img.min() >= 0.03 and img.max() <= 30.0
+    # every 16th row (offset 5: rows of different tile rows and of both row halves of a lane) of both cameras against the oracle's rays
+    for ci, cam in enumerate(["zed_cam_left", "wrist_cam_right"]):
+        rows = e.render_depth_rows(cam, H, W, 5, 16, 30)
+        assert (rows < 30).mean() > 0.2
+        compare(img[0, ci, 5::16][:30], rows)
+        assert np.array_equal(img[0, ci], img[1, ci])
     small = sim.render_depth(["zed_cam_left"], 48, 72)[0, 0]            # 72 = 2 tiles + 8 pixels
     compare(small, e.render_depth("zed_cam_left", 48, 72))
     # the 120 x 160 image samples the same scene: its pixel (i, j) centre is the corner shared by four full-size pixels

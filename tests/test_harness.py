@@ -181,3 +181,54 @@ def test_check_dataset_reward_steps_the_recorded_actions_open_loop():
     idle["/action"][:] = idle["/action"][0]
     ok2, r2 = harness.check_dataset_reward("gym_guided_vision/HookPackage-3Arms-v0", [idle])
     assert not ok2[0] and r2.max() == 0
+
+
+@pytest.mark.gpu
+def test_rerender_replay_of_a_recorded_episode_for_another_camera_configuration(tmp_path):
+    """gym_guided_vision/scripts/replay_sim_episode.py:47-113: a recorded episode's full states are put back frame by frame on the gym env of
+    ANOTHER camera configuration and its registered cameras rendered; the new file holds those images next to qpos / qvel / action cut to 14
+    columns for a 2-arm env.  harness.rerender_episode runs the T frames as T envs of one batched handle.  Checked: layout and slicing for the
+    2-arm and the 3-arm id, the file round trip under <dataset_dir>/<EnvName>/, frames that differ over time, and three frames pixel by pixel
+    against the oracle's ray caster over the visual scene (oracle/orc_vis.c) at the recorded states."""
+    from av_aloha_amd.env import make
+    from av_aloha_amd.sim_env import make_sim_env
+    from orc_env import OrcEnv
+    from test_gpu_visual import agree, scene_of
+    cenv = make_sim_env("sim_slot_insertion", cameras=[])
+    np.random.seed(5)
+    obs, _ = cenv.reset()
+    target = np.concatenate([obs["poses"]["left"], [0.0], obs["poses"]["right"], [0.0], obs["poses"]["middle"]])
+    acts = np.repeat(target[None], 9, 0)
+    acts[:, 0] += 0.01 * np.arange(9)             # the left hand moves 8 cm
+    acts[:, 18] += 0.005 * np.arange(9)           # the camera arm rises
+    ep = harness.record_episode(cenv, acts)
+    cenv.close()
+    T = 10
+    d = str(tmp_path)
+    harness.save_episode(ep, d, 0)
+    # 2-arm configuration at the registry's size, through the data-set entry point
+    written, fps = harness.rerender_dataset(d, "gym_guided_vision/SlotInsertion-2Arms-v0", frames_per_batch=4)      # 10 frames in chunks of 4, 4, 2
+    assert written == [os.path.join(d, "SlotInsertion-2Arms-v0", "episode_0.hdf5")] and fps > 0
+    out = harness.load_episode(written[0])
+    cams2 = ["overhead_cam", "worms_eye_cam", "wrist_cam_left", "wrist_cam_right"]
+    assert set(out) == {"/observations/qpos", "/observations/qvel", "/action"} | {f"/observations/images/{c}" for c in cams2}
+    assert out["/observations/qpos"].shape == (T, 14) and out["/observations/qvel"].shape == (T, 14) and out["/action"].shape == (T, 14)
+    assert np.array_equal(out["/observations/qpos"], ep["/observations/qpos"][:, :14]) and np.array_equal(out["/action"], ep["/action"][:, :14])
+    for c in cams2:
+        im = out[f"/observations/images/{c}"]
+        assert im.shape == (T, 480, 640, 3) and im.dtype == np.uint8 and im.std() > 10
+    assert (out["/observations/images/overhead_cam"][0] != out["/observations/images/overhead_cam"][-1]).any()       # the arm moved
+    # 3-arm configuration at a size the oracle's brute-force ray caster finishes: frames 0, 4, 9 against it
+    H, W = 60, 80
+    env3 = make("gym_guided_vision/SlotInsertion-3Arms-v0", observation_height=H, observation_width=W, num_envs=4)
+    out3 = harness.rerender_episode(ep, "gym_guided_vision/SlotInsertion-3Arms-v0", env=env3)
+    env3.close()
+    assert out3["/observations/qpos"].shape == (T, 21) and out3["/observations/images/zed_cam_left"].shape == (T, H, W, 3)
+    scene = scene_of("slot_insertion", 3)
+    e = OrcEnv("slot_insertion", 3)
+    for t in (0, 4, 9):
+        e.set_qpos(ep["/observations/all_qpos"][t].astype(np.float64))
+        for cam in ("zed_cam_left", "overhead_cam", "wrist_cam_left"):
+            ref, tid, dep = e.render_visual(cam, H, W, scene)
+            agree(out3[f"/observations/images/{cam}"][t], ref, 0.02)
+    e.close()

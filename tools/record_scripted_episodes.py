@@ -34,12 +34,18 @@ if __name__ == "__main__":
     args = ap.parse_args()
     cams = [c for c in args.cameras.split(",") if c]
     t0 = time.time()
-    eps = harness.record_scripted(args.task_name, args.num_episodes, cameras=cams, seed=args.seed, only_success=args.only_success)
+    paths, t_save, T = [], [0.0], [0]
+
+    def sink(e):            # written as its batch finishes: one batch of images in host memory at a time
+        ts = time.time()
+        paths.append(harness.save_episode(e["data"], args.dataset_dir, len(paths)))
+        T[0] = e["data"]["/action"].shape[0]
+        t_save[0] += time.time() - ts
+    eps = harness.record_scripted(args.task_name, args.num_episodes, cameras=cams, seed=args.seed, only_success=args.only_success, sink=sink)
     t1 = time.time()
-    paths = [harness.save_episode(e["data"], args.dataset_dir, i) for i, e in enumerate(eps)]
-    T = eps[0]["data"]["/action"].shape[0] if eps else 0
-    print(f"{args.task_name}: {len(eps)} episodes of {T} steps recorded in {t1 - t0:.1f} s ({args.num_episodes} run side by side), "
-          f"{sum(e['success'] for e in eps)} end at max_reward {eps[0]['max_reward'] if eps else '-'}; saved to {args.dataset_dir} in {time.time() - t1:.1f} s")
+    print(f"{args.task_name}: {len(eps)} episodes of {T[0]} steps recorded and saved to {args.dataset_dir} in {t1 - t0:.1f} s ({t_save[0]:.1f} s of it writing; "
+          f"{args.num_episodes} run side by side, in batches under the image budget), {sum(e['success'] for e in eps)} reach max_reward {eps[0]['max_reward'] if eps else '-'} "
+          f"({sum(e['final_success'] for e in eps)} end there), {args.num_episodes - len(eps)} dropped (diverged{' / unsuccessful' if args.only_success else ''})")
     if args.check and eps:
         from av_aloha_amd.env import make
         key = next(v for k, v in GYM_ID.items() if k in args.task_name)
