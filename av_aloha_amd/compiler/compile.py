@@ -712,6 +712,32 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
     return arrays, manifest
 
 
+def write_full_hulls(assets, out_dir):
+    """`--oracle-hulls full`: the FULL convex hulls (scipy qhull over every STL vertex, scaled as the <mesh> asset says) of the collision
+    meshes of all tasks -- what MuJoCo collides [EXT: mesh geoms collide as the convex hull of the mesh] -- for the CPU oracle's faithful
+    mode (oracle/orc.h orc_model_set_hulls, tests/orc_ffi.py load_model(hulls="full")).  The device keeps the decimated hulls of the model
+    blobs; the oracle has no LDS or register budget to respect.  -> models/oracle_full_hulls.avh (full_vert f64 [n, 3], full_adr, full_num)
+    + .json (mesh names in the blob's order)."""
+    from .mjcf import parse as _parse
+    names, verts = [], []
+    for t in TASKS:
+        m = _parse(os.path.join(assets, TASKS[t][0]))
+        for g in m.geoms:
+            if (g["contype"] or g["conaffinity"]) and g.get("mesh") and g["mesh"] not in names:
+                me = m.meshes[g["mesh"]]
+                pts = hullmod.read_stl(me["file"]) * me["scale"]
+                from scipy.spatial import ConvexHull
+                names.append(g["mesh"])
+                verts.append(pts[ConvexHull(pts).vertices])
+    adr = np.cumsum([0] + [len(v) for v in verts[:-1]]).astype(np.int32)
+    num = np.array([len(v) for v in verts], dtype=np.int32)
+    write_blob(os.path.join(out_dir, "oracle_full_hulls.avh"), {"full_vert": np.concatenate(verts), "full_adr": adr, "full_num": num})
+    with open(os.path.join(out_dir, "oracle_full_hulls.json"), "w") as f:
+        json.dump({"mesh_names": names, "nvert": [int(x) for x in num],
+                   "note": "full qhull vertex sets of the collision meshes (geom frame, metres), for the CPU oracle only"}, f, indent=1)
+    print(f"oracle full hulls: {len(names)} meshes, {int(num.sum())} vertices")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--assets", default=None)
@@ -723,12 +749,19 @@ def main():
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "..", "models"))
     ap.add_argument("--tasks", nargs="*", default=list(TASKS))
     ap.add_argument("--vis-budget", type=int, default=20000, help="triangles of the biggest visual scene after decimation")
+    ap.add_argument("--oracle-hulls", choices=["none", "full"], default="none",
+                    help="full: also write models/oracle_full_hulls.* -- the undecimated convex hulls of the collision meshes for the CPU oracle's faithful mode")
+    ap.add_argument("--only-oracle-hulls", action="store_true", help="write the oracle's full hulls and nothing else")
     args = ap.parse_args()
     if args.assets is None:
         args.assets = {"gym": "/root/reference/gym_guided_vision/gym_guided_vision/assets",
                        "data_collection": "/root/reference/data_collection_scripts/assets"}[args.variant]
     prefix = "dc_" if args.variant == "data_collection" else ""
     os.makedirs(args.out, exist_ok=True)
+    if args.oracle_hulls == "full" or args.only_oracle_hulls:
+        write_full_hulls(args.assets, args.out)
+        if args.only_oracle_hulls:
+            return
     # the visual mesh library, shared by every model (the gym and data-collection assets hold the same meshes): decimated so that the
     # biggest scene stays under the triangle budget
     lib_path = os.path.join(args.out, "visual_meshes.avv")

@@ -12,6 +12,11 @@ namespace avs {
 enum { G_SPHERE = 2, G_CYLINDER = 5, G_BOX = 6, G_MESH = 7 };
 // narrow-phase result slot of one candidate pair: up to 5 contacts (box-box keeps <= 4, multiccd <= 1 + 4) that share a normal
 constexpr int SLOT_W = 24, SLOT_P = 5, SLOT_N = 20, SLOT_MAXC = 5;
+// box-box manifolds hold up to 8 points (every vertex of the clipped incident face that lies behind the reference face, as MuJoCo's
+// mjc_BoxBox returns [EXT]): points 0..3 go to the pair's LDS result slot, points 4..7 -- a quadrilateral cut by the reference rectangle
+// into a polygon of five to eight vertices: rare -- to a per-pair overflow record of BOX_OVF_W words in global scratch (point 4 + j at
+// words 4 j .. 4 j + 3: dist, pos), so that the eight-point manifold costs no LDS
+constexpr int BOX_MAXC = 8, BOX_SLOTC = 4, BOX_OVF_W = 16;
 
 template <typename T>
 struct Shape {
@@ -374,11 +379,12 @@ AVS_DEV int sphere_box(const Shape<T>& a, const Shape<T>& b, T* dist, T* pos, T*
 template <typename T> AVS_DEV T sel3(const T* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
 template <typename T> AVS_DEV void col3(const T* M, int k, T* o) { o[0] = sel3(M, k); o[1] = sel3(M + 3, k); o[2] = sel3(M + 6, k); }
 
-// box-box: 15-axis SAT then reference-face clipping (face contact, <=4 points) or closest edge points.
+// box-box: 15-axis SAT then reference-face clipping (face contact, <= 8 points: BOX_MAXC) or closest edge points.
 // `work` = 56 words of LDS scratch for the clipped polygon (dynamic indexing would otherwise spill it to scratch memory),
-// `scr` = the lane's result slot (SLOT_W words): dist [0,5), pos [SLOT_P, SLOT_P + 15), common normal [SLOT_N, SLOT_N + 3).
-template <typename T>
-__device__ int box_box(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, AVS_LDS(T) work) {
+// `scr` = the lane's result slot (SLOT_W words): dist [0,5), pos [SLOT_P, SLOT_P + 15), common normal [SLOT_N, SLOT_N + 3);
+// `ovf` = the pair's overflow record for points 4..7 (BOX_OVF_W words, any pointer type).
+template <typename T, typename OVF>
+__device__ int box_box(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, AVS_LDS(T) work, OVF ovf) {
     const T *Ra = a.mat, *Rb = b.mat;
     T p[3], pa[3], pb[3];
     sub3(b.pos, a.pos, p);
@@ -540,44 +546,23 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, AVS
         if (dq >= 0) { dst[3 * m] = px; dst[3 * m + 1] = py; dst[3 * m + 2] = pz; dep[m] = dq; m++; }
     }
     if (m == 0) return 0;
-    int keep[4], nk = 0;
-    if (m <= 4) { for (int q = 0; q < m; q++) keep[nk++] = q; }
-    else {
-        // ties are structural here (equal depths on a flat contact; two vertices of an edge parallel to the base line have equal
-        // cross products): a later vertex wins only by more than the TieTol margins
-        int i0 = 0;
-        for (int q = 1; q < m; q++) if (dep[q] > dep[i0] + TieTol<T>::len) i0 = q;
-        int i1 = i0;
-        T bd = -1;
-        for (int q = 0; q < m; q++) {
-            T dx = tmp[3 * q + a1] - tmp[3 * i0 + a1], dy = tmp[3 * q + a2] - tmp[3 * i0 + a2], dd = dx * dx + dy * dy;
-            if (dd > bd + TieTol<T>::rel * fabs(bd)) { bd = dd; i1 = q; }
-        }
-        T ex = tmp[3 * i1 + a1] - tmp[3 * i0 + a1], ey = tmp[3 * i1 + a2] - tmp[3 * i0 + a2];
-        int i2 = -1, i3 = -1;
-        T mx = T(1e-18), mn = T(-1e-18);
-        for (int q = 0; q < m; q++) {
-            T cr = ex * (tmp[3 * q + a2] - tmp[3 * i0 + a2]) - ey * (tmp[3 * q + a1] - tmp[3 * i0 + a1]);
-            if (cr > mx + TieTol<T>::rel * fabs(mx)) { mx = cr; i2 = q; }
-            if (cr < mn - TieTol<T>::rel * fabs(mn)) { mn = cr; i3 = q; }
-        }
-        keep[nk++] = i0; keep[nk++] = i1;
-        if (i2 >= 0) keep[nk++] = i2;
-        if (i3 >= 0) keep[nk++] = i3;
-    }
-    for (int x = 0; x < nk; x++)
-        for (int y = x + 1; y < nk; y++)
-            if (keep[y] < keep[x]) { int t = keep[x]; keep[x] = keep[y]; keep[y] = t; }
+    // every clipped vertex behind the reference face is a contact, in polygon order (at most 8)
+    const int nk = m < BOX_MAXC ? m : BOX_MAXC;
     for (int x = 0; x < nk; x++) {
-        int q = keep[x];
+        const int q = x;
         T l[3] = {tmp[3 * q], tmp[3 * q + 1], tmp[3 * q + 2]};
 #pragma unroll
         for (int j = 0; j < 3; j++) l[j] += (j == ax) ? T(0.5) * dep[q] * face : T(0);
         T wv[3];
         mulmat(rmat, l, wv);
         T dq_ = dep[q];
-        for (int c = 0; c < 3; c++) scr[SLOT_P + 3 * x + c] = wv[c] + rpos[c];
-        scr[x] = -dq_;
+        if (x < BOX_SLOTC) {
+            for (int c = 0; c < 3; c++) scr[SLOT_P + 3 * x + c] = wv[c] + rpos[c];
+            scr[x] = -dq_;
+        } else {
+            ovf[4 * (x - BOX_SLOTC)] = -dq_;
+            for (int c = 0; c < 3; c++) ovf[4 * (x - BOX_SLOTC) + 1 + c] = wv[c] + rpos[c];
+        }
     }
     for (int c = 0; c < 3; c++) scr[SLOT_N + c] = n[c];
     return nk;
@@ -593,8 +578,8 @@ __device__ int box_box(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, AVS
 template <typename T> AVS_DEV T sel33(const T (*M)[3], int i, int j) { return sel3(i == 0 ? M[0] : (i == 1 ? M[1] : M[2]), j); }
 template <typename T> AVS_DEV T row_get(T x, int g16, int l) { return __shfl(x, g16 | l, 64); }
 
-template <typename T>
-__device__ int box_box16(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, AVS_LDS(T) work, int lane, bool on) {
+template <typename T, typename OVF>
+__device__ int box_box16(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, AVS_LDS(T) work, OVF ovf, int lane, bool on) {
     const int t = lane & 15, g16 = lane & ~15;
     const unsigned rowmask_sh = g16;
     const T *Ra = a.mat, *Rb = b.mat;
@@ -783,45 +768,23 @@ __device__ int box_box16(const Shape<T>& a, const Shape<T>& b, AVS_LDS(T) scr, A
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    int keep[4], nk = 0;
-    if (m <= 4) { for (int q = 0; q < m; q++) keep[nk++] = q; }
-    else {
-        // rare (more than four polygon vertices): every lane replays the serial selection on the LDS copy
-        // ties are structural here (equal depths on a flat contact; two vertices of an edge parallel to the base line have equal
-        // cross products): a later vertex wins only by more than the TieTol margins
-        int i0 = 0;
-        for (int q = 1; q < m; q++) if (dep[q] > dep[i0] + TieTol<T>::len) i0 = q;
-        int i1 = i0;
-        T bd = -1;
-        for (int q = 0; q < m; q++) {
-            T dx = tmp[3 * q + a1] - tmp[3 * i0 + a1], dy = tmp[3 * q + a2] - tmp[3 * i0 + a2], dd = dx * dx + dy * dy;
-            if (dd > bd + TieTol<T>::rel * fabs(bd)) { bd = dd; i1 = q; }
-        }
-        T ex = tmp[3 * i1 + a1] - tmp[3 * i0 + a1], ey = tmp[3 * i1 + a2] - tmp[3 * i0 + a2];
-        int i2 = -1, i3 = -1;
-        T mx = T(1e-18), mn = T(-1e-18);
-        for (int q = 0; q < m; q++) {
-            T cr = ex * (tmp[3 * q + a2] - tmp[3 * i0 + a2]) - ey * (tmp[3 * q + a1] - tmp[3 * i0 + a1]);
-            if (cr > mx + TieTol<T>::rel * fabs(mx)) { mx = cr; i2 = q; }
-            if (cr < mn - TieTol<T>::rel * fabs(mn)) { mn = cr; i3 = q; }
-        }
-        keep[nk++] = i0; keep[nk++] = i1;
-        if (i2 >= 0) keep[nk++] = i2;
-        if (i3 >= 0) keep[nk++] = i3;
-        for (int x = 0; x < nk; x++)
-            for (int y = x + 1; y < nk; y++)
-                if (keep[y] < keep[x]) { int tq = keep[x]; keep[x] = keep[y]; keep[y] = tq; }
-    }
-    if (on && t < nk) {          // lane x writes contact x
-        const int q = t == 0 ? keep[0] : (t == 1 ? keep[1] : (t == 2 ? keep[2] : keep[3]));
+    // every clipped vertex behind the reference face is a contact, in polygon order (at most 8): lane x writes contact x
+    const int nk = m < BOX_MAXC ? m : BOX_MAXC;
+    if (on && t < nk) {
+        const int q = t;
         T l[3] = {tmp[3 * q], tmp[3 * q + 1], tmp[3 * q + 2]};
         const T dq_ = dep[q];
 #pragma unroll
         for (int j = 0; j < 3; j++) l[j] += (j == ax) ? T(0.5) * dq_ * face : T(0);
         T wv[3];
         mulmat(rmat, l, wv);
-        for (int c = 0; c < 3; c++) scr[SLOT_P + 3 * t + c] = wv[c] + rpos[c];
-        scr[t] = -dq_;
+        if (t < BOX_SLOTC) {
+            for (int c = 0; c < 3; c++) scr[SLOT_P + 3 * t + c] = wv[c] + rpos[c];
+            scr[t] = -dq_;
+        } else {
+            ovf[4 * (t - BOX_SLOTC)] = -dq_;
+            for (int c = 0; c < 3; c++) ovf[4 * (t - BOX_SLOTC) + 1 + c] = wv[c] + rpos[c];
+        }
     }
     if (on && t == 0) { for (int c = 0; c < 3; c++) scr[SLOT_N + c] = n[c]; }
     (void)rowmask_sh;

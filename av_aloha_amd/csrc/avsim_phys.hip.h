@@ -149,6 +149,7 @@ struct DevModel {
     int* near_glob;     // Verlet neighbour lists int[N][NEAR_MAX] (rebuilt when a geom moved more than skin / 2)
     int* cand_glob;     // exact broad-phase survivors int[N][CAND_MAX]
     real* gref_glob;    // geom centres at the last rebuild, real[N][ngeom][3]
+    real* bxo_glob;     // box-box overflow records real[N][64][BOX_OVF_W]: points 4..7 of a pair's manifold (avsim_collide.hip.h)
     // observation
     GLB_PTR(const int) obs_qposadr;
     GLB_PTR(const real) obs_offset;
@@ -1860,6 +1861,7 @@ struct Env {
     AVS_DEV GLB_PTR(real) coup_() const { return (GLB_PTR(real))ka->m.gA_glob + (size_t)env * ka->lay.ggrp * GA_W; }
     AVS_DEV GLB_PTR(int) near_() const { return (GLB_PTR(int))ka->m.near_glob + (size_t)env * NEAR_MAX; }
     AVS_DEV GLB_PTR(int) cand_() const { return (GLB_PTR(int))ka->m.cand_glob + (size_t)env * CAND_MAX; }
+    AVS_DEV GLB_PTR(real) bxo_() const { return (GLB_PTR(real))ka->m.bxo_glob + (size_t)env * 64 * BOX_OVF_W; }
     AVS_DEV GLB_PTR(real) gref_() const { return (GLB_PTR(real))ka->m.gref_glob + (size_t)env * ka->m.ngeom * 3; }
     AVS_DEV const int* body_parent_() const { return LI() + ka->mo.body_parent; }
     AVS_DEV const int* body_jntadr_() const { return LI() + ka->mo.body_jntadr; }
@@ -2434,6 +2436,7 @@ struct Env {
         // else, then the multiccd perturbations of the convex pairs found in contact: the wave executes the clipping code and the
         // MPR code once each instead of both in every pass.
         int* mlist = ii + ka->lay.cand;      // lanes of the pairs that get the multiccd treatment (the kinematics' table is idle here)
+        GLB_PTR(real) bxo = bxo_();          // points 4..7 of the box-box manifolds of this pass, one record per lane
         for (int base = 0; base < ncand; base += G) {
             const int ci = base + lane;
             int n = 0, p = 0, nn = 0;
@@ -2470,7 +2473,7 @@ struct Env {
                     Shape<real> a, b;
                     load_shape(pga, a);
                     load_shape(pgb, b);
-                    const int n16 = box_box16(a, b, (LDS_PTR(real))(r + ka->lay.scr + SLOT_W * src), (LDS_PTR(real))(r + ka->lay.scr + SLOT_W * G + 56 * row), lane, on);
+                    const int n16 = box_box16(a, b, (LDS_PTR(real))(r + ka->lay.scr + SLOT_W * src), (LDS_PTR(real))(r + ka->lay.scr + SLOT_W * G + 56 * row), bxo + BOX_OVF_W * src, lane, on);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     const int got = __shfl(on ? n16 : 0, 16 * ((rk - b0) & 3), 64);
@@ -2533,27 +2536,30 @@ struct Env {
                 }
             }
             int keepmask = 0;
+            GLB_PTR(const real) ov = bxo + BOX_OVF_W * lane;
             if (valid) {
-                // drop separated points (margin = 0 here) while keeping order
+                // drop separated points (margin = 0 here) while keeping order; a box pair's points 4..7 sit in its overflow record
                 real mg = ka->m.pair_margin[p];
                 for (int k = 0; k < nn; k++)
-                    if (scr[k] < mg) { keepmask |= 1 << k; n++; }
+                    if ((isbox && k >= BOX_SLOTC ? ov[4 * (k - BOX_SLOTC)] : scr[k]) < mg) { keepmask |= 1 << k; n++; }
             }
             int off = 0, tot = 0;
-            for (int j = 1; j <= SLOT_MAXC; j++) {
+            for (int j = 1; j <= BOX_MAXC; j++) {
                 int tj, rj = group_rank<G>(n >= j, grp, lane, &tj);
+                if (tj == 0) break;                     // (the env's lanes agree: no pair of this pass has j contacts)
                 off += rj;
                 tot += tj;
             }
             int w = 0;
-            for (int k = 0; k < SLOT_MAXC; k++)
+            for (int k = 0; k < BOX_MAXC; k++)
                 if ((keepmask >> k) & 1) {
                     int c = ncon + off + w;
                     w++;
                     if (c < ka->lay.maxcon) {
-                        cdist[c] = scr[k];
+                        const bool o = isbox && k >= BOX_SLOTC;
+                        cdist[c] = o ? ov[4 * (k - BOX_SLOTC)] : scr[k];
                         cpair[c] = p;
-                        for (int q = 0; q < 3; q++) { cpos[3 * c + q] = scr[SLOT_P + 3 * k + q]; cnrm[3 * c + q] = scr[SLOT_N + q]; }
+                        for (int q = 0; q < 3; q++) { cpos[3 * c + q] = o ? ov[4 * (k - BOX_SLOTC) + 1 + q] : scr[SLOT_P + 3 * k + q]; cnrm[3 * c + q] = scr[SLOT_N + q]; }
                     }
                 }
             if (ncon + tot > ka->lay.maxcon) ovf = 1;
@@ -3784,8 +3790,9 @@ struct PhysHost {
         if (d_near) (void)hipFree(d_near);
         if (d_gref) (void)hipFree(d_gref);
         d_coup = nullptr; d_near = nullptr; d_gref = nullptr;
-        if (hipMalloc(&d_gref, (size_t)N * dims[4] * 3 * (f64 ? 8 : 4)) != hipSuccess) throw std::runtime_error("hipMalloc of the Verlet reference buffer failed");
+        if (hipMalloc(&d_gref, ((size_t)N * dims[4] * 3 + (size_t)N * 64 * BOX_OVF_W) * (f64 ? 8 : 4)) != hipSuccess) throw std::runtime_error("hipMalloc of the Verlet reference buffer failed");
         mf.gref_glob = (float*)d_gref; md.gref_glob = (double*)d_gref;
+        mf.bxo_glob = mf.gref_glob + (size_t)N * dims[4] * 3; md.bxo_glob = md.gref_glob + (size_t)N * dims[4] * 3;      // box-box overflow records behind the reference centres
         if (hipMalloc(&d_coup, (size_t)N * lay2.maxgrp * GA_W * (f64 ? 8 : 4)) != hipSuccess || hipMalloc((void**)&d_near, (size_t)N * (NEAR_MAX + CAND_MAX) * 4) != hipSuccess)
             throw std::runtime_error("hipMalloc of the coupling / neighbour buffers failed");
         mf.gA_glob = (float*)d_coup; md.gA_glob = (double*)d_coup; mf.near_glob = d_near; md.near_glob = d_near; mf.cand_glob = md.cand_glob = d_near + (size_t)N * NEAR_MAX;

@@ -534,7 +534,7 @@ def main():
             "value": value, "value_per_gpu": value / world, "unit": "env-steps/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
-            "multi_rank": {"allgather_ms": max(rank_allgather_ms), "allgather_ms_per_rank": rank_allgather_ms, "allgather_host_ms_rank0": allgather_host_ms,
+            "multi_rank": {"allgather_ms": max(rank_allgather_ms), "allgather_ms_per_rank": rank_allgather_ms, "allgather_host_ms_rank0_incl_stream_drain": allgather_host_ms,
                            "allgather_bytes_per_rank": int(N * 8), "backend": (args.backend if dist is not None else None),
                            "ms_per_step_rank_min": min(rank_ms), "ms_per_step_rank_max": max(rank_ms), "ms_per_step_per_rank": rank_ms,
                            "k_phys_ms_per_rank": rank_kernel_ms,

@@ -37,8 +37,8 @@ enum { ORC_PH_OTHER = 0, ORC_PH_KINEMATICS, ORC_PH_CRB, ORC_PH_COLLIDE, ORC_PH_R
 #define ORC_PHASE(k) ((void)0)
 #endif
 
-#define ORC_MAXCON 64
-#define ORC_MAXEFC 400
+#define ORC_MAXCON 128   /* (64 / 400 until round 4: box-box manifolds of up to 8 points need more) */
+#define ORC_MAXEFC 640
 #define ORC_MAXNV 48
 
 enum { ORC_FREE = 0, ORC_BALL = 1, ORC_SLIDE = 2, ORC_HINGE = 3 };
@@ -75,6 +75,7 @@ typedef struct {
     const int *ik_n, *ik_qadr;
     const double *ik_w0, *ik_p0, *ik_site0, *ik_range;
     void* blob; /* owned copy */
+    void* hull_override; /* owned: orc_model_set_hulls */
     /* depth render (orc_render.c): hull half-spaces, visibility, cameras */
     int ncam;
     const int *geom_hplane, *geom_visible, *cam_body;
@@ -122,6 +123,7 @@ typedef struct {
 orc_model* orc_model_load(const void* blob, size_t nbytes);
 void orc_model_free(orc_model* m);
 orc_data* orc_data_new(const orc_model* m);
+int orc_capacity(int which);   /* 0: ORC_MAXCON, 1: ORC_MAXEFC, 2: sizeof(orc_data) -- for the Python mirror of the struct (tests/orc_env.py) */
 void orc_data_free(orc_data* d);
 
 /* depth image of camera `cam` at the current state (positions must be fresh: orc_forward / orc_step): float32 metres along
@@ -154,6 +156,15 @@ void orc_make_constraints(orc_data* d);
 void orc_solve(orc_data* d);
 void orc_solve_newton(orc_data* d);
 void orc_noslip(orc_data* d);
+
+/* box-box manifolds: 8 (default; every clipped vertex, as MuJoCo's mjc_BoxBox [EXT]) or 4 (the reduced manifold of rounds 1-4) */
+void orc_set_boxbox_maxpoints(int n);
+int orc_get_boxbox_maxpoints(void);
+/* replace the mesh geoms' hull vertices (the blob's decimated hulls) by other ones -- the FULL convex hulls of the STL files, as MuJoCo
+ * collides them [EXT]: vert double[nvert][3] in the geoms' frames, geom_hull int[ngeom][2] = (first vertex, count) per geom (0, 0 for
+ * non-mesh geoms), rbound double[ngeom] bounding radii about geom_bcenter.  Copies are owned by the model.  Collision only: the depth
+ * images keep the blob's hull planes. */
+void orc_model_set_hulls(orc_model* m, const double* vert, int nvert, const int* geom_hull, const double* rbound);
 
 /* narrow phase entry for tests: geometry types as ORC_*; returns number of contacts (<=8) */
 int orc_narrow(int t1, const double* size1, const double* pos1, const double* mat1, const double* hull1, int nh1,

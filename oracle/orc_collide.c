@@ -2,10 +2,15 @@
  *
  * Restates the geometry MuJoCo's mj_collision [EXT] applies to the reference scenes
  * (aloha_sim.xml:103-111 collision class, scene.xml:55 table box, task_*.xml boxes/cylinders):
- *   sphere-sphere, sphere-box: closed form;  box-box: separating axes + reference-face clipping
- *   (<=4 points kept);  everything involving a convex mesh or a cylinder: Minkowski Portal
- *   Refinement on support functions, the scheme of libccd's ccdMPRPenetration that MuJoCo 3.2
- *   calls for these pairs (tolerance 1e-6, 50 iterations), one contact per pair (no multiccd).
+ *   sphere-sphere, sphere-box: closed form;  box-box: separating axes + reference-face clipping,
+ *   every clipped vertex behind the reference face is a contact (<= 8: a quadrilateral clipped by a
+ *   rectangle; MuJoCo's mjc_BoxBox returns up to 8 [EXT]) -- orc_set_boxbox_maxpoints(4) restores the
+ *   rounds 1-4 reduction to four extremal points;  everything involving a convex mesh or a cylinder:
+ *   Minkowski Portal Refinement on support functions, the scheme of libccd's ccdMPRPenetration that
+ *   MuJoCo 3.2 calls for these pairs (tolerance 1e-6, 50 iterations) + the multiccd perturbation passes.
+ *   Mesh geoms: the hull vertices of the model blob (decimated to 20 / 64 vertices for the device), or,
+ *   after orc_model_set_hulls, the FULL convex hulls of the STL files as MuJoCo collides them [EXT]
+ *   (tests/orc_ffi.py load_model(hulls="full"); models/oracle_full_hulls.*).
  * Contact convention (MuJoCo): normal points from geom1 to geom2, pos is midway between the
  * surfaces, dist < 0 is penetration.
  */
@@ -289,6 +294,10 @@ static int sphere_box(const shape* a, const shape* b, double* dist, double* pos,
     return 1;
 }
 
+static int boxbox_maxpoints = 8;
+void orc_set_boxbox_maxpoints(int n) { boxbox_maxpoints = n >= 8 ? 8 : 4; }
+int orc_get_boxbox_maxpoints(void) { return boxbox_maxpoints; }
+
 /* box-box: 15-axis SAT, then reference-face clipping (face contact) or closest edge points */
 static int box_box(const shape* a, const shape* b, double* dist, double* pos, double* nrm) {
     const double *Ra = a->mat, *Rb = b->mat;
@@ -435,9 +444,11 @@ static int box_box(const shape* a, const shape* b, double* dist, double* pos, do
         if (dq >= 0) { memcpy(tmp[m], poly[q], 24); dep[m] = dq; m++; }
     }
     if (m == 0) return 0;
-    /* reduce to at most 4: deepest, farthest from it, farthest from that segment on either side */
-    int keep[4], nk = 0;
-    if (m <= 4) { for (int q = 0; q < m; q++) keep[nk++] = q; }
+    /* every clipped vertex is a contact (<= 8); boxbox_maxpoints == 4: reduce to at most 4 -- deepest, farthest from it, farthest from
+       that segment on either side (the selection of rounds 1-4, kept for comparison) */
+    int keep[8], nk = 0;
+    if (m > 8) m = 8;
+    if (m <= boxbox_maxpoints) { for (int q = 0; q < m; q++) keep[nk++] = q; }
     else {
         int i0 = 0;
         for (int q = 1; q < m; q++) if (dep[q] > dep[i0] + TIE_LEN) i0 = q;

@@ -73,6 +73,8 @@ orc_data* orc_data_new(const orc_model* m) {
     return d;
 }
 
+int orc_capacity(int which) { return which == 0 ? ORC_MAXCON : (which == 1 ? ORC_MAXEFC : (int)sizeof(orc_data)); }
+
 void orc_data_free(orc_data* d) {
     if (!d) return;
     double* p[] = {d->qpos, d->qvel, d->ctrl, d->qacc_warmstart, d->xpos, d->xquat, d->xmat, d->xipos, d->ximat, d->xanchor,

@@ -61,8 +61,23 @@ orc_model* orc_model_load(const void* blob_in, size_t nbytes) {
     return m;
 }
 
+void orc_model_set_hulls(orc_model* m, const double* vert, int nvert, const int* geom_hull, const double* rbound) {
+    size_t nb_v = sizeof(double) * 3 * (size_t)nvert, nb_h = sizeof(int) * 2 * (size_t)m->ngeom, nb_r = sizeof(double) * (size_t)m->ngeom;
+    char* p = (char*)malloc(nb_v + nb_r + nb_h);
+    memcpy(p, vert, nb_v);
+    memcpy(p + nb_v, rbound, nb_r);
+    memcpy(p + nb_v + nb_r, geom_hull, nb_h);
+    free(m->hull_override);
+    m->hull_override = p;
+    m->hull_vert = (const double*)p;
+    m->geom_rbound = (const double*)(p + nb_v);
+    m->geom_hull = (const int*)(p + nb_v + nb_r);
+    m->nhullvert = nvert;
+}
+
 void orc_model_free(orc_model* m) {
     if (!m) return;
+    free(m->hull_override);
     free(m->blob);
     free(m);
 }

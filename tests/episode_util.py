@@ -57,8 +57,12 @@ def make_script(task, home, qpos0):
     return Lift()
 
 
+ORACLE_MODE = {"hulls": "model", "boxbox_points": 8}     # tools/fidelity.py switches these per run: "full" hulls = the faithful oracle; 4 points = rounds 1-4
+
+
 def _new_env(task, pose):
-    e = OrcEnv(MODEL_OF.get(task, task), 3, VARIANT)
+    e = OrcEnv(MODEL_OF.get(task, task), 3, VARIANT, hulls=ORACLE_MODE["hulls"])
+    e.L.orc_set_boxbox_maxpoints(int(ORACLE_MODE["boxbox_points"]))
     e.d.solver = 1                  # Newton, the reference's solver (MuJoCo default; aloha_sim.xml:4 does not change it)
     e.reset(pose)
     return e

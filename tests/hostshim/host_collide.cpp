@@ -26,9 +26,10 @@ static int run(int t1, const double* size1, const double* pos1, const double* ma
     fill(b, t2, size2, pos2, mat2, h2, nh2);
     if (c1) for (int k = 0; k < 3; k++) a.center[k] = (T)c1[k];
     if (c2) for (int k = 0; k < 3; k++) b.center[k] = (T)c2[k];
-    T scr[SLOT_W], work[56];
+    T scr[SLOT_W], work[56], ovf[BOX_OVF_W];
     int n;
-    if (t1 == G_BOX && t2 == G_BOX) n = box_box(a, b, scr, work);
+    const bool isbox = t1 == G_BOX && t2 == G_BOX;
+    if (isbox) n = box_box(a, b, scr, work, ovf);
     else {
         n = narrow(a, b, scr);
         // multiccd for the convex (MPR) pairs, spheres excluded -- the kernel's rule (Env::collide_i)
@@ -36,8 +37,9 @@ static int run(int t1, const double* size1, const double* pos1, const double* ma
             n = multiccd_serial(a, b, MultiCcd<T>::reltol * (T)(rb1 < rb2 ? rb1 : rb2), scr, scr + SLOT_P, scr + SLOT_N);
     }
     for (int k = 0; k < n; k++) {
-        dist[k] = scr[k];
-        for (int c = 0; c < 3; c++) pos[3 * k + c] = scr[SLOT_P + 3 * k + c];
+        const bool o = isbox && k >= BOX_SLOTC;         // points 4..7 of a box-box manifold: the overflow record
+        dist[k] = o ? ovf[4 * (k - BOX_SLOTC)] : scr[k];
+        for (int c = 0; c < 3; c++) pos[3 * k + c] = o ? ovf[4 * (k - BOX_SLOTC) + 1 + c] : scr[SLOT_P + 3 * k + c];
     }
     for (int c = 0; c < 3; c++) normal[c] = n ? scr[SLOT_N + c] : 0;
     return n;

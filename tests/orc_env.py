@@ -7,7 +7,7 @@ import numpy as np
 
 from orc_ffi import ROOT, dp, ip, lib, load_model
 
-MAXCON, MAXEFC = 64, 400
+MAXCON, MAXEFC = 128, 640        # ORC_MAXCON / ORC_MAXEFC (oracle/orc.h), checked against orc_capacity() in OrcEnv.__init__
 
 
 class Contact(C.Structure):
@@ -35,9 +35,10 @@ class Data(C.Structure):
 
 
 class OrcEnv:
-    def __init__(self, task="slot_insertion", num_arms=3, variant="gym"):
+    def __init__(self, task="slot_insertion", num_arms=3, variant="gym", hulls="model"):
         self.L = lib()
-        self.m = load_model(task, num_arms, variant)
+        assert (self.L.orc_capacity(0), self.L.orc_capacity(1), self.L.orc_capacity(2)) == (MAXCON, MAXEFC, C.sizeof(Data)), "tests/orc_env.py Data is out of step with oracle/orc.h orc_data"
+        self.m = load_model(task, num_arms, variant, hulls=hulls)
         self.man = json.load(open(os.path.join(ROOT, "models", f"{'dc_' if variant == 'data_collection' else ''}{task}_{num_arms}arms.json")))
         self.nq, self.nv, self.nu = self.man["nq"], self.man["nv"], self.man["nu"]
         self.nj = 21 if num_arms == 3 else 14

@@ -79,7 +79,7 @@ def compare(host, q, fn, pert, tol, only_boxes):
     rng = np.random.default_rng(1)
     f = getattr(host, fn)
     tot = bad = 0
-    multi = np.zeros(6, dtype=np.int64)          # histogram of contacts per pair
+    multi = np.zeros(9, dtype=np.int64)          # histogram of contacts per pair
     for i in range(q.shape[0]):
         e.L.orc_set_qpos(e.dptr, q[i].ctypes.data)
         gx = np.ctypeslib.as_array(e.d.geom_xpos, shape=(ng, 3)).copy()
@@ -107,7 +107,7 @@ def compare(host, q, fn, pert, tol, only_boxes):
             dist, pos, nrm = np.zeros(8), np.zeros(24), np.zeros(3)
             nn = f(t1, dp(a[0]), dp(a[1]), dp(a[2]), dp(a[3]), a[4], dp(a[5]), t2, dp(b[0]), dp(b[1]), dp(b[2]), dp(b[3]), b[4], dp(b[5]),
                    C.c_double(float(md["geom_rbound"][g1])), C.c_double(float(md["geom_rbound"][g2])), dp(dist), dp(pos), dp(nrm))
-            multi[min(nn, 5)] += 1
+            multi[min(nn, 8)] += 1
             tot += 1
             bad += nn != len(ref) or np.abs(dist[:nn] - ref).max() > tol
     e.close()
@@ -119,6 +119,8 @@ def test_device_box_box_source_equals_the_oracle_and_ignores_rounding_noise(host
     q = box_poses(192)
     tot, bad = compare(host, q, "dev_narrow_f64", 0.0, 0.0, True)
     assert tot > 900 and bad == 0, (tot, bad)
+    print("box-box contacts per pair:", compare.multi.tolist())
+    assert compare.multi[5:].sum() >= 20 and compare.multi[6:].sum() >= 5       # manifolds of five and six points occur and agree (<= 4 kept until round 4)
     for _ in range(2):
         tot, bad = compare(host, q, "dev_narrow_f64", 2e-16, 1e-9, True)
         assert bad == 0, (tot, bad)
