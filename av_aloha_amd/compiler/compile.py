@@ -181,7 +181,7 @@ def read_blob(path):
     return out
 
 
-def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbose=False, vis_ids=None):
+def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbose=False, vis_ids=None, kmax_collision=128):
     xml, task_id = TASKS[task]
     m = parse(os.path.join(assets, xml))
     if num_arms == 2:
@@ -379,6 +379,13 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
     hull_info = {}
     report = {}
 
+    # Two hulls per collision mesh.  COLLISION (chull_*): up to kmax_collision = 128 vertices (outside error <= 0.3 mm, <= 0.14 mm for the
+    # gripper parts, 0.02 mm for the fingers; MuJoCo collides the full hull [EXT] -- oracle faithful mode, profiles/r05_fidelity.json), behind
+    # a support table (hull.support_table: cube-map cells -> candidate vertices), so that the narrow phase's support function costs two
+    # round trips whatever the vertex count.  DEPTH IMAGES (hull_*): the 20 / 32-vertex polyhedra of rounds 1-4, whose faces, face
+    # vertices and edges the rasteriser of convex polyhedra holds in registers and 32 / 64-bit masks (avsim_render.hip.h).
+    chull_verts, chull_info, ctab = [], {}, {}
+
     def get_hull(name, finger):
         if name in hull_info:
             return hull_info[name]
@@ -391,7 +398,12 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
         adr = sum(len(h) for h in hull_verts)
         hull_verts.append(hv)
         hull_info[name] = (adr, len(hv))
-        report[name] = {"nvert": int(len(hv)), "err_m": err}
+        cv, cerr = _collision_hull(key, tuple(np.atleast_1d(me["scale"]).tolist()), pts, kmax_collision)
+        chull_info[name] = (sum(len(h) for h in chull_verts), len(cv))
+        chull_verts.append(cv)
+        ctab[name] = _support_table(key, tuple(np.atleast_1d(me["scale"]).tolist()), kmax_collision, cv)
+        report[name] = {"nvert": int(len(hv)), "err_m": err, "collision_nvert": int(len(cv)), "collision_err_m": cerr, "support_table_R": int(ctab[name][0]),
+                        "support_table_candidates_p50_p99_max": [float(x) for x in np.percentile([len(c) for c in ctab[name][1]], [50, 99, 100])]}
         return hull_info[name]
 
     ng = len(cg)
@@ -401,6 +413,7 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
     g_quat = np.zeros((ng, 4))
     g_size = np.zeros((ng, 3))
     g_hull = np.zeros((ng, 2), dtype=np.int32)
+    g_chull = np.zeros((ng, 2), dtype=np.int32)
     g_condim = np.zeros(ng, dtype=np.int32)
     g_fric = np.zeros((ng, 3))
     g_solref = np.zeros((ng, 2))
@@ -427,7 +440,8 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
         g_size[k] = s
         if g["type"] == "mesh":
             g_hull[k] = get_hull(g["mesh"], "finger" in g["mesh"])
-            hv = hull_verts[[i for i, (n, v) in enumerate(hull_info.items()) if n == g["mesh"]][0]]
+            g_chull[k] = chull_info[g["mesh"]]
+            hv = chull_verts[[i for i, n in enumerate(chull_info) if n == g["mesh"]][0]]      # bounding sphere of the COLLISION hull
             lo, hi = hv.min(0), hv.max(0)
             g_bcen[k] = 0.5 * (lo + hi)
             g_rb[k] = np.linalg.norm(hv - g_bcen[k], axis=1).max()
@@ -450,6 +464,24 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
               geom_solref=g_solref, geom_solimp=g_solimp, geom_margin=g_margin, geom_gap=g_gap,
               geom_class=g_class, geom_bcenter=g_bcen, geom_rbound=g_rb)
     md["hull_vert"] = np.concatenate(hull_verts) if hull_verts else np.zeros((0, 3))
+    # collision hulls and their support tables: chull_cells[cell] = (first candidate << 8) | count, candidates = vertex indices local to the hull
+    md["chull_vert"] = np.concatenate(chull_verts) if chull_verts else np.zeros((0, 3))
+    md["geom_chull"] = g_chull
+    cells_all, cand_all, tab_of = [], [], {}
+    for name in chull_info:
+        R, cells = ctab[name]
+        tab_of[name] = (len(cells_all), R)
+        for c in cells:
+            assert len(c) < 256 and len(cand_all) < (1 << 23)
+            cells_all.append((len(cand_all) << 8) | len(c))
+            cand_all.extend(int(i) for i in c)
+    md["chull_cells"] = np.array(cells_all, dtype=np.int32) if cells_all else np.zeros(1, dtype=np.int32)
+    md["chull_cand"] = np.array(cand_all, dtype=np.int32) if cand_all else np.zeros(1, dtype=np.int32)
+    g_ctab = np.zeros((ng, 2), dtype=np.int32)
+    for k, gi in enumerate(cg):
+        if m.geoms[gi]["type"] == "mesh":
+            g_ctab[k] = tab_of[m.geoms[gi]["mesh"]]
+    md["geom_ctab"] = g_ctab
     # half-space form of every hull for the depth ray-caster: rows [nx ny nz d], inside = {x : n.x <= d}, geom-local frame
     plane_of = {}
     planes = []
@@ -544,8 +576,8 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
         R = kin["xmat"][b] @ quat_to_mat(g_quat[k])
         p = kin["xpos"][b] + kin["xmat"][b] @ g_pos[k]
         if g_type[k] == GEOM_MESH:
-            adr, n = g_hull[k]
-            v = md["hull_vert"][adr:adr + n] @ R.T + p
+            adr, n = g_chull[k]
+            v = md["chull_vert"][adr:adr + n] @ R.T + p
         elif g_type[k] == GEOM_BOX:
             s = g_size[k]
             corners = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]) * s
@@ -710,6 +742,23 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
         if arrays[k].dtype.kind in "iub":
             arrays[k] = arrays[k].astype(np.int32)
     return arrays, manifest
+
+
+_CH_CACHE, _ST_CACHE = {}, {}
+
+
+def _collision_hull(key, scale, pts, kmax):
+    k = (key, scale, kmax)
+    if k not in _CH_CACHE:
+        _CH_CACHE[k] = hullmod.decimate_hull(pts, kmax)
+    return _CH_CACHE[k]
+
+
+def _support_table(key, scale, kmax, verts):
+    k = (key, scale, kmax)
+    if k not in _ST_CACHE:
+        _ST_CACHE[k] = hullmod.support_table_for(verts, max_count=16)
+    return _ST_CACHE[k]
 
 
 def write_full_hulls(assets, out_dir):

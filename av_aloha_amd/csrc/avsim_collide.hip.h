@@ -24,7 +24,13 @@ struct Shape {
     T size[3];
     T pos[3];      // world position of the geom frame
     T mat[9];      // geom->world rotation, row-major
-    GLB_PTR(const T) hull; // hull vertices in the geom frame (global memory)
+    // mesh geoms: the collision hull (<= 128 vertices, compile.py) behind its support table -- the unit sphere of directions cut into the
+    // 6 R^2 cells of a cube map, every cell listing the vertices that support SOME direction of the (padded) cell (compiler/hull.py
+    // support_table).  hcell = the hull's cell records ((first candidate << 8) | count), hull = the model's candidate records, four
+    // words each: the vertex in the geom frame and its index in the hull (sorted by index within a cell)
+    GLB_PTR(const T) hull;
+    GLB_PTR(const int) hcell;
+    int hR;
     int nh;
     T center[3];   // an interior point (world)
     T lc[3], lh[3]; // local bounding box: centre and half extents in the geom frame
@@ -37,6 +43,8 @@ struct Shape {
 template <typename T> struct TieTol;
 template <> struct TieTol<double> { static constexpr double rel = 1e-9, len = 1e-12; };
 template <> struct TieTol<float> { static constexpr float rel = 1e-5f, len = 1e-7f; };
+
+template <typename T> AVS_DEV T sel3c(const T* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
 
 template <typename T>
 AVS_DEV void support(const Shape<T>& s, const T* d, T* out) {
@@ -63,30 +71,53 @@ AVS_DEV void support(const Shape<T>& s, const T* d, T* out) {
             break;
         }
         default: {
-            // the vertex with the largest projection; a later vertex must beat the best so far by a margin (TieTol: a rounding-level
-            // fraction of |l| x 0.1 m), so that the vertices of a face the direction is normal to -- equal projections up to
-            // rounding -- always resolve to the lowest index, on the device and in the oracle alike
-            int best = 0;
+            // the vertex with the largest projection, and among the vertices within the tie margin of it (TieTol: a rounding-level fraction
+            // of |l| x 0.1 m -- the vertices of a face the direction is normal to have equal projections up to rounding) the one with the
+            // LOWEST INDEX, on the device and in the oracle alike.  Only the candidates of the direction's cube-map cell are looked at:
+            // typically two to eight of the hull's <= 128 vertices, one round trip for the cell record and one for eight candidates
+            const T ax = fabs(l[0]), ay = fabs(l[1]), az = fabs(l[2]);
+            const int a = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+            const T lm = sel3c(l, a), am = fabs(lm), inv = am > T(0) ? T(1) / am : T(0);
+            const T u = sel3c(l, a == 2 ? 0 : a + 1) * inv, v = sel3c(l, a == 0 ? 2 : a - 1) * inv;
+            const int R = s.hR;
+            int iu = (int)((u + T(1)) * T(0.5) * T(R)), iv = (int)((v + T(1)) * T(0.5) * T(R));
+            iu = iu > 0 ? (iu < R - 1 ? iu : R - 1) : 0;
+            iv = iv > 0 ? (iv < R - 1 ? iv : R - 1) : 0;
+            const int rec = s.hcell[((2 * a + (lm < T(0) ? 1 : 0)) * R + iu) * R + iv];
+            const int cnt = rec & 255, last = cnt - 1;
+            GLB_PTR(const T) C = s.hull + 4 * (size_t)(rec >> 8);
+            const T tie = TieTol<T>::rel * T(0.1) * (ax + ay + az);
+            T vx[8], vy[8], vz[8], pr[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {           // the first eight candidates stay in registers (entries past the end repeat the last one)
+                const int ik = k < last ? k : last;
+                vx[k] = C[4 * ik]; vy[k] = C[4 * ik + 1]; vz[k] = C[4 * ik + 2];
+            }
             T bd = T(-1e30);
-            const T tie = TieTol<T>::rel * T(0.1) * (fabs(l[0]) + fabs(l[1]) + fabs(l[2]));
-            // eight vertices per round trip to memory (indices past the end repeat the last vertex, which cannot beat itself), the
-            // comparisons in index order as before; the winner's coordinates ride along instead of being fetched again
-            T bx = 0, by = 0, bz = 0;
-            const int last = s.nh - 1;
-            for (int i = 0; i < s.nh; i += 8) {
-                T vx[8], vy[8], vz[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int iu = i + u < last ? i + u : last;
-                    vx[u] = s.hull[3 * iu]; vy[u] = s.hull[3 * iu + 1]; vz[u] = s.hull[3 * iu + 2];
-                }
+            for (int k = 0; k < 8; k++) { pr[k] = vx[k] * l[0] + vy[k] * l[1] + vz[k] * l[2]; bd = pr[k] > bd ? pr[k] : bd; }
+            for (int i = 8; i < cnt; i += 8) {      // (cells at the normal of a face with many vertices)
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const T v = vx[u] * l[0] + vy[u] * l[1] + vz[u] * l[2];
-                    if (v > bd + tie) { bd = v; best = i + u; bx = vx[u]; by = vy[u]; bz = vz[u]; }
+                for (int k = 0; k < 8; k++) {
+                    const int ik = i + k < last ? i + k : last;
+                    const T q = C[4 * ik] * l[0] + C[4 * ik + 1] * l[1] + C[4 * ik + 2] * l[2];
+                    bd = q > bd ? q : bd;
                 }
             }
-            (void)best;
+            const T thr = bd - tie;
+            bool found = false;
+            T bx = vx[0], by = vy[0], bz = vz[0];
+#pragma unroll
+            for (int k = 7; k >= 0; k--)            // (descending: the lowest index is assigned last)
+                if (pr[k] >= thr) { bx = vx[k]; by = vy[k]; bz = vz[k]; found = true; }
+            for (int i = 8; i < cnt && !found; i += 8) {
+#pragma unroll
+                for (int k = 7; k >= 0; k--) {
+                    const int ik = i + k < last ? i + k : last;
+                    const T qx = C[4 * ik], qy = C[4 * ik + 1], qz = C[4 * ik + 2];
+                    if (qx * l[0] + qy * l[1] + qz * l[2] >= thr) { bx = qx; by = qy; bz = qz; found = true; }
+                }
+            }
             p[0] = bx; p[1] = by; p[2] = bz;
         }
     }

@@ -132,7 +132,8 @@ struct DevModel {
     GLB_PTR(const real) geom_cen0;
     GLB_PTR(const real) geom_aabb0;
     GLB_PTR(const real) geom_lbox;
-    GLB_PTR(const real) hull_vert;
+    GLB_PTR(const real) hull_vert;     // candidate records of the collision hulls' support tables: (x, y, z, index) per entry (avsim_collide.hip.h Shape)
+    GLB_PTR(const int) hull_cells;     // cell records of all hulls; geom_hull[g] = (first cell of the geom's hull, cube-map resolution R)
     // pairs
     GLB_PTR(const int) pair_geom;
     GLB_PTR(const int) pair_condim;
@@ -2323,8 +2324,10 @@ struct Env {
         real *xpos = r + ka->lay.xpos, *xmat = r + ka->lay.xmat, *gcen = r + ka->lay.gcen;
         s.type = geom_type_()[g];
         for (int k = 0; k < 3; k++) s.size[k] = ka->m.geom_size[3 * g + k];
-        s.hull = ka->m.hull_vert + 3 * ka->m.geom_hull[2 * g];
-        s.nh = ka->m.geom_hull[2 * g + 1];
+        s.hull = ka->m.hull_vert;
+        s.hcell = ka->m.hull_cells + ka->m.geom_hull[2 * g];
+        s.hR = ka->m.geom_hull[2 * g + 1];
+        s.nh = 0;
         for (int k = 0; k < 3; k++) { s.lc[k] = ka->m.geom_lbox[6 * g + k]; s.lh[k] = ka->m.geom_lbox[6 * g + 3 + k]; }
         if (geom_static_()[g]) {
             for (int k = 0; k < 3; k++) { s.pos[k] = ka->m.geom_xpos0[3 * g + k]; s.center[k] = ka->m.geom_cen0[3 * g + k]; }
@@ -3663,7 +3666,7 @@ struct PhysHost {
         std::vector<double> gmat(9 * ng), gcp(3 * ng), gx0(3 * ng, 0.0), gm0(9 * ng, 0.0), gc0(3 * ng, 0.0);
         std::vector<int> gstat(ng);
         std::vector<double> gaabb(6 * ng, 0.0), glbox(6 * ng, 0.0);   // world AABB of static geoms; local box (centre, half extents) of every geom
-        auto ghull = I("geom_hull"); auto gtype = I("geom_type"); auto gsize = F("geom_size"); auto hv = F("hull_vert");
+        auto ghull = I("geom_chull"); auto gtype = I("geom_type"); auto gsize = F("geom_size"); auto hv = F("chull_vert");      // the COLLISION hulls (hull_vert / geom_hull: the depth images' polyhedra)
         for (int g = 0; g < ng; g++) {
             q2m(&gquat[4 * g], &gmat[9 * g]);
             for (int i = 0; i < 3; i++)
@@ -3709,10 +3712,29 @@ struct PhysHost {
                     }
             }
         }
-        m.geom_type = up(I("geom_type")); moff.geom_type = (int)img_int.size(); { auto v_ = I("geom_type"); img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.geom_body = up(gbody); moff.geom_body = (int)img_int.size(); { auto v_ = gbody; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.geom_hull = up(I("geom_hull")); m.geom_class = up(I("geom_class")); m.geom_static = up(gstat); moff.geom_static = (int)img_int.size(); { auto v_ = gstat; img_int.insert(img_int.end(), v_.begin(), v_.end()); }
+        m.geom_type = up(I("geom_type")); moff.geom_type = (int)img_int.size(); { auto v_ = I("geom_type"); img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.geom_body = up(gbody); moff.geom_body = (int)img_int.size(); { auto v_ = gbody; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.geom_hull = up(I("geom_ctab")); m.geom_class = up(I("geom_class")); m.geom_static = up(gstat); moff.geom_static = (int)img_int.size(); { auto v_ = gstat; img_int.insert(img_int.end(), v_.begin(), v_.end()); }
         m.geom_pos = upr<real>(gpos); m.geom_mat = upr<real>(gmat); m.geom_size = upr<real>(F("geom_size")); m.geom_cpos = upr<real>(gcp); moff.geom_cpos = (int)img_real.size(); { auto v_ = gcp; img_real.insert(img_real.end(), v_.begin(), v_.end()); }
         m.geom_rbound = upr<real>(F("geom_rbound")); moff.geom_rbound = (int)img_real.size(); { auto v_ = F("geom_rbound"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.geom_xpos0 = upr<real>(gx0); m.geom_xmat0 = upr<real>(gm0); m.geom_cen0 = upr<real>(gc0); m.geom_aabb0 = upr<real>(gaabb); m.geom_lbox = upr<real>(glbox);
-        m.hull_vert = upr<real>(F("hull_vert"));
+        {   // support tables of the collision hulls (compiler/hull.py support_table): the candidate lists hold vertex indices local to their
+            // hull; here every entry becomes (x, y, z, index), so that a support call fetches coordinates, not indices to follow
+            auto ctab = I("geom_ctab"), cells = I("chull_cells"), cand = I("chull_cand");
+            std::vector<double> c4(4 * cand.size(), 0.0);
+            for (int g = 0; g < ng; g++) {
+                if (gtype[g] != G_MESH) continue;
+                const int cb = ctab[2 * g], R = ctab[2 * g + 1], adr = ghull[2 * g];
+                for (int c = 0; c < 6 * R * R; c++) {
+                    const int rec = cells[cb + c], off = rec >> 8, cnt = rec & 255;
+                    for (int k = 0; k < cnt; k++) {
+                        const int v = cand[off + k];
+                        if (v < 0 || v >= ghull[2 * g + 1]) throw std::runtime_error("support table: candidate index outside its hull");
+                        for (int q = 0; q < 3; q++) c4[4 * (size_t)(off + k) + q] = hv[3 * (size_t)(adr + v) + q];
+                        c4[4 * (size_t)(off + k) + 3] = (double)v;
+                    }
+                }
+            }
+            m.hull_vert = upr<real>(c4);
+            m.hull_cells = up(cells);
+        }
         m.pair_geom = up(I("pair_geom")); m.pair_condim = up(I("pair_condim"));
         m.pair_friction = upr<real>(F("pair_friction")); m.pair_solref = upr<real>(F("pair_solref")); m.pair_solimp = upr<real>(F("pair_solimp"));
         m.pair_margin = upr<real>(F("pair_margin")); m.pair_gap = upr<real>(F("pair_gap"));

@@ -81,13 +81,18 @@ static void support(const shape* s, const double* d, double* out) {
             break;
         }
         case ORC_MESH: {
+            /* the vertex with the largest projection; among vertices within the tie margin of it (the vertices of a face the direction is
+               normal to: equal projections up to rounding) the LOWEST INDEX, whatever order they are looked at in -- the device looks at the
+               candidates of the direction's support-table cell only (avsim_collide.hip.h support) */
             int best = 0;
             double bd = -1e30;
             const double tie = TIE_REL * 0.1 * (fabs(l[0]) + fabs(l[1]) + fabs(l[2]));
             for (int i = 0; i < s->nh; i++) {
                 double v = dot3(s->hull + 3 * i, l);
-                if (v > bd + tie) { bd = v; best = i; }
+                if (v > bd) bd = v;
             }
+            for (int i = 0; i < s->nh; i++)
+                if (dot3(s->hull + 3 * i, l) >= bd - tie) { best = i; break; }
             memcpy(p, s->hull + 3 * best, sizeof p);
             break;
         }

@@ -47,8 +47,13 @@ orc_model* orc_model_load(const void* blob_in, size_t nbytes) {
     LF(dof_armature); LF(dof_damping); LF(dof_frictionloss); LF(dof_invweight0); LF(dof_solref); LF(dof_solimp);
     LI(act_dof); LI(act_qposadr); LI(act_ctrllimited); LF(act_kp); LF(act_kv); LF(act_gear); LF(act_ctrlrange);
     LI(eq_dof1); LI(eq_dof2); LI(eq_qpos1); LI(eq_qpos2); LF(eq_polycoef); LF(eq_solref); LF(eq_solimp);
-    LI(geom_type); LI(geom_body); LI(geom_hull); LI(geom_class);
-    LF(geom_pos); LF(geom_quat); LF(geom_size); LF(geom_bcenter); LF(geom_rbound); LF(hull_vert);
+    LI(geom_type); LI(geom_body); LI(geom_class);
+    LF(geom_pos); LF(geom_quat); LF(geom_size); LF(geom_bcenter); LF(geom_rbound);
+    /* collision hulls (compile.py: <= 128 vertices per mesh; the blob's hull_vert / geom_hull are the depth images' polyhedra, which this
+       oracle reads through hull_plane only).  The device finds support points through the blob's support tables (chull_cells / chull_cand);
+       the oracle scans all vertices. */
+    m->geom_hull = I(b, "geom_chull");
+    m->hull_vert = F(b, "chull_vert");
     LI(pair_geom); LI(pair_condim); LF(pair_friction); LF(pair_solref); LF(pair_solimp); LF(pair_margin); LF(pair_gap);
     LF(qpos0); LF(qpos_home); LF(ctrl_home); LF(obs_offset); LF(obs_scale); LF(grip_range);
     LI(obs_qposadr); LI(obs_dofadr); LI(objects_qposadr);
@@ -56,7 +61,7 @@ orc_model* orc_model_load(const void* blob_in, size_t nbytes) {
     LI(geom_hplane); LI(geom_visible); LI(cam_body); LF(hull_plane); LF(cam_pos); LF(cam_quat); LF(cam_fovy); LF(cam_clip); LF(geom_rgba); LF(render_light);
     m->ncam = (int)(find(b, "cam_body")->nbytes / 4);
     m->nobj = (int)(find(b, "objects_qposadr")->nbytes / 4);
-    m->nhullvert = (int)(find(b, "hull_vert")->nbytes / 24);
+    m->nhullvert = (int)(find(b, "chull_vert")->nbytes / 24);
     if (m->nv > ORC_MAXNV) { fprintf(stderr, "nv too large\n"); abort(); }
     return m;
 }

@@ -37,7 +37,7 @@ def lib():
 
 
 def load_model(task="slot_insertion", num_arms=3, variant="gym", hulls="model"):
-    """hulls: "model" = the hull vertices of the model blob (decimated for the device); "full" = the FULL convex hulls of the STL files
+    """hulls: "model" = the collision hulls of the model blob (<= 128 vertices per mesh, what the device collides); "full" = the FULL convex hulls of the STL files
     (models/oracle_full_hulls.*, compile.py --oracle-hulls full), as MuJoCo collides mesh geoms [EXT] -- the oracle's faithful mode."""
     import json
     base = os.path.join(ROOT, "models", f"{'dc_' if variant == 'data_collection' else ''}{task}_{num_arms}arms")
@@ -57,8 +57,8 @@ def load_model(task="slot_insertion", num_arms=3, variant="gym", hulls="model"):
         adr, name_of = 0, {}
         for name, info in man["hulls"].items():
             name_of[adr] = name
-            adr += info["nvert"]
-        gh = np.asarray(md["geom_hull"], dtype=np.int32).reshape(-1, 2)
+            adr += info["collision_nvert"]
+        gh = np.asarray(md["geom_chull"], dtype=np.int32).reshape(-1, 2)
         bc = np.asarray(md["geom_bcenter"], dtype=np.float64).reshape(-1, 3)
         rb = np.asarray(md["geom_rbound"], dtype=np.float64).copy()
         new = np.zeros_like(gh)

@@ -40,6 +40,30 @@ def host(tmp_path_factory):
     return C.CDLL(so)
 
 
+def ipv(a):
+    """int32 array (possibly a view into a larger one) -> pointer to its first element"""
+    assert a.dtype == np.int32
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def expand_candidates(md):
+    """The candidate records of the model's support tables as the device holds them (PhysHost::build): (x, y, z, index) per entry of
+    chull_cand, the index local to the entry's hull."""
+    gh, hv = md["geom_chull"].reshape(-1, 2), md["chull_vert"].reshape(-1, 3)
+    ctab, cells, cand = md["geom_ctab"].reshape(-1, 2), md["chull_cells"], md["chull_cand"]
+    out = np.zeros((len(cand), 4))
+    for g in range(len(gh)):
+        if gh[g, 1] == 0:
+            continue
+        cb, R = ctab[g]
+        for rec in cells[cb:cb + 6 * R * R]:
+            off, cnt = int(rec) >> 8, int(rec) & 255
+            idx = cand[off:off + cnt]
+            out[off:off + cnt, :3] = hv[gh[g, 0] + idx]
+            out[off:off + cnt, 3] = idx
+    return np.ascontiguousarray(out.reshape(-1))
+
+
 def box_poses(n):
     md = model_dict()
     rng = np.random.default_rng(5)
@@ -75,7 +99,9 @@ def compare(host, q, fn, pert, tol, only_boxes):
     e = OrcEnv()
     e.L.orc_set_qpos.argtypes = [C.c_void_p, C.c_void_p]
     ng = md["geom_type"].shape[0]
-    gh, hv, bc = md["geom_hull"].reshape(-1, 2), md["hull_vert"].reshape(-1, 3), md["geom_bcenter"].reshape(-1, 3)
+    gh, hv, bc = md["geom_chull"].reshape(-1, 2), md["chull_vert"].reshape(-1, 3), md["geom_bcenter"].reshape(-1, 3)
+    ctab, cells_all = md["geom_ctab"].reshape(-1, 2), np.ascontiguousarray(md["chull_cells"], dtype=np.int32)
+    cand4 = expand_candidates(md)
     rng = np.random.default_rng(1)
     f = getattr(host, fn)
     tot = bad = 0
@@ -98,15 +124,16 @@ def compare(host, q, fn, pert, tol, only_boxes):
             ref = np.array([x.dist for x in cs if (x.geom1, x.geom2) == (g1, g2)])
 
             def shape(g):
-                h = np.ascontiguousarray(hv[gh[g, 0]:gh[g, 0] + gh[g, 1]]).reshape(-1) if gh[g, 1] > 0 else np.zeros(3)
+                # (the hull's cell records; a geom without a hull gets the first cell of the model, never looked at)
+                cl = cells_all[ctab[g, 0]:] if gh[g, 1] > 0 else cells_all
                 p = gx[g] * (1 + rng.normal(size=3) * pert)
                 m = gm[g] * (1 + rng.normal(size=9) * pert)
                 cen = p + m.reshape(3, 3) @ bc[g] if pert else gx[g] + gm[g].reshape(3, 3) @ bc[g]
-                return np.ascontiguousarray(md["geom_size"][g]), p, m, h, int(gh[g, 1]), np.ascontiguousarray(cen)
+                return np.ascontiguousarray(md["geom_size"][g]), p, m, cl, int(ctab[g, 1]), np.ascontiguousarray(cen)
             a, b = shape(g1), shape(g2)
             dist, pos, nrm = np.zeros(8), np.zeros(24), np.zeros(3)
-            nn = f(t1, dp(a[0]), dp(a[1]), dp(a[2]), dp(a[3]), a[4], dp(a[5]), t2, dp(b[0]), dp(b[1]), dp(b[2]), dp(b[3]), b[4], dp(b[5]),
-                   C.c_double(float(md["geom_rbound"][g1])), C.c_double(float(md["geom_rbound"][g2])), dp(dist), dp(pos), dp(nrm))
+            nn = f(t1, dp(a[0]), dp(a[1]), dp(a[2]), ipv(a[3]), a[4], dp(a[5]), t2, dp(b[0]), dp(b[1]), dp(b[2]), ipv(b[3]), b[4], dp(b[5]),
+                   dp(cand4), len(cand4) // 4, C.c_double(float(md["geom_rbound"][g1])), C.c_double(float(md["geom_rbound"][g2])), dp(dist), dp(pos), dp(nrm))
             multi[min(nn, 8)] += 1
             tot += 1
             bad += nn != len(ref) or np.abs(dist[:nn] - ref).max() > tol
@@ -153,8 +180,9 @@ def test_multiccd_gives_a_flat_contact_its_rim(host):
         Rc = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]]).reshape(-1).copy()
         cp, bp = np.array([0.01, 0.02, 0.02 + 0.03 - 1e-4]), np.zeros(3)
         dist, pos, nrm = np.zeros(8), np.zeros(24), np.zeros(3)
-        n = host.dev_narrow_f64(5, dp(cyl), dp(cp), dp(Rc), dp(z), 0, dp(cp.copy()), 6, dp(box), dp(bp), dp(I), dp(z), 0, dp(bp.copy()),
-                                C.c_double(0.05), C.c_double(0.05), dp(dist), dp(pos), dp(nrm))
+        none, c4 = np.zeros(8, dtype=np.int32), np.zeros(4)
+        n = host.dev_narrow_f64(5, dp(cyl), dp(cp), dp(Rc), ipv(none), 1, dp(cp.copy()), 6, dp(box), dp(bp), dp(I), ipv(none), 1, dp(bp.copy()),
+                                dp(c4), 1, C.c_double(0.05), C.c_double(0.05), dp(dist), dp(pos), dp(nrm))
         do, po, no = np.zeros(8), np.zeros(24), np.zeros(24)
         m = L.orc_narrow(5, dp(cyl), dp(cp), dp(Rc), dp(z), 0, 6, dp(box), dp(bp), dp(I), dp(z), 0, dp(do), dp(po), dp(no))
         assert n == m and np.array_equal(dist[:n], do[:n]) and np.array_equal(pos[:3 * n], po[:3 * n])

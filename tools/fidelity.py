@@ -3,7 +3,9 @@
 
 The CPU oracle has no LDS or register budget, so since round 5 it can run what MuJoCo runs where the device takes a shortcut:
   * mesh geoms collide as the FULL convex hulls of their STL files (18 032 vertices over 27 meshes; models/oracle_full_hulls.*,
-    compile.py --oracle-hulls full) instead of the device's hulls decimated to 20 / 32 vertices (aloha_sim.xml:106-111 class "collision");
+    compile.py --oracle-hulls full) instead of the device's collision hulls (<= 128 vertices per mesh behind a support table since round 5:
+    at most 0.3 mm of a mesh sticks out, 0.02 mm for the fingers; 20 / 32 vertices and up to 8.9 mm in rounds 1-4:
+    profiles/r05_fidelity_decimated20_32.json is this report for those) (aloha_sim.xml:106-111 class "collision");
   * box-box manifolds keep every clipped vertex, up to 8 (the device does too since round 5; the four-point reduction of rounds 1-4 is
     kept in the oracle as a switch so that its effect is a number here).
 The scripted policy of every task runs closed loop on the device (f64 physics), its ctrl sequence and per-step states are recorded, and
@@ -46,7 +48,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_fidelity.json"))
     ap.add_argument("--tasks", nargs="*", default=TASKS)
     a = ap.parse_args()
-    out = {"note": __doc__.split("\n\n")[0] + "  See tools/fidelity.py for what every field is.", "envs_per_task": a.envs, "device": "f64 physics (AVSIM_F64_PHYSICS), decimated hulls, 8-point box-box",
+    out = {"note": __doc__.split("\n\n")[0] + "  See tools/fidelity.py for what every field is.", "envs_per_task": a.envs, "device": "f64 physics (AVSIM_F64_PHYSICS), collision hulls of <= 128 vertices (support tables), 8-point box-box",
            "modes": MODES, "tasks": {}}
     for task in a.tasks:
         dev = U.device_episode(task, a.envs, f64=True, record_state=True)

@@ -22,7 +22,7 @@ for task, n64, n32 in (("slot_insertion", 16, 128), ("insert_peg", 16, 128), ("s
     if only and task not in only:
         continue
     for mode, n in (("f64", n64), ("f32", n32)):
-        dev = U.device_episode(task, n, f64=mode == "f64", record_state=mode == "f32")
+        dev = U.device_episode(task, n, f64=mode == "f64", record_state=True)
         rows = U.compare_with_replay(task, dev)
         e = np.array([r["max_qpos_err"] for r in rows])
         mism = [r for r in rows if r["dev_success"] != r["orc_success"]]
@@ -38,21 +38,27 @@ for task, n64, n32 in (("slot_insertion", 16, 128), ("insert_peg", 16, 128), ("s
             "device_max_reward_hist": np.bincount([r["dev_max_reward"] for r in rows], minlength=6).tolist(),
             "envs_with_identical_contact_counts": int(sum(r["ncon_diff_steps"] == 0 for r in rows)),
             "max_qpos_err_p50_p90_max": [float(np.percentile(e, 50)), float(np.percentile(e, 90)), float(e.max())],
+            "held_phase": {"what": "the steps before the script's release / pour phase (tests/episode_util.py release_step): objects in the grippers or at rest",
+                           "steps": rows[0]["held_steps"], "reward_diff_steps_total": int(sum(r["held_reward_diff"] for r in rows)),
+                           "max_qpos_err_p50_p90_max": [float(x) for x in np.percentile([r["held_max_qpos_err"] for r in rows], [50, 90, 100])],
+                           "ncon_diff_steps_p50_p90_max": [float(x) for x in np.percentile([r["held_ncon_diff_steps"] for r in rows], [50, 90, 100])]},
+            "arm_joints_max_qpos_err_p50_p90_max": [float(x) for x in np.percentile([r["arm_max_qpos_err"] for r in rows], [50, 90, 100])],
+            "ncon_diff_steps_p50_p90_max": [float(x) for x in np.percentile([r["ncon_diff_steps"] for r in rows], [50, 90, 100])],
             "diverged_envs": int(dev["diverged"].sum()), "capped_envs": int(dev["capped"].sum()),
             "mismatching_envs": mism[:16], "reward_diff_envs": [r for r in rows if r["first_reward_diff"] != -1][:16],
         }
-        if mode == "f32":
+        if True:
             ls = U.compare_lockstep(task, dev)
             tot = sum(r["steps"] for r in ls)
             out[f"{task}_{mode}"]["lockstep"] = {
-                "what": "the oracle put into the device's f32 state at the start of every env-step and stepped once with the device's ctrl (teacher-forced): per-step flags without the divergence of two chaotic trajectories",
+                "what": "the oracle put into the device's state at the start of every env-step and stepped once with the device's ctrl (teacher-forced): per-step flags without the divergence of two chaotic trajectories",
                 "env_steps": tot, "reward_diff_steps": int(sum(r["reward_diff_steps"] for r in ls)), "success_flag_diff_steps": int(sum(r["success_diff_steps"] for r in ls)),
                 "final_success_flag_mismatches": int(sum(r["dev_success"] != r["orc_success"] for r in ls)),
                 "envs_with_identical_reward_sequence": int(sum(r["reward_diff_steps"] == 0 for r in ls)),
                 "ncon_diff_steps": int(sum(r["ncon_diff_steps"] for r in ls)),
                 "max_one_step_qpos_err_p50_p99_max": [float(x) for x in np.percentile([r["max_step_err"] for r in ls], [50, 99, 100])]}
         print(task, mode, json.dumps({k: v for k, v in out[f"{task}_{mode}"].items() if not k.endswith("_envs") or k in ("diverged_envs", "capped_envs")}), flush=True)
-path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r04_episode_parity.json")
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r05_episode_parity.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
 print("wrote", path)
