@@ -55,6 +55,7 @@ struct DevGuard {
         return AVSIM_EHIP;                                                                                  \
     }
 
+constexpr size_t EV_RING = 1024;      // HIP event pairs kept per timing list before they are folded into a running sum
 struct avsim {
     int device = 0;
     uint32_t flags = 0;
@@ -85,6 +86,8 @@ struct avsim {
     bool ktiming = false;
     std::vector<hipEvent_t> kev;
     size_t kev_used = 0;
+    double kev_ms = 0;            // launches folded out of the event list (it holds at most EV_RING pairs: a long run with kernel_timing on
+    int64_t kev_n = 0;            // and nobody asking does not grow it)
 
     void set_error(const char* fmt, ...) {
         char buf[1024];
@@ -497,9 +500,9 @@ int avsim_kernel_time(avsim_t* h, int reset, double* total_ms, int64_t* launches
         HIPCHK(h, hipEventElapsedTime(&ms, h->kev[i], h->kev[i + 1]));
         tot += ms;
     }
-    if (total_ms) *total_ms = tot;
-    if (launches) *launches = (int64_t)(h->kev_used / 2);
-    if (reset) h->kev_used = 0;
+    if (total_ms) *total_ms = tot + h->kev_ms;
+    if (launches) *launches = (int64_t)(h->kev_used / 2) + h->kev_n;
+    if (reset) { h->kev_used = 0; h->kev_ms = 0; h->kev_n = 0; }
     return AVSIM_OK;
 }
 
@@ -513,9 +516,9 @@ int avsim_render_kernel_time(avsim_t* h, int reset, double* total_ms, int64_t* l
         HIPCHK(h, hipEventElapsedTime(&ms, h->render.tev[i], h->render.tev[i + 1]));
         tot += ms;
     }
-    if (total_ms) *total_ms = tot;
-    if (launches) *launches = (int64_t)(h->render.tev_used / 2);
-    if (reset) h->render.tev_used = 0;
+    if (total_ms) *total_ms = tot + h->render.tev_ms;
+    if (launches) *launches = (int64_t)(h->render.tev_used / 2) + h->render.tev_n;
+    if (reset) { h->render.tev_used = 0; h->render.tev_ms = 0; h->render.tev_n = 0; }
     return AVSIM_OK;
 }
 
@@ -620,6 +623,16 @@ static int step_common(avsim_t* h, const float* d_action, int nsub, double* agen
     if (reward && (rc = h->out_begin(5, reward, sizeof(int32_t) * N, &drw))) return rc;
     if (success && (rc = h->out_begin(6, success, N, &dsu))) return rc;
     if (h->ktiming) {
+        if (h->kev_used >= 2 * EV_RING) {      // fold the recorded pairs into the running sum (waits for the newest of them: once per EV_RING launches)
+            for (size_t i = 0; i + 1 < h->kev_used; i += 2) {
+                float ms = 0;
+                HIPCHK(h, hipEventSynchronize(h->kev[i + 1]));
+                HIPCHK(h, hipEventElapsedTime(&ms, h->kev[i], h->kev[i + 1]));
+                h->kev_ms += ms;
+            }
+            h->kev_n += (int64_t)(h->kev_used / 2);
+            h->kev_used = 0;
+        }
         while (h->kev.size() < h->kev_used + 2) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->kev.push_back(e); }
         HIPCHK(h, hipEventRecord(h->kev[h->kev_used], h->stream));
     }

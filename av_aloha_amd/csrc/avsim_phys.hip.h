@@ -3251,7 +3251,7 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
     // (the pairs' flags: 2 x MAXW / 2 ints behind the tables in the dynamic LDS of a RETRY launch)
     int* const pair_want = reinterpret_cast<int*>(smem + (size_t)(blockDim.x >> 6) * ka_small->lay.bytes_per_env + (size_t)ka_small->mo.nreal * sizeof(real) + (size_t)ka_small->mo.nint * 4);
     int* const pair_grant = pair_want + MAXW / 2;
-    if (RETRY && threadIdx.x < MAXW) pair_want[threadIdx.x] = 0;
+    if (RETRY && threadIdx.x < MAXW / 2) { pair_want[threadIdx.x] = 0; pair_grant[threadIdx.x] = 0; }      // (both arrays, each MAXW / 2 ints, by name)
     static_assert(G == 64, "one env per wavefront");
 #ifdef AVSIM_NO_PROF
     o_prof = nullptr;
@@ -3978,6 +3978,9 @@ struct PhysHost {
                                d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof, d_xpose, order, order_envs ? d_cost : (int*)nullptr, head, next,
                                d_retry, two ? (1 + 2 * par) | pairing : 0, (KPtr<real>)d_kargs2);
         }
+        // the second pass gets the first tier's capacities in two 10-bit fields of retry_mode, above the three mode bits and the pairing bit
+        static_assert((8 | 7) < (1 << 8), "retry_mode: mode bits and pairing flag below bit 8");
+        if (two && (maxcon1 >= 1024 || maxefc1 >= 1024 || maxcon1 < 0 || maxefc1 < 0)) { err = "first-tier capacities do not fit the 10-bit fields of retry_mode (maxcon_first / maxefc_first < 1024)"; return -1; }
         if (two) {
             // second pass: the envs the first one gave up on, with the full capacities; one workgroup per CU is plenty for the few there
             // are (the workgroups loop over the list), and a launch that finds the list empty returns at once

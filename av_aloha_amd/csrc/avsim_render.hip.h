@@ -782,6 +782,8 @@ struct RenderHost {
     bool timing = false;
     std::vector<hipEvent_t> tev;
     size_t tev_used = 0;
+    double tev_ms = 0;             // launches folded out of the event list (at most 1024 pairs are kept: a long run that renders every step with
+    long long tev_n = 0;           // "kernel_timing" on does not grow it)
 
     template <typename T>
     T* up(const std::vector<T>& v) {
@@ -935,6 +937,15 @@ struct RenderHost {
         const int bin_tx = bin_width((W + TILE_W - 1) / TILE_W);
         const int tiles = (((W + TILE_W - 1) / TILE_W + bin_tx - 1) / bin_tx) * (((H + TILE_H - 1) / TILE_H + BIN_TY - 1) / BIN_TY);     // bins
         if (timing) {
+            if (tev_used >= 2 * 1024) {
+                for (size_t i = 0; i + 1 < tev_used; i += 2) {
+                    float ms = 0;
+                    (void)hipEventSynchronize(tev[i + 1]);
+                    if (hipEventElapsedTime(&ms, tev[i], tev[i + 1]) == hipSuccess) tev_ms += ms;
+                }
+                tev_n += (long long)(tev_used / 2);
+                tev_used = 0;
+            }
             while (tev.size() < tev_used + 2) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) { err = "hipEventCreate failed"; return -3; } tev.push_back(ev); }
             (void)hipEventRecord(tev[tev_used], st);
         }

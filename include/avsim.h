@@ -88,7 +88,9 @@ int avsim_dims(const avsim_t* h, int32_t dims[AVSIM_NDIMS]);
  *   "order_envs"        1 (default): workgroups take the envs in the order of their cost in the previous step, most expensive
  *                       first (results do not depend on it); 0 = in index order
  *   "export_contacts"   0 skips the per-step contact export (avsim_get_contacts); "kernel_timing" 1 brackets every physics
- *                       launch with HIP events (avsim_kernel_time); "profile_phases" 1 enables avsim_get_phase_cycles */
+ *                       launch AND every image kernel of avsim_render_depth / the proxy mode of avsim_render_rgb with HIP events
+ *                       (avsim_kernel_time, avsim_render_kernel_time; at most 1024 event pairs are kept per list, older ones are folded
+ *                       into a running sum); "profile_phases" 1 enables avsim_get_phase_cycles */
 int avsim_set_option(avsim_t* h, const char* name, double value);
 
 /* env.py:228-249 + task reset: envs with mask[i]!=0 (NULL = all) go to the home pose, zero velocity,

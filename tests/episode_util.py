@@ -234,5 +234,6 @@ def compare_lockstep(task, dev, envs=None):
     for k, (rw, su, er, nc) in zip(envs, res):
         rows.append(dict(env=k, reward_diff_steps=int((rw != dev["reward"][:, k]).sum()), success_diff_steps=int((su != dev["success"][:, k]).sum()),
                          dev_success=bool(dev["success"][-1, k]), orc_success=bool(su[-1]), dev_max_reward=int(dev["reward"][:, k].max()),
-                         max_step_err=float(er.max()), ncon_diff_steps=int((nc != dev["ncon"][:, k]).sum()), steps=int(len(rw))))
+                         max_step_err=float(er.max()), median_step_err=float(np.median(er)), steps_err_above_1e6=int((er > 1e-6).sum()),
+                         ncon_diff_steps=int((nc != dev["ncon"][:, k]).sum()), steps=int(len(rw))))
     return rows

@@ -56,7 +56,9 @@ for task, n64, n32 in (("slot_insertion", 16, 128), ("insert_peg", 16, 128), ("s
                 "final_success_flag_mismatches": int(sum(r["dev_success"] != r["orc_success"] for r in ls)),
                 "envs_with_identical_reward_sequence": int(sum(r["reward_diff_steps"] == 0 for r in ls)),
                 "ncon_diff_steps": int(sum(r["ncon_diff_steps"] for r in ls)),
-                "max_one_step_qpos_err_p50_p99_max": [float(x) for x in np.percentile([r["max_step_err"] for r in ls], [50, 99, 100])]}
+                "max_one_step_qpos_err_p50_p99_max": [float(x) for x in np.percentile([r["max_step_err"] for r in ls], [50, 99, 100])],
+                "median_one_step_qpos_err_max_over_envs": float(max(r["median_step_err"] for r in ls)),
+                "steps_with_one_step_err_above_1e-6": int(sum(r["steps_err_above_1e6"] for r in ls))}
         print(task, mode, json.dumps({k: v for k, v in out[f"{task}_{mode}"].items() if not k.endswith("_envs") or k in ("diverged_envs", "capped_envs")}), flush=True)
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r05_episode_parity.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
