@@ -38,6 +38,7 @@ def lib():
         L.avsim_reset.argtypes = [vp, vp, vp]
         L.avsim_step.argtypes = [vp, vp, i32, vp, vp, vp]
         L.avsim_step_cartesian.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+        L.avsim_step_ctrl.argtypes = [vp, i32, vp, vp, vp]
         L.avsim_ik.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp]
         L.avsim_fk_jac.argtypes = [vp, i32, i32, vp, vp, vp]
         L.avsim_observe.argtypes = [vp, vp, vp, vp]

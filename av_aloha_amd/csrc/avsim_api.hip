@@ -658,6 +658,12 @@ int avsim_step(avsim_t* h, const float* action, int nsub, double* agent_pos, int
     return step_common(h, (const float*)da, nsub, agent_pos, reward, success);
 }
 
+int avsim_step_ctrl(avsim_t* h, int nsub, double* agent_pos, int32_t* reward, uint8_t* success) {
+    if (!h || nsub < 0) { if (h) h->set_error("avsim_step_ctrl: bad arguments"); return AVSIM_EINVAL; }
+    AVS_ON_DEVICE(h);
+    return step_common(h, nullptr, nsub, agent_pos, reward, success);
+}
+
 int avsim_step_cartesian(avsim_t* h, const double* action23, int ik_mode, int nsub, double* agent_pos, int32_t* reward,
                          uint8_t* success) {
     if (!h || !action23 || nsub < 0 || (ik_mode != AVSIM_IK_REFERENCE && ik_mode != AVSIM_IK_DLS)) {

@@ -26,11 +26,13 @@ struct Shape {
     T mat[9];      // geom->world rotation, row-major
     // mesh geoms: the collision hull (<= 128 vertices, compile.py) behind its support table -- the unit sphere of directions cut into the
     // 6 R^2 cells of a cube map, every cell listing the vertices that support SOME direction of the (padded) cell (compiler/hull.py
-    // support_table).  hcell = the hull's cell records ((first candidate << 8) | count), hull = the model's candidate records, four
-    // words each: the vertex in the geom frame and its index in the hull (sorted by index within a cell)
+    // support_table).  `hull` = the model's table: one record of eight entries per cell (four words each: a candidate vertex in the geom
+    // frame; the fourth word of entry 0 holds the cell's candidate count, that of entry 1 the first of its further candidates in the
+    // overflow part -- cells with more than eight: the normal of a face with many vertices), lists sorted by vertex index, short lists
+    // padded with their last vertex: a support call is ONE round trip of eight 16-byte loads (a 128-byte line in f32) for most directions.
+    // hbase = the hull's first cell record, hR = its cube-map resolution, hovf = entry index at which the overflow part starts
     GLB_PTR(const T) hull;
-    GLB_PTR(const int) hcell;
-    int hR;
+    int hbase, hR, hovf;
     int nh;
     T center[3];   // an interior point (world)
     T lc[3], lh[3]; // local bounding box: centre and half extents in the geom frame
@@ -83,24 +85,25 @@ AVS_DEV void support(const Shape<T>& s, const T* d, T* out) {
             int iu = (int)((u + T(1)) * T(0.5) * T(R)), iv = (int)((v + T(1)) * T(0.5) * T(R));
             iu = iu > 0 ? (iu < R - 1 ? iu : R - 1) : 0;
             iv = iv > 0 ? (iv < R - 1 ? iv : R - 1) : 0;
-            const int rec = s.hcell[((2 * a + (lm < T(0) ? 1 : 0)) * R + iu) * R + iv];
-            const int cnt = rec & 255, last = cnt - 1;
-            GLB_PTR(const T) C = s.hull + 4 * (size_t)(rec >> 8);
+            GLB_PTR(const T) C = s.hull + 32 * (size_t)(s.hbase + ((2 * a + (lm < T(0) ? 1 : 0)) * R + iu) * R + iv);
             const T tie = TieTol<T>::rel * T(0.1) * (ax + ay + az);
-            T vx[8], vy[8], vz[8], pr[8];
+            T vx[8], vy[8], vz[8], pr[8], w0, w1;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {           // the first eight candidates stay in registers (entries past the end repeat the last one)
-                const int ik = k < last ? k : last;
-                vx[k] = C[4 * ik]; vy[k] = C[4 * ik + 1]; vz[k] = C[4 * ik + 2];
+            for (int k = 0; k < 8; k++) {           // the cell's record: eight candidates, one round trip
+                vx[k] = C[4 * k]; vy[k] = C[4 * k + 1]; vz[k] = C[4 * k + 2];
             }
+            w0 = C[3]; w1 = C[7];
+            const int cnt = (int)w0;
             T bd = T(-1e30);
 #pragma unroll
             for (int k = 0; k < 8; k++) { pr[k] = vx[k] * l[0] + vy[k] * l[1] + vz[k] * l[2]; bd = pr[k] > bd ? pr[k] : bd; }
-            for (int i = 8; i < cnt; i += 8) {      // (cells at the normal of a face with many vertices)
+            GLB_PTR(const T) O = s.hull + 4 * ((size_t)s.hovf + (size_t)(cnt > 8 ? (int)w1 : 0));
+            const int more = cnt - 8, lastm = more - 1;
+            for (int i = 0; i < more; i += 8) {     // (cells at the normal of a face with many vertices: the further candidates)
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    const int ik = i + k < last ? i + k : last;
-                    const T q = C[4 * ik] * l[0] + C[4 * ik + 1] * l[1] + C[4 * ik + 2] * l[2];
+                    const int ik = i + k < lastm ? i + k : lastm;
+                    const T q = O[4 * ik] * l[0] + O[4 * ik + 1] * l[1] + O[4 * ik + 2] * l[2];
                     bd = q > bd ? q : bd;
                 }
             }
@@ -110,11 +113,11 @@ AVS_DEV void support(const Shape<T>& s, const T* d, T* out) {
 #pragma unroll
             for (int k = 7; k >= 0; k--)            // (descending: the lowest index is assigned last)
                 if (pr[k] >= thr) { bx = vx[k]; by = vy[k]; bz = vz[k]; found = true; }
-            for (int i = 8; i < cnt && !found; i += 8) {
+            for (int i = 0; i < more && !found; i += 8) {
 #pragma unroll
                 for (int k = 7; k >= 0; k--) {
-                    const int ik = i + k < last ? i + k : last;
-                    const T qx = C[4 * ik], qy = C[4 * ik + 1], qz = C[4 * ik + 2];
+                    const int ik = i + k < lastm ? i + k : lastm;
+                    const T qx = O[4 * ik], qy = O[4 * ik + 1], qz = O[4 * ik + 2];
                     if (qx * l[0] + qy * l[1] + qz * l[2] >= thr) { bx = qx; by = qy; bz = qz; found = true; }
                 }
             }

@@ -132,8 +132,8 @@ struct DevModel {
     GLB_PTR(const real) geom_cen0;
     GLB_PTR(const real) geom_aabb0;
     GLB_PTR(const real) geom_lbox;
-    GLB_PTR(const real) hull_vert;     // candidate records of the collision hulls' support tables: (x, y, z, index) per entry (avsim_collide.hip.h Shape)
-    GLB_PTR(const int) hull_cells;     // cell records of all hulls; geom_hull[g] = (first cell of the geom's hull, cube-map resolution R)
+    GLB_PTR(const real) hull_vert;     // the collision hulls' support tables: a record of eight candidate entries per cube-map cell, then the overflow part (avsim_collide.hip.h Shape)
+    int hull_ovf;                      // entry index at which the overflow part starts; geom_hull[g] = (first cell record of the geom's hull, cube-map resolution R)
     // pairs
     GLB_PTR(const int) pair_geom;
     GLB_PTR(const int) pair_condim;
@@ -2325,8 +2325,9 @@ struct Env {
         s.type = geom_type_()[g];
         for (int k = 0; k < 3; k++) s.size[k] = ka->m.geom_size[3 * g + k];
         s.hull = ka->m.hull_vert;
-        s.hcell = ka->m.hull_cells + ka->m.geom_hull[2 * g];
+        s.hbase = ka->m.geom_hull[2 * g];
         s.hR = ka->m.geom_hull[2 * g + 1];
+        s.hovf = ka->m.hull_ovf;
         s.nh = 0;
         for (int k = 0; k < 3; k++) { s.lc[k] = ka->m.geom_lbox[6 * g + k]; s.lh[k] = ka->m.geom_lbox[6 * g + 3 + k]; }
         if (geom_static_()[g]) {
@@ -3715,25 +3716,44 @@ struct PhysHost {
         m.geom_type = up(I("geom_type")); moff.geom_type = (int)img_int.size(); { auto v_ = I("geom_type"); img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.geom_body = up(gbody); moff.geom_body = (int)img_int.size(); { auto v_ = gbody; img_int.insert(img_int.end(), v_.begin(), v_.end()); } m.geom_hull = up(I("geom_ctab")); m.geom_class = up(I("geom_class")); m.geom_static = up(gstat); moff.geom_static = (int)img_int.size(); { auto v_ = gstat; img_int.insert(img_int.end(), v_.begin(), v_.end()); }
         m.geom_pos = upr<real>(gpos); m.geom_mat = upr<real>(gmat); m.geom_size = upr<real>(F("geom_size")); m.geom_cpos = upr<real>(gcp); moff.geom_cpos = (int)img_real.size(); { auto v_ = gcp; img_real.insert(img_real.end(), v_.begin(), v_.end()); }
         m.geom_rbound = upr<real>(F("geom_rbound")); moff.geom_rbound = (int)img_real.size(); { auto v_ = F("geom_rbound"); img_real.insert(img_real.end(), v_.begin(), v_.end()); } m.geom_xpos0 = upr<real>(gx0); m.geom_xmat0 = upr<real>(gm0); m.geom_cen0 = upr<real>(gc0); m.geom_aabb0 = upr<real>(gaabb); m.geom_lbox = upr<real>(glbox);
-        {   // support tables of the collision hulls (compiler/hull.py support_table): the candidate lists hold vertex indices local to their
-            // hull; here every entry becomes (x, y, z, index), so that a support call fetches coordinates, not indices to follow
+        {   // support tables of the collision hulls (compiler/hull.py support_table).  The blob holds, per cube-map cell, a list of vertex
+            // indices local to the cell's hull; the device gets one record of eight (x, y, z, w) entries per cell -- the first eight
+            // candidates, a shorter list padded with its last vertex; w of entry 0 = the count, w of entry 1 = where the cell's further
+            // candidates start in the overflow part that follows the records -- so that a support call is one round trip
             auto ctab = I("geom_ctab"), cells = I("chull_cells"), cand = I("chull_cand");
-            std::vector<double> c4(4 * cand.size(), 0.0);
+            const size_t ncell = cells.size();
+            std::vector<double> tab(32 * ncell, 0.0), ovf;
+            std::vector<char> done(ncell, 0);
             for (int g = 0; g < ng; g++) {
                 if (gtype[g] != G_MESH) continue;
                 const int cb = ctab[2 * g], R = ctab[2 * g + 1], adr = ghull[2 * g];
                 for (int c = 0; c < 6 * R * R; c++) {
+                    if (done[cb + c]) continue;
+                    done[cb + c] = 1;
                     const int rec = cells[cb + c], off = rec >> 8, cnt = rec & 255;
-                    for (int k = 0; k < cnt; k++) {
+                    if (cnt < 1) throw std::runtime_error("support table: empty cell");
+                    double* o = &tab[32 * (size_t)(cb + c)];
+                    for (int k = 0; k < 8; k++) {
+                        const int v = cand[off + (k < cnt ? k : cnt - 1)];
+                        if (v < 0 || v >= ghull[2 * g + 1]) throw std::runtime_error("support table: candidate index outside its hull");
+                        for (int q = 0; q < 3; q++) o[4 * k + q] = hv[3 * (size_t)(adr + v) + q];
+                        o[4 * k + 3] = (double)v;
+                    }
+                    o[3] = (double)cnt;
+                    o[7] = (double)(ovf.size() / 4);
+                    for (int k = 8; k < cnt; k++) {
                         const int v = cand[off + k];
                         if (v < 0 || v >= ghull[2 * g + 1]) throw std::runtime_error("support table: candidate index outside its hull");
-                        for (int q = 0; q < 3; q++) c4[4 * (size_t)(off + k) + q] = hv[3 * (size_t)(adr + v) + q];
-                        c4[4 * (size_t)(off + k) + 3] = (double)v;
+                        for (int q = 0; q < 3; q++) ovf.push_back(hv[3 * (size_t)(adr + v) + q]);
+                        ovf.push_back((double)v);
                     }
                 }
             }
-            m.hull_vert = upr<real>(c4);
-            m.hull_cells = up(cells);
+            if (ovf.size() / 4 >= (1u << 24)) throw std::runtime_error("support table: overflow part too large");
+            m.hull_ovf = (int)(tab.size() / 4);
+            tab.insert(tab.end(), ovf.begin(), ovf.end());
+            if (tab.empty()) tab.assign(4, 0.0);
+            m.hull_vert = upr<real>(tab);
         }
         m.pair_geom = up(I("pair_geom")); m.pair_condim = up(I("pair_condim"));
         m.pair_friction = upr<real>(F("pair_friction")); m.pair_solref = upr<real>(F("pair_solref")); m.pair_solimp = upr<real>(F("pair_solimp"));

@@ -61,6 +61,14 @@ class BatchedSim:
         self.h.check(self.h.L.avsim_step(self.h.h, a.ctypes.data, nsub, ap.ctypes.data, _ffi.ptr(rw), _ffi.ptr(su)))
         return ap, rw, (su.astype(bool) if su is not None else None)
 
+    def step_ctrl(self, nsub=SIM_PHYSICS_ENV_STEP_RATIO):
+        """nsub substeps driven by the ctrl vector as it stands (set_state / an earlier step): dm_control's physics.step(nsub)."""
+        ap = np.empty((self.N, self.nj))
+        rw = np.empty(self.N, dtype=np.int32)
+        su = np.empty(self.N, dtype=np.uint8)
+        self.h.check(self.h.L.avsim_step_ctrl(self.h.h, nsub, ap.ctypes.data, rw.ctypes.data, su.ctypes.data))
+        return ap, rw, su.astype(bool)
+
     def step_cartesian(self, action23, ik_mode=_ffi.IK_REFERENCE, nsub=SIM_PHYSICS_ENV_STEP_RATIO):
         a = np.ascontiguousarray(action23, dtype=np.float64).reshape(self.N, 23)
         ap = np.empty((self.N, 21))

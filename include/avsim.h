@@ -102,6 +102,11 @@ int avsim_reset(avsim_t* h, const uint8_t* mask, const double* obj_qpos);
  * agent_pos double[N][num_joints], reward int32[N], success uint8[N]. Any output may be NULL. */
 int avsim_step(avsim_t* h, const float* action, int nsub, double* agent_pos, int32_t* reward, uint8_t* success);
 
+/* `physics.step(nstep)` with the control vector as it stands (env.py:218 after env.py:203-215 has written physics.data.ctrl; dm_control's
+ * Physics.step): nsub substeps driven by the handle's ctrl -- what avsim_set_state / an earlier step left there --, outputs as avsim_step.
+ * A replay of recorded actuator commands and substep-by-substep debugging go through this. */
+int avsim_step_ctrl(avsim_t* h, int nsub, double* agent_pos, int32_t* reward, uint8_t* success);
+
 /* sim_env.py:277-312: action double[N][23] Cartesian targets; IK on measured qpos -> ctrl; physics.
  * Outputs as avsim_step (agent_pos has 21 entries per env here). */
 int avsim_step_cartesian(avsim_t* h, const double* action23, int ik_mode, int nsub, double* agent_pos,

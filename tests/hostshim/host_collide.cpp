@@ -8,27 +8,29 @@
 using namespace avs;
 
 template <typename T>
-static void fill(Shape<T>& s, int type, const double* size, const double* pos, const double* mat, const T* cand4, const int* cells, int R) {
+static void fill(Shape<T>& s, int type, const double* size, const double* pos, const double* mat, const T* tab, int hbase, int R, int hovf) {
     s.type = type;
     for (int k = 0; k < 3; k++) { s.size[k] = (T)size[k]; s.pos[k] = (T)pos[k]; s.center[k] = (T)pos[k]; s.lc[k] = 0; s.lh[k] = (T)1e9; }
     for (int k = 0; k < 9; k++) s.mat[k] = (T)mat[k];
-    s.hull = cand4;
-    s.hcell = cells;
+    s.hull = tab;
+    s.hbase = hbase;
     s.hR = R;
+    s.hovf = hovf;
     s.nh = 0;
 }
 
-// cand4 / ncand4: the model's candidate records (x, y, z, index per entry: tests/test_host_collide.py expands the blob's chull_cand as
-// PhysHost::build does); cells1 / cells2: the two hulls' cell records; R1 / R2 their cube-map resolutions
+// tab / ntab: the model's support tables as the device holds them (tests/test_host_collide.py expands the blob's chull_cells / chull_cand as
+// PhysHost::build does: ntab words); hbase1 / hbase2: the two hulls' first cell records, R1 / R2 their cube-map resolutions, hovf: the entry
+// index at which the overflow part starts
 template <typename T>
-static int run(int t1, const double* size1, const double* pos1, const double* mat1, const int* cells1, int R1, const double* c1,
-               int t2, const double* size2, const double* pos2, const double* mat2, const int* cells2, int R2, const double* c2,
-               const double* cand4, int ncand4, double rb1, double rb2, double* dist, double* pos, double* normal) {
+static int run(int t1, const double* size1, const double* pos1, const double* mat1, int hbase1, int R1, const double* c1,
+               int t2, const double* size2, const double* pos2, const double* mat2, int hbase2, int R2, const double* c2,
+               const double* tab, int ntab, int hovf, double rb1, double rb2, double* dist, double* pos, double* normal) {
     static thread_local std::vector<T> c4;
-    c4.assign(cand4, cand4 + 4 * (size_t)ncand4);
+    c4.assign(tab, tab + (size_t)ntab);
     Shape<T> a, b;
-    fill(a, t1, size1, pos1, mat1, c4.data(), cells1, R1);
-    fill(b, t2, size2, pos2, mat2, c4.data(), cells2, R2);
+    fill(a, t1, size1, pos1, mat1, c4.data(), hbase1, R1, hovf);
+    fill(b, t2, size2, pos2, mat2, c4.data(), hbase2, R2, hovf);
     if (c1) for (int k = 0; k < 3; k++) a.center[k] = (T)c1[k];
     if (c2) for (int k = 0; k < 3; k++) b.center[k] = (T)c2[k];
     T scr[SLOT_W], work[56], ovf[BOX_OVF_W];
@@ -50,13 +52,13 @@ static int run(int t1, const double* size1, const double* pos1, const double* ma
     return n;
 }
 
-extern "C" int dev_narrow_f64(int t1, const double* size1, const double* pos1, const double* mat1, const int* cells1, int R1, const double* c1,
-                              int t2, const double* size2, const double* pos2, const double* mat2, const int* cells2, int R2, const double* c2,
-                              const double* cand4, int ncand4, double rb1, double rb2, double* dist, double* pos, double* normal) {
-    return run<double>(t1, size1, pos1, mat1, cells1, R1, c1, t2, size2, pos2, mat2, cells2, R2, c2, cand4, ncand4, rb1, rb2, dist, pos, normal);
+extern "C" int dev_narrow_f64(int t1, const double* size1, const double* pos1, const double* mat1, int hbase1, int R1, const double* c1,
+                              int t2, const double* size2, const double* pos2, const double* mat2, int hbase2, int R2, const double* c2,
+                              const double* tab, int ntab, int hovf, double rb1, double rb2, double* dist, double* pos, double* normal) {
+    return run<double>(t1, size1, pos1, mat1, hbase1, R1, c1, t2, size2, pos2, mat2, hbase2, R2, c2, tab, ntab, hovf, rb1, rb2, dist, pos, normal);
 }
-extern "C" int dev_narrow_f32(int t1, const double* size1, const double* pos1, const double* mat1, const int* cells1, int R1, const double* c1,
-                              int t2, const double* size2, const double* pos2, const double* mat2, const int* cells2, int R2, const double* c2,
-                              const double* cand4, int ncand4, double rb1, double rb2, double* dist, double* pos, double* normal) {
-    return run<float>(t1, size1, pos1, mat1, cells1, R1, c1, t2, size2, pos2, mat2, cells2, R2, c2, cand4, ncand4, rb1, rb2, dist, pos, normal);
+extern "C" int dev_narrow_f32(int t1, const double* size1, const double* pos1, const double* mat1, int hbase1, int R1, const double* c1,
+                              int t2, const double* size2, const double* pos2, const double* mat2, int hbase2, int R2, const double* c2,
+                              const double* tab, int ntab, int hovf, double rb1, double rb2, double* dist, double* pos, double* normal) {
+    return run<float>(t1, size1, pos1, mat1, hbase1, R1, c1, t2, size2, pos2, mat2, hbase2, R2, c2, tab, ntab, hovf, rb1, rb2, dist, pos, normal);
 }

@@ -46,22 +46,32 @@ def ipv(a):
     return a.ctypes.data_as(C.POINTER(C.c_int))
 
 
-def expand_candidates(md):
-    """The candidate records of the model's support tables as the device holds them (PhysHost::build): (x, y, z, index) per entry of
-    chull_cand, the index local to the entry's hull."""
+def expand_tables(md):
+    """The model's support tables as the device holds them (PhysHost::build): per cube-map cell a record of eight (x, y, z, w) entries --
+    the first eight candidates, a shorter list padded with its last vertex; w of entry 0 = the count, w of entry 1 = where the cell's
+    further candidates start in the overflow part behind the records.  -> (flat float64 array, entry index of the overflow part)"""
     gh, hv = md["geom_chull"].reshape(-1, 2), md["chull_vert"].reshape(-1, 3)
     ctab, cells, cand = md["geom_ctab"].reshape(-1, 2), md["chull_cells"], md["chull_cand"]
-    out = np.zeros((len(cand), 4))
+    tab = np.zeros((len(cells), 8, 4))
+    ovf, done = [], np.zeros(len(cells), dtype=bool)
     for g in range(len(gh)):
         if gh[g, 1] == 0:
             continue
-        cb, R = ctab[g]
-        for rec in cells[cb:cb + 6 * R * R]:
-            off, cnt = int(rec) >> 8, int(rec) & 255
+        cb, R = (int(x) for x in ctab[g])
+        for c in range(cb, cb + 6 * R * R):
+            if done[c]:
+                continue
+            done[c] = True
+            off, cnt = int(cells[c]) >> 8, int(cells[c]) & 255
             idx = cand[off:off + cnt]
-            out[off:off + cnt, :3] = hv[gh[g, 0] + idx]
-            out[off:off + cnt, 3] = idx
-    return np.ascontiguousarray(out.reshape(-1))
+            first = np.concatenate([idx[:8], np.repeat(idx[-1:], max(0, 8 - cnt))])
+            tab[c, :, :3] = hv[gh[g, 0] + first]
+            tab[c, :, 3] = first
+            tab[c, 0, 3], tab[c, 1, 3] = cnt, len(ovf)
+            for v in idx[8:]:
+                ovf.append(np.concatenate([hv[gh[g, 0] + v], [v]]))
+    flat = np.concatenate([tab.reshape(-1), np.array(ovf).reshape(-1)]) if ovf else tab.reshape(-1)
+    return np.ascontiguousarray(flat), tab.size // 4
 
 
 def box_poses(n):
@@ -100,8 +110,8 @@ def compare(host, q, fn, pert, tol, only_boxes):
     e.L.orc_set_qpos.argtypes = [C.c_void_p, C.c_void_p]
     ng = md["geom_type"].shape[0]
     gh, hv, bc = md["geom_chull"].reshape(-1, 2), md["chull_vert"].reshape(-1, 3), md["geom_bcenter"].reshape(-1, 3)
-    ctab, cells_all = md["geom_ctab"].reshape(-1, 2), np.ascontiguousarray(md["chull_cells"], dtype=np.int32)
-    cand4 = expand_candidates(md)
+    ctab = md["geom_ctab"].reshape(-1, 2)
+    tab, hovf = expand_tables(md)
     rng = np.random.default_rng(1)
     f = getattr(host, fn)
     tot = bad = 0
@@ -124,16 +134,14 @@ def compare(host, q, fn, pert, tol, only_boxes):
             ref = np.array([x.dist for x in cs if (x.geom1, x.geom2) == (g1, g2)])
 
             def shape(g):
-                # (the hull's cell records; a geom without a hull gets the first cell of the model, never looked at)
-                cl = cells_all[ctab[g, 0]:] if gh[g, 1] > 0 else cells_all
                 p = gx[g] * (1 + rng.normal(size=3) * pert)
                 m = gm[g] * (1 + rng.normal(size=9) * pert)
                 cen = p + m.reshape(3, 3) @ bc[g] if pert else gx[g] + gm[g].reshape(3, 3) @ bc[g]
-                return np.ascontiguousarray(md["geom_size"][g]), p, m, cl, int(ctab[g, 1]), np.ascontiguousarray(cen)
+                return np.ascontiguousarray(md["geom_size"][g]), p, m, int(ctab[g, 0]), int(ctab[g, 1]), np.ascontiguousarray(cen)
             a, b = shape(g1), shape(g2)
             dist, pos, nrm = np.zeros(8), np.zeros(24), np.zeros(3)
-            nn = f(t1, dp(a[0]), dp(a[1]), dp(a[2]), ipv(a[3]), a[4], dp(a[5]), t2, dp(b[0]), dp(b[1]), dp(b[2]), ipv(b[3]), b[4], dp(b[5]),
-                   dp(cand4), len(cand4) // 4, C.c_double(float(md["geom_rbound"][g1])), C.c_double(float(md["geom_rbound"][g2])), dp(dist), dp(pos), dp(nrm))
+            nn = f(t1, dp(a[0]), dp(a[1]), dp(a[2]), a[3], a[4], dp(a[5]), t2, dp(b[0]), dp(b[1]), dp(b[2]), b[3], b[4], dp(b[5]),
+                   dp(tab), len(tab), hovf, C.c_double(float(md["geom_rbound"][g1])), C.c_double(float(md["geom_rbound"][g2])), dp(dist), dp(pos), dp(nrm))
             multi[min(nn, 8)] += 1
             tot += 1
             bad += nn != len(ref) or np.abs(dist[:nn] - ref).max() > tol
@@ -180,9 +188,9 @@ def test_multiccd_gives_a_flat_contact_its_rim(host):
         Rc = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]]).reshape(-1).copy()
         cp, bp = np.array([0.01, 0.02, 0.02 + 0.03 - 1e-4]), np.zeros(3)
         dist, pos, nrm = np.zeros(8), np.zeros(24), np.zeros(3)
-        none, c4 = np.zeros(8, dtype=np.int32), np.zeros(4)
-        n = host.dev_narrow_f64(5, dp(cyl), dp(cp), dp(Rc), ipv(none), 1, dp(cp.copy()), 6, dp(box), dp(bp), dp(I), ipv(none), 1, dp(bp.copy()),
-                                dp(c4), 1, C.c_double(0.05), C.c_double(0.05), dp(dist), dp(pos), dp(nrm))
+        c4 = np.zeros(32)
+        n = host.dev_narrow_f64(5, dp(cyl), dp(cp), dp(Rc), 0, 1, dp(cp.copy()), 6, dp(box), dp(bp), dp(I), 0, 1, dp(bp.copy()),
+                                dp(c4), 32, 8, C.c_double(0.05), C.c_double(0.05), dp(dist), dp(pos), dp(nrm))
         do, po, no = np.zeros(8), np.zeros(24), np.zeros(24)
         m = L.orc_narrow(5, dp(cyl), dp(cp), dp(Rc), dp(z), 0, 6, dp(box), dp(bp), dp(I), dp(z), 0, dp(do), dp(po), dp(no))
         assert n == m and np.array_equal(dist[:n], do[:n]) and np.array_equal(pos[:3 * n], po[:3 * n])
