@@ -825,6 +825,9 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         for (int k = lane; k < nv; k += 64) { const real s = A.g[k]; gn2 += s * s; }
         gn2 = wave_sum(gn2);
         NPROF(1);
+#ifdef AVSIM_DEBUG_NEWTON
+        if (lane == 0 && A.iters == 99) printf("  newton it %d: |g| scaled %.6e  (ne %d ncon %d nlead %d coupled %d)\n", it, (double)(sqrt(gn2) * A.scale), ne, A.ncon, A.nlead, (int)coupled);
+#endif
         if (sqrt(gn2) * A.scale < A.tol) { forces_current = true; break; }     // residuals and forces were just computed at this a
         // ---- active set now: scalar rows with curvature, contacts in the bottom / middle zone ----
         unsigned long long cur_lead = __ballot(lane < A.nlead && A.jv[lane < A.nlead ? lane : 0] != 0), cur_z1[NCH];
@@ -926,8 +929,12 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
                 cj0[ch][j] = on ? A.rowS[RS_S * (con[ch].head + j) + 2] : real(0);
                 cjv[ch][j] = on ? A.jv[con[ch].head + j] : real(0);
             }
-        real alpha = 0, lo = 0, hi = -1, dphi0 = 0;
-        for (int ls = 0; ls < 40; ls++) {
+        // Newton on phi' with a bracket [lo, hi], safeguarded as rtsafe (Numerical Recipes 9.4): a step that leaves the bracket OR is longer
+        // than half the step before last becomes the bracket's midpoint.  The cone's middle-zone cost is not quadratic: phi'' along a line can
+        // be four times larger in the middle than at its ends, and plain Newton then cycles between the two flat ends of the bracket (the
+        // two-arm grasp of HookPackage: 100 stalled Newton iterations; oracle/orc_newton.c has the story and the same rule)
+        real alpha = 0, lo = 0, hi = -1, dphi0 = 0, dxold = 0, dx = 0;
+        for (int ls = 0; ls < 51; ls++) {
             real gsum = 0, hsum = 0;
             for (int i = lane; i < A.nlead; i += 64) {
                 real f, h;
@@ -949,21 +956,30 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
                 }
             }
             const real dphi = q1 + alpha * q2 + wave_sum(gsum), ddphi = q2 + wave_sum(hsum);
+#ifdef AVSIM_DEBUG_NEWTON
+            if (lane == 0 && A.iters == 99 && it == 2) printf("         ls %d: alpha %.12e dphi %.6e ddphi %.6e lo %.6e hi %.6e\n", ls, (double)alpha, (double)dphi, (double)ddphi, (double)lo, (double)hi);
+#endif
             if (ls == 0) {
                 dphi0 = dphi;
                 if (!(dphi0 < 0)) break;
                 alpha = -dphi0 / ddphi;
+                dxold = alpha; dx = alpha;
                 continue;
             }
             if (fabs(dphi) < A.ls_tol * fabs(dphi0)) break;
             if (dphi < 0) lo = alpha; else hi = alpha;
             real nx = alpha - dphi / ddphi;
             if (hi < 0) { if (!(nx > lo)) nx = 2 * alpha + real(1e-12); }
-            else if (!(nx > lo && nx < hi)) nx = real(0.5) * (lo + hi);
-            if (fabs(nx - alpha) < real(1e-7) * A.ls_tol * (1 + fabs(alpha))) { alpha = nx; break; }
+            else if (!(nx > lo && nx < hi) || fabs(nx - alpha) > real(0.5) * fabs(dxold)) nx = real(0.5) * (lo + hi);
+            dxold = dx;
+            dx = nx - alpha;
+            if (fabs(nx - alpha) < (sizeof(real) == 8 ? real(1e-14) : real(1e-7)) * (1 + fabs(alpha))) { alpha = nx; break; }
             alpha = nx;
         }
         NPROF(4);
+#ifdef AVSIM_DEBUG_NEWTON
+        if (lane == 0 && A.iters == 99) printf("      line search: dphi0 %.6e alpha %.6e q1 %.6e q2 %.6e lo %.6e hi %.6e  same-H %d middle %d\n", (double)dphi0, (double)alpha, (double)q1, (double)q2, (double)lo, (double)hi, (int)(same && !middle), (int)middle);
+#endif
         if (!(dphi0 < 0)) break;
         real st2 = 0;
         for (int k = lane; k < nv; k += 64) { const real s = alpha * A.dl[k]; A.a[k] += s; st2 += s * s; }

@@ -10,6 +10,7 @@
  * Exact Hessian + dense Cholesky, safeguarded 1-D Newton line search on the piecewise-quadratic cost.
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -162,6 +163,7 @@ void orc_solve_newton(orc_data* d) {
            *jv = (double*)calloc(ne + 1, 8), *g = (double*)calloc(nv, 8), *dl = (double*)calloc(nv, 8), *Md = (double*)calloc(nv, 8),
            *H = (double*)calloc((size_t)nv * nv, 8), *tmp = (double*)calloc(nv, 8);
     int* zone = (int*)calloc(ORC_MAXCON, sizeof(int));
+    const int dbg = getenv("ORC_DEBUG_NEWTON") != NULL;      /* per-iteration trace on stderr (tools/dbg_newton_options.py) */
     /* start: warm start or smooth acceleration, whichever costs less */
     double best = 1e300;
     for (int trial = 0; trial < 2; trial++) {
@@ -185,6 +187,7 @@ void orc_solve_newton(orc_data* d) {
             g[i] = s;
             gnorm += s * s;
         }
+        if (dbg) fprintf(stderr, "  orc newton it %d: |g| scaled %.6e\n", it, sqrt(gnorm) * d->pgs_scale);
         if (sqrt(gnorm) * d->pgs_scale < d->newton_tol) break;
         /* Hessian */
         memcpy(H, d->M, sizeof(double) * nv * nv);
@@ -215,18 +218,48 @@ void orc_solve_newton(orc_data* d) {
         double dphi0, ddphi0, dphi, ddphi;
         ls_eval(d, jar, jv, 0.0, q1, q2, &dphi0, &ddphi0, jar2, force, hd, zone);
         if (!(dphi0 < 0)) break;
-        double lo = 0, hi = -1, alpha = -dphi0 / ddphi0, glo = dphi0;
+        if (dbg && it == 2) {       /* the cost and its two derivatives along the line, sampled: finite differences must agree with them */
+            double prev_c = 0, prev_g = 0;
+            for (int k = 0; k <= 20; k++) {
+                double al = 0.05 * k, g1, h1;
+                ls_eval(d, jar, jv, al, q1, q2, &g1, &h1, jar2, force, hd, zone);
+                double cst = eval_rows(d, jar2, NULL, NULL, NULL);
+                /* smooth part: 1/2 (a + al dl - as)' M (a + al dl - as) = const + al q1 + 1/2 al^2 q2 */
+                cst += al * q1 + 0.5 * al * al * q2;
+                int nm = 0, nb = 0, nt = 0;
+                for (int ci = 0; ci < d->ncon; ci++) if (d->contact[ci].efc_adr >= 0) { nm += zone[ci] == 2; nb += zone[ci] == 1; nt += zone[ci] == 0; }
+                fprintf(stderr, "         sample alpha %.2f: cost %.9e dphi %.6e ddphi %.6e | FD dphi %.6e FD ddphi %.6e | zones top %d middle %d bottom %d\n", al, cst, g1, h1,
+                        k ? (cst - prev_c) / 0.05 : 0.0, k ? (g1 - prev_g) / 0.05 : 0.0, nt, nm, nb);
+                prev_c = cst; prev_g = g1;
+            }
+        }
+        /* Newton on phi' with a bracket [lo, hi] (phi'(lo) < 0 <= phi'(hi)), safeguarded as rtsafe (Numerical Recipes 9.4): a Newton step
+         * that leaves the bracket OR is longer than half the step before last is replaced by the bracket's midpoint.  The second rule
+         * matters: the cone's middle-zone cost is not quadratic, phi'' along a line can be four times larger in the middle than at the ends
+         * (a sigmoid-shaped phi'), and plain Newton then cycles between the two flat ends of the bracket for ever -- it did, on the two-arm
+         * grasp of HookPackage (tools/dbg_newton_options.py, tools/dbg_state_hook7_183.npz): 100 stalled Newton iterations on the device,
+         * a lucky parity of the evaluation count in this oracle.  (Rounds 1-4 had the first rule only.)  Same rule, same numbers in
+         * avsim_newton.hip.h. */
+        double lo = 0, hi = -1, alpha = -dphi0 / ddphi0, glo = dphi0, dxold = alpha, dx = alpha;
         for (int ls = 0; ls < 50; ls++) {
             ls_eval(d, jar, jv, alpha, q1, q2, &dphi, &ddphi, jar2, force, hd, zone);
+            if (dbg && it == 2) fprintf(stderr, "         orc ls %d: alpha %.12e dphi %.6e ddphi %.6e lo %.6e hi %.6e (ddphi0 %.6e)\n", ls + 1, alpha, dphi, ddphi, lo, hi, ddphi0);
             if (fabs(dphi) < 1e-10 * fabs(dphi0) + 1e-300) break;
             if (dphi < 0) { lo = alpha; glo = dphi; } else hi = alpha;
             double nx = alpha - dphi / ddphi;
             if (hi < 0) { if (!(nx > lo)) nx = 2 * alpha + 1e-12; }
-            else if (!(nx > lo && nx < hi)) nx = 0.5 * (lo + hi);
+            else if (!(nx > lo && nx < hi) || fabs(nx - alpha) > 0.5 * fabs(dxold)) nx = 0.5 * (lo + hi);
+            dxold = dx;
+            dx = nx - alpha;
             if (fabs(nx - alpha) < 1e-14 * (1 + fabs(alpha))) { alpha = nx; break; }
             alpha = nx;
         }
         (void)glo;
+        if (dbg) {
+            int nmid = 0, nbot = 0;
+            for (int ci = 0; ci < d->ncon; ci++) { nmid += zone[ci] == 2; nbot += zone[ci] == 1; }
+            fprintf(stderr, "      orc line search: dphi0 %.6e alpha %.6e q1 %.6e q2 %.6e lo %.6e hi %.6e  zones at the new point: middle %d bottom %d\n", dphi0, alpha, q1, q2, lo, hi, nmid, nbot);
+        }
         double step2 = 0;
         for (int i = 0; i < nv; i++) { a[i] += alpha * dl[i]; step2 += alpha * dl[i] * alpha * dl[i]; }
         if (sqrt(step2) * d->pgs_scale < 1e-2 * d->newton_tol) break;
