@@ -10,11 +10,10 @@ carry onto the hook and release (HookPackage, 410), two side grasps and the ball
 the device's IK produced at every step is recorded and the oracle steps the SAME ctrl sequence from the same reset state
 (tests/episode_util.py).
 
-  * f64 device mode vs the oracle, open-loop replay: the reward of every step and the final is_success are identical (HookPackage: in
-    all envs but at most one, whose released package swings on the nearly frictionless hook, friction 0.01 -- a handful of steps);
-    the median over the envs of the largest position difference stays below 1e-6 (observed 7e-10 ... 2e-7: the two sides multiply
-    their kinematic chains out in a different order, 1e-16 per substep, a grasp held by friction amplifies that by about e per 170
-    substeps, a released object that falls or swings by much more: single envs reach centimetres there, with the same rewards).
+  * f64 device mode vs the oracle, open-loop replay of whole episodes: at MuJoCo's default Newton tolerance the reward of every step, the
+    final is_success and the contact count of every step are identical in every env and positions stay within 1e-6 (1e-4 HookPackage)
+    for the whole episode; with the tolerance at 1e-12 on both sides everything agrees to 1e-7 (observed 1e-9), TubeTransfer's ball
+    included.  (Rounds 3-4 saw millimetres to centimetres in single envs and blamed chaos; it was a line search that cycled, see below.)
   * f32 product mode vs the f64 oracle, 128 seeds per task, two comparisons:
       - teacher-forced (`lockstep`): at every env-step the oracle is put into the device's f32 state and steps the device's ctrl once.
         Per-step reward and success flags without the divergence of two chaotic trajectories in between: a differing flag needs a
@@ -33,42 +32,71 @@ import episode_util as U
 
 pytestmark = pytest.mark.gpu
 
-F64_POS_TOL_MEDIAN = 1e-6
-# (script, envs, max_reward the episode reaches, tasks whose bodies never fall or swing freely: max position difference bounded too)
-# (the lift of config 3 holds the needle in a gripper that GradIK steers: the secant descent amplifies the 1e-16 between the two sides by
-# 1.5 - 2 per iteration, 50 iterations a step -- DESIGN.md 2 --, so single envs reach millimetres with the same rewards: 4.5e-3 observed)
-F64_CASES = [("slot_insertion", 8, 4, 1e-3), ("insert_peg", 8, 4, None), ("sew_needle_thread", 8, 5, None), ("hook_package", 8, 4, None), ("tube_transfer", 8, 3, None),
-             ("sew_needle", 8, None, 1e-2)]
+# ---- f64 device mode against the oracle -------------------------------------------------------------------------------------------
+# Round 5 found what rounds 3-4 had taken for chaos.  Both sides' exact line search was a Newton iteration on phi' that only fell back on
+# bisection when a step LEFT the bracket; the elliptic cone's middle-zone cost is not quadratic, and on a sigmoid-shaped phi' that
+# iteration cycles between the two ends of its bracket until the evaluation cap, ending on whichever end the cap's parity chooses
+# (oracle/orc_newton.c has the trace).  Device (cap 40) and oracle (cap 50) then took different steps from identical states -- a
+# millimetre in one env-step, centimetres by the end of the episode.  With the rtsafe safeguard on both sides the episodes agree as the
+# tables below say; what is left at MuJoCo's default tolerance is the solver's own freedom (both sides stop within 1e-8 of the minimiser,
+# each on its own side of it), and at a tolerance of 1e-12 both converge to the minimiser and whole episodes agree to 1e-9.
+#
+# (script, envs, max_reward the episode reaches, bound on the largest position difference over the WHOLE episode at MuJoCo's default Newton
+# tolerance 1e-8 -- observed with 16 envs, profiles/r05_episode_parity.json: 6e-11, 3e-13, 2.5e-12, 1.6e-6, (tube: see below), 1e-9)
+F64_CASES = [("slot_insertion", 8, 4, 1e-6), ("insert_peg", 8, 4, 1e-6), ("sew_needle_thread", 8, 5, 1e-6), ("hook_package", 8, 4, 1e-4), ("tube_transfer", 8, 3, None),
+             ("sew_needle", 8, None, 1e-6)]
 
 
 @pytest.mark.parametrize("task,n,max_reward,pos_tol", F64_CASES)
 def test_f64_full_episode_rewards_and_success_identical(task, n, max_reward, pos_tol):
+    """MuJoCo's default solver tolerance (the product's setting): the oracle replays the device's ctrl sequence open loop for the whole
+    episode.  Reward of EVERY step, final is_success and the contact count of every step identical in every env, positions within
+    pos_tol over the whole episode; TubeTransfer's 0.5 g ball (a billiard inside the carried tube, 2.3 cm of clearance) turns the
+    solver's 1e-8 into another bounce in single envs AFTER the pour: identical up to the pour phase, flags and final rewards identical."""
     dev = U.device_episode(task, n, f64=True)
     assert not dev["diverged"].any() and not dev["capped"].any()
     rows = U.compare_with_replay(task, dev)
     differing = [r for r in rows if r["first_reward_diff"] != -1]
-    if task == "hook_package":           # the released package swings on the hook (friction 0.01): a few steps of one env may differ
-        assert len(differing) <= 1 and all(r["n_reward_diff"] <= 40 for r in differing), differing
-    elif task == "tube_transfer":
-        # the 0.5 g ball rattles in a tube with 2.3 cm of clearance while the arm carries and rolls it: a billiard, chaotic from the lift
-        # on.  The 1e-16 between the two sides becomes a different bounce within the episode, the ball meets the pin a few steps earlier
-        # or later (observed: 4 - 6 of 16 envs, at most 9 steps), its orientation is another one altogether -- flags and final rewards are
-        # asserted below for every env; teacher-forced (f32 test below) not one of 65 920 env-steps differs
-        assert len(differing) <= 3 * n // 4 and all(r["n_reward_diff"] <= 20 for r in differing), differing
-    else:
-        assert not differing, f"{task}: reward sequences differ: {differing}"
     for r in rows:
         assert r["dev_success"] == r["orc_success"], r
         assert r["dev_final_reward"] == r["orc_final_reward"], r
-        if pos_tol is not None:
-            assert r["ncon_diff_steps"] <= 25 and r["max_qpos_err"] < pos_tol, r      # (a contact at the edge of its margin: a handful of steps; 20 observed in one env)
-    if task != "tube_transfer":
-        assert np.median([r["max_qpos_err"] for r in rows]) < F64_POS_TOL_MEDIAN
+        assert r["held_reward_diff"] == 0, r                       # (the steps before the script lets go / pours)
+    if task == "tube_transfer":
+        assert len(differing) <= n // 4 and all(r["n_reward_diff"] <= 10 for r in differing), differing        # observed: 0 of 16 envs
+        assert all(r["held_max_qpos_err"] < 3e-3 and r["arm_max_qpos_err"] < 2e-2 for r in rows), rows          # observed: 2.9e-4, 1.8e-3
+        assert np.median([r["max_qpos_err"] for r in rows]) < 1e-6                                              # observed: 4e-10
+    else:
+        assert not differing, f"{task}: reward sequences differ: {differing}"
+        for r in rows:
+            assert r["ncon_diff_steps"] == 0 and r["max_qpos_err"] < pos_tol, r
     if max_reward is not None:            # the episodes are real ones: they end at max_reward = success (env.py:224) on both sides
         assert sum(r["dev_success"] and r["dev_final_reward"] == max_reward for r in rows) >= n - 1, rows
         assert sum(r["orc_success"] for r in rows) >= n - 1, rows
     else:                                  # config 3's lift: the needle is held off the table by the gripper (reward 2, env.py:666-671)
         assert sum(r["dev_final_reward"] >= 2 for r in rows) >= n - 1, rows
+
+
+@pytest.mark.parametrize("task,n", [(c[0], c[1]) for c in F64_CASES])
+def test_f64_whole_episodes_agree_to_1e7_when_the_solver_converges(task, n):
+    """The IMPLEMENTATION against the oracle: Newton tolerance 1e-12 on both sides (tests/episode_util.py NEWTON_TOL; MuJoCo's default 1e-8
+    leaves each side within 1e-8 of the minimiser, on its own side of it).  Open-loop replay of whole episodes that grasp, carry, thread,
+    hang and pour (250 - 536 env-steps = 5 000 - 10 720 substeps): the reward of every step, the success flag and the CONTACT COUNT of every
+    step identical in every env, every joint and object position within 1e-7 for the whole episode (observed: 2e-13 ... 9e-10,
+    TubeTransfer's ball included); teacher-forced, one env-step from the device's state: within 1e-8 (observed 1e-13 ... 3e-10)."""
+    U.NEWTON_TOL = 1e-12
+    try:
+        dev = U.device_episode(task, n, f64=True, record_state=True)
+        assert not dev["diverged"].any() and not dev["capped"].any()
+        rows = U.compare_with_replay(task, dev)
+        ls = U.compare_lockstep(task, dev)
+    finally:
+        U.NEWTON_TOL = None
+    for r in rows:
+        assert r["first_reward_diff"] == -1 and r["dev_success"] == r["orc_success"] and r["ncon_diff_steps"] == 0, r
+        assert r["max_qpos_err"] < 1e-7, r
+    for r in ls:
+        assert r["reward_diff_steps"] == 0 and r["success_diff_steps"] == 0 and r["ncon_diff_steps"] == 0 and r["max_step_err"] < 1e-8, r
+    assert np.mean([r["dev_success"] for r in rows]) >= (0.8 if task != "sew_needle" else 0.0)
 
 
 # task: (open-loop replay: bound on final-flag mismatches of 128; lockstep: bounds on differing success-flag steps, differing reward
