@@ -76,6 +76,7 @@ struct NewtonArgs {
     LDS_PTR(int) prof;           // optional cycle counters (8 ints) or null
     int nv, nefc, ncon, nlead, ntree, iters;
     real tol, scale, ls_tol;
+    int early_exit;              // option "newton_early_exit": leave without the confirming gradient after an exact step of a quadratic piece
     // this lane's dof (lane < nv <= 64): first dof and size of its tree, offset of its row in the tree's block of M
     int k_a0, k_n, k_mb;
 };
@@ -720,6 +721,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         A.nefc = __builtin_amdgcn_readfirstlane(nefc); A.ncon = __builtin_amdgcn_readfirstlane(ncon);
         A.nlead = __builtin_amdgcn_readfirstlane(nlead); A.iters = __builtin_amdgcn_readfirstlane(iters);
         A.tol = tol; A.scale = scale; A.ls_tol = sizeof(real) == 8 ? real(1e-10) : real(1e-4);
+        A.early_exit = __builtin_amdgcn_readfirstlane(ka->m.newton_early_exit);
     }
     const int nv = A.nv, ne = A.nefc;
     {   // nv <= 64 (one dof per lane; the register row of the dense factorisation holds 48)
@@ -776,7 +778,10 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
     unsigned long long sig_lead = 0, sig_z1[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) sig_z1[ch] = 0;
-    bool forces_current = false;
+    bool forces_current = false, quad_step = false;
+    unsigned long long prev_lead = 0, prev_sgn = 0, prev_z1[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) prev_z1[ch] = 0;
     real alpha_prev = 0;
     for (int it = 0; it < A.iters; it++) {
         used++;
@@ -810,6 +815,33 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
                 for (int j = 0; j < 6; j++) if (j < c.dim) A.rowS[RS_S * (c.head + j) + 6] = f[j];
             }
         }
+        // ---- active set now: scalar rows with curvature, contacts in the bottom / middle zone ----
+        NSYNC();
+        unsigned long long cur_lead = __ballot(lane < A.nlead && A.jv[lane < A.nlead ? lane : 0] != 0), cur_z1[NCH];
+        bool middle = false, same = have_L && A.nlead <= 64 && cur_lead == sig_lead;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            cur_z1[ch] = 0;
+            if (ch * 64 >= A.ncon) break;
+            cur_z1[ch] = __ballot(zone[ch] == 1);
+            middle = middle || __ballot(zone[ch] == 2) != 0;
+            same = same && cur_z1[ch] == sig_z1[ch];
+        }
+        // The step just taken ended in the zones it started from -- the same scalar rows quadratic, the saturated dry-friction rows on the
+        // same side, the same contacts in the bottom zone -- and no contact of either end sits in the cone's middle zone: every row's cost
+        // is ONE quadratic on the whole segment (the zones are convex sets, a segment with both ends inside stays inside), the factor was
+        // that quadratic's Hessian and the line search exact -- this point is the minimiser, its gradient is zero to rounding.  The
+        // gradient (a third of an iteration) would only confirm it: the forces just computed are the solution's.
+        const unsigned long long cur_sgn = __ballot(lane < A.nlead && A.rowS[RS_S * (lane < A.nlead ? lane : 0) + 6] > 0);
+        {
+            bool unchanged = it > 0 && A.nlead <= 64 && cur_lead == prev_lead && cur_sgn == prev_sgn;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) unchanged = unchanged && cur_z1[ch] == prev_z1[ch];
+            if (unchanged && !middle && quad_step && A.early_exit) { forces_current = true; break; }
+            prev_lead = cur_lead; prev_sgn = cur_sgn;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) prev_z1[ch] = cur_z1[ch];
+        }
         // ---- gradient g = M (a - a_s) - J^T f ----
         for (int k = lane; k < nv; k += 64) {
             const int a0 = A.k_a0, n = A.k_n, mb = A.k_mb;
@@ -829,17 +861,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         if (lane == 0 && A.iters == 99) printf("  newton it %d: |g| scaled %.6e  (ne %d ncon %d nlead %d coupled %d)\n", it, (double)(sqrt(gn2) * A.scale), ne, A.ncon, A.nlead, (int)coupled);
 #endif
         if (sqrt(gn2) * A.scale < A.tol) { forces_current = true; break; }     // residuals and forces were just computed at this a
-        // ---- active set now: scalar rows with curvature, contacts in the bottom / middle zone ----
-        unsigned long long cur_lead = __ballot(lane < A.nlead && A.jv[lane < A.nlead ? lane : 0] != 0), cur_z1[NCH];
-        bool middle = false, same = have_L && A.nlead <= 64 && cur_lead == sig_lead;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ch++) {
-            cur_z1[ch] = 0;
-            if (ch * 64 >= A.ncon) break;
-            cur_z1[ch] = __ballot(zone[ch] == 1);
-            middle = middle || __ballot(zone[ch] == 2) != 0;
-            same = same && cur_z1[ch] == sig_z1[ch];
-        }
+        quad_step = !middle;       // (this iteration's step starts from a point without middle-zone contacts)
         if (!(same && !middle)) {
             // ---- Hessian: packed lower triangle ----
             // (block-diagonal case: only entries inside the tree blocks are read, and the M blocks below overwrite all of them)

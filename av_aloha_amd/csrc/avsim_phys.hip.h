@@ -44,6 +44,7 @@ struct DevModel {
     int noslip_iters;
     int noslip_trees;             // 1 (default): noslip passes whose contacts all touch one kinematic tree run per tree, the trees' chains side by side (option "noslip_trees")
     int qcqp_tridiag;             // sliding contacts' multiplier iteration: 0 MuJoCo's Cholesky per iterate (f64 default), 1 the same iterates through the tridiagonal form, 2 tridiagonal form + secular-equation steps (f32 default); option "qcqp_tridiag"
+    int newton_early_exit;        // 1 (default): Newton leaves without the confirming gradient evaluation after an exact step inside one quadratic piece (option "newton_early_exit")
     int newton_component;         // 1 (default): in scenes with rows that couple two trees Newton's dense factorisation / substitutions take the coupled component only; 0: all nv columns (option "newton_component"; same bits)
     int noslip_per_tree;          // 1: the dry-friction rows of the noslip pass go per kinematic tree (needs <= 8 trees); option "noslip_per_tree"
     int solver, newton_iters;     // 0 = PGS (dual), 1 = Newton (primal, the reference's default solver)
@@ -3560,7 +3561,7 @@ struct PhysHost {
         m.nj = b.scalar("num_arms") == 3 ? 21 : 14;
         auto opt = F("opt");
         m.timestep = (real)opt[0]; m.gravity[0] = (real)opt[1]; m.gravity[1] = (real)opt[2]; m.gravity[2] = (real)opt[3];
-        m.impratio = (real)opt[4]; m.noslip_iters = (int)opt[5]; m.noslip_per_tree = 1; m.noslip_trees = 1; m.newton_component = 1; m.qcqp_tridiag = sizeof(real) == 4 ? 2 : 0;
+        m.impratio = (real)opt[4]; m.noslip_iters = (int)opt[5]; m.noslip_per_tree = 1; m.noslip_trees = 1; m.newton_component = 1; m.newton_early_exit = 1; m.qcqp_tridiag = sizeof(real) == 4 ? 2 : 0;
         m.solver = 1; m.newton_iters = 100; m.newton_tol = sizeof(real) == 8 ? (real)1e-8 : (real)1e-6;     // MuJoCo defaults: iterations 100, tolerance 1e-8
         m.nscale = (real)(1.0 / ((opt.size() > 7 && opt[7] > 0 ? opt[7] : 1.0) * std::max(1, m.nv)));
         auto gr = F("grip_range");
@@ -3910,6 +3911,7 @@ struct PhysHost {
         if (n == "noslip_per_tree") { mf.noslip_per_tree = md.noslip_per_tree = v != 0; return true; }
         if (n == "noslip_trees") { mf.noslip_trees = md.noslip_trees = v != 0; return true; }
         if (n == "newton_component") { mf.newton_component = md.newton_component = v != 0; return true; }
+        if (n == "newton_early_exit") { mf.newton_early_exit = md.newton_early_exit = v != 0; return true; }
         if (n == "persist_blocks") { int x = (int)v; if (x >= 1 && x <= 64) { persist_over = x; return true; } return false; }
         if (n == "waves_per_block") { int x = (int)v; if (x >= 0 && x <= 8) { wpb_override = x; return true; } return false; }
         if (n == "profile_phases") {

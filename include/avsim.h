@@ -85,6 +85,9 @@ int avsim_dims(const avsim_t* h, int32_t dims[AVSIM_NDIMS]);
  *   "newton_component"  1 (default): in a scene where some contact couples two kinematic trees (a needle in a gripper) Newton's dense
  *                       factorisation and substitutions run over the dofs of the coupled trees only, the other trees in their lane
  *                       octets; 0 = over all nv columns (the same bits: the entries in between are zeros)
+ *   "newton_early_exit" 1 (default): when a Newton step ends in the active set it started from and no contact of either end is in the cone's
+ *                       middle zone, the cost was one quadratic along the step and the point is its minimiser: the solver returns without
+ *                       evaluating the gradient that would confirm it (a third of an iteration; same qacc, same forces); 0 = always evaluate
  *   "order_envs"        1 (default): workgroups take the envs in the order of their cost in the previous step, most expensive
  *                       first (results do not depend on it); 0 = in index order
  *   "export_contacts"   0 skips the per-step contact export (avsim_get_contacts); "kernel_timing" 1 brackets every physics
