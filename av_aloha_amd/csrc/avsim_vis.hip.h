@@ -69,6 +69,37 @@ __device__ inline bool vis_tile_outside(const float4 r0, const float4 r1, const 
     return e0 < 0 || e1 < 0 || e2 < 0;
 }
 
+// is the tile entirely INSIDE the triangle (all three edge functions >= 0 at every pixel centre)?  Such an entry needs no edge tests.
+__device__ inline bool vis_tile_inside(const float4 r0, const float4 r1, const float4 r2, float x0, float y0) {
+    const float xa = x0 + 0.5f, xb = x0 + VIS_TILE - 0.5f, ya = y0 + 0.5f, yb = y0 + VIS_TILE - 0.5f;
+    const float e0 = r0.x * (r0.x > 0 ? xa : xb) + r0.y * (r0.y > 0 ? ya : yb) + r0.z;
+    const float e1 = r0.w * (r0.w > 0 ? xa : xb) + r1.x * (r1.x > 0 ? ya : yb) + r1.y;
+    const float e2 = r1.z * (r1.z > 0 ? xa : xb) + r1.w * (r1.w > 0 ? ya : yb) + r2.x;
+    return e0 >= 0 && e1 >= 0 && e2 >= 0;
+}
+
+// Scalar loads for the tile stage.  A tile's records are the same for all 64 lanes (pixels) of its wave: fetched by the SCALAR unit they
+// land in SGPRs, where the per-pixel arithmetic reads them as operands -- no vector load + v_readlane per word (15 of the ~35 VALU
+// instructions per tile-list entry until round 4).  The compiler does not emit s_load for memory the kernel itself has written, and it
+// assumes an inline asm's outputs are ready when the asm ends: so every asm block below issues its loads AND waits for them
+// (s_waitcnt lgkmcnt(0)), four records at a time so that the round trip is paid once per four entries; the scalar cache is invalidated
+// once per view (s_dcache_inv), after the barrier that follows the vector stores of the records and lists.
+typedef int vis_v4i __attribute__((ext_vector_type(4)));
+typedef int vis_v16i __attribute__((ext_vector_type(16)));
+__device__ inline const void* vis_uni(const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    return (const void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v));
+}
+__device__ inline vis_v4i vis_sload4(const void* p) {
+    vis_v4i r;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(vis_uni(p)) : "memory");
+    return r;
+}
+__device__ inline void vis_sload16x4(const void* p0, const void* p1, const void* p2, const void* p3, vis_v16i& r0, vis_v16i& r1, vis_v16i& r2, vis_v16i& r3) {
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %5, 0x0\n\ts_load_dwordx16 %2, %6, 0x0\n\ts_load_dwordx16 %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3) : "s"(vis_uni(p0)), "s"(vis_uni(p1)), "s"(vis_uni(p2)), "s"(vis_uni(p3)) : "memory");
+}
+
 // Tile lists.  Records are taken 64 at a time by a wavefront, one per lane.  A triangle whose box covers a few tiles is walked by its
 // own lane; a big one (the table top covers every tile of the overhead view, a frame bar crosses the image) is handed to the whole
 // wavefront in turn, lane k taking every 64th tile of its box -- otherwise the wave waits for one lane walking thousands of tiles.
@@ -86,7 +117,8 @@ __device__ inline void vis_bin(const float4* __restrict__ rec, const int* __rest
         auto visit = [&](const float4 q0, const float4 q1, const float4 q2, int tx, int ty, int idx) {
             if (vis_tile_outside(q0, q1, q2, (float)(tx * VIS_TILE), (float)(ty * VIS_TILE))) return;
             const int p = atomicAdd(&cnt[ty * tw + tx], 1);
-            if (FILL) { if (p < listcap) list[p] = idx; else flag |= 2; }
+            // (bit 31 of a list entry: the tile lies entirely inside the triangle, the tile stage skips the edge functions)
+            if (FILL) { if (p < listcap) list[p] = idx | (vis_tile_inside(q0, q1, q2, (float)(tx * VIS_TILE), (float)(ty * VIS_TILE)) ? (int)0x80000000 : 0); else flag |= 2; }
         };
         const bool big = nt > 16;
         if (valid && !big)
@@ -286,48 +318,45 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
         __syncthreads();
         const long long tc3 = __builtin_readcyclecounter();
         vis_bin<true>(rec, bbox, nrec, tcur, list, X.listcap, tw, lane, wave, flag);
-        __threadfence_block();
+        __threadfence();              // (agent scope: the records and lists are read back through the scalar cache, from L2)
         __syncthreads();
         const long long tc4 = __builtin_readcyclecounter();
         // 4. tiles: one wavefront each, lane = pixel
         unsigned char* img = out + (size_t)view * H * W * 3;
-        // (the first 64 records of the wave's NEXT tile are fetched while it works on the current one: a tile is otherwise two dependent
-        // round trips to memory -- list, then records -- with nothing to do in between)
-        struct Batch { int mi, qt; unsigned qc; float4 q0, q1, q2; };
-        auto fetch = [&](int tile_, int eb, Batch& b) {
-            const int e1_ = tile_ < ntile ? min(toff[tile_ + 1], X.listcap) : 0;
-            b.mi = (tile_ < ntile && eb + lane < e1_) ? list[eb + lane] : 0;
-            b.q0 = rec[4 * b.mi]; b.q1 = rec[4 * b.mi + 1]; b.q2 = rec[4 * b.mi + 2];
-            const float4 q3 = rec[4 * b.mi + 3];
-            b.qc = __float_as_uint(q3.x); b.qt = __float_as_int(q3.y);
-        };
-        Batch cur, nxt;
-        fetch(wave, wave < ntile ? toff[wave] : 0, cur);
+        // (records and lists were written with vector stores: the barrier above made them visible in L2, this drops what the scalar cache
+        // still holds of the slot's previous view)
+        __builtin_amdgcn_s_dcache_inv();
         for (int tile = wave; tile < ntile; tile += VIS_THREADS / 64) {
             const int ty = tile / tw, tx = tile - ty * tw;
             const int ix = tx * VIS_TILE + (lane & 7), iy = ty * VIS_TILE + (lane >> 3);
             const float fx = ix + 0.5f, fy = iy + 0.5f;
-            const int e0 = toff[tile], e1 = min(toff[tile + 1], X.listcap);
-            const int tnext = tile + VIS_THREADS / 64;
-            fetch(tnext, tnext < ntile ? toff[tnext] : 0, nxt);
+            const int e0 = __builtin_amdgcn_readfirstlane(toff[tile]), e1 = __builtin_amdgcn_readfirstlane(min(toff[tile + 1], X.listcap));
             float bw = 0.0f;
-            int bi = -1, bt = 0x7fffffff;
+            int bt = 0x7fffffff;
             unsigned bcol = 0;
-            auto bc = [](float x, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), j)); };
-            for (int eb = e0; eb < e1; eb += 64) {
-                if (eb > e0) fetch(tile, eb, cur);       // (a tile with more than 64 entries: the later batches are fetched in place)
-                const int n = min(64, e1 - eb);
-                for (int j = 0; j < n; j++) {
-                    const float l0 = bc(cur.q0.x, j) * fx + bc(cur.q0.y, j) * fy + bc(cur.q0.z, j);
-                    const float l1 = bc(cur.q0.w, j) * fx + bc(cur.q1.x, j) * fy + bc(cur.q1.y, j);
-                    const float l2 = bc(cur.q1.z, j) * fx + bc(cur.q1.w, j) * fy + bc(cur.q2.x, j);
-                    const float w = bc(cur.q2.y, j) * fx + bc(cur.q2.z, j) * fy + bc(cur.q2.w, j);
-                    const int t = __builtin_amdgcn_readlane(cur.qt, j), i = __builtin_amdgcn_readlane(cur.mi, j);
-                    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)cur.qc, j);
-                    if (l0 >= 0 && l1 >= 0 && l2 >= 0 && w > 0 && (w > bw || (w == bw && t < bt))) { bw = w; bi = i; bt = t; bcol = c; }
-                }
+            for (int eb = e0; eb < e1; eb += 4) {
+                // four list entries and their records through the scalar unit (entries past the tile's end repeat its first of this batch:
+                // a record tested twice changes nothing)
+                const vis_v4i id = vis_sload4(list + eb);
+                const int n = e1 - eb;
+                const int i0 = id[0], i1 = n > 1 ? id[1] : id[0], i2 = n > 2 ? id[2] : id[0], i3 = n > 3 ? id[3] : id[0];
+                vis_v16i R0, R1, R2, R3;
+                vis_sload16x4(rec + 4 * (size_t)(i0 & 0x7fffffff), rec + 4 * (size_t)(i1 & 0x7fffffff), rec + 4 * (size_t)(i2 & 0x7fffffff), rec + 4 * (size_t)(i3 & 0x7fffffff), R0, R1, R2, R3);
+                auto test = [&](const vis_v16i& R, int idw) {
+                    const float w = __int_as_float(R[9]) * fx + __int_as_float(R[10]) * fy + __int_as_float(R[11]);
+                    bool in = w > 0;
+                    if (idw >= 0) {          // (wave-uniform: the tile is not entirely inside this triangle)
+                        const float l0 = __int_as_float(R[0]) * fx + __int_as_float(R[1]) * fy + __int_as_float(R[2]);
+                        const float l1 = __int_as_float(R[3]) * fx + __int_as_float(R[4]) * fy + __int_as_float(R[5]);
+                        const float l2 = __int_as_float(R[6]) * fx + __int_as_float(R[7]) * fy + __int_as_float(R[8]);
+                        in = in && l0 >= 0 && l1 >= 0 && l2 >= 0;
+                    }
+                    const int t = R[13];
+                    if (in && (w > bw || (w == bw && t < bt))) { bw = w; bt = t; bcol = (unsigned)R[12]; }
+                };
+                test(R0, i0); test(R1, i1); test(R2, i2); test(R3, i3);
             }
-            cur = nxt;
+            const int bi = bt == 0x7fffffff ? -1 : 0;
             if (ix < W && iy < H) {
                 unsigned col;
                 const float dx = (fx - 0.5f * W) * scale, dy = -(fy - 0.5f * H) * scale;
@@ -479,7 +508,7 @@ struct VisHost {
             for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list}) if (p) (void)hipFree(p);
             X.vcam = nullptr; X.rec = nullptr; X.bbox = nullptr; X.list = nullptr; slots = 0;
             if (hipMalloc((void**)&X.vcam, (size_t)want * S.nvert * sizeof(float4)) != hipSuccess || hipMalloc((void**)&X.rec, (size_t)want * X.reccap * 4 * sizeof(float4)) != hipSuccess ||
-                hipMalloc((void**)&X.bbox, (size_t)want * X.reccap * 4 * sizeof(int)) != hipSuccess || hipMalloc((void**)&X.list, (size_t)want * X.listcap * sizeof(int)) != hipSuccess) {
+                hipMalloc((void**)&X.bbox, (size_t)want * X.reccap * 4 * sizeof(int)) != hipSuccess || hipMalloc((void**)&X.list, ((size_t)want * X.listcap + 16) * sizeof(int)) != hipSuccess) {      // (+ 16: the tile stage reads its list four entries at a time)
                 for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list}) if (p) (void)hipFree(p);
                 X.vcam = nullptr; X.rec = nullptr; X.bbox = nullptr; X.list = nullptr;
                 err = "hipMalloc(visual render scratch) failed"; return -3;
