@@ -352,7 +352,8 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
                         in = in && l0 >= 0 && l1 >= 0 && l2 >= 0;
                     }
                     const int t = R[13];
-                    if (in && (w > bw || (w == bw && t < bt))) { bw = w; bt = t; bcol = (unsigned)R[12]; }
+                    const bool better = in && (w > bw || (w == bw && t < bt));        // (selects, not a branch: no exec-mask round trip per entry)
+                    bw = better ? w : bw; bt = better ? t : bt; bcol = better ? (unsigned)R[12] : bcol;
                 };
                 test(R0, i0); test(R1, i1); test(R2, i2); test(R3, i3);
             }
