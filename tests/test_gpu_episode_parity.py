@@ -6,7 +6,7 @@ The scripted policies (tests/scripted.py, av_aloha_amd/workloads.py) run closed 
 max_reward: grasp - carry - insert (SlotInsertion, 350 env-steps = 7000 substeps), two pitched grasps and the peg into the tube
 (InsertPeg, 350), grasp - thread through the wall's window - hand over to the left gripper (SewNeedle, all five stages, 535), two-arm
 carry onto the hook and release (HookPackage, 410), two side grasps and the ball poured from one tube into the other (TubeTransfer,
-535); plus BASELINE config 3's reach - grasp - lift (SewNeedle, 250).  The ctrl vector
+515); plus BASELINE config 3's reach - grasp - lift (SewNeedle, 250).  The ctrl vector
 the device's IK produced at every step is recorded and the oracle steps the SAME ctrl sequence from the same reset state
 (tests/episode_util.py).
 
