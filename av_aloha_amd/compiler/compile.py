@@ -520,7 +520,9 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
     # lights of the colour render (scene.xml:9 headlight, :48 directional light with MuJoCo's default diffuse 0.7) and the
     # skybox gradient (scene.xml:34): [headlight ambient, headlight diffuse, light diffuse, 0], light direction (world),
     # sky rgb at the zenith, sky rgb at the nadir
-    md["render_light"] = np.array([0.3, 0.6, 0.7, 0.0,  0.0, 0.0, -1.0, 0.0,  0.3, 0.5, 0.7, 0.0,  0.0, 0.0, 0.0, 0.0])
+    # The spare fourth words hold the directional light's shadow box (round 5): [3] half extent = <statistic extent="0.6"> x MuJoCo's default
+    # shadowclip 1 [EXT], [7] [11] [15] its centre = <statistic center="0 -0.1 0.2"> (scene.xml:6, the same in both asset sets)
+    md["render_light"] = np.array([0.3, 0.6, 0.7, 0.6,  0.0, 0.0, -1.0, 0.0,  0.3, 0.5, 0.7, -0.1,  0.0, 0.0, 0.0, 0.2])
     # instances of the visual mesh library (models/visual_meshes.avv, compiler/vismesh.py): what the colour renderer draws
     if vis_ids is not None:
         rows = vismesh.instance_table(m, lambda g: geom_colour(m, g))

@@ -443,6 +443,8 @@ int avsim_set_option(avsim_t* h, const char* name, double value) {
     AVS_ON_DEVICE(h);               // "maxefc" / "maxcon" / "profile_phases" allocate on the handle's device
     if (!std::strcmp(name, "kernel_timing")) { h->ktiming = value != 0; h->render.timing = value != 0; return AVSIM_OK; }
     if (!std::strcmp(name, "render_proxies")) { h->render_proxies = value != 0; return AVSIM_OK; }
+    if (!std::strcmp(name, "render_samples")) { if (value != 1 && value != 4) { h->set_error("render_samples is 1 or 4"); return AVSIM_EINVAL; } h->vis.samples = (int)value; return AVSIM_OK; }
+    if (!std::strcmp(name, "render_shadows")) { h->vis.shadows = value != 0; return AVSIM_OK; }
     if (!std::strcmp(name, "diffik_iters")) { h->ik.diff_iters = (int)value; return AVSIM_OK; }
     if (!std::strcmp(name, "gradik_iters")) { h->ik.grad_iters = (int)value; return AVSIM_OK; }
     try {

@@ -13,11 +13,16 @@
 //   4. one wavefront per tile, lane = pixel: the tile's records are wave-uniform loads, the depth test is on 1 / depth with the
 //      triangle index as tie-break (the image does not depend on the order of the lists); the winner's colour -- for the textured
 //      table the pixel ray is intersected with the triangle for perspective-correct texture coordinates -- or the sky gradient.
-// Back faces are culled.  No shadows, specular terms, anti-aliasing or transparency: parity with the reference's OpenGL pixels is unpinned.
+// Back faces are culled.  Round 5, both optional (avsim_set_option "render_shadows", "render_samples"): SHADOWS of the scene's directional light
+// (scene.xml:48) from a depth map rendered from the light, one per env (k_vis_shadow: heights above the plane normal to the light over the
+// light's shadow box, 512 x 512 texels, atomicMax of ordered keys), looked up per sample; and 2 x 2 SUPERSAMPLING (MuJoCo's offscreen buffer
+// is multisampled, <quality offsamples> default 4 [EXT]): every lane tests the four samples at +-1/4 pixel of its pixel against the tile's
+// records and averages their colours.  No specular terms, haze or transparency: parity with the reference's OpenGL pixels is unpinned.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -40,9 +45,15 @@ struct VisScene {
     int texn;
     const int* cam_body;
     const float *cam_pos, *cam_mat, *cam_fovy;   // cam_fovy: tan(fovy / 2)
-    const float* light;     // as RenderModel::light
+    const float* light;     // as RenderModel::light; [3] half extent of the light's shadow box (0: none), [7] [11] [15] its centre (world)
     float znear;
+    const unsigned* shmap;  // shadow maps [N][VIS_SM][VIS_SM]: ordered keys of the largest height towards the light (null: no shadows)
+    float le1[3], le2[3], lw[3];   // light frame: e1, e2 span the plane normal to the unit light direction lw (oracle/orc_vis.c light_frame)
+    float sh_s0, sh_t0, sh_itex;   // light-space corner of the shadow box, texels per metre
 };
+constexpr int VIS_SM = 512;
+__device__ __host__ inline unsigned vis_hkey(float f) { unsigned b; memcpy(&b, &f, 4); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }      // order-preserving
+__device__ inline float vis_hval(unsigned k) { const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; return __uint_as_float(b); }
 
 // per-slot scratch (a workgroup's view in flight)
 struct VisScratch {
@@ -61,8 +72,9 @@ __device__ inline unsigned vis_pack(float r, float g, float b) {
 }
 
 // is the tile [x0, x0 + 8) x [y0, y0 + 8) (pixel centres) entirely outside one of the triangle's edges?
+// (sample positions: the pixel centres, and with supersampling 1/4 pixel either side of them: the tests take the wider range)
 __device__ inline bool vis_tile_outside(const float4 r0, const float4 r1, const float4 r2, float x0, float y0) {
-    const float xa = x0 + 0.5f, xb = x0 + VIS_TILE - 0.5f, ya = y0 + 0.5f, yb = y0 + VIS_TILE - 0.5f;
+    const float xa = x0 + 0.25f, xb = x0 + VIS_TILE - 0.25f, ya = y0 + 0.25f, yb = y0 + VIS_TILE - 0.25f;
     const float e0 = r0.x * (r0.x > 0 ? xb : xa) + r0.y * (r0.y > 0 ? yb : ya) + r0.z;
     const float e1 = r0.w * (r0.w > 0 ? xb : xa) + r1.x * (r1.x > 0 ? yb : ya) + r1.y;
     const float e2 = r1.z * (r1.z > 0 ? xb : xa) + r1.w * (r1.w > 0 ? yb : ya) + r2.x;
@@ -71,7 +83,7 @@ __device__ inline bool vis_tile_outside(const float4 r0, const float4 r1, const 
 
 // is the tile entirely INSIDE the triangle (all three edge functions >= 0 at every pixel centre)?  Such an entry needs no edge tests.
 __device__ inline bool vis_tile_inside(const float4 r0, const float4 r1, const float4 r2, float x0, float y0) {
-    const float xa = x0 + 0.5f, xb = x0 + VIS_TILE - 0.5f, ya = y0 + 0.5f, yb = y0 + VIS_TILE - 0.5f;
+    const float xa = x0 + 0.25f, xb = x0 + VIS_TILE - 0.25f, ya = y0 + 0.25f, yb = y0 + VIS_TILE - 0.25f;
     const float e0 = r0.x * (r0.x > 0 ? xa : xb) + r0.y * (r0.y > 0 ? ya : yb) + r0.z;
     const float e1 = r0.w * (r0.w > 0 ? xa : xb) + r1.x * (r1.x > 0 ? ya : yb) + r1.y;
     const float e2 = r1.z * (r1.z > 0 ? xa : xb) + r1.w * (r1.w > 0 ? ya : yb) + r2.x;
@@ -138,6 +150,60 @@ __device__ inline void vis_bin(const float4* __restrict__ rec, const int* __rest
     }
 }
 
+// Shadow map of one env per workgroup: every triangle of the scene, in the light's frame (s, t across, h towards the light), rasterised over
+// the texel centres it covers with atomicMax of its height's ordered key.  Small triangles by their own thread; a triangle whose box holds
+// more than 64 texels (the table top covers the whole map) goes to an LDS queue that the workgroup then works through together.
+__global__ void __launch_bounds__(VIS_THREADS) k_vis_shadow(VisScene S, const float* __restrict__ xpose, unsigned* __restrict__ shmap, int N) {
+    __shared__ float Q[1024 * 9];
+    __shared__ int nq;
+    const int env = blockIdx.x, tid = threadIdx.x;
+    if (env >= N) return;
+    unsigned* map = shmap + (size_t)env * VIS_SM * VIS_SM;
+    for (int i = tid; i < VIS_SM * VIS_SM; i += VIS_THREADS) map[i] = 0u;
+    if (tid == 0) nq = 0;
+    __threadfence();
+    __syncthreads();
+    const float* xb = xpose + (size_t)env * S.nbody * 12;
+    auto raster = [&](const float* P, int first, int stride) {      // P: three (x, y, h) in texel units / metres
+        const float x0 = P[0], y0 = P[1], x1 = P[3], y1 = P[4], x2 = P[6], y2 = P[7];
+        const float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+        if (!(fabsf(area) > 1e-12f)) return;
+        const float ia = 1.0f / area;
+        const int ix0 = max(0, (int)ceilf(fminf(x0, fminf(x1, x2)) - 0.5f)), ix1 = min(VIS_SM - 1, (int)floorf(fmaxf(x0, fmaxf(x1, x2)) - 0.5f));
+        const int iy0 = max(0, (int)ceilf(fminf(y0, fminf(y1, y2)) - 0.5f)), iy1 = min(VIS_SM - 1, (int)floorf(fmaxf(y0, fmaxf(y1, y2)) - 0.5f));
+        if (ix0 > ix1 || iy0 > iy1) return;
+        const int bw = ix1 - ix0 + 1, n = bw * (iy1 - iy0 + 1);
+        for (int k = first; k < n; k += stride) {
+            const int ix = ix0 + k % bw, iy = iy0 + k / bw;
+            const float fx = ix + 0.5f, fy = iy + 0.5f;
+            const float l0 = ((x1 - fx) * (y2 - fy) - (x2 - fx) * (y1 - fy)) * ia, l1 = ((x2 - fx) * (y0 - fy) - (x0 - fx) * (y2 - fy)) * ia, l2 = 1.0f - l0 - l1;
+            if (l0 >= 0 && l1 >= 0 && l2 >= 0) atomicMax(&map[iy * VIS_SM + ix], vis_hkey(l0 * P[2] + l1 * P[5] + l2 * P[8]));
+        }
+    };
+    for (int t = tid; t < S.ntri; t += VIS_THREADS) {
+        float P[9];
+        for (int c = 0; c < 3; c++) {
+            const int v = S.tri[3 * t + c];
+            const float *pb = xb + 12 * S.vbody[v], *Rb = pb + 3;
+            const float x = S.vert[3 * v], y = S.vert[3 * v + 1], z = S.vert[3 * v + 2];
+            const float w[3] = {Rb[0] * x + Rb[1] * y + Rb[2] * z + pb[0], Rb[3] * x + Rb[4] * y + Rb[5] * z + pb[1], Rb[6] * x + Rb[7] * y + Rb[8] * z + pb[2]};
+            P[3 * c] = (w[0] * S.le1[0] + w[1] * S.le1[1] + w[2] * S.le1[2] - S.sh_s0) * S.sh_itex;
+            P[3 * c + 1] = (w[0] * S.le2[0] + w[1] * S.le2[1] + w[2] * S.le2[2] - S.sh_t0) * S.sh_itex;
+            P[3 * c + 2] = -(w[0] * S.lw[0] + w[1] * S.lw[1] + w[2] * S.lw[2]);
+        }
+        const float bx = fmaxf(P[0], fmaxf(P[3], P[6])) - fminf(P[0], fminf(P[3], P[6])), by = fmaxf(P[1], fmaxf(P[4], P[7])) - fminf(P[1], fminf(P[4], P[7]));
+        const bool big = (bx + 1.0f) * (by + 1.0f) > 64.0f;
+        int slot = -1;
+        if (big) { slot = atomicAdd(&nq, 1); if (slot >= 1024) slot = -1; }
+        if (slot >= 0) { for (int c = 0; c < 9; c++) Q[9 * slot + c] = P[c]; }
+        else raster(P, 0, 1);            // a small triangle, or the queue is full
+    }
+    __syncthreads();
+    const int n = nq < 1024 ? nq : 1024;
+    for (int q = 0; q < n; q++) raster(Q + 9 * q, tid, VIS_THREADS);
+}
+
+template <int SS>
 __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScratch X, const float* __restrict__ xpose, const int* __restrict__ cam_ids, int ncam_sel,
                                                             int N, int H, int W, unsigned char* __restrict__ out) {
     __shared__ float Rcb[VIS_MAXBODY * 12];
@@ -200,7 +266,8 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
             const int t = t0 + tid;
             int nout = 0;
             float px[4], py[4], pw[4];
-            unsigned colour = 0;
+            unsigned colour = 0, colour2 = 0;
+            float sbias = -1.0f;
             if (t < S.ntri) {
                 const float4 a = vcam[S.tri[3 * t]], b = vcam[S.tri[3 * t + 1]], c = vcam[S.tri[3 * t + 2]];
                 const float da = -a.z, db = -b.z, dc = -c.z;
@@ -239,9 +306,13 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
                         const float ch = -(n[0] * g[0] + n[1] * g[1] + n[2] * g[2]) * in * ig;
                         if (!(ch > 0)) nout = 0;
                         const float cl = -(n[0] * cam[12] + n[1] * cam[13] + n[2] * cam[14]) * in;
-                        const float lum = fminf(1.0f, amb + hd * ch + ld * fmaxf(cl, 0.0f));
-                        if (S.tex[t]) colour = 0x80000000u | (unsigned)(lum * 65535.0f + 0.5f);      // textured: the shade, colour at the pixel
-                        else colour = vis_pack(S.rgb[3 * t] * lum, S.rgb[3 * t + 1] * lum, S.rgb[3 * t + 2] * lum);
+                        const float lum = fminf(1.0f, amb + hd * ch + ld * fmaxf(cl, 0.0f)), lum2 = fminf(1.0f, amb + hd * ch);
+                        if (S.tex[t]) { colour = 0x80000000u | (unsigned)(lum * 65535.0f + 0.5f); colour2 = 0x80000000u | (unsigned)(lum2 * 65535.0f + 0.5f); }      // textured: the shade, colour at the pixel
+                        else { colour = vis_pack(S.rgb[3 * t] * lum, S.rgb[3 * t + 1] * lum, S.rgb[3 * t + 2] * lum); colour2 = vis_pack(S.rgb[3 * t] * lum2, S.rgb[3 * t + 1] * lum2, S.rgb[3 * t + 2] * lum2); }
+                        // in the light's shadow the light's term goes (colour2); the depth map's texels are S.sh_itex^-1 wide, so a lit surface
+                        // tilted by theta against the light lies up to texel x tan(theta) below its own texel's height: slope-scaled bias.
+                        // A surface that faces away from the light has no such term to lose: bias < 0 = no look-up
+                        sbias = cl > 0.0f ? 1e-3f + 1.5f * sqrtf(fmaxf(0.0f, 1.0f - cl * cl)) / fmaxf(cl, 0.05f) / S.sh_itex : -1.0f;
                     }
                 }
             }
@@ -259,8 +330,10 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
                     const float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
                     const float xmin = fminf(x0, fminf(x1, x2)), xmax = fmaxf(x0, fmaxf(x1, x2)), ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
                     // pixel centres covered by the bounding box
-                    const int ix0 = max(0, (int)ceilf(fmaxf(xmin, -1e6f) - 0.5f)), ix1 = min(W - 1, (int)floorf(fminf(xmax, 1e6f) - 0.5f));
-                    const int iy0 = max(0, (int)ceilf(fmaxf(ymin, -1e6f) - 0.5f)), iy1 = min(H - 1, (int)floorf(fminf(ymax, 1e6f) - 0.5f));
+                    // pixels with a sample inside the bounding box (pixel centres; with supersampling the samples sit 1/4 pixel off them)
+                    constexpr float so = SS > 1 ? 0.25f : 0.0f;
+                    const int ix0 = max(0, (int)ceilf(fmaxf(xmin, -1e6f) - 0.5f - so)), ix1 = min(W - 1, (int)floorf(fminf(xmax, 1e6f) - 0.5f + so));
+                    const int iy0 = max(0, (int)ceilf(fmaxf(ymin, -1e6f) - 0.5f - so)), iy1 = min(H - 1, (int)floorf(fminf(ymax, 1e6f) - 0.5f + so));
                     if (!(fabsf(area) > 1e-12f) || ix0 > ix1 || iy0 > iy1 || !(xmax - xmin < 1e7f) || !(ymax - ymin < 1e7f)) keep[k] = false;
                     else {
                         const float ia = 1.0f / area;
@@ -272,7 +345,7 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
                         R[k][0] = make_float4(a0, b0, c0, a1);
                         R[k][1] = make_float4(b1, c1, a2, b2);
                         R[k][2] = make_float4(c2, a0 * w0 + a1 * w1 + a2 * w2, b0 * w0 + b1 * w1 + b2 * w2, c0 * w0 + c1 * w1 + c2 * w2);
-                        R[k][3] = make_float4(__uint_as_float(colour), __int_as_float(t), 0.0f, 0.0f);
+                        R[k][3] = make_float4(__uint_as_float(colour), __int_as_float(t), __uint_as_float(colour2), sbias);
                         B[k] = make_int4(ix0 / VIS_TILE, ix1 / VIS_TILE, iy0 / VIS_TILE, iy1 / VIS_TILE);
                     }
                 }
@@ -331,9 +404,12 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
             const int ix = tx * VIS_TILE + (lane & 7), iy = ty * VIS_TILE + (lane >> 3);
             const float fx = ix + 0.5f, fy = iy + 0.5f;
             const int e0 = __builtin_amdgcn_readfirstlane(toff[tile]), e1 = __builtin_amdgcn_readfirstlane(min(toff[tile + 1], X.listcap));
-            float bw = 0.0f;
-            int bt = 0x7fffffff;
-            unsigned bcol = 0;
+            constexpr int NS = SS * SS;               // samples per pixel: the centre, or the four points 1/4 pixel off it
+            float bw[NS], bbias[NS];
+            int bt[NS];
+            unsigned bcol[NS], bcol2[NS];
+#pragma unroll
+            for (int q = 0; q < NS; q++) { bw[q] = 0.0f; bt[q] = 0x7fffffff; bcol[q] = 0; bcol2[q] = 0; bbias[q] = -1.0f; }
             for (int eb = e0; eb < e1; eb += 4) {
                 // four list entries and their records through the scalar unit (entries past the tile's end repeat its first of this batch:
                 // a record tested twice changes nothing)
@@ -343,56 +419,86 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
                 vis_v16i R0, R1, R2, R3;
                 vis_sload16x4(rec + 4 * (size_t)(i0 & 0x7fffffff), rec + 4 * (size_t)(i1 & 0x7fffffff), rec + 4 * (size_t)(i2 & 0x7fffffff), rec + 4 * (size_t)(i3 & 0x7fffffff), R0, R1, R2, R3);
                 auto test = [&](const vis_v16i& R, int idw) {
-                    const float w = __int_as_float(R[9]) * fx + __int_as_float(R[10]) * fy + __int_as_float(R[11]);
-                    bool in = w > 0;
+                    const float wc = __int_as_float(R[9]) * fx + __int_as_float(R[10]) * fy + __int_as_float(R[11]);
+                    float l0c = 0, l1c = 0, l2c = 0;
                     if (idw >= 0) {          // (wave-uniform: the tile is not entirely inside this triangle)
-                        const float l0 = __int_as_float(R[0]) * fx + __int_as_float(R[1]) * fy + __int_as_float(R[2]);
-                        const float l1 = __int_as_float(R[3]) * fx + __int_as_float(R[4]) * fy + __int_as_float(R[5]);
-                        const float l2 = __int_as_float(R[6]) * fx + __int_as_float(R[7]) * fy + __int_as_float(R[8]);
-                        in = in && l0 >= 0 && l1 >= 0 && l2 >= 0;
+                        l0c = __int_as_float(R[0]) * fx + __int_as_float(R[1]) * fy + __int_as_float(R[2]);
+                        l1c = __int_as_float(R[3]) * fx + __int_as_float(R[4]) * fy + __int_as_float(R[5]);
+                        l2c = __int_as_float(R[6]) * fx + __int_as_float(R[7]) * fy + __int_as_float(R[8]);
                     }
                     const int t = R[13];
-                    const bool better = in && (w > bw || (w == bw && t < bt));        // (selects, not a branch: no exec-mask round trip per entry)
-                    bw = better ? w : bw; bt = better ? t : bt; bcol = better ? (unsigned)R[12] : bcol;
+#pragma unroll
+                    for (int q = 0; q < NS; q++) {
+                        const float ox = NS == 1 ? 0.0f : ((q & 1) ? 0.25f : -0.25f), oy = NS == 1 ? 0.0f : ((q & 2) ? 0.25f : -0.25f);
+                        const float w = NS == 1 ? wc : wc + __int_as_float(R[9]) * ox + __int_as_float(R[10]) * oy;
+                        bool in = w > 0;
+                        if (idw >= 0) {
+                            const float l0 = NS == 1 ? l0c : l0c + __int_as_float(R[0]) * ox + __int_as_float(R[1]) * oy;
+                            const float l1 = NS == 1 ? l1c : l1c + __int_as_float(R[3]) * ox + __int_as_float(R[4]) * oy;
+                            const float l2 = NS == 1 ? l2c : l2c + __int_as_float(R[6]) * ox + __int_as_float(R[7]) * oy;
+                            in = in && l0 >= 0 && l1 >= 0 && l2 >= 0;
+                        }
+                        const bool better = in && (w > bw[q] || (w == bw[q] && t < bt[q]));        // (selects, not a branch: no exec-mask round trip per entry)
+                        bw[q] = better ? w : bw[q]; bt[q] = better ? t : bt[q]; bcol[q] = better ? (unsigned)R[12] : bcol[q];
+                        bcol2[q] = better ? (unsigned)R[14] : bcol2[q]; bbias[q] = better ? __int_as_float(R[15]) : bbias[q];
+                    }
                 };
                 test(R0, i0); test(R1, i1); test(R2, i2); test(R3, i3);
             }
-            const int bi = bt == 0x7fffffff ? -1 : 0;
             if (ix < W && iy < H) {
-                unsigned col;
-                const float dx = (fx - 0.5f * W) * scale, dy = -(fy - 0.5f * H) * scale;
-                if (bi >= 0) {
-                    col = bcol;
+                float accr = 0.0f, accg = 0.0f, accb = 0.0f;
+                unsigned col = 0;
+#pragma unroll
+                for (int q = 0; q < NS; q++) {
+                    const float ox = NS == 1 ? 0.0f : ((q & 1) ? 0.25f : -0.25f), oy = NS == 1 ? 0.0f : ((q & 2) ? 0.25f : -0.25f);
+                    const float dx = (fx + ox - 0.5f * W) * scale, dy = -(fy + oy - 0.5f * H) * scale;
+                    if (bt[q] != 0x7fffffff) {
+                        col = bcol[q];
+                        if (S.shmap && bbias[q] >= 0.0f) {
+                            // the sample's surface point in the world: depth 1 / w along the optical axis; its place and height in the light's frame
+                            const float depth = 1.0f / bw[q], px = dx * depth, py = dy * depth, pz = -depth;
+                            const float wx = cam[9] + cam[0] * px + cam[1] * py + cam[2] * pz, wy = cam[10] + cam[3] * px + cam[4] * py + cam[5] * pz, wz = cam[11] + cam[6] * px + cam[7] * py + cam[8] * pz;
+                            const float su = (wx * S.le1[0] + wy * S.le1[1] + wz * S.le1[2] - S.sh_s0) * S.sh_itex, sv = (wx * S.le2[0] + wy * S.le2[1] + wz * S.le2[2] - S.sh_t0) * S.sh_itex;
+                            const float hh = -(wx * S.lw[0] + wy * S.lw[1] + wz * S.lw[2]);
+                            if (su >= 0.0f && sv >= 0.0f && su < (float)VIS_SM && sv < (float)VIS_SM) {
+                                const unsigned key = S.shmap[(size_t)env * VIS_SM * VIS_SM + (size_t)((int)sv) * VIS_SM + (int)su];
+                                if (key != 0u && vis_hval(key) > hh + bbias[q]) col = bcol2[q];
+                            }
+                        }
 #ifdef VIS_NO_TEX
-                    if (false) {
+                        if (false) {
 #else
-                    if (col & 0x80000000u) {
+                        if (col & 0x80000000u) {
 #endif
-                        // textured: pixel ray against the triangle's plane in the camera frame -> barycentric -> uv -> texel
-                        const float lum = (float)(col & 0xffffu) * (1.0f / 65535.0f);
-                        const float4 a = vcam[S.tri[3 * bt]], b = vcam[S.tri[3 * bt + 1]], c = vcam[S.tri[3 * bt + 2]];
-                        const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z, e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
-                        // Moeller-Trumbore with origin 0 and direction (dx, dy, -1)
-                        const float hx = dy * e2z + e2y, hy = -e2x - dx * e2z, hz = dx * e2y - dy * e2x;      // d x e2
-                        const float det = e1x * hx + e1y * hy + e1z * hz;
-                        const float idet = fabsf(det) > 1e-20f ? 1.0f / det : 0.0f;
-                        const float sx = -a.x, sy = -a.y, sz = -a.z;
-                        float u = (sx * hx + sy * hy + sz * hz) * idet;
-                        const float qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;      // s x e1
-                        float v = (dx * qx + dy * qy - qz) * idet;
-                        u = fminf(fmaxf(u, 0.0f), 1.0f); v = fminf(fmaxf(v, 0.0f), 1.0f - u);
-                        const float* uv = S.uv + 6 * bt;
-                        const float tu = uv[0] + u * (uv[2] - uv[0]) + v * (uv[4] - uv[0]), tv = uv[1] + u * (uv[3] - uv[1]) + v * (uv[5] - uv[1]);
-                        const float fu = tu - floorf(tu), fv = tv - floorf(tv);
-                        const int txi = min(S.texn - 1, (int)(fu * S.texn)), tyi = min(S.texn - 1, (int)((1.0f - fv) * S.texn));
-                        const unsigned tx_ = S.texel[tyi * S.texn + txi];
-                        col = vis_pack((float)(tx_ & 255u) * (lum / 255.0f), (float)((tx_ >> 8) & 255u) * (lum / 255.0f), (float)((tx_ >> 16) & 255u) * (lum / 255.0f));
+                            // textured: pixel ray against the triangle's plane in the camera frame -> barycentric -> uv -> texel
+                            const int btq = bt[q];
+                            const float lum = (float)(col & 0xffffu) * (1.0f / 65535.0f);
+                            const float4 a = vcam[S.tri[3 * btq]], b = vcam[S.tri[3 * btq + 1]], c = vcam[S.tri[3 * btq + 2]];
+                            const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z, e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+                            // Moeller-Trumbore with origin 0 and direction (dx, dy, -1)
+                            const float hx = dy * e2z + e2y, hy = -e2x - dx * e2z, hz = dx * e2y - dy * e2x;      // d x e2
+                            const float det = e1x * hx + e1y * hy + e1z * hz;
+                            const float idet = fabsf(det) > 1e-20f ? 1.0f / det : 0.0f;
+                            const float sx = -a.x, sy = -a.y, sz = -a.z;
+                            float u = (sx * hx + sy * hy + sz * hz) * idet;
+                            const float qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;      // s x e1
+                            float v = (dx * qx + dy * qy - qz) * idet;
+                            u = fminf(fmaxf(u, 0.0f), 1.0f); v = fminf(fmaxf(v, 0.0f), 1.0f - u);
+                            const float* uv = S.uv + 6 * btq;
+                            const float tu = uv[0] + u * (uv[2] - uv[0]) + v * (uv[4] - uv[0]), tv = uv[1] + u * (uv[3] - uv[1]) + v * (uv[5] - uv[1]);
+                            const float fu = tu - floorf(tu), fv = tv - floorf(tv);
+                            const int txi = min(S.texn - 1, (int)(fu * S.texn)), tyi = min(S.texn - 1, (int)((1.0f - fv) * S.texn));
+                            const unsigned tx_ = S.texel[tyi * S.texn + txi];
+                            col = vis_pack((float)(tx_ & 255u) * (lum / 255.0f), (float)((tx_ >> 8) & 255u) * (lum / 255.0f), (float)((tx_ >> 16) & 255u) * (lum / 255.0f));
+                        }
+                    } else {
+                        const float idn = rsqrtf(dx * dx + dy * dy + 1.0f);
+                        const float w = 0.5f + 0.5f * (cam[15] * dx + cam[16] * dy - cam[17]) * idn;
+                        col = vis_pack(S.light[12] + (S.light[8] - S.light[12]) * w, S.light[13] + (S.light[9] - S.light[13]) * w, S.light[14] + (S.light[10] - S.light[14]) * w);
                     }
-                } else {
-                    const float idn = rsqrtf(dx * dx + dy * dy + 1.0f);
-                    const float w = 0.5f + 0.5f * (cam[15] * dx + cam[16] * dy - cam[17]) * idn;
-                    col = vis_pack(S.light[12] + (S.light[8] - S.light[12]) * w, S.light[13] + (S.light[9] - S.light[13]) * w, S.light[14] + (S.light[10] - S.light[14]) * w);
+                    accr += (float)(col & 255u); accg += (float)((col >> 8) & 255u); accb += (float)((col >> 16) & 255u);
                 }
+                if (NS > 1) col = (unsigned)(accr * (1.0f / NS) + 0.5f) | ((unsigned)(accg * (1.0f / NS) + 0.5f) << 8) | ((unsigned)(accb * (1.0f / NS) + 0.5f) << 16);
                 unsigned char* d = img + ((size_t)iy * W + ix) * 3;
                 d[0] = (unsigned char)(col & 255u); d[1] = (unsigned char)((col >> 8) & 255u); d[2] = (unsigned char)((col >> 16) & 255u);
             }
@@ -421,6 +527,11 @@ struct VisHost {
     int slots = 0, max_slots = 0, nviews_cap = 0, last_nviews = 0;     // scratch slots allocated / the most a launch uses (4 x CUs); flag rows allocated / written by the last launch
     bool attr_done = false;
     int* d_cam_ids = nullptr;
+    int samples = 1;                 // option "render_samples": 1, or 4 = 2 x 2 supersampling
+    bool shadows = false;            // option "render_shadows": the directional light casts shadows (depth map from the light, one per env)
+    unsigned* d_shmap = nullptr;
+    int shmap_envs = 0;
+    double light_host[16] = {0};     // the model's render_light (lights, sky, shadow box)
 
     template <typename T>
     T* up(const std::vector<T>& v) {
@@ -434,6 +545,7 @@ struct VisHost {
         try {
             inst_mesh = b.i("vis_inst_mesh"); inst_body = b.i("vis_inst_body"); inst_tex = b.i("vis_inst_tex");
             inst_pos = b.f("vis_inst_pos"); inst_mat = b.f("vis_inst_mat"); inst_scale = b.f("vis_inst_scale"); inst_rgba = b.f("vis_inst_rgba");
+            { auto L = b.f("render_light"); for (size_t k = 0; k < 16 && k < L.size(); k++) light_host[k] = L[k]; }
             have_inst = true;
         } catch (const std::exception&) { have_inst = false; }      // a model compiled without the visual scene: the proxy image only
     }
@@ -474,13 +586,31 @@ struct VisHost {
         S.texel = up(texel);
         S.texn = (int)std::lround(std::sqrt((double)texel.size()));
         S.cam_body = d_cam_body; S.cam_pos = d_cam_pos; S.cam_mat = d_cam_mat; S.cam_fovy = d_cam_fovy; S.light = d_light; S.znear = znear;
+        {   // the light's frame and its shadow box (oracle/orc_vis.c light_frame; render_light[3] half extent, [7] [11] [15] centre)
+            const double* L = light_host;
+            double lw[3] = {L[4], L[5], L[6]}, ln = std::sqrt(lw[0] * lw[0] + lw[1] * lw[1] + lw[2] * lw[2]);
+            if (!(ln > 0)) { lw[0] = 0; lw[1] = 0; lw[2] = -1; ln = 1; }
+            for (int k = 0; k < 3; k++) lw[k] /= ln;
+            const double ax[3] = {std::fabs(lw[0]) < 0.9 ? 1.0 : 0.0, std::fabs(lw[0]) < 0.9 ? 0.0 : 1.0, 0.0};
+            double d = ax[0] * lw[0] + ax[1] * lw[1] + ax[2] * lw[2], e1[3], e2[3];
+            for (int k = 0; k < 3; k++) e1[k] = ax[k] - d * lw[k];
+            d = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+            for (int k = 0; k < 3; k++) e1[k] /= d;
+            e2[0] = lw[1] * e1[2] - lw[2] * e1[1]; e2[1] = lw[2] * e1[0] - lw[0] * e1[2]; e2[2] = lw[0] * e1[1] - lw[1] * e1[0];
+            for (int k = 0; k < 3; k++) { S.le1[k] = (float)e1[k]; S.le2[k] = (float)e2[k]; S.lw[k] = (float)lw[k]; }
+            const double half = L[3] > 0 ? L[3] : 1.0, c[3] = {L[7], L[11], L[15]};
+            S.sh_s0 = (float)(c[0] * e1[0] + c[1] * e1[1] + c[2] * e1[2] - half);
+            S.sh_t0 = (float)(c[0] * e2[0] + c[1] * e2[1] + c[2] * e2[2] - half);
+            S.sh_itex = (float)(VIS_SM / (2.0 * half));
+            S.shmap = nullptr;
+        }
         loaded = true;
     }
     void destroy() {
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
-        for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.flags, (void*)d_cam_ids}) if (p) (void)hipFree(p);
-        X = VisScratch{}; d_cam_ids = nullptr; loaded = false; slots = 0; max_slots = 0; nviews_cap = 0; last_nviews = 0;
+        for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.flags, (void*)d_cam_ids, (void*)d_shmap}) if (p) (void)hipFree(p);
+        X = VisScratch{}; d_cam_ids = nullptr; d_shmap = nullptr; shmap_envs = 0; loaded = false; slots = 0; max_slots = 0; nviews_cap = 0; last_nviews = 0;
     }
     // overflow flags of the last launch, OR over the views (bit 0: triangle records, bit 1: tile lists); synchronises the stream
     int launch(hipStream_t st, int N, const float* d_xpose, const int* cam_ids_host, int ncam_sel, int ncam_model, int H, int W, void* d_out, std::string& err) {
@@ -527,10 +657,25 @@ struct VisHost {
         const int grid = nviews < slots ? nviews : slots;
         const size_t shmem = (size_t)(2 * ntile + 1) * sizeof(int);
         if (!attr_done) {
-            if (hipFuncSetAttribute((const void*)k_vis_render, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) { err = "hipFuncSetAttribute(visual render) failed"; return -3; }
+            if (hipFuncSetAttribute((const void*)k_vis_render<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_vis_render<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) { err = "hipFuncSetAttribute(visual render) failed"; return -3; }
             attr_done = true;
         }
-        hipLaunchKernelGGL(k_vis_render, dim3(grid), dim3(VIS_THREADS), shmem, st, S, X, d_xpose, (const int*)d_cam_ids, ncam_sel, N, H, W, (unsigned char*)d_out);
+        S.shmap = nullptr;
+        if (shadows && light_host[3] > 0) {
+            // one depth map from the light per env (shared by the env's cameras): VIS_SM^2 keys, 1 MB an env
+            if (N > shmap_envs) {
+                if (hipStreamSynchronize(st) != hipSuccess) { err = "visual render: stream synchronisation failed"; return -3; }
+                if (d_shmap) (void)hipFree(d_shmap);
+                d_shmap = nullptr; shmap_envs = 0;
+                if (hipMalloc((void**)&d_shmap, (size_t)N * VIS_SM * VIS_SM * sizeof(unsigned)) != hipSuccess) { err = "hipMalloc(shadow maps) failed"; return -3; }
+                shmap_envs = N;
+            }
+            S.shmap = d_shmap;
+            hipLaunchKernelGGL(k_vis_shadow, dim3(N), dim3(VIS_THREADS), 0, st, S, d_xpose, d_shmap, N);
+        }
+        if (samples > 1) hipLaunchKernelGGL(k_vis_render<2>, dim3(grid), dim3(VIS_THREADS), shmem, st, S, X, d_xpose, (const int*)d_cam_ids, ncam_sel, N, H, W, (unsigned char*)d_out);
+        else hipLaunchKernelGGL(k_vis_render<1>, dim3(grid), dim3(VIS_THREADS), shmem, st, S, X, d_xpose, (const int*)d_cam_ids, ncam_sel, N, H, W, (unsigned char*)d_out);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("visual render kernel launch: ") + hipGetErrorString(e); return -3; }
         return 0;

@@ -168,8 +168,11 @@ int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height,
  * do that on first use) the VISUAL scene is rasterised: the decimated visual meshes of the robots, the frame and camera mounts,
  * the textured table, the task objects (k_vis_render; flat Lambert shading under the scene's headlight scene.xml:9 and directional
  * light :48, table texture, skybox gradient :34).  Without a loaded visual scene, or with option "render_proxies" 1, the collision
- * proxies are drawn in their flat material colours instead (the depth rasteriser's colour variant).  Neither has shadows, specular
- * terms, anti-aliasing or transparency: a stand-in for MuJoCo's OpenGL output, not a pixel match.  A view that runs out of triangle
+ * proxies are drawn in their flat material colours instead (the depth rasteriser's colour variant).  Options of the visual image (round 5):
+ * "render_shadows" 1 -- the scene's directional light (scene.xml:48) casts shadows inside its shadow box (<statistic center extent>,
+ * scene.xml:6), from a 512 x 512 depth map rendered from the light per env; "render_samples" 4 -- 2 x 2 supersampling (MuJoCo's offscreen
+ * buffer is multisampled, offsamples default 4 [EXT]).  Both are off at the C-ABI and on in the gym facades.  No specular terms, haze or
+ * transparency: a stand-in for MuJoCo's OpenGL output, not a pixel match.  A view that runs out of triangle
  * records or tile-list entries sets the overflow flags of avsim_visual_info (the image then lacks triangles).  Pointer conventions
  * as avsim_render_depth. */
 int avsim_render_rgb(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, uint8_t* out);

@@ -135,6 +135,9 @@ int orc_render_rgb(const orc_data* d, int cam, int H, int W, unsigned char* out,
 int orc_vis_render(const orc_data* d, int cam, int nvert, const double* vert, const int* vbody, int ntri, const int* tri, const double* rgb,
                    const double* uv, const int* tex, const int* texel, int texn, int H, int W, unsigned char* out, int* tri_out, double* depth_out);
 
+int orc_vis_render_ex(const orc_data* d, int cam, int nvert, const double* vert, const int* vbody, int ntri, const int* tri, const double* rgb,
+                      const double* uv, const int* tex, const int* texel, int texn, int H, int W, int ss, int shadows, unsigned char* out, int* tri_out, double* depth_out);
+
 /* env-level (env.py:203-249): reset to home pose with given object free-joint poses (nobj x 7) */
 void orc_reset(orc_data* d, const double* obj_qpos);
 void orc_set_qpos(orc_data* d, const double* qpos);                 /* env.py:251-253 */

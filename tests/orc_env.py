@@ -111,7 +111,7 @@ class OrcEnv:
         assert hits >= 0
         return out, dep
 
-    def render_visual(self, cam, H, W, scene):
+    def render_visual(self, cam, H, W, scene, ss=1, shadows=False):
         """Colour image uint8 [H, W, 3] of the visual scene (scene = vismesh.expand_instances(library, model blob)), the index of the
         triangle every pixel sees (-1: sky) and its depth: oracle/orc_vis.c, one ray per pixel against every triangle."""
         ci = self.man["camera_names"].index(cam) if isinstance(cam, str) else int(cam)
@@ -124,9 +124,10 @@ class OrcEnv:
         tid = np.empty((H, W), dtype=np.int32)
         dep = np.empty((H, W), dtype=np.float64)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
-        self.L.orc_vis_render.restype = C.c_int
-        hits = self.L.orc_vis_render(self.dptr, ci, len(vbody), vp(vert), vp(vbody), len(tex), vp(tri), vp(rgb), vp(uv), vp(tex), vp(texel),
-                                     int(round(len(texel) ** 0.5)), H, W, vp(out), vp(tid), vp(dep))
+        # ss = 2: the four samples 1/4 pixel off the centre averaged; shadows: an exact ray towards the scene's directional light per sample
+        self.L.orc_vis_render_ex.restype = C.c_int
+        hits = self.L.orc_vis_render_ex(self.dptr, ci, len(vbody), vp(vert), vp(vbody), len(tex), vp(tri), vp(rgb), vp(uv), vp(tex), vp(texel),
+                                        int(round(len(texel) ** 0.5)), H, W, int(ss), int(bool(shadows)), vp(out), vp(tid), vp(dep))
         assert hits >= 0
         return out, tid, dep
 
