@@ -314,8 +314,9 @@ AVS_DEV void rotate_shape(Shape<T>& sh, const T* ax, T c, T s, const T* o) {
 
 // perturbation `pert` (0..3: tangent 1 +, tangent 1 -, tangent 2 +, tangent 2 -) of the pair about the contact point p0 with
 // normal n0: 1 with the contact's distance and position, or 0
+// (inlined into its caller: as an out-of-line function its two Shapes -- 79 dwords per lane -- are passed through the wave's private segment)
 template <typename T>
-__device__ int mpr_perturbed(Shape<T> A, Shape<T> B, const T* p0, const T* n0, int pert, T* dist, T* pos) {
+AVS_DEV int mpr_perturbed(Shape<T> A, Shape<T> B, const T* p0, const T* n0, int pert, T* dist, T* pos) {
     T t1[3], t2[3];
     make_frame(n0, t1, t2);
     T ax[3];

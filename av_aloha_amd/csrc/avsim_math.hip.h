@@ -5,6 +5,18 @@
 namespace avs {
 
 #define AVS_DEV __device__ __forceinline__
+// Out-of-line device functions.  Internal linkage: the compiler then knows every call site, the callee saves no callee-saved VGPRs in its
+// prologue (30-46 dwords per lane through the wave's private segment per call otherwise) and the callers see its exact clobber set.
+#ifndef AVS_OUTLINE_MODE
+#define AVS_OUTLINE_MODE 2
+#endif
+#if AVS_OUTLINE_MODE == 2
+#define AVS_OUTLINE __attribute__((noinline, internal_linkage, not_tail_called))
+#elif AVS_OUTLINE_MODE == 1
+#define AVS_OUTLINE __attribute__((noinline, internal_linkage))
+#else
+#define AVS_OUTLINE __attribute__((noinline))
+#endif
 #ifndef GLB_PTR
 #define GLB_PTR(T) __attribute__((address_space(1))) T*   // global memory, so that loads are global_load, not flat_load
 #endif

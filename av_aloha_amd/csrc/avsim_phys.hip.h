@@ -416,6 +416,25 @@ struct NoslipLead {
     int ntree, nv, neq, nfloss, nlg; // nlg = groups of leading (non-contact) rows; -1: no per-tree pass (more than 8 trees)
 };
 
+// A struct argument of an out-of-line function is passed in memory (12 dwords per lane through the wave's private segment, per call): the
+// noslip functions take it as three 4-vectors, which travel in registers.
+typedef int nl_v4 __attribute__((ext_vector_type(4)));
+#define NL_PARAMS nl_v4 nl_a_, nl_v4 nl_b_, nl_v4 nl_c_
+#define NL_ARGS(nl) nl_pack_a(nl), nl_pack_b(nl), nl_pack_c(nl)
+#define NL_UNPACK(real) NoslipLead<real> nl = nl_unpack<real>(nl_a_, nl_b_, nl_c_)
+template <typename real> AVS_DEV nl_v4 nl_pack_a(const NoslipLead<real>& n) {
+    return nl_v4{(int)(__SIZE_TYPE__)n.Minv, (int)(__SIZE_TYPE__)n.tadr, (int)(__SIZE_TYPE__)n.tnum, (int)(__SIZE_TYPE__)n.floss_dof};
+}
+template <typename real> AVS_DEV nl_v4 nl_pack_b(const NoslipLead<real>& n) { return nl_v4{(int)(__SIZE_TYPE__)n.dmap, (int)(__SIZE_TYPE__)n.prof, n.tridiag, n.ntree}; }
+template <typename real> AVS_DEV nl_v4 nl_pack_c(const NoslipLead<real>& n) { return nl_v4{n.nv, n.neq, n.nfloss, n.nlg}; }
+template <typename real> AVS_DEV NoslipLead<real> nl_unpack(nl_v4 a, nl_v4 b, nl_v4 c) {
+    NoslipLead<real> n;
+    n.Minv = (LDS_PTR(const real))(__SIZE_TYPE__)(unsigned)a.x; n.tadr = (LDS_PTR(const int))(__SIZE_TYPE__)(unsigned)a.y; n.tnum = (LDS_PTR(const int))(__SIZE_TYPE__)(unsigned)a.z;
+    n.floss_dof = (LDS_PTR(const int))(__SIZE_TYPE__)(unsigned)a.w; n.dmap = (LDS_PTR(int))(__SIZE_TYPE__)(unsigned)b.x; n.prof = (LDS_PTR(int))(__SIZE_TYPE__)(unsigned)b.y;
+    n.tridiag = b.z; n.ntree = b.w; n.nv = c.x; n.neq = c.y; n.nfloss = c.z; n.nlg = c.w;
+    return n;
+}
+
 // arguments of a non-kernel function arrive in VGPRs: the wave-uniform ones go back to SGPRs (scalar branches, scalar addressing)
 template <typename T> AVS_DEV LDS_PTR(T) uni_lds(LDS_PTR(T) p) {
     return (LDS_PTR(T))(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)p);
@@ -437,9 +456,10 @@ template <typename T> AVS_DEV T secular_step(T val, T r2, T r, T yw) {
 }
 
 template <typename real>
-__device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
+__device__ AVS_OUTLINE void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
                                                      LDS_PTR(real) q, LDS_PTR(const int) gI, GLB_PTR(const real) gA, int ngrp, int iters,
-                                                     int noslip_iters, real noslip_tol_scaled, NoslipLead<real> nl) {
+                                                     int noslip_iters, real noslip_tol_scaled, NL_PARAMS) {
+    NL_UNPACK(real);
     const long long tent = __builtin_readcyclecounter();
     rowS = uni_lds(rowS); rowI = uni_lds(rowI); q = uni_lds(q); gI = uni_lds(gI);
     rJ = uni_glb(rJ); rB = uni_glb(rB); gA = uni_glb(gA);
@@ -944,7 +964,7 @@ __device__ __attribute__((noinline)) void pgs_groups(LDS_PTR(real) rowS, LDS_PTR
 // scaled block, as in pgs_groups (same operations in the same order), the block gathered by octet broadcasts instead of wave-wide
 // ones; redundantly on the eight lanes of the octet.  Returns the new force of this lane's row (lanes 1..n), *change = the cost change.
 template <typename real>
-__device__ __attribute__((noinline)) real qcqp_slide_octet(GLB_PTR(const real) gA, int g, int n, int fi, real res_r, real f0, real muinv, real invn, real qc5, real fn,
+__device__ AVS_OUTLINE real qcqp_slide_octet(GLB_PTR(const real) gA, int g, int n, int fi, real res_r, real f0, real muinv, real invn, real qc5, real fn,
                                                           int tridiag, real* change_out) {
     struct { int tridiag; } nl{tridiag};
     struct { real f0, muinv, invn; real qc[GA_QW]; int g; } cur;
@@ -1109,9 +1129,10 @@ __device__ __attribute__((noinline)) real qcqp_slide_octet(GLB_PTR(const real) g
 // Returns 1 when the pass is done, 0 for "use pgs_groups" (two-tree contact, more than 64 contacts, sliding contact, odd layout).
 // ------------------------------------------------------------------------------------------------
 template <typename real>
-__device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const int) cefc, GLB_PTR(const real) rJ,
+__device__ AVS_OUTLINE int noslip_trees(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const int) cefc, GLB_PTR(const real) rJ,
                                                       LDS_PTR(real) q, LDS_PTR(const int) gI, GLB_PTR(const real) gA, int ncon, int nefc, int noslip_iters,
-                                                      real noslip_tol_scaled, NoslipLead<real> nl) {
+                                                      real noslip_tol_scaled, NL_PARAMS) {
+    NL_UNPACK(real);
     rowS = uni_lds(rowS); rowI = uni_lds(rowI); cefc = uni_lds(cefc); q = uni_lds(q); gI = uni_lds(gI);
     rJ = uni_glb(rJ); gA = uni_glb(gA);
     ncon = __builtin_amdgcn_readfirstlane(ncon); nefc = __builtin_amdgcn_readfirstlane(nefc); noslip_iters = __builtin_amdgcn_readfirstlane(noslip_iters);
@@ -1343,9 +1364,10 @@ __device__ __attribute__((noinline)) int noslip_trees(LDS_PTR(real) rowS, LDS_PT
 // contraction out of the sums).  A function of its own, entered when noslip_trees returns 2: with the two-tree bookkeeping in
 // noslip_trees the headline workload, which has no such contact, lost 1.6 %; this way 0.3 %.
 template <typename real>
-__device__ __attribute__((noinline)) int noslip_trees2(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const int) cefc, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
+__device__ AVS_OUTLINE int noslip_trees2(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const int) cefc, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
                                                       LDS_PTR(real) q, LDS_PTR(const int) gI, GLB_PTR(const real) gA, int ncon, int nefc, int noslip_iters,
-                                                      real noslip_tol_scaled, NoslipLead<real> nl) {
+                                                      real noslip_tol_scaled, NL_PARAMS) {
+    NL_UNPACK(real);
     rowS = uni_lds(rowS); rowI = uni_lds(rowI); cefc = uni_lds(cefc); q = uni_lds(q); gI = uni_lds(gI);
     rJ = uni_glb(rJ); rB = uni_glb(rB); gA = uni_glb(gA);
     ncon = __builtin_amdgcn_readfirstlane(ncon); nefc = __builtin_amdgcn_readfirstlane(nefc); noslip_iters = __builtin_amdgcn_readfirstlane(noslip_iters);
@@ -2349,7 +2371,26 @@ struct Env {
     // ---- P3 ------------------------------------------------------------------------------------
     // out of line, on a copy of the object: the members then live in registers (a callee reached through `this` reloads them
     // from memory after every store, and the kernel-argument pointer with them: vector loads instead of s_load)
-    __device__ __attribute__((noinline)) void collide() {
+    // One multiccd perturbation of the pair (pga, pgb) whose first contact sits in result slot `src`; leaves distance and position in
+    // entry 1 + pert of that slot (1e30: none).  Out of line with register arguments only: the MPR code
+    // is 27 KB, and as a call of mpr_perturbed itself the two Shapes went through the wave's private segment -- 79 dwords per lane,
+    // 20 KB written and read back per narrow-phase pass, most of the kernel's spill traffic (profiles/r05_experiments.txt section 7).
+    __device__ AVS_OUTLINE static void multi_perturb(KPtr<real> ka_, real* r_, int* i_, int lane_, int grp_, const real* lr_, const int* li_, int env_,
+                                                                   int pga, int pgb, int src, int pert) {
+        Env e(ka_, r_, i_, lane_, grp_, lr_, li_);       // (an Env by value is an aggregate of 22 dwords: passed in memory)
+        e.env = env_;
+        LDS_PTR(real) os = (LDS_PTR(real))(e.r + e.ka->lay.scr + SLOT_W * src);
+        const real p0[3] = {os[SLOT_P], os[SLOT_P + 1], os[SLOT_P + 2]}, n0[3] = {os[SLOT_N], os[SLOT_N + 1], os[SLOT_N + 2]};
+        Shape<real> a, b;
+        e.load_shape(pga, a);
+        e.load_shape(pgb, b);
+        real dk = real(1e30), pk[3] = {0, 0, 0};
+        if (!mpr_perturbed(a, b, p0, n0, pert, &dk, pk)) dk = real(1e30);
+        os[1 + pert] = dk;
+        for (int c = 0; c < 3; c++) os[SLOT_P + 3 * (1 + pert) + c] = pk[c];
+    }
+
+    __device__ AVS_OUTLINE void collide() {
         Env e(*this);
         e.collide_i();
         diverged = e.diverged; nit_sum = e.nit_sum; nit_max = e.nit_max; t_broad = e.t_broad; t_narrow = e.t_narrow;
@@ -2510,17 +2551,7 @@ struct Env {
                         const bool on = q < nm;
                         const int src = on ? mlist[q] : 0;
                         const int pga = __shfl(ga, src, 64), pgb = __shfl(gb, src, 64);
-                        if (on) {
-                            LDS_PTR(real) os = (LDS_PTR(real))(r + ka->lay.scr + SLOT_W * src);
-                            const real p0[3] = {os[SLOT_P], os[SLOT_P + 1], os[SLOT_P + 2]}, n0[3] = {os[SLOT_N], os[SLOT_N + 1], os[SLOT_N + 2]};
-                            Shape<real> a, b;
-                            load_shape(pga, a);
-                            load_shape(pgb, b);
-                            real dk = real(1e30), pk[3] = {0, 0, 0};
-                            if (!mpr_perturbed(a, b, p0, n0, pert, &dk, pk)) dk = real(1e30);
-                            os[1 + pert] = dk;
-                            for (int c = 0; c < 3; c++) os[SLOT_P + 3 * (1 + pert) + c] = pk[c];
-                        }
+                        if (on) multi_perturb(ka, r, ii, lane, grp, lr, li, env, pga, pgb, src, pert);
                     }
                     GSYNC();
                     if (multi) {
@@ -2578,7 +2609,7 @@ struct Env {
     // ---- P4 ------------------------------------------------------------------------------------
     // out of line, on a copy of the object: the members then live in registers (a callee reached through `this` reloads them
     // from memory after every store, and the kernel-argument pointer with them: vector loads instead of s_load)
-    __device__ __attribute__((noinline)) void make_constraints() {
+    __device__ AVS_OUTLINE void make_constraints() {
         Env e(*this);
         e.make_constraints_i();
         diverged = e.diverged; nit_sum = e.nit_sum; nit_max = e.nit_max; t_broad = e.t_broad; t_narrow = e.t_narrow;
@@ -3025,7 +3056,7 @@ struct Env {
     // ---- P8 ------------------------------------------------------------------------------------
     // out of line, on a copy of the object: the members then live in registers (a callee reached through `this` reloads them
     // from memory after every store, and the kernel-argument pointer with them: vector loads instead of s_load)
-    __device__ __attribute__((noinline)) void solve(int pgs_iters, int solver, int newton_iters, real newton_tol, real scale) {
+    __device__ AVS_OUTLINE void solve(int pgs_iters, int solver, int newton_iters, real newton_tol, real scale) {
         Env e(*this);
         e.solve_i(pgs_iters, solver, newton_iters, newton_tol, scale);
         diverged = e.diverged; nit_sum = e.nit_sum; nit_max = e.nit_max; t_broad = e.t_broad; t_narrow = e.t_narrow;
@@ -3064,14 +3095,14 @@ struct Env {
             int done_ = 0;
             if (ka->m.noslip_trees && lead_per_tree() && __builtin_amdgcn_readfirstlane(misc[8]) == 0)
                 done_ = noslip_trees<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const int))cefc, (GLB_PTR(const real))rJ, (LDS_PTR(real))qacc,
-                                           (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), ncon, nefc, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
+                                           (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), ncon, nefc, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, NL_ARGS(noslip_lead()));
             if (__builtin_amdgcn_readfirstlane(done_) == 2)
                 done_ = noslip_trees2<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (LDS_PTR(const int))cefc, (GLB_PTR(const real))rJ, (GLB_PTR(const real))rowsB_(), (LDS_PTR(real))qacc,
-                                            (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), ncon, nefc, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
+                                            (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), ncon, nefc, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, NL_ARGS(noslip_lead()));
             if (__builtin_amdgcn_readfirstlane(done_) != 1 && lane == 0) misc[8] = 1;
             if (__builtin_amdgcn_readfirstlane(done_) != 1)
             pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (GLB_PTR(const real))rJ, (GLB_PTR(const real))rowsB_(), (LDS_PTR(real))qacc,
-                             (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], 0, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
+                             (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], 0, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, NL_ARGS(noslip_lead()));
             if (profiling && lane == 0) (ii + ka->lay.nprof)[6] += (int)(__builtin_readcyclecounter() - tn0);
         } else {
         // warm-start forces of friction blocks back onto their cones (one contact per lane)
@@ -3097,7 +3128,7 @@ struct Env {
         // Gauss-Seidel sweeps (+ noslip sweeps) in the register-resident wave kernel
         static_assert(G == 64, "the solver maps one env to one wavefront");
         pgs_groups<real>((LDS_PTR(real))rowS, (LDS_PTR(const int))rowI, (GLB_PTR(const real))rJ, (GLB_PTR(const real))rowsB_(), (LDS_PTR(real))qacc,
-                         (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], pgs_iters, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, noslip_lead());
+                         (LDS_PTR(const int))(ii + ka->lay.gI), (GLB_PTR(const real))coup_(), misc[5], pgs_iters, ka->m.noslip_iters, real(1e-6) / ka->m.nscale, NL_ARGS(noslip_lead()));
         }
         GSYNC();
         // qfrc_constraint = J^T f

@@ -31,7 +31,15 @@
 
 namespace avs {
 
-constexpr int VIS_TILE = 8, VIS_THREADS = 256, VIS_MAXBODY = 64, VIS_MAXTILES = 16384, VIS_REC = 16;
+#ifndef VIS_THREADS_N
+#define VIS_THREADS_N 1024
+#endif
+// One workgroup of VIS_THREADS per view, 16 wavefronts per CU in all.  Sixteen wavefronts on ONE view (1024 threads, one workgroup per CU) rather
+// than four views of four: a view in flight holds ~0.5 MB of records, lists and camera-frame vertices next to its 0.9 MB image, and 4 x 256
+// of them overflow the 256 MB Infinity Cache -- the tile stage's dependent loads then wait for HBM (6.7 ms per 1024 views against 3.6 ms per
+// 512: profiles/r05_experiments.txt section 8).
+constexpr int VIS_THREADS = VIS_THREADS_N, VIS_WG_PER_CU = 1024 / VIS_THREADS_N, VIS_SHADOW_THREADS = 256;
+constexpr int VIS_TILE = 8, VIS_MAXBODY = 64, VIS_MAXTILES = 16384, VIS_REC = 16, VIS_TEXCAP = 512;
 
 struct VisScene {
     int nvert, ntri, nbody, ncam;
@@ -61,6 +69,8 @@ struct VisScratch {
     float4* rec;      // [slots][reccap][4]
     int* bbox;        // [slots][reccap][4] tile ranges
     int* list;        // [slots][listcap]
+    int* bigq;        // [slots][reccap]: the records whose boxes cover more than 16 tiles (vis_bin)
+    float4* trec;     // [slots][VIS_TEXCAP][3]: per textured triangle the planes U, V, D over the image: texture coordinate = U / D, V / D at a sample
     int* flags;       // [nviews][8]: overflow bits (0: records, 1: lists), shader-clock cycles / 1024 of the five stages, records, list entries
     int reccap, listcap;
 };
@@ -112,40 +122,70 @@ __device__ inline void vis_sload16x4(const void* p0, const void* p1, const void*
                  : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3) : "s"(vis_uni(p0)), "s"(vis_uni(p1)), "s"(vis_uni(p2)), "s"(vis_uni(p3)) : "memory");
 }
 
+// the twelve words of four records that the tile loop reads (three edge functions and the plane of 1 / depth; words 12-15 -- colours, bias --
+// are fetched for the winner only): 48 SGPRs instead of 64 per batch, which the kernel's other wave-uniform values no longer spill around
+typedef int vis_v8i __attribute__((ext_vector_type(8)));
+struct VisRec12 { vis_v8i a; vis_v4i b; };
+__device__ inline void vis_sload12x4(const void* p0, const void* p1, const void* p2, const void* p3, VisRec12& r0, VisRec12& r1, VisRec12& r2, VisRec12& r3) {
+    asm volatile("s_load_dwordx8 %0, %8, 0x0\n\ts_load_dwordx4 %1, %8, 0x20\n\ts_load_dwordx8 %2, %9, 0x0\n\ts_load_dwordx4 %3, %9, 0x20\n\t"
+                 "s_load_dwordx8 %4, %10, 0x0\n\ts_load_dwordx4 %5, %10, 0x20\n\ts_load_dwordx8 %6, %11, 0x0\n\ts_load_dwordx4 %7, %11, 0x20\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(r0.a), "=&s"(r0.b), "=&s"(r1.a), "=&s"(r1.b), "=&s"(r2.a), "=&s"(r2.b), "=&s"(r3.a), "=&s"(r3.b)
+                 : "s"(vis_uni(p0)), "s"(vis_uni(p1)), "s"(vis_uni(p2)), "s"(vis_uni(p3)) : "memory");
+}
+
 // Tile lists.  Records are taken 64 at a time by a wavefront, one per lane.  A triangle whose box covers a few tiles is walked by its
-// own lane; a big one (the table top covers every tile of the overhead view, a frame bar crosses the image) is handed to the whole
-// wavefront in turn, lane k taking every 64th tile of its box -- otherwise the wave waits for one lane walking thousands of tiles.
-// FILL = false counts (cnt[tile]++), FILL = true appends the record index at cur[tile]++.
+// own lane.  A big one (the table top covers every tile of the overhead view, a frame bar crosses the image) goes to a queue that the whole
+// workgroup then works through: chunks of 64 tiles of a queued triangle's box, dealt round-robin over the wavefronts, lane k of a chunk taking
+// its k-th tile -- the big triangles come in runs of one mesh (the table's 92), which as the work of whichever wavefront took that run of
+// records were a third of the view's time once sixteen wavefronts shared a view.  The queue is built by the counting pass and reused by
+// the fill pass.  FILL = false counts (cnt[tile]++), FILL = true appends the record index at cur[tile]++.
 template <bool FILL>
 __device__ inline void vis_bin(const float4* __restrict__ rec, const int* __restrict__ bbox, int nrec, int* cnt, int* __restrict__ list, int listcap, int tw, int lane, int wave,
-                               int& flag) {
+                               int& flag, int* __restrict__ bigq, int* bign) {
+    auto visit = [&](const float4 q0, const float4 q1, const float4 q2, int tx, int ty, int idx) {
+        if (vis_tile_outside(q0, q1, q2, (float)(tx * VIS_TILE), (float)(ty * VIS_TILE))) return;
+        const int p = atomicAdd(&cnt[ty * tw + tx], 1);
+        // (bit 31 of a list entry: the tile lies entirely inside the triangle, the tile stage skips the edge functions)
+        if (FILL) { if (p < listcap) list[p] = idx | (vis_tile_inside(q0, q1, q2, (float)(tx * VIS_TILE), (float)(ty * VIS_TILE)) ? (int)0x80000000 : 0); else flag |= 2; }
+    };
     for (int i0 = wave * 64; i0 < nrec; i0 += VIS_THREADS) {
         const int i = i0 + lane;
-        const bool valid = i < nrec;
-        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
-        int4 bb = make_int4(0, -1, 0, -1);
-        if (valid) { r0 = rec[4 * i]; r1 = rec[4 * i + 1]; r2 = rec[4 * i + 2]; bb = ((const int4*)bbox)[i]; }
-        const int bw = bb.y - bb.x + 1, nt = valid ? bw * (bb.w - bb.z + 1) : 0;
-        auto visit = [&](const float4 q0, const float4 q1, const float4 q2, int tx, int ty, int idx) {
-            if (vis_tile_outside(q0, q1, q2, (float)(tx * VIS_TILE), (float)(ty * VIS_TILE))) return;
-            const int p = atomicAdd(&cnt[ty * tw + tx], 1);
-            // (bit 31 of a list entry: the tile lies entirely inside the triangle, the tile stage skips the edge functions)
-            if (FILL) { if (p < listcap) list[p] = idx | (vis_tile_inside(q0, q1, q2, (float)(tx * VIS_TILE), (float)(ty * VIS_TILE)) ? (int)0x80000000 : 0); else flag |= 2; }
-        };
-        const bool big = nt > 16;
-        if (valid && !big)
-            for (int ty = bb.z; ty <= bb.w; ty++)
-                for (int tx = bb.x; tx <= bb.y; tx++) visit(r0, r1, r2, tx, ty, i);
-        unsigned long long m = __ballot(big);
-        while (m) {
-            const int src = __builtin_ctzll(m);
-            m &= m - 1;
-            float4 q0, q1, q2;
-            q0.x = __shfl(r0.x, src, 64); q0.y = __shfl(r0.y, src, 64); q0.z = __shfl(r0.z, src, 64); q0.w = __shfl(r0.w, src, 64);
-            q1.x = __shfl(r1.x, src, 64); q1.y = __shfl(r1.y, src, 64); q1.z = __shfl(r1.z, src, 64); q1.w = __shfl(r1.w, src, 64);
-            q2.x = __shfl(r2.x, src, 64); q2.y = 0; q2.z = 0; q2.w = 0;
-            const int x0 = __shfl(bb.x, src, 64), y0 = __shfl(bb.z, src, 64), w = __shfl(bw, src, 64), n = __shfl(nt, src, 64);
-            for (int k = lane; k < n; k += 64) visit(q0, q1, q2, x0 + k % w, y0 + k / w, i0 + src);
+        if (i >= nrec) continue;
+        const int4 bb = ((const int4*)bbox)[i];
+        const int nt = (bb.y - bb.x + 1) * (bb.w - bb.z + 1);
+        if (nt > 16) {
+            if (!FILL) bigq[atomicAdd(bign, 1)] = i;        // (at most one entry per record: the queue has the records' capacity)
+            continue;
+        }
+        const float4 r0 = rec[4 * i], r1 = rec[4 * i + 1], r2 = rec[4 * i + 2];
+        for (int ty = bb.z; ty <= bb.w; ty++)
+            for (int tx = bb.x; tx <= bb.y; tx++) visit(r0, r1, r2, tx, ty, i);
+    }
+    if (!FILL) { __threadfence_block(); __syncthreads(); }      // the queue is complete (the fill pass comes after barriers of its own)
+    const int nbig = *bign;
+    constexpr int NW = VIS_THREADS / 64;
+    // one queued triangle per wavefront at a time, lane = tile row of its box: the row's span of tiles follows from the three edge functions
+    // (a thin bar across the image has a box of thousands of tiles and touches a hundred: walking the box was most of both passes)
+    for (int q = wave; q < nbig; q += NW) {
+        const int i = __builtin_amdgcn_readfirstlane(bigq[q]);
+        const float4 r0 = rec[4 * i], r1 = rec[4 * i + 1], r2 = rec[4 * i + 2];
+        const int4 bb = ((const int4*)bbox)[i];
+        const float ea[3] = {r0.x, r0.w, r1.z}, eb[3] = {r0.y, r1.x, r1.w}, ec[3] = {r0.z, r1.y, r2.x};
+        for (int row = bb.z + lane; row <= bb.w; row += 64) {
+            const float ya = (float)(row * VIS_TILE) + 0.25f, yb = (float)(row * VIS_TILE + VIS_TILE) - 0.25f;
+            float lo = (float)(bb.x * VIS_TILE), hi = (float)(bb.y * VIS_TILE + VIS_TILE);
+            bool none = false;
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                const float v = eb[e] * (eb[e] > 0 ? yb : ya) + ec[e];        // the edge function's largest value over the row, less its x term
+                if (ea[e] > 0) lo = fmaxf(lo, -v / ea[e]);
+                else if (ea[e] < 0) hi = fminf(hi, -v / ea[e]);
+                else none = none || v < 0;
+            }
+            if (none || !(lo <= hi + 0.02f)) continue;
+            // tiles whose samples [8 tx + 1/4, 8 tx + 7 3/4] reach into [lo, hi] (a tile more on either side does no harm: visit() tests exactly)
+            const int tx0 = max(bb.x, (int)floorf((lo - 0.01f - (VIS_TILE - 0.25f)) * (1.0f / VIS_TILE))), tx1 = min(bb.y, (int)floorf((hi + 0.01f - 0.25f) * (1.0f / VIS_TILE)));
+            for (int tx = tx0; tx <= tx1; tx++) visit(r0, r1, r2, tx, row, i);
         }
     }
 }
@@ -153,15 +193,15 @@ __device__ inline void vis_bin(const float4* __restrict__ rec, const int* __rest
 // Shadow map of one env per workgroup: every triangle of the scene, in the light's frame (s, t across, h towards the light), rasterised over
 // the texel centres it covers with atomicMax of its height's ordered key.  Small triangles by their own thread; a triangle whose box holds
 // more than 64 texels (the table top covers the whole map) goes to an LDS queue that the workgroup then works through together.
-__global__ void __launch_bounds__(VIS_THREADS) k_vis_shadow(VisScene S, const float* __restrict__ xpose, unsigned* __restrict__ shmap, int N) {
+__global__ void __launch_bounds__(VIS_SHADOW_THREADS) k_vis_shadow(VisScene S, const float* __restrict__ xpose, unsigned* __restrict__ shmap, int N) {
     __shared__ float Q[1024 * 9];
     __shared__ int nq;
     const int env = blockIdx.x, tid = threadIdx.x;
     if (env >= N) return;
     unsigned* map = shmap + (size_t)env * VIS_SM * VIS_SM;
-    for (int i = tid; i < VIS_SM * VIS_SM; i += VIS_THREADS) map[i] = 0u;
+    for (int i = tid; i < VIS_SM * VIS_SM; i += VIS_SHADOW_THREADS) map[i] = 0u;
     if (tid == 0) nq = 0;
-    __threadfence();
+    __threadfence_block();
     __syncthreads();
     const float* xb = xpose + (size_t)env * S.nbody * 12;
     auto raster = [&](const float* P, int first, int stride) {      // P: three (x, y, h) in texel units / metres
@@ -180,7 +220,7 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_shadow(VisScene S, const fl
             if (l0 >= 0 && l1 >= 0 && l2 >= 0) atomicMax(&map[iy * VIS_SM + ix], vis_hkey(l0 * P[2] + l1 * P[5] + l2 * P[8]));
         }
     };
-    for (int t = tid; t < S.ntri; t += VIS_THREADS) {
+    for (int t = tid; t < S.ntri; t += VIS_SHADOW_THREADS) {
         float P[9];
         for (int c = 0; c < 3; c++) {
             const int v = S.tri[3 * t + c];
@@ -200,16 +240,24 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_shadow(VisScene S, const fl
     }
     __syncthreads();
     const int n = nq < 1024 ? nq : 1024;
-    for (int q = 0; q < n; q++) raster(Q + 9 * q, tid, VIS_THREADS);
+    for (int q = 0; q < n; q++) raster(Q + 9 * q, tid, VIS_SHADOW_THREADS);
 }
 
-template <int SS>
-__global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScratch X, const float* __restrict__ xpose, const int* __restrict__ cam_ids, int ncam_sel,
+#ifdef VIS_NO_OCC4
+#define VIS_OCC_ATTR
+#else
+#define VIS_OCC_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))      // 128 VGPRs: sixteen wavefronts per CU
+#endif
+template <int SS, bool SH>       // SS x SS samples per pixel; SH: shadows of the directional light (S.shmap)
+__global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScene S, VisScratch X, const float* __restrict__ xpose, const int* __restrict__ cam_ids, int ncam_sel,
                                                             int N, int H, int W, unsigned char* __restrict__ out) {
     __shared__ float Rcb[VIS_MAXBODY * 12];
-    __shared__ float cam[24];                // Rc (9), pc (3), light dir in the camera frame (3), world up in the camera frame (3), scale
+    __shared__ float cam[32];                // Rc (9), pc (3), light dir in the camera frame (3), world up in the camera frame (3), scale; [19..30] the light's frame
+                                             // and shadow box (VisScene le1, le2, lw, sh_s0, sh_t0, sh_itex: read from here, not from SGPRs, by the few lanes that need them)
     extern __shared__ int vis_dyn[];         // toff[ntile + 1]: tile -> first list entry (after the scan), counters before; tcur[ntile]
     __shared__ int wsum[2 * (VIS_THREADS / 64)];
+    __shared__ int texcnt;                   // textured triangles of this view so far (slots of trec)
+    __shared__ int nbig;                     // records in the queue of big triangles (vis_bin)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tw = (W + VIS_TILE - 1) / VIS_TILE, th = (H + VIS_TILE - 1) / VIS_TILE, ntile = tw * th;
     const int nviews = N * ncam_sel, slot = blockIdx.x;
@@ -219,6 +267,8 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
     float4* rec = X.rec + (size_t)slot * X.reccap * 4;
     int* bbox = X.bbox + (size_t)slot * X.reccap * 4;
     int* list = X.list + (size_t)slot * X.listcap;
+    float4* trec = X.trec + (size_t)slot * VIS_TEXCAP * 3;
+    int* bigq = X.bigq + (size_t)slot * X.reccap;
     for (int view = blockIdx.x; view < nviews; view += gridDim.x) {
         const int env = view / ncam_sel, cs = view - env * ncam_sel, cid = cam_ids[cs];
         const float* xb = xpose + (size_t)env * S.nbody * 12;
@@ -237,6 +287,10 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
                 cam[15 + j] = cam[6 + j];                                                          // Rc^T e_z
             }
             cam[18] = 2.0f * S.cam_fovy[cid] / (float)H;
+            texcnt = 0;
+            nbig = 0;
+            for (int k = 0; k < 3; k++) { cam[19 + k] = S.le1[k]; cam[22 + k] = S.le2[k]; cam[25 + k] = S.lw[k]; }
+            cam[28] = S.sh_s0; cam[29] = S.sh_t0; cam[30] = S.sh_itex;
         }
         for (int t = tid; t <= ntile; t += VIS_THREADS) toff[t] = 0;
         __syncthreads();
@@ -268,6 +322,7 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
             float px[4], py[4], pw[4];
             unsigned colour = 0, colour2 = 0;
             float sbias = -1.0f;
+            int tag = t;               // word 13 of the record: the triangle, or for a textured one its slot in trec
             if (t < S.ntri) {
                 const float4 a = vcam[S.tri[3 * t]], b = vcam[S.tri[3 * t + 1]], c = vcam[S.tri[3 * t + 2]];
                 const float da = -a.z, db = -b.z, dc = -c.z;
@@ -307,7 +362,29 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
                         if (!(ch > 0)) nout = 0;
                         const float cl = -(n[0] * cam[12] + n[1] * cam[13] + n[2] * cam[14]) * in;
                         const float lum = fminf(1.0f, amb + hd * ch + ld * fmaxf(cl, 0.0f)), lum2 = fminf(1.0f, amb + hd * ch);
-                        if (S.tex[t]) { colour = 0x80000000u | (unsigned)(lum * 65535.0f + 0.5f); colour2 = 0x80000000u | (unsigned)(lum2 * 65535.0f + 0.5f); }      // textured: the shade, colour at the pixel
+                        if (S.tex[t]) {      // textured: the record carries the shade, the colour comes from the texture at the sample
+                            colour = 0x80000000u | (unsigned)(lum * 65535.0f + 0.5f); colour2 = 0x80000000u | (unsigned)(lum2 * 65535.0f + 0.5f);
+                            if (nout > 0) {
+                                // Texture coordinates over the image without going back to the vertices per pixel: a point s d of the triangle's plane
+                                // (d = the sample's ray) has barycentrics s M^-1 d, M = [a b c]; the rows of M^-1 are b x c, c x a, a x b over det(M),
+                                // so (u, v) = (sum_i u_i r_i . d, sum_i v_i r_i . d) / (sum_i r_i . d) -- three functions affine in the pixel, and the
+                                // determinant cancels.  One slot of three float4 per textured triangle (the table: ~200 of them).
+                                const int ts = atomicAdd(&texcnt, 1);
+                                if (ts < VIS_TEXCAP) {
+                                    tag = ts;
+                                    const float r0[3] = {b.y * c.z - b.z * c.y, b.z * c.x - b.x * c.z, b.x * c.y - b.y * c.x};
+                                    const float r1[3] = {c.y * a.z - c.z * a.y, c.z * a.x - c.x * a.z, c.x * a.y - c.y * a.x};
+                                    const float r2[3] = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+                                    const float* uv = S.uv + 6 * t;
+#pragma unroll
+                                    for (int f = 0; f < 3; f++) {
+                                        const float k0 = f == 0 ? uv[0] : f == 1 ? uv[1] : 1.0f, k1 = f == 0 ? uv[2] : f == 1 ? uv[3] : 1.0f, k2 = f == 0 ? uv[4] : f == 1 ? uv[5] : 1.0f;
+                                        const float vx = k0 * r0[0] + k1 * r1[0] + k2 * r2[0], vy = k0 * r0[1] + k1 * r1[1] + k2 * r2[1], vz = k0 * r0[2] + k1 * r1[2] + k2 * r2[2];
+                                        trec[3 * ts + f] = make_float4(vx * scale, -vy * scale, -vx * scale * 0.5f * W + vy * scale * 0.5f * H - vz, 0.0f);
+                                    }
+                                } else { tag = VIS_TEXCAP - 1; flag |= 1; }
+                            }
+                        }
                         else { colour = vis_pack(S.rgb[3 * t] * lum, S.rgb[3 * t + 1] * lum, S.rgb[3 * t + 2] * lum); colour2 = vis_pack(S.rgb[3 * t] * lum2, S.rgb[3 * t + 1] * lum2, S.rgb[3 * t + 2] * lum2); }
                         // in the light's shadow the light's term goes (colour2); the depth map's texels are S.sh_itex^-1 wide, so a lit surface
                         // tilted by theta against the light lies up to texel x tan(theta) below its own texel's height: slope-scaled bias.
@@ -345,7 +422,7 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
                         R[k][0] = make_float4(a0, b0, c0, a1);
                         R[k][1] = make_float4(b1, c1, a2, b2);
                         R[k][2] = make_float4(c2, a0 * w0 + a1 * w1 + a2 * w2, b0 * w0 + b1 * w1 + b2 * w2, c0 * w0 + c1 * w1 + c2 * w2);
-                        R[k][3] = make_float4(__uint_as_float(colour), __int_as_float(t), __uint_as_float(colour2), sbias);
+                        R[k][3] = make_float4(__uint_as_float(colour), __int_as_float(tag), __uint_as_float(colour2), sbias);
                         B[k] = make_int4(ix0 / VIS_TILE, ix1 / VIS_TILE, iy0 / VIS_TILE, iy1 / VIS_TILE);
                     }
                 }
@@ -353,7 +430,7 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
             // ordered compaction of the block's records (the record index follows the triangle index): one barrier per pass, the
             // per-wave totals double-buffered, the running total kept by every thread
             const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]), lower = (1ull << lane) - 1ull;
-            int* ws = wsum + 4 * ((t0 / VIS_THREADS) & 1);
+            int* ws = wsum + (VIS_THREADS / 64) * ((t0 / VIS_THREADS) & 1);
             if (lane == 0) ws[wave] = __popcll(m0) + __popcll(m1);
             __syncthreads();
             int idx = nrec_run;
@@ -373,7 +450,7 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
         __threadfence_block();
         __syncthreads();
         const long long tc2 = __builtin_readcyclecounter();
-        vis_bin<false>(rec, bbox, nrec, toff, list, X.listcap, tw, lane, wave, flag);
+        vis_bin<false>(rec, bbox, nrec, toff, list, X.listcap, tw, lane, wave, flag, bigq, &nbig);
         __syncthreads();
         // 3. exclusive scan of the tile counts (one wave), then the fill pass
         if (wave == 0) {
@@ -390,57 +467,79 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
         }
         __syncthreads();
         const long long tc3 = __builtin_readcyclecounter();
-        vis_bin<true>(rec, bbox, nrec, tcur, list, X.listcap, tw, lane, wave, flag);
-        __threadfence();              // (agent scope: the records and lists are read back through the scalar cache, from L2)
+        vis_bin<true>(rec, bbox, nrec, tcur, list, X.listcap, tw, lane, wave, flag, bigq, &nbig);
+        // (the stores of the records and lists are acknowledged by L2, which is where the scalar cache reads them from: a workgroup-scope
+        // release waits for exactly that.  An agent-scope fence here wrote the XCD's whole L2 back -- other views' images included -- once
+        // per view: 270 of the fill stage's 465 k cycles)
+        __threadfence_block();
         __syncthreads();
         const long long tc4 = __builtin_readcyclecounter();
         // 4. tiles: one wavefront each, lane = pixel
         unsigned char* img = out + (size_t)view * H * W * 3;
+        const unsigned* shenv = SH ? S.shmap + (size_t)env * VIS_SM * VIS_SM : nullptr;
         // (records and lists were written with vector stores: the barrier above made them visible in L2, this drops what the scalar cache
         // still holds of the slot's previous view)
         __builtin_amdgcn_s_dcache_inv();
+        int tx = wave % tw, ty = wave / tw;          // this wave's tile, stepped along with the tile index (no division per tile)
+        const float lxf = (float)(lane & 7) + 0.5f, lyf = (float)(lane >> 3) + 0.5f;
         for (int tile = wave; tile < ntile; tile += VIS_THREADS / 64) {
-            const int ty = tile / tw, tx = tile - ty * tw;
             const int ix = tx * VIS_TILE + (lane & 7), iy = ty * VIS_TILE + (lane >> 3);
-            const float fx = ix + 0.5f, fy = iy + 0.5f;
+            const float fx = (float)(tx * VIS_TILE) + lxf, fy = (float)(ty * VIS_TILE) + lyf;
+            tx += VIS_THREADS / 64;
+            while (tx >= tw) { tx -= tw; ty++; }
             const int e0 = __builtin_amdgcn_readfirstlane(toff[tile]), e1 = __builtin_amdgcn_readfirstlane(min(toff[tile + 1], X.listcap));
             constexpr int NS = SS * SS;               // samples per pixel: the centre, or the four points 1/4 pixel off it
-            float bw[NS], bbias[NS];
-            int bt[NS];
-            unsigned bcol[NS], bcol2[NS];
+            // per sample: the nearest record so far -- 1 / depth and the record's index, which also breaks ties (the records are in triangle
+            // order, the image does not depend on the order of the lists); colours, shadow bias and texture come from the winner's record
+            // after the loop (three selects per entry and sample less than carrying them along)
+            float bw[NS];
+            int bi[NS];
 #pragma unroll
-            for (int q = 0; q < NS; q++) { bw[q] = 0.0f; bt[q] = 0x7fffffff; bcol[q] = 0; bcol2[q] = 0; bbias[q] = -1.0f; }
+            for (int q = 0; q < NS; q++) { bw[q] = 0.0f; bi[q] = 0x7fffffff; }
             for (int eb = e0; eb < e1; eb += 4) {
-                // four list entries and their records through the scalar unit (entries past the tile's end repeat its first of this batch:
-                // a record tested twice changes nothing)
-                const vis_v4i id = vis_sload4(list + eb);
+                // four list entries and their records through the scalar unit; entries past the tile's end repeat the batch's first: a record
+                // tested twice changes nothing
                 const int n = e1 - eb;
+                const vis_v4i id = vis_sload4(list + eb);
                 const int i0 = id[0], i1 = n > 1 ? id[1] : id[0], i2 = n > 2 ? id[2] : id[0], i3 = n > 3 ? id[3] : id[0];
-                vis_v16i R0, R1, R2, R3;
-                vis_sload16x4(rec + 4 * (size_t)(i0 & 0x7fffffff), rec + 4 * (size_t)(i1 & 0x7fffffff), rec + 4 * (size_t)(i2 & 0x7fffffff), rec + 4 * (size_t)(i3 & 0x7fffffff), R0, R1, R2, R3);
-                auto test = [&](const vis_v16i& R, int idw) {
-                    const float wc = __int_as_float(R[9]) * fx + __int_as_float(R[10]) * fy + __int_as_float(R[11]);
+                VisRec12 R0, R1, R2, R3;
+                vis_sload12x4(rec + 4 * (size_t)(i0 & 0x7fffffff), rec + 4 * (size_t)(i1 & 0x7fffffff), rec + 4 * (size_t)(i2 & 0x7fffffff), rec + 4 * (size_t)(i3 & 0x7fffffff), R0, R1, R2, R3);
+                auto test = [&](const VisRec12& R, int idw) {
+                    const int i = idw & 0x7fffffff;
+                    const bool edges = idw >= 0;          // (wave-uniform: the tile is not entirely inside this triangle)
+                    const float wc = __int_as_float(R.b[1]) * fx + (__int_as_float(R.b[2]) * fy + __int_as_float(R.b[3]));
                     float l0c = 0, l1c = 0, l2c = 0;
-                    if (idw >= 0) {          // (wave-uniform: the tile is not entirely inside this triangle)
-                        l0c = __int_as_float(R[0]) * fx + __int_as_float(R[1]) * fy + __int_as_float(R[2]);
-                        l1c = __int_as_float(R[3]) * fx + __int_as_float(R[4]) * fy + __int_as_float(R[5]);
-                        l2c = __int_as_float(R[6]) * fx + __int_as_float(R[7]) * fy + __int_as_float(R[8]);
+                    if (edges) {
+                        l0c = __int_as_float(R.a[0]) * fx + (__int_as_float(R.a[1]) * fy + __int_as_float(R.a[2]));
+                        l1c = __int_as_float(R.a[3]) * fx + (__int_as_float(R.a[4]) * fy + __int_as_float(R.a[5]));
+                        l2c = __int_as_float(R.a[6]) * fx + (__int_as_float(R.a[7]) * fy + __int_as_float(R.b[0]));
                     }
-                    const int t = R[13];
-#pragma unroll
-                    for (int q = 0; q < NS; q++) {
-                        const float ox = NS == 1 ? 0.0f : ((q & 1) ? 0.25f : -0.25f), oy = NS == 1 ? 0.0f : ((q & 2) ? 0.25f : -0.25f);
-                        const float w = NS == 1 ? wc : wc + __int_as_float(R[9]) * ox + __int_as_float(R[10]) * oy;
-                        bool in = w > 0;
-                        if (idw >= 0) {
-                            const float l0 = NS == 1 ? l0c : l0c + __int_as_float(R[0]) * ox + __int_as_float(R[1]) * oy;
-                            const float l1 = NS == 1 ? l1c : l1c + __int_as_float(R[3]) * ox + __int_as_float(R[4]) * oy;
-                            const float l2 = NS == 1 ? l2c : l2c + __int_as_float(R[6]) * ox + __int_as_float(R[7]) * oy;
-                            in = in && l0 >= 0 && l1 >= 0 && l2 >= 0;
+                    // (w > 0 needs no test of its own: bw starts at 0.  The conditions are combined with & and |, not && and ||: lane masks in
+                    // SGPRs, no exec-mask round trip per entry)
+                    if (NS == 1) {
+                        const bool in = fminf(fminf(l0c, l1c), l2c) >= 0.0f;
+                        const bool better = in & ((wc > bw[0]) | ((wc == bw[0]) & (i < bi[0])));
+                        bw[0] = better ? wc : bw[0]; bi[0] = better ? i : bi[0];
+                    } else {
+                        // the four samples sit at (-+1/4, -+1/4) off the centre: a plane a x + b y + c there is its centre value -+ (a + b) / 4 and
+                        // -+ (a - b) / 4 -- two wave-uniform terms per plane, one fma per plane and sample
+                        const float ws = __int_as_float(R.b[1]) + __int_as_float(R.b[2]), wd = __int_as_float(R.b[1]) - __int_as_float(R.b[2]);
+                        const float w[4] = {wc - 0.25f * ws, wc + 0.25f * wd, wc - 0.25f * wd, wc + 0.25f * ws};
+                        float m[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (edges) {
+                            const float s0 = __int_as_float(R.a[0]) + __int_as_float(R.a[1]), d0 = __int_as_float(R.a[0]) - __int_as_float(R.a[1]);
+                            const float s1 = __int_as_float(R.a[3]) + __int_as_float(R.a[4]), d1 = __int_as_float(R.a[3]) - __int_as_float(R.a[4]);
+                            const float s2 = __int_as_float(R.a[6]) + __int_as_float(R.a[7]), d2 = __int_as_float(R.a[6]) - __int_as_float(R.a[7]);
+                            m[0] = fminf(fminf(l0c - 0.25f * s0, l1c - 0.25f * s1), l2c - 0.25f * s2);
+                            m[1] = fminf(fminf(l0c + 0.25f * d0, l1c + 0.25f * d1), l2c + 0.25f * d2);
+                            m[2] = fminf(fminf(l0c - 0.25f * d0, l1c - 0.25f * d1), l2c - 0.25f * d2);
+                            m[3] = fminf(fminf(l0c + 0.25f * s0, l1c + 0.25f * s1), l2c + 0.25f * s2);
                         }
-                        const bool better = in && (w > bw[q] || (w == bw[q] && t < bt[q]));        // (selects, not a branch: no exec-mask round trip per entry)
-                        bw[q] = better ? w : bw[q]; bt[q] = better ? t : bt[q]; bcol[q] = better ? (unsigned)R[12] : bcol[q];
-                        bcol2[q] = better ? (unsigned)R[14] : bcol2[q]; bbias[q] = better ? __int_as_float(R[15]) : bbias[q];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const bool better = (m[q] >= 0.0f) & ((w[q] > bw[q]) | ((w[q] == bw[q]) & (i < bi[q])));
+                            bw[q] = better ? w[q] : bw[q]; bi[q] = better ? i : bi[q];
+                        }
                     }
                 };
                 test(R0, i0); test(R1, i1); test(R2, i2); test(R3, i3);
@@ -451,41 +550,30 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
 #pragma unroll
                 for (int q = 0; q < NS; q++) {
                     const float ox = NS == 1 ? 0.0f : ((q & 1) ? 0.25f : -0.25f), oy = NS == 1 ? 0.0f : ((q & 2) ? 0.25f : -0.25f);
-                    const float dx = (fx + ox - 0.5f * W) * scale, dy = -(fy + oy - 0.5f * H) * scale;
-                    if (bt[q] != 0x7fffffff) {
-                        col = bcol[q];
-                        if (S.shmap && bbias[q] >= 0.0f) {
+                    const float sx = fx + ox, sy = fy + oy;
+                    const float dx = (sx - 0.5f * W) * scale, dy = -(sy - 0.5f * H) * scale;
+                    if (bi[q] != 0x7fffffff) {
+                        const float4 r3 = rec[4u * (unsigned)bi[q] + 3u];      // colour, triangle or texture slot, colour without the light's term, shadow bias
+                        col = __float_as_uint(r3.x);
+                        if (SH && r3.w >= 0.0f) {
                             // the sample's surface point in the world: depth 1 / w along the optical axis; its place and height in the light's frame
-                            const float depth = 1.0f / bw[q], px = dx * depth, py = dy * depth, pz = -depth;
+                            const float depth = __builtin_amdgcn_rcpf(bw[q]), px = dx * depth, py = dy * depth, pz = -depth;
                             const float wx = cam[9] + cam[0] * px + cam[1] * py + cam[2] * pz, wy = cam[10] + cam[3] * px + cam[4] * py + cam[5] * pz, wz = cam[11] + cam[6] * px + cam[7] * py + cam[8] * pz;
-                            const float su = (wx * S.le1[0] + wy * S.le1[1] + wz * S.le1[2] - S.sh_s0) * S.sh_itex, sv = (wx * S.le2[0] + wy * S.le2[1] + wz * S.le2[2] - S.sh_t0) * S.sh_itex;
-                            const float hh = -(wx * S.lw[0] + wy * S.lw[1] + wz * S.lw[2]);
+                            const float su = (wx * cam[19] + wy * cam[20] + wz * cam[21] - cam[28]) * cam[30], sv = (wx * cam[22] + wy * cam[23] + wz * cam[24] - cam[29]) * cam[30];
+                            const float hh = -(wx * cam[25] + wy * cam[26] + wz * cam[27]);
                             if (su >= 0.0f && sv >= 0.0f && su < (float)VIS_SM && sv < (float)VIS_SM) {
-                                const unsigned key = S.shmap[(size_t)env * VIS_SM * VIS_SM + (size_t)((int)sv) * VIS_SM + (int)su];
-                                if (key != 0u && vis_hval(key) > hh + bbias[q]) col = bcol2[q];
+                                const unsigned key = shenv[(unsigned)((int)sv * VIS_SM + (int)su)];
+                                if (key != 0u && vis_hval(key) > hh + r3.w) col = __float_as_uint(r3.z);
                             }
                         }
-#ifdef VIS_NO_TEX
-                        if (false) {
-#else
                         if (col & 0x80000000u) {
-#endif
-                            // textured: pixel ray against the triangle's plane in the camera frame -> barycentric -> uv -> texel
-                            const int btq = bt[q];
+                            // textured: (u, v) = (U, V) / D with the triangle's three planes over the image (set-up), then the texel
                             const float lum = (float)(col & 0xffffu) * (1.0f / 65535.0f);
-                            const float4 a = vcam[S.tri[3 * btq]], b = vcam[S.tri[3 * btq + 1]], c = vcam[S.tri[3 * btq + 2]];
-                            const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z, e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
-                            // Moeller-Trumbore with origin 0 and direction (dx, dy, -1)
-                            const float hx = dy * e2z + e2y, hy = -e2x - dx * e2z, hz = dx * e2y - dy * e2x;      // d x e2
-                            const float det = e1x * hx + e1y * hy + e1z * hz;
-                            const float idet = fabsf(det) > 1e-20f ? 1.0f / det : 0.0f;
-                            const float sx = -a.x, sy = -a.y, sz = -a.z;
-                            float u = (sx * hx + sy * hy + sz * hz) * idet;
-                            const float qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;      // s x e1
-                            float v = (dx * qx + dy * qy - qz) * idet;
-                            u = fminf(fmaxf(u, 0.0f), 1.0f); v = fminf(fmaxf(v, 0.0f), 1.0f - u);
-                            const float* uv = S.uv + 6 * btq;
-                            const float tu = uv[0] + u * (uv[2] - uv[0]) + v * (uv[4] - uv[0]), tv = uv[1] + u * (uv[3] - uv[1]) + v * (uv[5] - uv[1]);
+                            const float4* tp = trec + 3 * __float_as_int(r3.y);
+                            const float4 pu = tp[0], pv = tp[1], pd = tp[2];
+                            const float den = pd.x * sx + (pd.y * sy + pd.z);
+                            const float iden = fabsf(den) > 1e-30f ? __builtin_amdgcn_rcpf(den) : 0.0f;
+                            const float tu = (pu.x * sx + (pu.y * sy + pu.z)) * iden, tv = (pv.x * sx + (pv.y * sy + pv.z)) * iden;
                             const float fu = tu - floorf(tu), fv = tv - floorf(tv);
                             const int txi = min(S.texn - 1, (int)(fu * S.texn)), tyi = min(S.texn - 1, (int)((1.0f - fv) * S.texn));
                             const unsigned tx_ = S.texel[tyi * S.texn + txi];
@@ -499,7 +587,7 @@ __global__ void __launch_bounds__(VIS_THREADS) k_vis_render(VisScene S, VisScrat
                     accr += (float)(col & 255u); accg += (float)((col >> 8) & 255u); accb += (float)((col >> 16) & 255u);
                 }
                 if (NS > 1) col = (unsigned)(accr * (1.0f / NS) + 0.5f) | ((unsigned)(accg * (1.0f / NS) + 0.5f) << 8) | ((unsigned)(accb * (1.0f / NS) + 0.5f) << 16);
-                unsigned char* d = img + ((size_t)iy * W + ix) * 3;
+                unsigned char* d = img + (unsigned)((iy * W + ix) * 3);
                 d[0] = (unsigned char)(col & 255u); d[1] = (unsigned char)((col >> 8) & 255u); d[2] = (unsigned char)((col >> 16) & 255u);
             }
         }
@@ -524,7 +612,7 @@ struct VisHost {
     VisScene S{};
     VisScratch X{};
     std::vector<void*> allocs;
-    int slots = 0, max_slots = 0, nviews_cap = 0, last_nviews = 0;     // scratch slots allocated / the most a launch uses (4 x CUs); flag rows allocated / written by the last launch
+    int slots = 0, max_slots = 0, nviews_cap = 0, last_nviews = 0;     // scratch slots allocated / the most a launch uses (VIS_WG_PER_CU x CUs); flag rows allocated / written by the last launch
     bool attr_done = false;
     int* d_cam_ids = nullptr;
     int samples = 1;                 // option "render_samples": 1, or 4 = 2 x 2 supersampling
@@ -609,7 +697,7 @@ struct VisHost {
     void destroy() {
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
-        for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.flags, (void*)d_cam_ids, (void*)d_shmap}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.trec, (void*)X.bigq, (void*)X.flags, (void*)d_cam_ids, (void*)d_shmap}) if (p) (void)hipFree(p);
         X = VisScratch{}; d_cam_ids = nullptr; d_shmap = nullptr; shmap_envs = 0; loaded = false; slots = 0; max_slots = 0; nviews_cap = 0; last_nviews = 0;
     }
     // overflow flags of the last launch, OR over the views (bit 0: triangle records, bit 1: tile lists); synchronises the stream
@@ -625,23 +713,24 @@ struct VisHost {
             int dev = 0, cus = 256;
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-            max_slots = 4 * cus;
+            max_slots = VIS_WG_PER_CU * cus;
             X.reccap = S.ntri + 2048;                  // near-plane clipping can split a triangle in two
             X.listcap = 8 * S.ntri + 4 * VIS_MAXTILES;
             if (hipMalloc((void**)&d_cam_ids, 16 * sizeof(int)) != hipSuccess) { err = "hipMalloc(visual render camera ids) failed"; max_slots = 0; return -3; }
         }
         // per-slot scratch (camera-frame vertices, triangle records, their boxes, tile lists: ~2.8 MB a slot for the 20 k-triangle
-        // scenes) for as many workgroups as this call can use -- a single env with one camera holds one slot, not 4 x CUs of them
+        // scenes) for as many workgroups as this call can use -- a single env with one camera holds one slot, not one per CU
         // (2.9 GB per handle: a vector env of single-env handles ran out of HBM); regrown when a later call has more views
         const int want = nviews < max_slots ? nviews : max_slots;
         if (want > slots) {
             if (hipStreamSynchronize(st) != hipSuccess) { err = "visual render: stream synchronisation failed"; return -3; }
-            for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list}) if (p) (void)hipFree(p);
-            X.vcam = nullptr; X.rec = nullptr; X.bbox = nullptr; X.list = nullptr; slots = 0;
+            for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.trec, (void*)X.bigq}) if (p) (void)hipFree(p);
+            X.vcam = nullptr; X.rec = nullptr; X.bbox = nullptr; X.list = nullptr; X.trec = nullptr; X.bigq = nullptr; slots = 0;
             if (hipMalloc((void**)&X.vcam, (size_t)want * S.nvert * sizeof(float4)) != hipSuccess || hipMalloc((void**)&X.rec, (size_t)want * X.reccap * 4 * sizeof(float4)) != hipSuccess ||
-                hipMalloc((void**)&X.bbox, (size_t)want * X.reccap * 4 * sizeof(int)) != hipSuccess || hipMalloc((void**)&X.list, ((size_t)want * X.listcap + 16) * sizeof(int)) != hipSuccess) {      // (+ 16: the tile stage reads its list four entries at a time)
-                for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list}) if (p) (void)hipFree(p);
-                X.vcam = nullptr; X.rec = nullptr; X.bbox = nullptr; X.list = nullptr;
+                hipMalloc((void**)&X.bbox, (size_t)want * X.reccap * 4 * sizeof(int)) != hipSuccess || hipMalloc((void**)&X.list, ((size_t)want * X.listcap + 16) * sizeof(int)) != hipSuccess ||      // (+ 16: the tile stage reads its list four entries at a time)
+                hipMalloc((void**)&X.trec, (size_t)want * VIS_TEXCAP * 3 * sizeof(float4)) != hipSuccess || hipMalloc((void**)&X.bigq, (size_t)want * X.reccap * sizeof(int)) != hipSuccess) {
+                for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.trec, (void*)X.bigq}) if (p) (void)hipFree(p);
+                X.vcam = nullptr; X.rec = nullptr; X.bbox = nullptr; X.list = nullptr; X.trec = nullptr; X.bigq = nullptr;
                 err = "hipMalloc(visual render scratch) failed"; return -3;
             }
             slots = want;
@@ -657,8 +746,10 @@ struct VisHost {
         const int grid = nviews < slots ? nviews : slots;
         const size_t shmem = (size_t)(2 * ntile + 1) * sizeof(int);
         if (!attr_done) {
-            if (hipFuncSetAttribute((const void*)k_vis_render<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_vis_render<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) { err = "hipFuncSetAttribute(visual render) failed"; return -3; }
+            if (hipFuncSetAttribute((const void*)k_vis_render<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_vis_render<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_vis_render<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_vis_render<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) { err = "hipFuncSetAttribute(visual render) failed"; return -3; }
             attr_done = true;
         }
         S.shmap = nullptr;
@@ -672,10 +763,13 @@ struct VisHost {
                 shmap_envs = N;
             }
             S.shmap = d_shmap;
-            hipLaunchKernelGGL(k_vis_shadow, dim3(N), dim3(VIS_THREADS), 0, st, S, d_xpose, d_shmap, N);
+            hipLaunchKernelGGL(k_vis_shadow, dim3(N), dim3(VIS_SHADOW_THREADS), 0, st, S, d_xpose, d_shmap, N);
         }
-        if (samples > 1) hipLaunchKernelGGL(k_vis_render<2>, dim3(grid), dim3(VIS_THREADS), shmem, st, S, X, d_xpose, (const int*)d_cam_ids, ncam_sel, N, H, W, (unsigned char*)d_out);
-        else hipLaunchKernelGGL(k_vis_render<1>, dim3(grid), dim3(VIS_THREADS), shmem, st, S, X, d_xpose, (const int*)d_cam_ids, ncam_sel, N, H, W, (unsigned char*)d_out);
+        const bool sh = S.shmap != nullptr;
+#define VIS_LAUNCH(SS_, SH_) hipLaunchKernelGGL((k_vis_render<SS_, SH_>), dim3(grid), dim3(VIS_THREADS), shmem, st, S, X, d_xpose, (const int*)d_cam_ids, ncam_sel, N, H, W, (unsigned char*)d_out)
+        if (samples > 1) { if (sh) VIS_LAUNCH(2, true); else VIS_LAUNCH(2, false); }
+        else { if (sh) VIS_LAUNCH(1, true); else VIS_LAUNCH(1, false); }
+#undef VIS_LAUNCH
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { err = std::string("visual render kernel launch: ") + hipGetErrorString(e); return -3; }
         return 0;

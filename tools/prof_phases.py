@@ -10,7 +10,7 @@ opts = {"pgs_iters": 20, "profile_phases": 1, "export_contacts": 0}
 task, arms = os.environ.get("TASK", "slot_insertion"), int(os.environ.get("ARMS", "3"))
 for a in sys.argv[2:]:
     k, v = a.split("="); opts[k] = float(v)
-sim = BatchedSim(task, arms, N, options=opts)
+sim = BatchedSim(task, arms, N, options=opts, f64=bool(int(os.environ.get("F64", "0"))))
 md = model_dict(task, arms)
 if task == "slot_insertion":
     sim.reset(np.repeat(OBJ[None], N, 0))

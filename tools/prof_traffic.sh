@@ -1,20 +1,24 @@
 #!/bin/bash
-# HBM-side traffic of k_phys per launch: FETCH_SIZE and WRITE_SIZE in separate PMC passes (usage: tools/prof_traffic.sh <tag>)
-tag=${1:-x}
+# HBM-side traffic of k_phys only (FETCH_SIZE / WRITE_SIZE, each in its own pass, no trace): tools/prof_traffic.sh <tag> [configs, default "2"]
+tag=${1:-x}; cfgs=${2:-2}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-o=gpurun_out/traffic_$tag
-mkdir -p $o
-rocprofv3 --pmc FETCH_SIZE -d $o/fetch -o p -f csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $o/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $o/write -o p -f csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $o/write.log 2>&1
+o=gpurun_out/traffic_$tag; mkdir -p $o
+for c in $cfgs; do
+  extra=""; [ $c = 3 ] && extra="--config 3 --warmup 150"; [ $c = 4 ] && extra="--config 4 --warmup 30"
+  rocprofv3 --pmc FETCH_SIZE -d $o/fetch$c -o p -f csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras $extra > $o/fetch$c.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE -d $o/write$c -o p -f csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras $extra > $o/write$c.log 2>&1
+done
 python - <<PY
-import csv, glob
-res = {}
-for name in ("fetch", "write"):
-    for f in glob.glob("$o/%s/**/*counter_collection.csv" % name, recursive=True):
-        vals = sorted(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_phys" in r["Kernel_Name"])
-        vals = [v for v in vals if v > 0.5 * vals[-1]] if vals else vals      # the env-step launches
-        res[name] = sum(vals) / max(1, len(vals))
-print("$tag", "KB per k_phys launch:", res, "GB total:", (res.get("fetch",0)+res.get("write",0))*1024/1e9)
+import csv, glob, json
+o = "$o"; res = {}
+for c in "$cfgs".split():
+    for name in ("fetch", "write"):
+        for f in glob.glob(o + "/%s%s/**/*counter_collection.csv" % (name, c), recursive=True):
+            rows = sorted((int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(open(f)) if "k_phys" in r["Kernel_Name"])
+            top = max([v for _, v in rows] or [0.0])
+            vals = [v for _, v in rows if v > 0.1 * top][-5:]
+            res["config%s_%s_KB_per_launch" % (c, name)] = sum(vals) / max(1, len(vals))
+json.dump(res, open(o + "/pmc_summary.json", "w"), indent=1)
+print(res)
 PY
-tail -1 $o/write.log | cut -c1-160

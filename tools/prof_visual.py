@@ -16,6 +16,9 @@ h = _ffi.Handle(blob, N, 0, _ffi.AVSIM_IO_DEVICE)
 L = h.L
 lib = open(os.path.join(MODEL_DIR, "visual_meshes.avv"), "rb").read()
 h.check(L.avsim_load_visual(h.h, lib, len(lib)))
+for opt, env in (("render_shadows", "SHADOWS"), ("render_samples", "SAMPLES")):      # SHADOWS=1 SAMPLES=4: the facades' defaults
+    if os.environ.get(env):
+        h.check(L.avsim_set_option(h.h, opt.encode(), float(os.environ[env])))
 obj = torch.tensor(np.repeat(OBJ[None], N, 0).reshape(N, -1), dtype=torch.float64, device="cuda")
 h.check(L.avsim_reset(h.h, None, obj.data_ptr()))
 cams = ["zed_cam_left", "wrist_cam_left", "wrist_cam_right", "overhead_cam"]
