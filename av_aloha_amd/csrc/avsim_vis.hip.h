@@ -164,28 +164,42 @@ __device__ inline void vis_bin(const float4* __restrict__ rec, const int* __rest
     if (!FILL) { __threadfence_block(); __syncthreads(); }      // the queue is complete (the fill pass comes after barriers of its own)
     const int nbig = *bign;
     constexpr int NW = VIS_THREADS / 64;
-    // one queued triangle per wavefront at a time, lane = tile row of its box: the row's span of tiles follows from the three edge functions
-    // (a thin bar across the image has a box of thousands of tiles and touches a hundred: walking the box was most of both passes)
-    for (int q = wave; q < nbig; q += NW) {
-        const int i = __builtin_amdgcn_readfirstlane(bigq[q]);
-        const float4 r0 = rec[4 * i], r1 = rec[4 * i + 1], r2 = rec[4 * i + 2];
-        const int4 bb = ((const int4*)bbox)[i];
-        const float ea[3] = {r0.x, r0.w, r1.z}, eb[3] = {r0.y, r1.x, r1.w}, ec[3] = {r0.z, r1.y, r2.x};
-        for (int row = bb.z + lane; row <= bb.w; row += 64) {
-            const float ya = (float)(row * VIS_TILE) + 0.25f, yb = (float)(row * VIS_TILE + VIS_TILE) - 0.25f;
-            float lo = (float)(bb.x * VIS_TILE), hi = (float)(bb.y * VIS_TILE + VIS_TILE);
-            bool none = false;
+    // The queue: 64 entries per wavefront at a time, one per lane (entry, record and box arrive with two round trips for the 64, not per entry),
+    // then one after the other, lane = tile row of the box: the row's span of tiles follows from the three edge functions (a thin bar across
+    // the image has a box of thousands of tiles and touches a hundred: walking the box was most of both passes)
+    // (the entries are dealt round-robin over the wavefronts: a mesh's big triangles sit next to each other in the queue)
+    for (int qb = 0; qb * NW + wave < nbig; qb += 64) {
+        const int q = (qb + lane) * NW + wave, mi = q < nbig ? bigq[q] : 0;
+        float4 m0 = make_float4(0, 0, 0, 0), m1 = m0, m2 = m0;
+        int4 mb = make_int4(0, -1, 0, -1);
+        if (q < nbig) { m0 = rec[4 * mi]; m1 = rec[4 * mi + 1]; m2 = rec[4 * mi + 2]; mb = ((const int4*)bbox)[mi]; }
+        const int ne = min(64, (nbig - wave - qb * NW + NW - 1) / NW);
+        for (int src = 0; src < ne; src++) {
+            float4 r0, r1, r2;
+            r0.x = __shfl(m0.x, src, 64); r0.y = __shfl(m0.y, src, 64); r0.z = __shfl(m0.z, src, 64); r0.w = __shfl(m0.w, src, 64);
+            r1.x = __shfl(m1.x, src, 64); r1.y = __shfl(m1.y, src, 64); r1.z = __shfl(m1.z, src, 64); r1.w = __shfl(m1.w, src, 64);
+            r2.x = __shfl(m2.x, src, 64); r2.y = 0; r2.z = 0; r2.w = 0;
+            const int4 bb = make_int4(__shfl(mb.x, src, 64), __shfl(mb.y, src, 64), __shfl(mb.z, src, 64), __shfl(mb.w, src, 64));
+            const int i = __shfl(mi, src, 64);
+            const float ea[3] = {r0.x, r0.w, r1.z}, eb[3] = {r0.y, r1.x, r1.w}, ec[3] = {r0.z, r1.y, r2.x};
+            for (int row = bb.z + lane; row <= bb.w; row += 64) {
+                const float ya = (float)(row * VIS_TILE) + 0.25f, yb = (float)(row * VIS_TILE + VIS_TILE) - 0.25f;
+                float lo = (float)(bb.x * VIS_TILE), hi = (float)(bb.y * VIS_TILE + VIS_TILE);
+                bool none = false;
 #pragma unroll
-            for (int e = 0; e < 3; e++) {
-                const float v = eb[e] * (eb[e] > 0 ? yb : ya) + ec[e];        // the edge function's largest value over the row, less its x term
-                if (ea[e] > 0) lo = fmaxf(lo, -v / ea[e]);
-                else if (ea[e] < 0) hi = fminf(hi, -v / ea[e]);
-                else none = none || v < 0;
+                for (int e = 0; e < 3; e++) {
+                    const float v = eb[e] * (eb[e] > 0 ? yb : ya) + ec[e];        // the edge function's largest value over the row, less its x term
+                    const float x = -v * __builtin_amdgcn_rcpf(ea[e]);
+                    if (ea[e] > 0) lo = fmaxf(lo, x);
+                    else if (ea[e] < 0) hi = fminf(hi, x);
+                    else none = none || v < 0;
+                }
+                if (none || !(lo <= hi + 0.5f)) continue;
+                // tiles whose samples [8 tx + 1/4, 8 tx + 7 3/4] reach into [lo, hi] (widened by half a pixel for the rounding of the reciprocal;
+                // a tile more on either side does no harm: visit() tests exactly)
+                const int tx0 = max(bb.x, (int)floorf((lo - 0.5f - (VIS_TILE - 0.25f)) * (1.0f / VIS_TILE))), tx1 = min(bb.y, (int)floorf((hi + 0.5f - 0.25f) * (1.0f / VIS_TILE)));
+                for (int tx = tx0; tx <= tx1; tx++) visit(r0, r1, r2, tx, row, i);
             }
-            if (none || !(lo <= hi + 0.02f)) continue;
-            // tiles whose samples [8 tx + 1/4, 8 tx + 7 3/4] reach into [lo, hi] (a tile more on either side does no harm: visit() tests exactly)
-            const int tx0 = max(bb.x, (int)floorf((lo - 0.01f - (VIS_TILE - 0.25f)) * (1.0f / VIS_TILE))), tx1 = min(bb.y, (int)floorf((hi + 0.01f - 0.25f) * (1.0f / VIS_TILE)));
-            for (int tx = tx0; tx <= tx1; tx++) visit(r0, r1, r2, tx, row, i);
         }
     }
 }
