@@ -445,6 +445,7 @@ int avsim_set_option(avsim_t* h, const char* name, double value) {
     if (!std::strcmp(name, "render_proxies")) { h->render_proxies = value != 0; return AVSIM_OK; }
     if (!std::strcmp(name, "render_samples")) { if (value != 1 && value != 4) { h->set_error("render_samples is 1 or 4"); return AVSIM_EINVAL; } h->vis.samples = (int)value; return AVSIM_OK; }
     if (!std::strcmp(name, "render_shadows")) { h->vis.shadows = value != 0; return AVSIM_OK; }
+    if (!std::strcmp(name, "render_chunk")) { if (value < 1) { h->set_error("render_chunk is a number of envs >= 1"); return AVSIM_EINVAL; } h->render.env_chunk = (int)value; return AVSIM_OK; }
     if (!std::strcmp(name, "diffik_iters")) { h->ik.diff_iters = (int)value; return AVSIM_OK; }
     if (!std::strcmp(name, "gradik_iters")) { h->ik.grad_iters = (int)value; return AVSIM_OK; }
     try {

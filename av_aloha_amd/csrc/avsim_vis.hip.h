@@ -4,15 +4,15 @@
 // as a software triangle rasteriser, one image per (env, camera).
 //
 // Scene = the model's instances of the decimated mesh library (compiler/vismesh.py: <= 20 k triangles per scene), expanded once on
-// the host into body-frame vertices and triangles.  One workgroup (4 wavefronts) per view, persistent over the views:
+// the host into body-frame vertices and triangles.  One workgroup (16 wavefronts, one per CU) per view, persistent over the views:
 //   1. camera-from-body transforms into LDS, every vertex into the camera frame (global scratch of the workgroup's slot);
 //   2. triangle set-up, one triangle per thread: clipped against the near plane (a camera sits inside its own mount), projected,
 //      its three edge functions and the plane of 1 / depth normalised into a 16-float record, flat Lambert shade (headlight +
 //      the scene's directional light, the terms of avsim_render.hip.h's proxy image) folded into an rgb8 colour;
-//   3. binning into 8 x 8 pixel tiles: count (LDS counters, tile-vs-edge test) -> prefix sum -> fill;
-//   4. one wavefront per tile, lane = pixel: the tile's records are wave-uniform loads, the depth test is on 1 / depth with the
-//      triangle index as tie-break (the image does not depend on the order of the lists); the winner's colour -- for the textured
-//      table the pixel ray is intersected with the triangle for perspective-correct texture coordinates -- or the sky gradient.
+//   3. binning into 8 x 8 pixel tiles: count (LDS counters, tile-vs-edge test) -> prefix sum -> fill; big triangles by tile rows (vis_bin);
+//   4. one wavefront per tile, lane = pixel: the tile's records are wave-uniform SCALAR loads, the depth test is on 1 / depth with the
+//      record index as tie-break (the image does not depend on the order of the lists); the winner's colour -- for the textured
+//      table through the triangle's texture-coordinate planes (set-up) -- or the sky gradient.
 // Back faces are culled.  Round 5, both optional (avsim_set_option "render_shadows", "render_samples"): SHADOWS of the scene's directional light
 // (scene.xml:48) from a depth map rendered from the light, one per env (k_vis_shadow: heights above the plane normal to the light over the
 // light's shadow box, 512 x 512 texels, atomicMax of ordered keys), looked up per sample; and 2 x 2 SUPERSAMPLING (MuJoCo's offscreen buffer

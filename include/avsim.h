@@ -160,7 +160,8 @@ int avsim_get_phase_cycles(avsim_t* h, int64_t* out);
  * renderer) by depth images (BASELINE config 5): out = float32[N][ncam][height][width], metres along the optical axis of
  * camera cam_ids[c] (index into the model's camera table, manifest "camera_names"; avsim_camera_count entries), row 0 = top,
  * pixels that see nothing = far plane (30 m).  Drawn are the collision proxies of the current state.  `out` is a host or a
- * device pointer according to AVSIM_IO_DEVICE; cam_ids is always a host pointer. */
+ * device pointer according to AVSIM_IO_DEVICE; cam_ids is always a host pointer.  Batches of more than 4096 envs (option "render_chunk")
+ * go through the kernels in chunks, so that the per-view scratch (~100 KB) is bounded by the chunk. */
 int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, float* out);
 
 /* The same cameras as colour images, the layout of the reference's "pixels" observation and of render()
