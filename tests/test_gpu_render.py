@@ -160,3 +160,24 @@ def test_rgb_and_depth_other_tasks(task):
         compare(dep[0, ci], rdep)
     sim.close()
     e.close()
+
+
+def test_chunked_batch_equals_one_pass():
+    """Option "render_chunk": a batch larger than the chunk goes through the kernels in several passes that share the chunk's scratch
+    (avsim_render.hip.h launch()); envs in different states, a chunk size that does not divide the batch, depth and proxy colour."""
+    from av_aloha_amd.sim import BatchedSim
+    N = 7
+    md = model_dict()
+    sim = BatchedSim("slot_insertion", 3, N)
+    sim.reset(np.repeat(OBJ[None], N, 0))
+    rng = np.random.default_rng(5)
+    acts = np.repeat(actions_wiggle(md, 1)[0][None], N, 0) + 0.05 * rng.standard_normal((N, 21))
+    for _ in range(3):
+        sim.step(acts)
+    ref = sim.render_depth(CAMS[:3], 45, 75)
+    ref_rgb = sim.render_rgb(CAMS[:2], 45, 75, visual=False)
+    assert not np.array_equal(ref[0], ref[1])
+    sim.set_option("render_chunk", 3)
+    assert np.array_equal(sim.render_depth(CAMS[:3], 45, 75), ref)
+    assert np.array_equal(sim.render_rgb(CAMS[:2], 45, 75, visual=False), ref_rgb)
+    sim.close()
