@@ -559,13 +559,12 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                 test(R0, i0); test(R1, i1); test(R2, i2); test(R3, i3);
             }
             if (ix < W && iy < H) {
-                float accr = 0.0f, accg = 0.0f, accb = 0.0f;
-                unsigned col = 0;
-#pragma unroll
-                for (int q = 0; q < NS; q++) {
+                // the colour of sample q: its record's, in the light's shadow without the light's term, from the texture, or the sky's
+                auto shade = [&](int q) -> unsigned {
                     const float ox = NS == 1 ? 0.0f : ((q & 1) ? 0.25f : -0.25f), oy = NS == 1 ? 0.0f : ((q & 2) ? 0.25f : -0.25f);
                     const float sx = fx + ox, sy = fy + oy;
                     const float dx = (sx - 0.5f * W) * scale, dy = -(sy - 0.5f * H) * scale;
+                    unsigned col;
                     if (bi[q] != 0x7fffffff) {
                         const float4 r3 = rec[4u * (unsigned)bi[q] + 3u];      // colour, triangle or texture slot, colour without the light's term, shadow bias
                         col = __float_as_uint(r3.x);
@@ -598,9 +597,31 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                         const float w = 0.5f + 0.5f * (cam[15] * dx + cam[16] * dy - cam[17]) * idn;
                         col = vis_pack(S.light[12] + (S.light[8] - S.light[12]) * w, S.light[13] + (S.light[9] - S.light[13]) * w, S.light[14] + (S.light[10] - S.light[14]) * w);
                     }
-                    accr += (float)(col & 255u); accg += (float)((col >> 8) & 255u); accb += (float)((col >> 16) & 255u);
+                    return col;
+                };
+                unsigned col;
+                if (NS == 1) col = shade(0);
+                else {
+                    // A fragment -- the samples of a pixel that one triangle wins, or that see the sky -- is shaded ONCE, at its first sample,
+                    // as a multisampled GL buffer does [EXT]; the pixel is the mean of its four samples' colours.  Pixels inside one triangle
+                    // (most of them) cost one shading, not four; a wave whose pixels all do skips the other three altogether.
+                    unsigned c[NS];
+                    c[0] = shade(0);
+#pragma unroll
+                    for (int q = 1; q < NS; q++) {
+                        bool need = true;
+                        unsigned cq = 0;
+#pragma unroll
+                        for (int p2 = q - 1; p2 >= 0; p2--)
+                            if (bi[q] == bi[p2]) { cq = c[p2]; need = false; }
+                        if (need) cq = shade(q);
+                        c[q] = cq;
+                    }
+                    float accr = 0.0f, accg = 0.0f, accb = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < NS; q++) { accr += (float)(c[q] & 255u); accg += (float)((c[q] >> 8) & 255u); accb += (float)((c[q] >> 16) & 255u); }
+                    col = (unsigned)(accr * (1.0f / NS) + 0.5f) | ((unsigned)(accg * (1.0f / NS) + 0.5f) << 8) | ((unsigned)(accb * (1.0f / NS) + 0.5f) << 16);
                 }
-                if (NS > 1) col = (unsigned)(accr * (1.0f / NS) + 0.5f) | ((unsigned)(accg * (1.0f / NS) + 0.5f) << 8) | ((unsigned)(accb * (1.0f / NS) + 0.5f) << 16);
                 unsigned char* d = img + (unsigned)((iy * W + ix) * 3);
                 d[0] = (unsigned char)(col & 255u); d[1] = (unsigned char)((col >> 8) & 255u); d[2] = (unsigned char)((col >> 16) & 255u);
             }

@@ -33,8 +33,9 @@ static void light_frame(const double* lw, double* e1, double* e2) {
 }
 
 /* out u8[H][W][3]; tri_out (optional) int[H][W]: index of the triangle seen, -1 for the sky; depth_out (optional) double[H][W].
- * orc_vis_render_ex: ss = 1 | 2 samples per pixel and axis (2: the four samples at +-1/4 pixel of the centre are shaded and averaged --
- * MuJoCo's offscreen buffer is multisampled, <quality offsamples> default 4 [EXT]); shadows != 0: a surface point that faces the scene's
+ * orc_vis_render_ex: ss = 1 | 2 samples per pixel and axis (2: the four samples at +-1/4 pixel of the centre are resolved and averaged; the
+ * samples of a pixel that see the same triangle share the colour of the first of them -- MuJoCo's offscreen buffer is multisampled,
+ * <quality offsamples> default 4 [EXT]); shadows != 0: a surface point that faces the scene's
  * directional light (scene.xml:48, castshadow default true [EXT]) and lies inside the light's shadow box (centre and half extent from
  * <statistic center extent>, scene.xml:6: render_light[7], [11], [15] and [3]) loses the light's diffuse term when another triangle lies
  * between it and the light -- one exact ray per sample where the device looks up a depth map rendered from the light.  tri_out /
@@ -87,6 +88,8 @@ int orc_vis_render_ex(const orc_data* d, int cam, int nvert, const double* vert,
     for (int i = 0; i < H; i++)
         for (int j = 0; j < W; j++) {
             double acc[3] = {0, 0, 0};
+            int sid[4] = {-2, -2, -2, -2};            /* what the samples shaded so far saw (-1: the sky) and their quantised colours */
+            double scol[4][3];
             for (int smp = -1; smp < ns; smp++) {
                 /* smp = -1: the pixel centre (tri_out / depth_out; the colour too when ss = 1); 0 .. 3: the samples at +-1/4 pixel */
                 if ((ss == 1) != (smp == -1)) { if (!(smp == -1 && (tri_out || depth_out))) continue; }
@@ -117,6 +120,16 @@ int orc_vis_render_ex(const orc_data* d, int cam, int nvert, const double* vert,
                     if (ss != 1) continue;
                 }
                 double col[3];
+                /* a fragment -- the samples of the pixel that one triangle wins, or that see the sky -- is shaded once, at its first sample, as a
+                 * multisampled GL buffer does [EXT]: a later sample of the same fragment takes that colour */
+                int prev = -1;
+                for (int s2 = 0; s2 < smp; s2++)
+                    if (sid[s2] == bt && prev < 0) prev = s2;
+                if (smp >= 0 && prev >= 0) {
+                    sid[smp] = bt;
+                    for (int k = 0; k < 3; k++) { scol[smp][k] = scol[prev][k]; acc[k] += scol[prev][k]; }
+                    continue;
+                }
                 if (bt >= 0) {
                     const double *a = vc + 3 * tri[3 * bt], *bb = vc + 3 * tri[3 * bt + 1], *c = vc + 3 * tri[3 * bt + 2];
                     double n[3] = {(bb[1] - a[1]) * (c[2] - a[2]) - (bb[2] - a[2]) * (c[1] - a[1]), (bb[2] - a[2]) * (c[0] - a[0]) - (bb[0] - a[0]) * (c[2] - a[2]),
@@ -169,7 +182,12 @@ int orc_vis_render_ex(const orc_data* d, int cam, int nvert, const double* vert,
                     for (int k = 0; k < 3; k++) col[k] = L[12 + k] + (L[8 + k] - L[12 + k]) * w;
                 }
                 /* (the device shades a triangle once, in rgb8, and averages those: quantise before averaging) */
-                for (int k = 0; k < 3; k++) acc[k] += (double)vq8(col[k]);
+                for (int k = 0; k < 3; k++) {
+                    const double qv = (double)vq8(col[k]);
+                    acc[k] += qv;
+                    if (smp >= 0) scol[smp][k] = qv;
+                }
+                if (smp >= 0) sid[smp] = bt;
             }
             for (int k = 0; k < 3; k++) out[((size_t)i * W + j) * 3 + k] = (unsigned char)(acc[k] / (ss == 1 ? 1 : ns) + 0.5);
         }
