@@ -347,20 +347,17 @@ def side_run(args, torch, cfg_id, N, local, f64, warmup, steps, render=""):
 def launch_ranks(n, share_gpu):
     """Re-run this command line as n ranks of one node through torch.distributed.run (rendezvous on 127.0.0.1, a free port), the
     form the driver itself uses for N > 1.  Fails loudly when the node has fewer GPUs than ranks (unless --share-gpu)."""
-    import socket
     import subprocess
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if have < n and not share_gpu:
         print(f"bench.py: --gpus {n} needs {n} GPUs on this node, {have} visible (--share-gpu runs every rank on cuda:0: a testing aid, not a measurement)", file=sys.stderr)
         return 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # --standalone: torch.distributed.run's own rendezvous store on a free port of 127.0.0.1 (no port picked here and raced for)
+    env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}",
            os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
