@@ -5,17 +5,46 @@
 namespace avs {
 
 #define AVS_DEV __device__ __forceinline__
-// Out-of-line device functions.  Internal linkage: the compiler then knows every call site, the callee saves no callee-saved VGPRs in its
-// prologue (30-46 dwords per lane through the wave's private segment per call otherwise) and the callers see its exact clobber set.
-#ifndef AVS_OUTLINE_MODE
-#define AVS_OUTLINE_MODE 2
+// Out-of-line device functions.  Without -fgpu-rdc every device function is internalised, so the compiler knows every call site; a callee whose
+// calls are not marked `tail` then saves no callee-saved VGPRs in its prologue (30-46 dwords per lane through the wave's private segment per call
+// otherwise) and its callers spill what THEY keep across the call instead.  TailCallElim marks every call that passes no pointer to a caller's
+// alloca; `not_tail_called` keeps a function out of that.  Which way is faster differs per function (profiles/r05_experiments.txt section 7): the
+// mask selects the functions that get the attribute -- bit 0 multi_perturb, 1 noslip_trees / noslip_trees2, 2 pgs_groups, 3 qcqp_slide_octet,
+// 4 ndense_chol, 5 newton_solve_coupled.
+#ifndef AVS_NTC_MASK
+#define AVS_NTC_MASK 6       // noslip_trees / noslip_trees2 and pgs_groups: + 1.5 % on every configuration, 3.09 -> 2.06 GB of L2 <-> fabric traffic per launch
 #endif
-#if AVS_OUTLINE_MODE == 2
-#define AVS_OUTLINE __attribute__((noinline, internal_linkage, not_tail_called))
-#elif AVS_OUTLINE_MODE == 1
-#define AVS_OUTLINE __attribute__((noinline, internal_linkage))
-#else
 #define AVS_OUTLINE __attribute__((noinline))
+#define AVS_OUTLINE_NTC __attribute__((noinline, not_tail_called))
+#if (AVS_NTC_MASK) & 1
+#define AVS_OUTLINE_0 AVS_OUTLINE_NTC
+#else
+#define AVS_OUTLINE_0 AVS_OUTLINE
+#endif
+#if (AVS_NTC_MASK) & 2
+#define AVS_OUTLINE_1 AVS_OUTLINE_NTC
+#else
+#define AVS_OUTLINE_1 AVS_OUTLINE
+#endif
+#if (AVS_NTC_MASK) & 4
+#define AVS_OUTLINE_2 AVS_OUTLINE_NTC
+#else
+#define AVS_OUTLINE_2 AVS_OUTLINE
+#endif
+#if (AVS_NTC_MASK) & 8
+#define AVS_OUTLINE_3 AVS_OUTLINE_NTC
+#else
+#define AVS_OUTLINE_3 AVS_OUTLINE
+#endif
+#if (AVS_NTC_MASK) & 16
+#define AVS_OUTLINE_4 AVS_OUTLINE_NTC
+#else
+#define AVS_OUTLINE_4 AVS_OUTLINE
+#endif
+#if (AVS_NTC_MASK) & 32
+#define AVS_OUTLINE_5 AVS_OUTLINE_NTC
+#else
+#define AVS_OUTLINE_5 AVS_OUTLINE
 #endif
 #ifndef GLB_PTR
 #define GLB_PTR(T) __attribute__((address_space(1))) T*   // global memory, so that loads are global_load, not flat_load

@@ -556,7 +556,7 @@ AVS_DEV void nblock_solve(const NewtonArgs<real>& A, int lane) {
 // holds, and the entries between the component and the other trees are zeros that stay zeros -- the same L and y, entry for entry,
 // as the factorisation over all nv columns.
 template <typename real>
-__device__ AVS_OUTLINE void ndense_chol(LDS_PTR(real) H_, int nv_, int mydof, int nc_, int oa0, int on, bool oact) {
+__device__ AVS_OUTLINE_4 void ndense_chol(LDS_PTR(real) H_, int nv_, int mydof, int nc_, int oa0, int on, bool oact) {
     const int lane = threadIdx.x & 63;
     LDS_PTR(real) H = uni_lds(H_);
     const int nv = __builtin_amdgcn_readfirstlane(nv_), nc = __builtin_amdgcn_readfirstlane(nc_);
@@ -1043,7 +1043,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
 // The coupled instances as functions of their own: what they keep in registers (the component, the batched Hessian rows) then
 // does not weigh on the register allocation of Env::solve, where the uncoupled instance of the headline scene is inlined.
 template <typename real, int NCH>
-__device__ AVS_OUTLINE int newton_solve_coupled(KPtr<real> ka, GLB_PTR(const real) rows, LDS_PTR(real) r_, LDS_PTR(int) ii_, LDS_PTR(const int) li_, int nefc, int ncon, int nlead,
+__device__ AVS_OUTLINE_5 int newton_solve_coupled(KPtr<real> ka, GLB_PTR(const real) rows, LDS_PTR(real) r_, LDS_PTR(int) ii_, LDS_PTR(const int) li_, int nefc, int ncon, int nlead,
                                                               int iters, real tol, real scale, int profiling) {
     return newton_solve<real, NCH, true>(ka, rows, r_, ii_, li_, nefc, ncon, nlead, iters, tol, scale, profiling);
 }

@@ -456,7 +456,7 @@ template <typename T> AVS_DEV T secular_step(T val, T r2, T r, T yw) {
 }
 
 template <typename real>
-__device__ AVS_OUTLINE void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
+__device__ AVS_OUTLINE_2 void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
                                                      LDS_PTR(real) q, LDS_PTR(const int) gI, GLB_PTR(const real) gA, int ngrp, int iters,
                                                      int noslip_iters, real noslip_tol_scaled, NL_PARAMS) {
     NL_UNPACK(real);
@@ -964,7 +964,7 @@ __device__ AVS_OUTLINE void pgs_groups(LDS_PTR(real) rowS, LDS_PTR(const int) ro
 // scaled block, as in pgs_groups (same operations in the same order), the block gathered by octet broadcasts instead of wave-wide
 // ones; redundantly on the eight lanes of the octet.  Returns the new force of this lane's row (lanes 1..n), *change = the cost change.
 template <typename real>
-__device__ AVS_OUTLINE real qcqp_slide_octet(GLB_PTR(const real) gA, int g, int n, int fi, real res_r, real f0, real muinv, real invn, real qc5, real fn,
+__device__ AVS_OUTLINE_3 real qcqp_slide_octet(GLB_PTR(const real) gA, int g, int n, int fi, real res_r, real f0, real muinv, real invn, real qc5, real fn,
                                                           int tridiag, real* change_out) {
     struct { int tridiag; } nl{tridiag};
     struct { real f0, muinv, invn; real qc[GA_QW]; int g; } cur;
@@ -1129,7 +1129,7 @@ __device__ AVS_OUTLINE real qcqp_slide_octet(GLB_PTR(const real) gA, int g, int 
 // Returns 1 when the pass is done, 0 for "use pgs_groups" (two-tree contact, more than 64 contacts, sliding contact, odd layout).
 // ------------------------------------------------------------------------------------------------
 template <typename real>
-__device__ AVS_OUTLINE int noslip_trees(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const int) cefc, GLB_PTR(const real) rJ,
+__device__ AVS_OUTLINE_1 int noslip_trees(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const int) cefc, GLB_PTR(const real) rJ,
                                                       LDS_PTR(real) q, LDS_PTR(const int) gI, GLB_PTR(const real) gA, int ncon, int nefc, int noslip_iters,
                                                       real noslip_tol_scaled, NL_PARAMS) {
     NL_UNPACK(real);
@@ -1364,7 +1364,7 @@ __device__ AVS_OUTLINE int noslip_trees(LDS_PTR(real) rowS, LDS_PTR(const int) r
 // contraction out of the sums).  A function of its own, entered when noslip_trees returns 2: with the two-tree bookkeeping in
 // noslip_trees the headline workload, which has no such contact, lost 1.6 %; this way 0.3 %.
 template <typename real>
-__device__ AVS_OUTLINE int noslip_trees2(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const int) cefc, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
+__device__ AVS_OUTLINE_1 int noslip_trees2(LDS_PTR(real) rowS, LDS_PTR(const int) rowI, LDS_PTR(const int) cefc, GLB_PTR(const real) rJ, GLB_PTR(const real) rB,
                                                       LDS_PTR(real) q, LDS_PTR(const int) gI, GLB_PTR(const real) gA, int ncon, int nefc, int noslip_iters,
                                                       real noslip_tol_scaled, NL_PARAMS) {
     NL_UNPACK(real);
@@ -2375,7 +2375,7 @@ struct Env {
     // entry 1 + pert of that slot (1e30: none).  Out of line with register arguments only: the MPR code
     // is 27 KB, and as a call of mpr_perturbed itself the two Shapes went through the wave's private segment -- 79 dwords per lane,
     // 20 KB written and read back per narrow-phase pass, most of the kernel's spill traffic (profiles/r05_experiments.txt section 7).
-    __device__ AVS_OUTLINE static void multi_perturb(KPtr<real> ka_, real* r_, int* i_, int lane_, int grp_, const real* lr_, const int* li_, int env_,
+    __device__ AVS_OUTLINE_0 static void multi_perturb(KPtr<real> ka_, real* r_, int* i_, int lane_, int grp_, const real* lr_, const int* li_, int env_,
                                                                    int pga, int pgb, int src, int pert) {
         Env e(ka_, r_, i_, lane_, grp_, lr_, li_);       // (an Env by value is an aggregate of 22 dwords: passed in memory)
         e.env = env_;
