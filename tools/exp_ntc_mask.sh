@@ -1,4 +1,5 @@
 #!/bin/bash
+# not_tail_called per out-of-line function (avsim_math.hip.h AVS_NTC_MASK): builds on the box, same-box comparison
 cd $GRAFT_REPO_ROOT
 b() { python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras $@ 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(round(d['value']), end=' ')"; }
 for rep in 1 2; do
