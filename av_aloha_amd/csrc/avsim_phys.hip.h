@@ -2607,6 +2607,19 @@ struct Env {
     }
 
     // ---- P4 ------------------------------------------------------------------------------------
+#ifndef AVS_NO_SPLIT_PRE
+    // the four smooth-dynamics phases and the integration step as out-of-line functions of their own (a register allocation each; measured on one
+    // box against the same phases inlined into the kernel's substep loop: config 3 367 -> 375 k env-steps/s, configs 2 / 4 and f64 unchanged)
+    __device__ AVS_OUTLINE void pre_phases() {
+        Env e(*this);
+        e.kinematics(); e.crb(); e.rne_bias(); e.smooth();
+    }
+    __device__ AVS_OUTLINE void post_phases() {
+        Env e(*this);
+        e.euler(); e.check_divergence();
+        diverged = e.diverged;
+    }
+#endif
     // out of line, on a copy of the object: the members then live in registers (a callee reached through `this` reloads them
     // from memory after every store, and the kernel-argument pointer with them: vector loads instead of s_load)
     __device__ AVS_OUTLINE void make_constraints() {
@@ -3395,6 +3408,9 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
     for (int s = 0; s < nsub; s++) {
         // E is reached through `this` by the out-of-line phases, so it lives in scratch memory; the phases inlined here run on a
         // copy that never has its address taken (registers, and dead again before the calls: nothing extra to save around them)
+#ifndef AVS_NO_SPLIT_PRE
+        PROF(0, E.pre_phases());
+#else
         {
             Env<real, G> e(E);
             PROF(0, e.kinematics());
@@ -3402,16 +3418,21 @@ __global__ void __launch_bounds__(64 * MAXW) AVSIM_PHYS_ATTR k_phys(KPtr<real> k
             PROF(2, e.rne_bias());
             PROF(3, e.smooth());
         }
+#endif
         PROF(4, E.collide());
         PROF(5, E.make_constraints());
         if (RETRY) beyond = beyond || ii[ka->lay.misc + 0] > cap1_con || ii[ka->lay.misc + 1] > cap1_efc;
         PROF(6, E.solve(pgs_iters, ka->m.solver, ka->m.newton_iters, ka->m.newton_tol, ka->m.nscale));
+#ifndef AVS_NO_SPLIT_PRE
+        PROF(7, E.post_phases());
+#else
         {
             Env<real, G> e(E);
             PROF(7, e.euler());
             e.check_divergence();
             E.diverged = e.diverged;
         }
+#endif
     }
     if (o_prof && lane == 0) {
         for (int k = 0; k < 8; k++) o_prof[(size_t)env * PROF_W + k] = tp[k];

@@ -30,6 +30,9 @@ sim.h.check(sim.h.L.avsim_get_phase_cycles(sim.h.h, out.ctypes.data))
 names = ["kinematics", "crb", "rne", "smooth", "collide", "rows", "solve", "euler"]
 print("broad/narrow per collide call:", out[:, 8].mean() / 21, out[:, 9].mean() / 21)
 m = out[:, :8].mean(0) / 20
+if m[1] == 0 and m[2] == 0:      # the default build runs kinematics .. smooth as ONE out-of-line function (AVS_NO_SPLIT_PRE builds them apart)
+    names[0] = "kin..smooth"
+    print("(kinematics, CRB, RNE and the smooth forces are one out-of-line function in this build: their sum is in the first line; build with AVSIM_EXTRA_FLAGS=-DAVS_NO_SPLIT_PRE for the four)")
 print("cycles per substep per wave (mean over envs):")
 for n, v in zip(names, m):
     print(f"  {n:10s} {v:10.0f}  {100 * v / m.sum():5.1f}%")
