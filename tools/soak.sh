@@ -1,8 +1,8 @@
 #!/bin/bash
-# Soak / size checks on one MI355X (round 4): ten whole episodes of config 2 with their auto-resets, config 4 at the 8-GPU job's TOTAL env count
-# on one GPU (32768 envs), config 3 over four scripted episodes, the depth images at 16384 views -> profiles/r04_soak.txt
+# Soak / size checks on one MI355X (rounds 4, 5): ten whole episodes of config 2 with their auto-resets, config 4 at the 8-GPU job's TOTAL env count
+# on one GPU (32768 envs), config 3 over four scripted episodes, the depth images at 16384 views -> profiles/r0N_soak.txt
 cd $GRAFT_REPO_ROOT
-o=gpurun_out/r4; mkdir -p $o
+o=gpurun_out/${SOAK_TAG:-r5}; mkdir -p $o
 pick() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']; print('value', round(d['value']), 'ms/step', round(d['ms_per_step'],3), 'envs', c['envs_total'], 'steps', d['steps'], 'resets', c['resets_in_timed_region'], 'nan_envs', c['nan_envs'], 'overflow_envs', c['overflow_envs'], 'mean_return', round(c['mean_return'],3), 'success_rate', c['success_rate'])"; }
 {
 echo "config 2, 3000 steps (ten 300-step episodes, auto-reset): $(python bench.py --steps 3000 --warmup 0 --no-extras --no-cpu-baseline 2>/dev/null | pick)"
