@@ -125,6 +125,7 @@ __device__ inline void vis_sload16x4(const void* p0, const void* p1, const void*
 // the twelve words of four records that the tile loop reads (three edge functions and the plane of 1 / depth; words 12-15 -- colours, bias --
 // are fetched for the winner only): 48 SGPRs instead of 64 per batch, which the kernel's other wave-uniform values no longer spill around
 typedef int vis_v8i __attribute__((ext_vector_type(8)));
+typedef float vis_f2 __attribute__((ext_vector_type(2)));
 struct VisRec12 { vis_v8i a; vis_v4i b; };
 __device__ inline void vis_sload12x4(const void* p0, const void* p1, const void* p2, const void* p3, VisRec12& r0, VisRec12& r1, VisRec12& r2, VisRec12& r3) {
     asm volatile("s_load_dwordx8 %0, %8, 0x0\n\ts_load_dwordx4 %1, %8, 0x20\n\ts_load_dwordx8 %2, %9, 0x0\n\ts_load_dwordx4 %3, %9, 0x20\n\t"
@@ -206,14 +207,18 @@ __device__ inline void vis_bin(const float4* __restrict__ rec, const int* __rest
 
 // Shadow map of one env per workgroup: every triangle of the scene, in the light's frame (s, t across, h towards the light), rasterised over
 // the texel centres it covers with atomicMax of its height's ordered key.  Small triangles by their own thread; a triangle whose box holds
-// more than 64 texels (the table top covers the whole map) goes to an LDS queue that the workgroup then works through together.
+// more than 64 texels goes to an LDS queue that the workgroup empties whenever it could overflow -- one queued triangle per wavefront, its
+// box's texels over the lanes.  (Round 5's first version took queue overflow to the triangle's own thread: the slot-insertion scene has
+// 2 746 such triangles, 2.0 of its 2.35 M texel tests, for 1 024 slots, and single lanes walked boxes of 42 496 texels: 27.9 ms per 1 024
+// envs where this takes ~2.)
+constexpr int VIS_SHQ = 1024;
 __global__ void __launch_bounds__(VIS_SHADOW_THREADS) k_vis_shadow(VisScene S, const float* __restrict__ xpose, unsigned* __restrict__ shmap, int N) {
-    __shared__ float Q[1024 * 9];
+    __shared__ float Q[VIS_SHQ * 9];
     __shared__ int nq;
-    const int env = blockIdx.x, tid = threadIdx.x;
+    const int env = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (env >= N) return;
     unsigned* map = shmap + (size_t)env * VIS_SM * VIS_SM;
-    for (int i = tid; i < VIS_SM * VIS_SM; i += VIS_SHADOW_THREADS) map[i] = 0u;
+    for (int i = tid; i < VIS_SM * VIS_SM / 4; i += VIS_SHADOW_THREADS) ((uint4*)map)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) nq = 0;
     __threadfence_block();
     __syncthreads();
@@ -227,34 +232,46 @@ __global__ void __launch_bounds__(VIS_SHADOW_THREADS) k_vis_shadow(VisScene S, c
         const int iy0 = max(0, (int)ceilf(fminf(y0, fminf(y1, y2)) - 0.5f)), iy1 = min(VIS_SM - 1, (int)floorf(fmaxf(y0, fmaxf(y1, y2)) - 0.5f));
         if (ix0 > ix1 || iy0 > iy1) return;
         const int bw = ix1 - ix0 + 1, n = bw * (iy1 - iy0 + 1);
+        // barycentrics and the height as functions affine in the texel centre
+        const float a0 = (y1 - y2) * ia, b0 = (x2 - x1) * ia, c0 = (x1 * y2 - x2 * y1) * ia;
+        const float a1 = (y2 - y0) * ia, b1 = (x0 - x2) * ia, c1 = (x2 * y0 - x0 * y2) * ia;
+        const float h0 = P[2], h1 = P[5], h2 = P[8];
+        const float ibw = 1.0f / (float)bw;
         for (int k = first; k < n; k += stride) {
-            const int ix = ix0 + k % bw, iy = iy0 + k / bw;
-            const float fx = ix + 0.5f, fy = iy + 0.5f;
-            const float l0 = ((x1 - fx) * (y2 - fy) - (x2 - fx) * (y1 - fy)) * ia, l1 = ((x2 - fx) * (y0 - fy) - (x0 - fx) * (y2 - fy)) * ia, l2 = 1.0f - l0 - l1;
-            if (l0 >= 0 && l1 >= 0 && l2 >= 0) atomicMax(&map[iy * VIS_SM + ix], vis_hkey(l0 * P[2] + l1 * P[5] + l2 * P[8]));
+            const int ry = (int)(((float)k + 0.5f) * ibw), rx = k - ry * bw;      // (k / bw, k % bw: exact for the boxes of a 512 x 512 map)
+            const float fx = (float)(ix0 + rx) + 0.5f, fy = (float)(iy0 + ry) + 0.5f;
+            const float l0 = a0 * fx + (b0 * fy + c0), l1 = a1 * fx + (b1 * fy + c1), l2 = 1.0f - l0 - l1;
+            if (fminf(fminf(l0, l1), l2) >= 0.0f) atomicMax(&map[(iy0 + ry) * VIS_SM + ix0 + rx], vis_hkey(l0 * h0 + l1 * h1 + l2 * h2));
         }
     };
-    for (int t = tid; t < S.ntri; t += VIS_SHADOW_THREADS) {
-        float P[9];
-        for (int c = 0; c < 3; c++) {
-            const int v = S.tri[3 * t + c];
-            const float *pb = xb + 12 * S.vbody[v], *Rb = pb + 3;
-            const float x = S.vert[3 * v], y = S.vert[3 * v + 1], z = S.vert[3 * v + 2];
-            const float w[3] = {Rb[0] * x + Rb[1] * y + Rb[2] * z + pb[0], Rb[3] * x + Rb[4] * y + Rb[5] * z + pb[1], Rb[6] * x + Rb[7] * y + Rb[8] * z + pb[2]};
-            P[3 * c] = (w[0] * S.le1[0] + w[1] * S.le1[1] + w[2] * S.le1[2] - S.sh_s0) * S.sh_itex;
-            P[3 * c + 1] = (w[0] * S.le2[0] + w[1] * S.le2[1] + w[2] * S.le2[2] - S.sh_t0) * S.sh_itex;
-            P[3 * c + 2] = -(w[0] * S.lw[0] + w[1] * S.lw[1] + w[2] * S.lw[2]);
+    for (int t0 = 0; t0 < S.ntri; t0 += VIS_SHADOW_THREADS) {
+        const int t = t0 + tid;
+        if (t < S.ntri) {
+            float P[9];
+            for (int c = 0; c < 3; c++) {
+                const int v = S.tri[3 * t + c];
+                const float *pb = xb + 12 * S.vbody[v], *Rb = pb + 3;
+                const float x = S.vert[3 * v], y = S.vert[3 * v + 1], z = S.vert[3 * v + 2];
+                const float w[3] = {Rb[0] * x + Rb[1] * y + Rb[2] * z + pb[0], Rb[3] * x + Rb[4] * y + Rb[5] * z + pb[1], Rb[6] * x + Rb[7] * y + Rb[8] * z + pb[2]};
+                P[3 * c] = (w[0] * S.le1[0] + w[1] * S.le1[1] + w[2] * S.le1[2] - S.sh_s0) * S.sh_itex;
+                P[3 * c + 1] = (w[0] * S.le2[0] + w[1] * S.le2[1] + w[2] * S.le2[2] - S.sh_t0) * S.sh_itex;
+                P[3 * c + 2] = -(w[0] * S.lw[0] + w[1] * S.lw[1] + w[2] * S.lw[2]);
+            }
+            const float bx = fmaxf(P[0], fmaxf(P[3], P[6])) - fminf(P[0], fminf(P[3], P[6])), by = fmaxf(P[1], fmaxf(P[4], P[7])) - fminf(P[1], fminf(P[4], P[7]));
+            if ((bx + 1.0f) * (by + 1.0f) > 64.0f) {
+                const int slot = atomicAdd(&nq, 1);          // (< VIS_SHQ: the queue is emptied while a pass of the workgroup still fits)
+                for (int c = 0; c < 9; c++) Q[9 * slot + c] = P[c];
+            } else raster(P, 0, 1);
         }
-        const float bx = fmaxf(P[0], fmaxf(P[3], P[6])) - fminf(P[0], fminf(P[3], P[6])), by = fmaxf(P[1], fmaxf(P[4], P[7])) - fminf(P[1], fminf(P[4], P[7]));
-        const bool big = (bx + 1.0f) * (by + 1.0f) > 64.0f;
-        int slot = -1;
-        if (big) { slot = atomicAdd(&nq, 1); if (slot >= 1024) slot = -1; }
-        if (slot >= 0) { for (int c = 0; c < 9; c++) Q[9 * slot + c] = P[c]; }
-        else raster(P, 0, 1);            // a small triangle, or the queue is full
+        __syncthreads();
+        const int n = nq;
+        if (n > VIS_SHQ - VIS_SHADOW_THREADS || t0 + VIS_SHADOW_THREADS >= S.ntri) {      // (the same for every thread)
+            for (int q = wave; q < n; q += VIS_SHADOW_THREADS / 64) raster(Q + 9 * q, lane, 64);
+            __syncthreads();
+            if (tid == 0) nq = 0;
+            __syncthreads();
+        }
     }
-    __syncthreads();
-    const int n = nq < 1024 ? nq : 1024;
-    for (int q = 0; q < n; q++) raster(Q + 9 * q, tid, VIS_SHADOW_THREADS);
 }
 
 #ifdef VIS_NO_OCC4
@@ -499,6 +516,8 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
         for (int tile = wave; tile < ntile; tile += VIS_THREADS / 64) {
             const int ix = tx * VIS_TILE + (lane & 7), iy = ty * VIS_TILE + (lane >> 3);
             const float fx = (float)(tx * VIS_TILE) + lxf, fy = (float)(ty * VIS_TILE) + lyf;
+            const vis_f2 xs2 = {fx - 0.25f, fx + 0.25f};          // (supersampling: the two sample columns, the two sample rows)
+            const float ysm = fy - 0.25f, ysp = fy + 0.25f;
             tx += VIS_THREADS / 64;
             while (tx >= tw) { tx -= tw; ty++; }
             const int e0 = __builtin_amdgcn_readfirstlane(toff[tile]), e1 = __builtin_amdgcn_readfirstlane(min(toff[tile + 1], X.listcap));
@@ -535,19 +554,25 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                         const bool better = in & ((wc > bw[0]) | ((wc == bw[0]) & (i < bi[0])));
                         bw[0] = better ? wc : bw[0]; bi[0] = better ? i : bi[0];
                     } else {
-                        // the four samples sit at (-+1/4, -+1/4) off the centre: a plane a x + b y + c there is its centre value -+ (a + b) / 4 and
-                        // -+ (a - b) / 4 -- two wave-uniform terms per plane, one fma per plane and sample
-                        const float ws = __int_as_float(R.b[1]) + __int_as_float(R.b[2]), wd = __int_as_float(R.b[1]) - __int_as_float(R.b[2]);
-                        const float w[4] = {wc - 0.25f * ws, wc + 0.25f * wd, wc - 0.25f * wd, wc + 0.25f * ws};
+                        // the four samples sit at (-+1/4, -+1/4) off the centre: a plane a x + b y + c is taken at the two sample columns at once
+                        // (v_pk_fma_f32: the x pair of the tile against the plane's value at x = 0 on the upper and on the lower sample row) --
+                        // two scalar and two packed fma per plane for the four samples
+                        auto p4 = [&](float pa, float pb, float pc, float* o) {
+                            const float tm = pb * ysm + pc, tp = pb * ysp + pc;
+                            const vis_f2 va = {pa, pa};
+                            const vis_f2 lo = __builtin_elementwise_fma(va, xs2, (vis_f2){tm, tm}), hi = __builtin_elementwise_fma(va, xs2, (vis_f2){tp, tp});
+                            o[0] = lo.x; o[1] = lo.y; o[2] = hi.x; o[3] = hi.y;
+                        };
+                        float w[4];
+                        p4(__int_as_float(R.b[1]), __int_as_float(R.b[2]), __int_as_float(R.b[3]), w);
                         float m[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                         if (edges) {
-                            const float s0 = __int_as_float(R.a[0]) + __int_as_float(R.a[1]), d0 = __int_as_float(R.a[0]) - __int_as_float(R.a[1]);
-                            const float s1 = __int_as_float(R.a[3]) + __int_as_float(R.a[4]), d1 = __int_as_float(R.a[3]) - __int_as_float(R.a[4]);
-                            const float s2 = __int_as_float(R.a[6]) + __int_as_float(R.a[7]), d2 = __int_as_float(R.a[6]) - __int_as_float(R.a[7]);
-                            m[0] = fminf(fminf(l0c - 0.25f * s0, l1c - 0.25f * s1), l2c - 0.25f * s2);
-                            m[1] = fminf(fminf(l0c + 0.25f * d0, l1c + 0.25f * d1), l2c + 0.25f * d2);
-                            m[2] = fminf(fminf(l0c - 0.25f * d0, l1c - 0.25f * d1), l2c - 0.25f * d2);
-                            m[3] = fminf(fminf(l0c + 0.25f * s0, l1c + 0.25f * s1), l2c + 0.25f * s2);
+                            float e0[4], e1[4], e2[4];
+                            p4(__int_as_float(R.a[0]), __int_as_float(R.a[1]), __int_as_float(R.a[2]), e0);
+                            p4(__int_as_float(R.a[3]), __int_as_float(R.a[4]), __int_as_float(R.a[5]), e1);
+                            p4(__int_as_float(R.a[6]), __int_as_float(R.a[7]), __int_as_float(R.b[0]), e2);
+#pragma unroll
+                            for (int q = 0; q < 4; q++) m[q] = fminf(fminf(e0[q], e1[q]), e2[q]);
                         }
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
