@@ -38,7 +38,7 @@ namespace avs {
 // than four views of four: a view in flight holds ~0.5 MB of records, lists and camera-frame vertices next to its 0.9 MB image, and 4 x 256
 // of them overflow the 256 MB Infinity Cache -- the tile stage's dependent loads then wait for HBM (6.7 ms per 1024 views against 3.6 ms per
 // 512: profiles/r05_experiments.txt section 8).
-constexpr int VIS_THREADS = VIS_THREADS_N, VIS_WG_PER_CU = 1024 / VIS_THREADS_N, VIS_SHADOW_THREADS = 256;
+constexpr int VIS_THREADS = VIS_THREADS_N, VIS_WG_PER_CU = 1024 / VIS_THREADS_N, VIS_SHADOW_THREADS = 1024;
 constexpr int VIS_TILE = 8, VIS_MAXBODY = 64, VIS_MAXTILES = 16384, VIS_REC = 16, VIS_TEXCAP = 512;
 
 struct VisScene {
@@ -211,7 +211,7 @@ __device__ inline void vis_bin(const float4* __restrict__ rec, const int* __rest
 // box's texels over the lanes.  (Round 5's first version took queue overflow to the triangle's own thread: the slot-insertion scene has
 // 2 746 such triangles, 2.0 of its 2.35 M texel tests, for 1 024 slots, and single lanes walked boxes of 42 496 texels: 27.9 ms per 1 024
 // envs where this takes ~2.)
-constexpr int VIS_SHQ = 1024;
+constexpr int VIS_SHQ = 2048;          // (> VIS_SHADOW_THREADS: a pass of the workgroup adds at most one entry per thread)
 __global__ void __launch_bounds__(VIS_SHADOW_THREADS) k_vis_shadow(VisScene S, const float* __restrict__ xpose, unsigned* __restrict__ shmap, int N) {
     __shared__ float Q[VIS_SHQ * 9];
     __shared__ int nq;
