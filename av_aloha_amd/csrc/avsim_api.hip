@@ -9,6 +9,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/avsim.h"
@@ -128,8 +129,52 @@ struct avsim {
         if (io_device) { *dev = p; return 0; }
         return io_buf(slot, bytes, dev);
     }
+    // Large results to pageable host memory (the images of avsim_render_*: 0.9 MB per 480 x 640 colour view).  hipMemcpy into pageable memory
+    // runs at ~5 GB/s here (measured: 354 MB of pixels in 66 of the 73 ms of a 64-env gym step).  Above 16 MB the copy is pipelined instead: the
+    // device buffer goes in 32 MB chunks by DMA into two pinned staging buffers while the previous chunk is copied on into the caller's memory by
+    // four threads.  Synchronous, like the plain path once finish() has run.
+    static constexpr size_t PIN_CHUNK = 32u << 20;
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    int out_end_pipelined(const char* src, char* dst, size_t bytes) {
+        for (int k = 0; k < 2; k++) {
+            if (!pin[k] && hipHostMalloc(&pin[k], PIN_CHUNK, hipHostMallocDefault) != hipSuccess) { pin[k] = nullptr; return 1; }      // (1: fall back to the plain copy)
+            if (!pin_ev[k] && hipEventCreateWithFlags(&pin_ev[k], hipEventDisableTiming) != hipSuccess) { pin_ev[k] = nullptr; return 1; }
+        }
+        const size_t nchunk = (bytes + PIN_CHUNK - 1) / PIN_CHUNK;
+        auto issue = [&](size_t c) -> hipError_t {
+            const size_t off = c * PIN_CHUNK, n = bytes - off < PIN_CHUNK ? bytes - off : PIN_CHUNK;
+            hipError_t e = hipMemcpyAsync(pin[c & 1], src + off, n, hipMemcpyDeviceToHost, stream);
+            return e != hipSuccess ? e : hipEventRecord(pin_ev[c & 1], stream);
+        };
+        hipError_t e = issue(0);
+        for (size_t c = 0; c < nchunk && e == hipSuccess; c++) {
+            if ((e = hipEventSynchronize(pin_ev[c & 1])) != hipSuccess) break;
+            if (c + 1 < nchunk && (e = issue(c + 1)) != hipSuccess) break;          // (the other buffer: its previous contents were copied out in the last round)
+            const size_t off = c * PIN_CHUNK, n = bytes - off < PIN_CHUNK ? bytes - off : PIN_CHUNK;
+            const char* from = (const char*)pin[c & 1];
+            constexpr int NT = 4;
+            const size_t part = ((n + NT - 1) / NT + 4095) & ~(size_t)4095;
+            std::thread th[NT - 1];
+            int started = 0;
+            for (int t = 1; t < NT; t++) {
+                const size_t a = (size_t)t * part;
+                if (a >= n) break;
+                const size_t m = n - a < part ? n - a : part;
+                th[started++] = std::thread([=] { std::memcpy(dst + off + a, from + a, m); });
+            }
+            std::memcpy(dst + off, from, n < part ? n : part);
+            for (int t = 0; t < started; t++) th[t].join();
+        }
+        if (e != hipSuccess) { set_error("D2H copy failed: %s", hipGetErrorString(e)); return AVSIM_EHIP; }
+        return 0;
+    }
     int out_end(int slot, void* p, size_t bytes) {
         if (io_device || !p) return 0;
+        if (bytes >= ((size_t)16 << 20)) {
+            const int rc = out_end_pipelined((const char*)d_io[slot], (char*)p, bytes);
+            if (rc != 1) return rc;
+        }
         hipError_t e = hipMemcpyAsync(p, d_io[slot], bytes, hipMemcpyDeviceToHost, stream);
         if (e != hipSuccess) { set_error("D2H copy failed: %s", hipGetErrorString(e)); return AVSIM_EHIP; }
         return 0;
@@ -422,6 +467,10 @@ void avsim_destroy(avsim_t* h) {
         if (p) (void)hipFree(p);
     for (void* p : h->d_io)
         if (p) (void)hipFree(p);
+    for (int k = 0; k < 2; k++) {
+        if (h->pin[k]) (void)hipHostFree(h->pin[k]);
+        if (h->pin_ev[k]) (void)hipEventDestroy(h->pin_ev[k]);
+    }
     for (auto& ev : h->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : h->kev) (void)hipEventDestroy(ev);
@@ -445,6 +494,7 @@ int avsim_set_option(avsim_t* h, const char* name, double value) {
     if (!std::strcmp(name, "render_proxies")) { h->render_proxies = value != 0; return AVSIM_OK; }
     if (!std::strcmp(name, "render_samples")) { if (value != 1 && value != 4) { h->set_error("render_samples is 1 or 4"); return AVSIM_EINVAL; } h->vis.samples = (int)value; return AVSIM_OK; }
     if (!std::strcmp(name, "render_shadows")) { h->vis.shadows = value != 0; return AVSIM_OK; }
+    if (!std::strcmp(name, "render_cam_major")) { h->vis.cam_major = value != 0; return AVSIM_OK; }
     if (!std::strcmp(name, "render_chunk")) { if (value < 1) { h->set_error("render_chunk is a number of envs >= 1"); return AVSIM_EINVAL; } h->render.env_chunk = (int)value; return AVSIM_OK; }
     if (!std::strcmp(name, "diffik_iters")) { h->ik.diff_iters = (int)value; return AVSIM_OK; }
     if (!std::strcmp(name, "gradik_iters")) { h->ik.grad_iters = (int)value; return AVSIM_OK; }
@@ -840,6 +890,7 @@ static int render_images(avsim_t* h, const int32_t* cam_ids, int ncam, int heigh
     rc = h->phys.launch(h->stream, h->N, 0, nullptr, h->nj, h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, h->d_latch, nullptr, nullptr, nullptr, h->err);
     h->phys.d_xpose = nullptr;
     if (rc) return rc;
+    if (rgb && h->vis.cam_major && !(h->vis.loaded && !h->render_proxies)) { h->set_error("option render_cam_major applies to the visual scene's images only (avsim_load_visual, render_proxies 0)"); return AVSIM_EINVAL; }
     if (rgb && h->vis.loaded && !h->render_proxies)
         rc = h->vis.launch(h->stream, h->N, h->render.d_xpose, (const int*)cam_ids, ncam, h->render.m.ncam, height, width, dout, h->err);
     else

@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(VIS_SHADOW_THREADS) k_vis_shadow(VisScene S, c
 #endif
 template <int SS, bool SH>       // SS x SS samples per pixel; SH: shadows of the directional light (S.shmap)
 __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScene S, VisScratch X, const float* __restrict__ xpose, const int* __restrict__ cam_ids, int ncam_sel,
-                                                            int N, int H, int W, unsigned char* __restrict__ out) {
+                                                            int N, int H, int W, unsigned char* __restrict__ out, int cam_major) {
     __shared__ float Rcb[VIS_MAXBODY * 12];
     __shared__ float cam[32];                // Rc (9), pc (3), light dir in the camera frame (3), world up in the camera frame (3), scale; [19..30] the light's frame
                                              // and shadow box (VisScene le1, le2, lw, sh_s0, sh_t0, sh_itex: read from here, not from SGPRs, by the few lanes that need them)
@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
         __syncthreads();
         const long long tc4 = __builtin_readcyclecounter();
         // 4. tiles: one wavefront each, lane = pixel
-        unsigned char* img = out + (size_t)view * H * W * 3;
+        unsigned char* img = out + (size_t)(cam_major ? cs * N + env : view) * H * W * 3;      // [N][cam] or (option render_cam_major) [cam][N]
         const unsigned* shenv = SH ? S.shmap + (size_t)env * VIS_SM * VIS_SM : nullptr;
         // (records and lists were written with vector stores: the barrier above made them visible in L2, this drops what the scalar cache
         // still holds of the slot's previous view)
@@ -676,6 +676,7 @@ struct VisHost {
     bool attr_done = false;
     int* d_cam_ids = nullptr;
     int samples = 1;                 // option "render_samples": 1, or 4 = 2 x 2 supersampling
+    bool cam_major = false;          // option "render_cam_major": the images as [cam][N][H][W][3] (every camera's batch contiguous) instead of [N][cam][H][W][3]
     bool shadows = false;            // option "render_shadows": the directional light casts shadows (depth map from the light, one per env)
     unsigned* d_shmap = nullptr;
     int shmap_envs = 0;
@@ -826,7 +827,7 @@ struct VisHost {
             hipLaunchKernelGGL(k_vis_shadow, dim3(N), dim3(VIS_SHADOW_THREADS), 0, st, S, d_xpose, d_shmap, N);
         }
         const bool sh = S.shmap != nullptr;
-#define VIS_LAUNCH(SS_, SH_) hipLaunchKernelGGL((k_vis_render<SS_, SH_>), dim3(grid), dim3(VIS_THREADS), shmem, st, S, X, d_xpose, (const int*)d_cam_ids, ncam_sel, N, H, W, (unsigned char*)d_out)
+#define VIS_LAUNCH(SS_, SH_) hipLaunchKernelGGL((k_vis_render<SS_, SH_>), dim3(grid), dim3(VIS_THREADS), shmem, st, S, X, d_xpose, (const int*)d_cam_ids, ncam_sel, N, H, W, (unsigned char*)d_out, cam_major ? 1 : 0)
         if (samples > 1) { if (sh) VIS_LAUNCH(2, true); else VIS_LAUNCH(2, false); }
         else { if (sh) VIS_LAUNCH(1, true); else VIS_LAUNCH(1, false); }
 #undef VIS_LAUNCH

@@ -140,8 +140,9 @@ class GuidedVisionEnv(_EnvBase):
     def _pixels(self):
         if not self.cameras:
             return {}
-        img = self.sim.render_rgb(self.cameras, self.observation_height, self.observation_width)
-        return {c: self._squeeze(img[:, i]).copy() for i, c in enumerate(self.cameras)}
+        # camera-major from the library: one contiguous array per camera, no second copy of the batch's pixels on the host
+        img = self.sim.render_rgb(self.cameras, self.observation_height, self.observation_width, cam_major=True)
+        return {c: self._squeeze(img[i]) for i, c in enumerate(self.cameras)}
 
     def _obs(self):
         return {"pixels": self._pixels(), "agent_pos": self._squeeze(self._agent_pos).copy()}

@@ -172,7 +172,8 @@ int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height,
  * proxies are drawn in their flat material colours instead (the depth rasteriser's colour variant).  Options of the visual image (round 5):
  * "render_shadows" 1 -- the scene's directional light (scene.xml:48) casts shadows inside its shadow box (<statistic center extent>,
  * scene.xml:6), from a 512 x 512 depth map rendered from the light per env; "render_samples" 4 -- 2 x 2 supersampling (MuJoCo's offscreen
- * buffer is multisampled, offsamples default 4 [EXT]).  Both are off at the C-ABI and on in the gym facades.  No specular terms, haze or
+ * buffer is multisampled, offsamples default 4 [EXT]).  Both are off at the C-ABI and on in the gym facades.  "render_cam_major" 1 -- out is
+ * uint8[ncam][N][height][width][3] (every camera's batch contiguous: the facades hand out one array per camera without copying).  No specular terms, haze or
  * transparency: a stand-in for MuJoCo's OpenGL output, not a pixel match.  A view that runs out of triangle
  * records or tile-list entries sets the overflow flags of avsim_visual_info (the image then lacks triangles).  Pointer conventions
  * as avsim_render_depth. */

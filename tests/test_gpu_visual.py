@@ -147,3 +147,28 @@ def test_shadows_and_supersampling_match_the_oracle():
     assert not np.array_equal(plain[0], ss[0])
     sim.close()
     e.close()
+
+
+def test_large_host_copies_take_the_pipelined_path_and_arrive_intact():
+    """Results of 16 MB and more go to host memory through two pinned staging buffers and four copy threads (avsim_api.hip out_end_pipelined)
+    instead of one pageable hipMemcpy: a 29 MB call (8 envs x 4 cameras x 480 x 640 x 3, not a multiple of the 32 MB chunk) and a 59 MB call
+    (depth, f32: two chunks) against the same images fetched one camera at a time (7 / 9.8 MB each: the plain path)."""
+    from av_aloha_amd.sim import BatchedSim
+    N = 8
+    sim = BatchedSim("slot_insertion", 3, N)
+    rng = np.random.default_rng(3)
+    obj = np.repeat(OBJ[None], N, 0).copy()
+    obj[:, :, :2] += 0.02 * rng.standard_normal((N, obj.shape[1], 2))
+    sim.reset(obj)
+    cams = ["zed_cam_left", "wrist_cam_left", "wrist_cam_right", "overhead_cam"]
+    big = sim.render_rgb(cams, 480, 640)
+    assert big.nbytes > (16 << 20)
+    for ci, c in enumerate(cams):
+        one = sim.render_rgb([c], 480, 640)
+        assert one.nbytes < (16 << 20) and np.array_equal(big[:, ci], one[:, 0]), c
+    cams8 = cams + ["zed_cam_right", "worms_eye_cam"]
+    dbig = sim.render_depth(cams8, 480, 640)
+    assert dbig.nbytes > (32 << 20)
+    for ci, c in enumerate(cams8):
+        assert np.array_equal(dbig[:, ci], sim.render_depth([c], 480, 640)[:, 0]), c
+    sim.close()
