@@ -110,7 +110,7 @@ class GuidedVisionEnv:
                 lr = self.sim.render_rgb(["zed_cam_left", "zed_cam_right"], 720, 720)
                 images["zed_cam"] = self._sq(np.concatenate([lr[:, 0], lr[:, 1]], axis=2))
             else:
-                images[camera] = self._sq(self.sim.render_rgb([_CAMERA_IDS[camera]], 480, 640)[:, 0]).copy()
+                images[camera] = self._sq(self.sim.render_rgb([_CAMERA_IDS[camera]], 480, 640)[:, 0])       # (a view of the call's own array: one camera, contiguous)
         return images
 
     # ---- gym-style surface (sim_env.py:220-312) ------------------------------------------------------
