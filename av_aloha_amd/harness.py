@@ -292,9 +292,13 @@ def rerender_episode(data, env_id: str, save_path: str | None = None, device: in
         if n < B:                                   # the last chunk: the spare envs repeat its last frame
             q = np.concatenate([q, np.repeat(q[-1:], B - n, 0)])
         env.sim.set_qpos(q)
-        img = env.sim.render_rgb(env.cameras, H, W, cam_major=True)   # [ncam, B, H, W, 3]: a camera's frames are one contiguous block
-        for ci, cam in enumerate(env.cameras):
-            out[f"/observations/images/{cam}"][t0:t0 + n] = img[ci, :n]
+        if n == B:      # a full chunk: every camera's frames straight from the device into their place in the episode's array
+            for cam in env.cameras:
+                env.sim.render_rgb([cam], H, W, cam_major=True, out=out[f"/observations/images/{cam}"][t0:t0 + B])
+        else:
+            img = env.sim.render_rgb(env.cameras, H, W, cam_major=True)   # [ncam, B, H, W, 3]: a camera's frames are one contiguous block
+            for ci, cam in enumerate(env.cameras):
+                out[f"/observations/images/{cam}"][t0:t0 + n] = img[ci, :n]
     if own:
         env.close()
     if save_path is not None:

@@ -143,7 +143,7 @@ class BatchedSim:
         self.h.check(self.h.L.avsim_visual_info(self.h.h, info.ctypes.data))
         return dict(zip(("triangles", "vertices", "overflow", "instances"), (int(x) for x in info)))
 
-    def render_rgb(self, cameras, height, width, visual=True, cam_major=False):
+    def render_rgb(self, cameras, height, width, visual=True, cam_major=False, out=None):
         """Colour images uint8 [N, len(cameras), height, width, 3] of the named cameras at the current state (the layout
         of the reference's "pixels" observation, env.py:180-188).  visual: the scene's visual meshes (loaded on first use from
         models/visual_meshes.avv); False: the collision proxies in flat colours (the depth renderer's geometry)."""
@@ -153,7 +153,11 @@ class BatchedSim:
         self.set_option("render_cam_major", 1 if (cam_major and visual) else 0)      # [len(cameras), N, height, width, 3]: every camera's batch contiguous
         names = self.manifest["camera_names"]
         ids = np.array([names.index(c) if isinstance(c, str) else int(c) for c in cameras], dtype=np.int32)
-        out = np.empty((len(ids), self.N, height, width, 3) if (cam_major and visual) else (self.N, len(ids), height, width, 3), dtype=np.uint8)
+        shape = (len(ids), self.N, height, width, 3) if (cam_major and visual) else (self.N, len(ids), height, width, 3)
+        if out is None:
+            out = np.empty(shape, dtype=np.uint8)
+        else:           # the caller's own memory (a slice of a data set's image array): no copy after the one from the device
+            assert out.dtype == np.uint8 and out.flags.c_contiguous and out.size == int(np.prod(shape)), "render_rgb(out=...): a C-contiguous uint8 array of the result's size"
         self.h.check(self.h.L.avsim_render_rgb(self.h.h, ids.ctypes.data, len(ids), height, width, out.ctypes.data))
         if visual:
             ov = self.visual_info()["overflow"]
