@@ -70,17 +70,36 @@ def _attr_msg(name: str, value) -> bytes:
 
 # ---- writer ------------------------------------------------------------------------------------------------------------------
 class _File:
-    def __init__(self):
-        self.buf = bytearray()
+    """Append-only writer straight to the file: a block is written where it is allocated (a data set's chunks from the array's own memory, no
+    intermediate copy of the file in a bytearray -- an episode with six cameras is 1.9 GB), the few back-patches (superblock, B-tree siblings)
+    seek."""
+    def __init__(self, path: str):
+        self.fh = open(path, "wb")
+        self.pos = 0
 
-    def alloc(self, data: bytes) -> int:
-        self.buf += b"\0" * (-len(self.buf) % 8)
-        addr = len(self.buf)
-        self.buf += data
+    def alloc(self, data, pad_to: int = 0) -> int:
+        """data: bytes, or a C-contiguous array (written through the buffer protocol); pad_to: zero-filled up to this many bytes."""
+        gap = -self.pos % 8
+        if gap:
+            self.fh.write(b"\0" * gap)
+            self.pos += gap
+        addr = self.pos
+        n = data.nbytes if isinstance(data, np.ndarray) else len(data)
+        if n:
+            self.fh.write(memoryview(data).cast("B") if isinstance(data, np.ndarray) else data)
+        if pad_to > n:
+            self.fh.write(b"\0" * (pad_to - n))
+            n = pad_to
+        self.pos += n
         return addr
 
     def patch(self, addr: int, data: bytes):
-        self.buf[addr:addr + len(data)] = data
+        self.fh.seek(addr)
+        self.fh.write(data)
+        self.fh.seek(self.pos)
+
+    def close(self):
+        self.fh.close()
 
 
 def _chunk_tree(f: _File, arr: np.ndarray, chunk) -> int:
@@ -94,9 +113,7 @@ def _chunk_tree(f: _File, arr: np.ndarray, chunk) -> int:
     entries = []                                     # (key offsets, child address)
     for k in range(nchunk):
         blk = arr[k * c0:(k + 1) * c0]
-        raw = np.ascontiguousarray(blk).tobytes()
-        raw += b"\0" * (csize - len(raw))            # a ragged last chunk is stored whole
-        entries.append((k * c0, f.alloc(raw)))
+        entries.append((k * c0, f.alloc(np.ascontiguousarray(blk), pad_to=csize)))      # (a ragged last chunk is stored whole)
     end = nchunk * c0
 
     def key(off0, size=csize):
@@ -136,7 +153,7 @@ def _dataset(f: _File, arr: np.ndarray, chunk) -> int:
         root = _chunk_tree(f, raw, chunk)
         lay = struct.pack("<BBBQ", 3, 2, arr.ndim + 1, root) + b"".join(struct.pack("<I", int(c)) for c in chunk) + struct.pack("<I", arr.itemsize)
     else:
-        addr = f.alloc(raw.tobytes()) if arr.size else UNDEF
+        addr = f.alloc(np.ascontiguousarray(raw)) if arr.size else UNDEF
         lay = struct.pack("<BBQQ", 3, 1, addr, arr.nbytes)
     msgs.append(_msg(0x0008, lay))
     return f.alloc(_object_header(msgs))
@@ -173,36 +190,39 @@ def _group(f: _File, children: dict, attrs: dict | None = None):
 def write(path: str, datasets: dict, attrs: dict | None = None, chunks: dict | None = None) -> None:
     """datasets: "/a/b/name" -> array; attrs: attributes of the root group; chunks: name -> chunk shape (first axis split only)."""
     chunks = chunks or {}
-    f = _File()
-    f.alloc(b"\0" * 96)                                   # superblock, patched at the end
-    tree: dict = {}
-    for name, arr in datasets.items():
-        parts = [p for p in name.split("/") if p]
-        node = tree
-        for p in parts[:-1]:
-            node = node.setdefault(p, {})
-            assert isinstance(node, dict), f"hdf5min: {name} passes through a data set"
-        node[parts[-1]] = (np.asarray(arr), chunks.get(name))
+    f = _File(path)
+    try:
+        f.alloc(b"\0" * 96)                                   # superblock, patched at the end
+        tree: dict = {}
+        for name, arr in datasets.items():
+            parts = [p for p in name.split("/") if p]
+            node = tree
+            for p in parts[:-1]:
+                node = node.setdefault(p, {})
+                assert isinstance(node, dict), f"hdf5min: {name} passes through a data set"
+            node[parts[-1]] = (np.asarray(arr), chunks.get(name))
 
-    def build(node, top):
-        ch = {}
-        for k, v in node.items():
-            if isinstance(v, dict):
-                oh, bt, hp = build(v, False)
-                ch[k] = (oh, (bt, hp))
-            else:
-                ch[k] = (_dataset(f, v[0], v[1]), None)
-        return _group(f, ch, attrs if top else None)
-    root_oh, root_bt, root_hp = build(tree, True)
-    eof = len(f.buf) + (-len(f.buf) % 8)
-    f.buf += b"\0" * (eof - len(f.buf))
-    sb = SIG + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, GROUP_LEAF_K, GROUP_INTERNAL_K, 0)
-    sb += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
-    sb += struct.pack("<QQII", 0, root_oh, 1, 0) + struct.pack("<QQ", root_bt, root_hp)
-    assert len(sb) == 96
-    f.patch(0, sb)
-    with open(path, "wb") as fh:
-        fh.write(f.buf)
+        def build(node, top):
+            ch = {}
+            for k, v in node.items():
+                if isinstance(v, dict):
+                    oh, bt, hp = build(v, False)
+                    ch[k] = (oh, (bt, hp))
+                else:
+                    ch[k] = (_dataset(f, v[0], v[1]), None)
+            return _group(f, ch, attrs if top else None)
+        root_oh, root_bt, root_hp = build(tree, True)
+        eof = f.pos + (-f.pos % 8)
+        if eof > f.pos:
+            f.fh.write(b"\0" * (eof - f.pos))
+            f.pos = eof
+        sb = SIG + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, GROUP_LEAF_K, GROUP_INTERNAL_K, 0)
+        sb += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
+        sb += struct.pack("<QQII", 0, root_oh, 1, 0) + struct.pack("<QQ", root_bt, root_hp)
+        assert len(sb) == 96
+        f.patch(0, sb)
+    finally:
+        f.close()
 
 
 # ---- reader ------------------------------------------------------------------------------------------------------------------
