@@ -74,6 +74,9 @@ struct avsim {
     PhysHost phys;  // device model image + launch configuration (avsim_phys.hip.h)
     RenderHost render;   // depth renderer (avsim_render.hip.h)
     VisHost vis;         // colour images of the visual meshes (avsim_vis.hip.h), once avsim_load_visual has run
+    // the state's version: bumped by everything that writes qpos (reset, the steps, set_state); the image calls skip their pose pass and the shadow
+    // map when they already hold this version's (a facade that fetches its cameras one call at a time repeats neither)
+    unsigned long long state_ver = 1, xpose_ver = 0;
     bool render_proxies = false;   // option "render_proxies": avsim_render_rgb draws the collision proxies even with a visual scene loaded
     // device state (real = float, or double with AVSIM_F64_PHYSICS)
     void *d_qpos = nullptr, *d_qvel = nullptr, *d_ctrl = nullptr, *d_warm = nullptr;
@@ -665,11 +668,13 @@ extern "C" {
 int avsim_reset(avsim_t* h, const uint8_t* mask, const double* obj_qpos) {
     if (!h || !obj_qpos) { if (h) h->set_error("avsim_reset: obj_qpos is required"); return AVSIM_EINVAL; }
     AVS_ON_DEVICE(h);
+    h->state_ver++;
     return h->f64 ? reset_impl<double>(h, mask, obj_qpos) : reset_impl<float>(h, mask, obj_qpos);
 }
 
 static int step_common(avsim_t* h, const float* d_action, int nsub, double* agent_pos, int32_t* reward, uint8_t* success) {
     int rc;
+    h->state_ver++;
     void *dap = nullptr, *drw = nullptr, *dsu = nullptr;
     size_t N = h->N;
     if (agent_pos && (rc = h->out_begin(4, agent_pos, sizeof(double) * N * h->nj, &dap))) return rc;
@@ -785,6 +790,7 @@ int avsim_get_state(avsim_t* h, double* qpos, double* qvel, double* ctrl, double
 int avsim_set_state(avsim_t* h, const double* qpos, const double* qvel, const double* ctrl, const double* warm) {
     if (!h) return AVSIM_EINVAL;
     AVS_ON_DEVICE(h);
+    h->state_ver++;
     size_t N = h->N;
     int rc;
     if ((rc = put(h, 0, qpos, h->d_qpos, N * h->nq))) return rc;
@@ -886,13 +892,16 @@ static int render_images(avsim_t* h, const int32_t* cam_ids, int ncam, int heigh
     void* dout = nullptr;
     const size_t bytes = (rgb ? 3 : sizeof(float)) * (size_t)h->N * ncam * height * width;
     if ((rc = h->out_begin(7, out, bytes, &dout))) return rc;
-    h->phys.d_xpose = h->render.d_xpose;
-    rc = h->phys.launch(h->stream, h->N, 0, nullptr, h->nj, h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, h->d_latch, nullptr, nullptr, nullptr, h->err);
-    h->phys.d_xpose = nullptr;
-    if (rc) return rc;
+    if (h->xpose_ver != h->state_ver) {          // body poses of the current state (a forward pass of the physics kernel, no substep)
+        h->phys.d_xpose = h->render.d_xpose;
+        rc = h->phys.launch(h->stream, h->N, 0, nullptr, h->nj, h->d_qpos, h->d_qvel, h->d_ctrl, h->d_warm, h->d_latch, nullptr, nullptr, nullptr, h->err);
+        h->phys.d_xpose = nullptr;
+        if (rc) return rc;
+        h->xpose_ver = h->state_ver;
+    }
     if (rgb && h->vis.cam_major && !(h->vis.loaded && !h->render_proxies)) { h->set_error("option render_cam_major applies to the visual scene's images only (avsim_load_visual, render_proxies 0)"); return AVSIM_EINVAL; }
     if (rgb && h->vis.loaded && !h->render_proxies)
-        rc = h->vis.launch(h->stream, h->N, h->render.d_xpose, (const int*)cam_ids, ncam, h->render.m.ncam, height, width, dout, h->err);
+        rc = h->vis.launch(h->stream, h->N, h->render.d_xpose, (const int*)cam_ids, ncam, h->render.m.ncam, height, width, dout, h->err, h->state_ver);
     else
         rc = h->render.launch(h->stream, (const int*)cam_ids, ncam, height, width, dout, rgb, h->err);
     if (rc) return rc < -1 ? AVSIM_EHIP : AVSIM_EINVAL;

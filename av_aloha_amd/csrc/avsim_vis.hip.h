@@ -680,6 +680,7 @@ struct VisHost {
     bool shadows = false;            // option "render_shadows": the directional light casts shadows (depth map from the light, one per env)
     unsigned* d_shmap = nullptr;
     int shmap_envs = 0;
+    unsigned long long shmap_ver = 0;   // the state version (avsim_api.hip) the shadow maps were rendered for
     double light_host[16] = {0};     // the model's render_light (lights, sky, shadow box)
 
     template <typename T>
@@ -759,10 +760,10 @@ struct VisHost {
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
         for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.trec, (void*)X.bigq, (void*)X.flags, (void*)d_cam_ids, (void*)d_shmap}) if (p) (void)hipFree(p);
-        X = VisScratch{}; d_cam_ids = nullptr; d_shmap = nullptr; shmap_envs = 0; loaded = false; slots = 0; max_slots = 0; nviews_cap = 0; last_nviews = 0;
+        X = VisScratch{}; d_cam_ids = nullptr; d_shmap = nullptr; shmap_envs = 0; shmap_ver = 0; loaded = false; slots = 0; max_slots = 0; nviews_cap = 0; last_nviews = 0;
     }
     // overflow flags of the last launch, OR over the views (bit 0: triangle records, bit 1: tile lists); synchronises the stream
-    int launch(hipStream_t st, int N, const float* d_xpose, const int* cam_ids_host, int ncam_sel, int ncam_model, int H, int W, void* d_out, std::string& err) {
+    int launch(hipStream_t st, int N, const float* d_xpose, const int* cam_ids_host, int ncam_sel, int ncam_model, int H, int W, void* d_out, std::string& err, unsigned long long state_ver = 0) {
         if (!loaded) { err = "avsim_render_rgb: no visual scene loaded (avsim_load_visual)"; return -1; }
         if (ncam_sel < 1 || ncam_sel > 16 || H < 1 || W < 1) { err = "avsim_render_rgb: bad camera count or image size"; return -1; }
         const int ntile = ((W + VIS_TILE - 1) / VIS_TILE) * ((H + VIS_TILE - 1) / VIS_TILE);
@@ -822,9 +823,13 @@ struct VisHost {
                 d_shmap = nullptr; shmap_envs = 0;
                 if (hipMalloc((void**)&d_shmap, (size_t)N * VIS_SM * VIS_SM * sizeof(unsigned)) != hipSuccess) { err = "hipMalloc(shadow maps) failed"; return -3; }
                 shmap_envs = N;
+                shmap_ver = 0;
             }
             S.shmap = d_shmap;
-            hipLaunchKernelGGL(k_vis_shadow, dim3(N), dim3(VIS_SHADOW_THREADS), 0, st, S, d_xpose, d_shmap, N);
+            if (state_ver == 0 || shmap_ver != state_ver) {      // (the maps of this state may be there already: an earlier call for other cameras)
+                hipLaunchKernelGGL(k_vis_shadow, dim3(N), dim3(VIS_SHADOW_THREADS), 0, st, S, d_xpose, d_shmap, N);
+                shmap_ver = state_ver;
+            }
         }
         const bool sh = S.shmap != nullptr;
 #define VIS_LAUNCH(SS_, SH_) hipLaunchKernelGGL((k_vis_render<SS_, SH_>), dim3(grid), dim3(VIS_THREADS), shmem, st, S, X, d_xpose, (const int*)d_cam_ids, ncam_sel, N, H, W, (unsigned char*)d_out, cam_major ? 1 : 0)

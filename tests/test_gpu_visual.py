@@ -172,3 +172,30 @@ def test_large_host_copies_take_the_pipelined_path_and_arrive_intact():
     for ci, c in enumerate(cams8):
         assert np.array_equal(dbig[:, ci], sim.render_depth([c], 480, 640)[:, 0]), c
     sim.close()
+
+
+def test_pose_pass_and_shadow_maps_are_reused_per_state_and_renewed_after_a_step():
+    """The image calls keep the body poses and the shadow maps of the state they were made for (avsim_api.hip state_ver): cameras fetched one
+    call at a time give the images of one call for all of them, and a step, a set_qpos and a reset each invalidate what is kept."""
+    from av_aloha_amd.sim import BatchedSim
+    md = model_dict()
+    sim = BatchedSim("slot_insertion", 3, 2, options={"render_shadows": 1})
+    sim.reset(np.repeat(OBJ[None], 2, 0))
+    cams = ["overhead_cam", "zed_cam_left"]
+    a = np.repeat(actions_wiggle(md, 1)[0][None], 2, 0)
+    both = sim.render_rgb(cams, 120, 160)
+    for ci, c in enumerate(cams):
+        assert np.array_equal(sim.render_rgb([c], 120, 160)[:, 0], both[:, ci])
+    for _ in range(5):
+        sim.step(a)
+    moved = sim.render_rgb(cams, 120, 160)
+    assert (moved != both).any(axis=-1).mean() > 1e-3                       # the arms moved: new poses, new shadows
+    fresh = BatchedSim("slot_insertion", 3, 2, options={"render_shadows": 1})
+    q = sim.get_state()[0]
+    fresh.reset(np.repeat(OBJ[None], 2, 0))
+    fresh.render_rgb(cams, 120, 160)                                         # (caches the home pose's passes)
+    fresh.set_qpos(q)
+    assert np.array_equal(fresh.render_rgb(cams, 120, 160), moved)
+    fresh.reset(np.repeat(OBJ[None], 2, 0))
+    assert np.array_equal(fresh.render_rgb(cams, 120, 160), both)
+    sim.close(); fresh.close()
