@@ -100,7 +100,8 @@ def _image_bytes_per_step(cameras) -> int:
 
 
 def record_scripted(task_name: str, num_episodes: int, cameras=(), seed: int | None = None, device: int = 0, only_success: bool = False,
-                    image_budget_bytes: int = 8 << 30, keep_diverged: bool = False, sink=None, **script_kw):
+                    image_budget_bytes: int = 8 << 30, keep_diverged: bool = False, sink=None, stream_dir: str | None = None, max_batch: int = 256,
+                    **script_kw):
     """The counterpart of record_sim_episodes.py:68-212 with a scripted teleoperator in the headset's place (av_aloha_amd/scripted.py):
     `num_episodes` episodes of `task_name` ("sim_insert_peg", ...) are run SIDE BY SIDE on the device -- one env each, object poses from the
     task's own reset sampling (global numpy RNG, `seed` seeds it) -- through the Cartesian-action env (sim_env.py:277-312), and come back as
@@ -115,7 +116,12 @@ def record_scripted(task_name: str, num_episodes: int, cameras=(), seed: int | N
     reference drops an episode whose physics raised (unless keep_diverged; it is flagged either way).  only_success: keep the episodes whose
     LARGEST reward over time is max_reward -- check_dataset_reward.py:52-58's criterion; "success" is that flag, "final_success" says
     whether the episode also ENDS at max_reward.  sink(episode): called for every kept episode as its batch finishes INSTEAD of collecting
-    them (a recorder that writes and forgets keeps one batch in memory; the function then returns the episodes' summaries without "data")."""
+    them (a recorder that writes and forgets keeps one batch in memory; the function then returns the episodes' summaries without "data").
+    stream_dir: the episodes are written as they are recorded -- every step's images go straight into `<stream_dir>/episode_<i>.hdf5`
+    (hdf5min.StreamWriter: a chunk per frame, as save_episode lays the image stacks out), the tables follow at the end, a dropped episode's file
+    is removed, the kept ones are numbered consecutively from the files already there.  No image stays in memory, so the batches are not sized by
+    the image budget but by `max_batch`: a step of 32 envs costs what a step of 3 costs (one wave each), which made the budgeted batches the
+    slow part of a recording with cameras.  The summaries then carry "path" instead of "data"."""
     from . import scripted
     from .env import sample_object_poses
     from .sim_env import make_sim_env, _TASK_OF_SUBSTRING
@@ -131,7 +137,7 @@ def record_scripted(task_name: str, num_episodes: int, cameras=(), seed: int | N
     while start < n_all:
         # batch size from the image budget: T is only known once the script exists, so size it with the longest script (600 steps)
         per_ep = _image_bytes_per_step(cameras) * 601
-        n = n_all - start if per_ep == 0 else max(1, min(n_all - start, int(image_budget_bytes // per_ep)))
+        n = min(n_all - start, max_batch) if (per_ep == 0 or stream_dir is not None) else max(1, min(n_all - start, int(image_budget_bytes // per_ep)))
         env = make_sim_env(task_name, cameras=cameras, num_envs=n, device=device)
         env.sim.reset(poses_all[start:start + n])
         obs = env.get_obs()
@@ -143,9 +149,15 @@ def record_scripted(task_name: str, num_episodes: int, cameras=(), seed: int | N
                   "/observations/all_qpos": lambda s: s["qpos"], "/action": lambda s: s["control"]}
         # per-episode arrays, written step by step
         data = [{name: np.empty((T,) + b(f(obs), n).shape[1:], dtype=np.float32) for name, f in fields.items()} for _ in range(n)]
-        for k in range(n):
-            for cam in obs.get("images", {}):
-                data[k][f"/observations/images/{cam}"] = np.empty((T,) + b(obs["images"][cam], n).shape[1:], dtype=np.uint8)
+        writers = None
+        if stream_dir is not None:
+            from . import hdf5min
+            os.makedirs(stream_dir, exist_ok=True)
+            writers = [hdf5min.StreamWriter(os.path.join(stream_dir, f".recording_{start + k}.part")) for k in range(n)]
+        else:
+            for k in range(n):
+                for cam in obs.get("images", {}):
+                    data[k][f"/observations/images/{cam}"] = np.empty((T,) + b(obs["images"][cam], n).shape[1:], dtype=np.uint8)
         rewards = np.zeros((T - 1, n), dtype=np.int32)
         diverged = np.zeros(n, dtype=bool)
 
@@ -157,19 +169,40 @@ def record_scripted(task_name: str, num_episodes: int, cameras=(), seed: int | N
             for cam, img in o.get("images", {}).items():
                 img = b(img, n)
                 for k in range(n):
-                    data[k][f"/observations/images/{cam}"][t] = img[k]
-        put(0, obs)
-        for t in range(1, T):
-            _, rw, _ = env.sim.step_cartesian(script.action(b(obs["qpos"], n)))
-            diverged |= (env.sim.diag()[:, 3] & 1).astype(bool)
-            rewards[t - 1] = rw
-            obs = env.get_obs()
-            put(t, obs)
-        env.close()
+                    if writers is not None:
+                        writers[k].append(f"/observations/images/{cam}", img[k])
+                    else:
+                        data[k][f"/observations/images/{cam}"][t] = img[k]
+        try:
+            put(0, obs)
+            for t in range(1, T):
+                _, rw, _ = env.sim.step_cartesian(script.action(b(obs["qpos"], n)))
+                diverged |= (env.sim.diag()[:, 3] & 1).astype(bool)
+                rewards[t - 1] = rw
+                obs = env.get_obs()
+                put(t, obs)
+        except BaseException:
+            for w in writers or []:
+                w.abort()                       # (no half-written episode files behind a failed recording)
+            raise
+        finally:
+            env.close()
         for k in range(n):
             reached = int(rewards[:, k].max())
             ok = reached == max_reward
             if (only_success and not ok) or (diverged[k] and not keep_diverged):
+                if writers is not None:
+                    writers[k].abort()
+                continue
+            if writers is not None:
+                writers[k].finish(data[k], attrs={"sim": np.bool_(True)})
+                i = 0
+                while os.path.exists(os.path.join(stream_dir, f"episode_{i}.hdf5")):
+                    i += 1
+                path = os.path.join(stream_dir, f"episode_{i}.hdf5")
+                os.replace(writers[k].path, path)
+                episodes.append({"path": path, "success": bool(ok), "final_success": bool(rewards[-1, k] == max_reward), "max_reward_reached": reached,
+                                 "rewards": rewards[:, k].copy(), "max_reward": int(max_reward), "diverged": bool(diverged[k]), "episode_index": start + k, "steps": T})
                 continue
             ep = {"data": data[k], "success": bool(ok), "final_success": bool(rewards[-1, k] == max_reward), "max_reward_reached": reached,
                              "rewards": rewards[:, k].copy(), "max_reward": int(max_reward), "diverged": bool(diverged[k]), "episode_index": start + k}

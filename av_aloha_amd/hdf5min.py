@@ -14,6 +14,7 @@ The reader handles what the writer makes plus object-header continuation blocks 
 with its defaults for this layout."""
 from __future__ import annotations
 
+import os
 import struct
 
 import numpy as np
@@ -104,7 +105,6 @@ class _File:
 
 def _chunk_tree(f: _File, arr: np.ndarray, chunk) -> int:
     """Writes the chunks of `arr` (only the first axis may be split: chunk = (c0, *arr.shape[1:])) and their B-tree; -> root address."""
-    rank = arr.ndim
     assert tuple(chunk[1:]) == tuple(arr.shape[1:]) and 1 <= chunk[0], "hdf5min: chunks may split the first axis only"
     c0 = int(chunk[0])
     nchunk = (arr.shape[0] + c0 - 1) // c0
@@ -114,8 +114,11 @@ def _chunk_tree(f: _File, arr: np.ndarray, chunk) -> int:
     for k in range(nchunk):
         blk = arr[k * c0:(k + 1) * c0]
         entries.append((k * c0, f.alloc(np.ascontiguousarray(blk), pad_to=csize)))      # (a ragged last chunk is stored whole)
-    end = nchunk * c0
+    return _chunk_index(f, arr.ndim, csize, entries, nchunk * c0)
 
+
+def _chunk_index(f: _File, rank: int, csize: int, entries: list, end: int) -> int:
+    """The chunk B-tree over chunks already in the file: entries = [(offset along the first axis, address)], `end` = the offset after the last."""
     def key(off0, size=csize):
         return struct.pack("<II", size, 0) + struct.pack("<Q", off0) + b"\0" * (8 * rank)      # rank + 1 offsets, the last (element) one 0
     klen = 8 + 8 * (rank + 1)
@@ -142,7 +145,23 @@ def _chunk_tree(f: _File, arr: np.ndarray, chunk) -> int:
         entries, level = nxt, level + 1
 
 
-def _dataset(f: _File, arr: np.ndarray, chunk) -> int:
+class _Streamed:
+    """A data set whose chunks (one per index of the first axis) were appended to the file as they came: StreamWriter.append."""
+    def __init__(self, frame: np.ndarray):
+        self.dtype, self.frame_shape, self.entries = frame.dtype, tuple(frame.shape), []
+
+
+def _dataset(f: _File, arr, chunk) -> int:
+    if isinstance(arr, _Streamed):
+        shape, dtype = (len(arr.entries),) + arr.frame_shape, arr.dtype
+        itemsize = np.dtype(dtype).itemsize
+        chunk = (1,) + arr.frame_shape
+        csize = int(np.prod(arr.frame_shape, dtype=np.int64)) * itemsize
+        msgs = [_msg(0x0001, _space_msg(shape)), _msg(0x0003, _dtype_msg(np.dtype(dtype)), flags=1), _msg(0x0005, struct.pack("<BBBB", 2, 3, 2, 0))]
+        root = _chunk_index(f, len(shape), csize, list(arr.entries), len(arr.entries))
+        lay = struct.pack("<BBBQ", 3, 2, len(shape) + 1, root) + b"".join(struct.pack("<I", int(c)) for c in chunk) + struct.pack("<I", itemsize)
+        msgs.append(_msg(0x0008, lay))
+        return f.alloc(_object_header(msgs))
     arr = np.ascontiguousarray(arr)
     if arr.dtype.byteorder == ">":
         arr = arr.astype(arr.dtype.newbyteorder("<"))
@@ -187,42 +206,75 @@ def _group(f: _File, children: dict, attrs: dict | None = None):
     return f.alloc(_object_header(msgs)), btree, heap
 
 
+class StreamWriter:
+    """A file written as its data arrives: `append(name, frame)` puts one more index of a chunked data set (chunk = one frame: the images of an
+    episode, a step at a time, several data sets interleaved) straight into the file; `finish(datasets, attrs)` adds the whole data sets and the
+    group structure.  Nothing of the streamed data is kept in memory but a chunk address per frame."""
+    def __init__(self, path: str):
+        self.path = path
+        self.f = _File(path)
+        self.f.alloc(b"\0" * 96)                             # superblock, patched at the end
+        self.streams: dict = {}
+        self.done = False
+
+    def append(self, name: str, frame) -> None:
+        frame = np.ascontiguousarray(frame)
+        st = self.streams.get(name)
+        if st is None:
+            st = self.streams[name] = _Streamed(frame)
+        assert frame.dtype == st.dtype and tuple(frame.shape) == st.frame_shape, f"hdf5min: a frame of {name} with another dtype or shape"
+        st.entries.append((len(st.entries), self.f.alloc(frame)))
+
+    def abort(self) -> None:
+        """Closes and removes the file (an episode that is not kept)."""
+        if not self.done:
+            self.done = True
+            self.f.close()
+            try:
+                os.remove(self.path)
+            except OSError:
+                pass
+
+    def finish(self, datasets: dict | None = None, attrs: dict | None = None, chunks: dict | None = None) -> None:
+        f, chunks = self.f, chunks or {}
+        try:
+            tree: dict = {}
+            leaves = {**{k: (np.asarray(v), chunks.get(k)) for k, v in (datasets or {}).items()}, **{k: (v, None) for k, v in self.streams.items()}}
+            for name, leaf in leaves.items():
+                parts = [p for p in name.split("/") if p]
+                node = tree
+                for p in parts[:-1]:
+                    node = node.setdefault(p, {})
+                    assert isinstance(node, dict), f"hdf5min: {name} passes through a data set"
+                node[parts[-1]] = leaf
+
+            def build(node, top):
+                ch = {}
+                for k, v in node.items():
+                    if isinstance(v, dict):
+                        oh, bt, hp = build(v, False)
+                        ch[k] = (oh, (bt, hp))
+                    else:
+                        ch[k] = (_dataset(f, v[0], v[1]), None)
+                return _group(f, ch, attrs if top else None)
+            root_oh, root_bt, root_hp = build(tree, True)
+            eof = f.pos + (-f.pos % 8)
+            if eof > f.pos:
+                f.fh.write(b"\0" * (eof - f.pos))
+                f.pos = eof
+            sb = SIG + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, GROUP_LEAF_K, GROUP_INTERNAL_K, 0)
+            sb += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
+            sb += struct.pack("<QQII", 0, root_oh, 1, 0) + struct.pack("<QQ", root_bt, root_hp)
+            assert len(sb) == 96
+            f.patch(0, sb)
+        finally:
+            self.done = True
+            f.close()
+
+
 def write(path: str, datasets: dict, attrs: dict | None = None, chunks: dict | None = None) -> None:
     """datasets: "/a/b/name" -> array; attrs: attributes of the root group; chunks: name -> chunk shape (first axis split only)."""
-    chunks = chunks or {}
-    f = _File(path)
-    try:
-        f.alloc(b"\0" * 96)                                   # superblock, patched at the end
-        tree: dict = {}
-        for name, arr in datasets.items():
-            parts = [p for p in name.split("/") if p]
-            node = tree
-            for p in parts[:-1]:
-                node = node.setdefault(p, {})
-                assert isinstance(node, dict), f"hdf5min: {name} passes through a data set"
-            node[parts[-1]] = (np.asarray(arr), chunks.get(name))
-
-        def build(node, top):
-            ch = {}
-            for k, v in node.items():
-                if isinstance(v, dict):
-                    oh, bt, hp = build(v, False)
-                    ch[k] = (oh, (bt, hp))
-                else:
-                    ch[k] = (_dataset(f, v[0], v[1]), None)
-            return _group(f, ch, attrs if top else None)
-        root_oh, root_bt, root_hp = build(tree, True)
-        eof = f.pos + (-f.pos % 8)
-        if eof > f.pos:
-            f.fh.write(b"\0" * (eof - f.pos))
-            f.pos = eof
-        sb = SIG + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, GROUP_LEAF_K, GROUP_INTERNAL_K, 0)
-        sb += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
-        sb += struct.pack("<QQII", 0, root_oh, 1, 0) + struct.pack("<QQ", root_bt, root_hp)
-        assert len(sb) == 96
-        f.patch(0, sb)
-    finally:
-        f.close()
+    StreamWriter(path).finish(datasets, attrs, chunks)
 
 
 # ---- reader ------------------------------------------------------------------------------------------------------------------

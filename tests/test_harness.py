@@ -164,6 +164,14 @@ def test_scripted_recording_writes_the_reference_layout_and_replays_to_max_rewar
     _, rewards = harness.replay_episode(genv, back)
     assert rewards.max() == genv.max_reward == 4
     genv.close()
+    # the same recording written while it runs (stream_dir: the images never sit in memory): the same episodes, file for file
+    sdir = str(tmp_path / "streamed")
+    seps = harness.record_scripted("sim_insert_peg", 4, cameras=["cam_right_wrist"], seed=11, stream_dir=sdir)
+    assert [os.path.basename(x["path"]) for x in seps] == [f"episode_{i}.hdf5" for i in range(4)] and not [f for f in os.listdir(sdir) if f.endswith(".part")]
+    for a, b_ in zip(eps, seps):
+        got = harness.load_episode(b_["path"])
+        assert set(got) == set(a["data"]) and all(np.array_equal(got[k], a["data"][k]) for k in got), b_["path"]
+        assert b_["success"] == a["success"] and np.array_equal(b_["rewards"], a["rewards"]) and b_["steps"] == T
 
 
 @pytest.mark.gpu

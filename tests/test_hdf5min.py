@@ -146,14 +146,12 @@ def _libhdf5():
     return None
 
 
-def test_real_libhdf5_reads_what_hdf5min_writes(tmp_path):
-    """An episode file of the home-made writer opened by the real HDF5 library (H5Fopen / H5Dopen2 / H5Dget_space / H5Dread /
-    H5Aexists): every dataset -- the chunked u8 image stacks and the contiguous f32 tables -- comes back identical and the root
-    carries the attribute `sim` (record_sim_episodes.py:186-206).  Skipped where no libhdf5 is installed."""
+def _libhdf5_check(path, data):
+    """Opens `path` with the real HDF5 library and compares every data set with `data`; False where no libhdf5 is installed."""
     import ctypes as C
     L = _libhdf5()
     if L is None:
-        pytest.skip("no libhdf5 shared library in this image")
+        return False
     hid = C.c_int64
     L.H5open.restype = C.c_int
     L.H5Fopen.restype = hid; L.H5Fopen.argtypes = [C.c_char_p, C.c_uint, hid]
@@ -167,8 +165,6 @@ def test_real_libhdf5_reads_what_hdf5min_writes(tmp_path):
         getattr(L, fn).restype = C.c_int; getattr(L, fn).argtypes = [hid]
     assert L.H5open() >= 0
     native = {np.dtype(np.float32): hid.in_dll(L, "H5T_NATIVE_FLOAT_g").value, np.dtype(np.uint8): hid.in_dll(L, "H5T_NATIVE_UCHAR_g").value}
-    data = episode(T=5, H=24, W=32)
-    path = harness.save_episode(data, str(tmp_path), 0, use_h5py=False)
     f = L.H5Fopen(path.encode(), 0, 0)                                     # H5F_ACC_RDONLY, H5P_DEFAULT
     assert f >= 0, "libhdf5 does not accept the file"
     assert L.H5Aexists(f, b"sim") > 0
@@ -185,3 +181,43 @@ def test_real_libhdf5_reads_what_hdf5min_writes(tmp_path):
         assert np.array_equal(got, want), name
         L.H5Sclose(sp); L.H5Dclose(d)
     L.H5Fclose(f)
+    return True
+
+
+def test_real_libhdf5_reads_what_hdf5min_writes(tmp_path):
+    """An episode file of the home-made writer opened by the real HDF5 library (H5Fopen / H5Dopen2 / H5Dget_space / H5Dread /
+    H5Aexists): every dataset -- the chunked u8 image stacks and the contiguous f32 tables -- comes back identical and the root
+    carries the attribute `sim` (record_sim_episodes.py:186-206).  Skipped where no libhdf5 is installed."""
+    data = episode(T=5, H=24, W=32)
+    path = harness.save_episode(data, str(tmp_path), 0, use_h5py=False)
+    if not _libhdf5_check(path, data):
+        pytest.skip("no libhdf5 shared library in this image")
+
+
+def test_streamed_episode_equals_the_one_written_at_once(tmp_path):
+    """hdf5min.StreamWriter: the image frames of an episode appended a step at a time, the cameras interleaved (what a recording that keeps no
+    images in memory does), then the tables and the attribute: reads back as the same episode (hdf5min's reader; the real library where there
+    is one); enough frames for a chunk B-tree of two levels; an aborted writer leaves no file."""
+    from av_aloha_amd import hdf5min
+    data = episode(T=150, H=6, W=10)
+    imgs = {k: v for k, v in data.items() if "/images/" in k}
+    rest = {k: v for k, v in data.items() if "/images/" not in k}
+    p = str(tmp_path / "episode_0.hdf5")
+    w = hdf5min.StreamWriter(p)
+    for t in range(150):
+        for k, v in imgs.items():
+            w.append(k, v[t])
+    w.finish(rest, attrs={"sim": np.bool_(True)})
+    got, attrs = hdf5min.read(p)
+    assert set(got) == set(data) and bool(attrs["sim"])
+    for k, v in data.items():
+        assert got[k].dtype == v.dtype and np.array_equal(got[k], v), k
+    _libhdf5_check(p, data)
+    with pytest.raises(AssertionError):
+        w2 = hdf5min.StreamWriter(str(tmp_path / "x.hdf5"))
+        w2.append("/a", np.zeros((2, 3), np.uint8))
+        try:
+            w2.append("/a", np.zeros((2, 4), np.uint8))
+        finally:
+            w2.abort()
+    assert not (tmp_path / "x.hdf5").exists()

@@ -34,17 +34,13 @@ if __name__ == "__main__":
     args = ap.parse_args()
     cams = [c for c in args.cameras.split(",") if c]
     t0 = time.time()
-    paths, t_save, T = [], [0.0], [0]
-
-    def sink(e):            # written as its batch finishes: one batch of images in host memory at a time
-        ts = time.time()
-        paths.append(harness.save_episode(e["data"], args.dataset_dir, len(paths)))
-        T[0] = e["data"]["/action"].shape[0]
-        t_save[0] += time.time() - ts
-    eps = harness.record_scripted(args.task_name, args.num_episodes, cameras=cams, seed=args.seed, only_success=args.only_success, sink=sink)
+    # the episodes are written while they are recorded (harness.record_scripted stream_dir: no image kept in memory, all episodes side by side)
+    eps = harness.record_scripted(args.task_name, args.num_episodes, cameras=cams, seed=args.seed, only_success=args.only_success, stream_dir=args.dataset_dir)
+    paths = [e["path"] for e in eps]
+    T = [eps[0]["steps"] if eps else 0]
     t1 = time.time()
-    print(f"{args.task_name}: {len(eps)} episodes of {T[0]} steps recorded and saved to {args.dataset_dir} in {t1 - t0:.1f} s ({t_save[0]:.1f} s of it writing; "
-          f"{args.num_episodes} run side by side, in batches under the image budget), {sum(e['success'] for e in eps)} reach max_reward {eps[0]['max_reward'] if eps else '-'} "
+    print(f"{args.task_name}: {len(eps)} episodes of {T[0]} steps recorded and saved to {args.dataset_dir} in {t1 - t0:.1f} s (written while recording; "
+          f"{args.num_episodes} run side by side), {sum(e['success'] for e in eps)} reach max_reward {eps[0]['max_reward'] if eps else '-'} "
           f"({sum(e['final_success'] for e in eps)} end there), {args.num_episodes - len(eps)} dropped (diverged{' / unsuccessful' if args.only_success else ''})")
     if args.check and eps:
         from av_aloha_amd.env import make
