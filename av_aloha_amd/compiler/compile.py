@@ -522,7 +522,9 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
     # sky rgb at the zenith, sky rgb at the nadir
     # The spare fourth words hold the directional light's shadow box (round 5): [3] half extent = <statistic extent="0.6"> x MuJoCo's default
     # shadowclip 1 [EXT], [7] [11] [15] its centre = <statistic center="0 -0.1 0.2"> (scene.xml:6, the same in both asset sets)
-    md["render_light"] = np.array([0.3, 0.6, 0.7, 0.6,  0.0, 0.0, -1.0, 0.0,  0.3, 0.5, 0.7, -0.1,  0.0, 0.0, 0.0, 0.2])
+    # [16] [17] the specular term of the directional light: light specular 0.3 (MJCF default; the headlight's is 0, scene.xml:9) x material specular 0.5
+    # (MJCF default: no material of the assets sets one), exponent 128 x shininess 0.5 = 64 [EXT: fixed-function GL, viewer at infinity]
+    md["render_light"] = np.array([0.3, 0.6, 0.7, 0.6,  0.0, 0.0, -1.0, 0.0,  0.3, 0.5, 0.7, -0.1,  0.0, 0.0, 0.0, 0.2,  0.15, 64.0, 0.0, 0.0])
     # instances of the visual mesh library (models/visual_meshes.avv, compiler/vismesh.py): what the colour renderer draws
     if vis_ids is not None:
         rows = vismesh.instance_table(m, lambda g: geom_colour(m, g))

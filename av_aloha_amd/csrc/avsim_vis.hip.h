@@ -17,7 +17,7 @@
 // (scene.xml:48) from a depth map rendered from the light, one per env (k_vis_shadow: heights above the plane normal to the light over the
 // light's shadow box, 512 x 512 texels, atomicMax of ordered keys), looked up per sample; and 2 x 2 SUPERSAMPLING (MuJoCo's offscreen buffer
 // is multisampled, <quality offsamples> default 4 [EXT]): every lane tests the four samples at +-1/4 pixel of its pixel against the tile's
-// records and averages their colours.  No specular terms, haze or transparency: parity with the reference's OpenGL pixels is unpinned.
+// records and averages their colours.  The light's specular term (Blinn, viewer at infinity) is part of the flat shade.  No per-vertex lighting or transparency: parity with the reference's OpenGL pixels is unpinned.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -58,6 +58,7 @@ struct VisScene {
     const unsigned* shmap;  // shadow maps [N][VIS_SM][VIS_SM]: ordered keys of the largest height towards the light (null: no shadows)
     float le1[3], le2[3], lw[3];   // light frame: e1, e2 span the plane normal to the unit light direction lw (oracle/orc_vis.c light_frame)
     float sh_s0, sh_t0, sh_itex;   // light-space corner of the shadow box, texels per metre
+    float spec_k, spec_n;          // the directional light's specular term: light specular x material specular, exponent (render_light[16], [17]; 0: none)
 };
 constexpr int VIS_SM = 512;
 __device__ __host__ inline unsigned vis_hkey(float f) { unsigned b; memcpy(&b, &f, 4); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }      // order-preserving
@@ -283,7 +284,7 @@ template <int SS, bool SH>       // SS x SS samples per pixel; SH: shadows of th
 __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScene S, VisScratch X, const float* __restrict__ xpose, const int* __restrict__ cam_ids, int ncam_sel,
                                                             int N, int H, int W, unsigned char* __restrict__ out, int cam_major) {
     __shared__ float Rcb[VIS_MAXBODY * 12];
-    __shared__ float cam[32];                // Rc (9), pc (3), light dir in the camera frame (3), world up in the camera frame (3), scale; [19..30] the light's frame
+    __shared__ float cam[36];                // [31..33] Blinn's half vector of the directional light (viewer at infinity), camera frame; Rc (9), pc (3), light dir in the camera frame (3), world up in the camera frame (3), scale; [19..30] the light's frame
                                              // and shadow box (VisScene le1, le2, lw, sh_s0, sh_t0, sh_itex: read from here, not from SGPRs, by the few lanes that need them)
     extern __shared__ int vis_dyn[];         // toff[ntile + 1]: tile -> first list entry (after the scan), counters before; tcur[ntile]
     __shared__ int wsum[2 * (VIS_THREADS / 64)];
@@ -318,6 +319,11 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                 cam[15 + j] = cam[6 + j];                                                          // Rc^T e_z
             }
             cam[18] = 2.0f * S.cam_fovy[cid] / (float)H;
+            {   // half vector between the direction TO the light and the viewer at infinity on the optical axis (fixed-function GL [EXT]); camera frame
+                const float hx = -cam[12], hy = -cam[13], hz = -cam[14] + 1.0f, hn = hx * hx + hy * hy + hz * hz;
+                const float ih = hn > 1e-24f ? rsqrtf(hn) : 0.0f;
+                cam[31] = hx * ih; cam[32] = hy * ih; cam[33] = hz * ih;
+            }
             texcnt = 0;
             nbig = 0;
             for (int k = 0; k < 3; k++) { cam[19 + k] = S.le1[k]; cam[22 + k] = S.le2[k]; cam[25 + k] = S.lw[k]; }
@@ -393,8 +399,16 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                         if (!(ch > 0)) nout = 0;
                         const float cl = -(n[0] * cam[12] + n[1] * cam[13] + n[2] * cam[14]) * in;
                         const float lum = fminf(1.0f, amb + hd * ch + ld * fmaxf(cl, 0.0f)), lum2 = fminf(1.0f, amb + hd * ch);
+                        // the light's specular term: light specular x material specular (S.spec_k) x (n . h)^exponent, white; it goes with the
+                        // light's diffuse term in shadow
+                        float spec = 0.0f;
+                        if (cl > 0.0f && S.spec_k > 0.0f) {
+                            const float nh = (n[0] * cam[31] + n[1] * cam[32] + n[2] * cam[33]) * in;
+                            if (nh > 0.0f) spec = S.spec_k * exp2f(S.spec_n * log2f(nh));
+                        }
                         if (S.tex[t]) {      // textured: the record carries the shade, the colour comes from the texture at the sample
-                            colour = 0x80000000u | (unsigned)(lum * 65535.0f + 0.5f); colour2 = 0x80000000u | (unsigned)(lum2 * 65535.0f + 0.5f);
+                            colour = 0x80000000u | ((unsigned)(fminf(spec, 1.0f) * 32767.0f + 0.5f) << 16) | (unsigned)(lum * 65535.0f + 0.5f);      // bit 31, specular 15 bits, shade 16 bits
+                            colour2 = 0x80000000u | (unsigned)(lum2 * 65535.0f + 0.5f);
                             if (nout > 0) {
                                 // Texture coordinates over the image without going back to the vertices per pixel: a point s d of the triangle's plane
                                 // (d = the sample's ray) has barycentrics s M^-1 d, M = [a b c]; the rows of M^-1 are b x c, c x a, a x b over det(M),
@@ -416,7 +430,7 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                                 } else { tag = VIS_TEXCAP - 1; flag |= 1; }
                             }
                         }
-                        else { colour = vis_pack(S.rgb[3 * t] * lum, S.rgb[3 * t + 1] * lum, S.rgb[3 * t + 2] * lum); colour2 = vis_pack(S.rgb[3 * t] * lum2, S.rgb[3 * t + 1] * lum2, S.rgb[3 * t + 2] * lum2); }
+                        else { colour = vis_pack(S.rgb[3 * t] * lum + spec, S.rgb[3 * t + 1] * lum + spec, S.rgb[3 * t + 2] * lum + spec); colour2 = vis_pack(S.rgb[3 * t] * lum2, S.rgb[3 * t + 1] * lum2, S.rgb[3 * t + 2] * lum2); }
                         // in the light's shadow the light's term goes (colour2); the depth map's texels are S.sh_itex^-1 wide, so a lit surface
                         // tilted by theta against the light lies up to texel x tan(theta) below its own texel's height: slope-scaled bias.
                         // A surface that faces away from the light has no such term to lose: bias < 0 = no look-up
@@ -606,7 +620,7 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                         }
                         if (col & 0x80000000u) {
                             // textured: (u, v) = (U, V) / D with the triangle's three planes over the image (set-up), then the texel
-                            const float lum = (float)(col & 0xffffu) * (1.0f / 65535.0f);
+                            const float lum = (float)(col & 0xffffu) * (1.0f / 65535.0f), spc = (float)((col >> 16) & 0x7fffu) * (1.0f / 32767.0f);
                             const float4* tp = trec + 3 * __float_as_int(r3.y);
                             const float4 pu = tp[0], pv = tp[1], pd = tp[2];
                             const float den = pd.x * sx + (pd.y * sy + pd.z);
@@ -615,7 +629,7 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                             const float fu = tu - floorf(tu), fv = tv - floorf(tv);
                             const int txi = min(S.texn - 1, (int)(fu * S.texn)), tyi = min(S.texn - 1, (int)((1.0f - fv) * S.texn));
                             const unsigned tx_ = S.texel[tyi * S.texn + txi];
-                            col = vis_pack((float)(tx_ & 255u) * (lum / 255.0f), (float)((tx_ >> 8) & 255u) * (lum / 255.0f), (float)((tx_ >> 16) & 255u) * (lum / 255.0f));
+                            col = vis_pack((float)(tx_ & 255u) * (lum / 255.0f) + spc, (float)((tx_ >> 8) & 255u) * (lum / 255.0f) + spc, (float)((tx_ >> 16) & 255u) * (lum / 255.0f) + spc);
                         }
                     } else {
                         const float idn = rsqrtf(dx * dx + dy * dy + 1.0f);
@@ -681,7 +695,7 @@ struct VisHost {
     unsigned* d_shmap = nullptr;
     int shmap_envs = 0;
     unsigned long long shmap_ver = 0;   // the state version (avsim_api.hip) the shadow maps were rendered for
-    double light_host[16] = {0};     // the model's render_light (lights, sky, shadow box)
+    double light_host[20] = {0};     // the model's render_light (lights, sky, shadow box, specular term)
 
     template <typename T>
     T* up(const std::vector<T>& v) {
@@ -695,7 +709,7 @@ struct VisHost {
         try {
             inst_mesh = b.i("vis_inst_mesh"); inst_body = b.i("vis_inst_body"); inst_tex = b.i("vis_inst_tex");
             inst_pos = b.f("vis_inst_pos"); inst_mat = b.f("vis_inst_mat"); inst_scale = b.f("vis_inst_scale"); inst_rgba = b.f("vis_inst_rgba");
-            { auto L = b.f("render_light"); for (size_t k = 0; k < 16 && k < L.size(); k++) light_host[k] = L[k]; }
+            { auto L = b.f("render_light"); for (size_t k = 0; k < 20 && k < L.size(); k++) light_host[k] = L[k]; }
             have_inst = true;
         } catch (const std::exception&) { have_inst = false; }      // a model compiled without the visual scene: the proxy image only
     }
@@ -753,6 +767,7 @@ struct VisHost {
             S.sh_t0 = (float)(c[0] * e2[0] + c[1] * e2[1] + c[2] * e2[2] - half);
             S.sh_itex = (float)(VIS_SM / (2.0 * half));
             S.shmap = nullptr;
+            S.spec_k = (float)L[16]; S.spec_n = (float)L[17];
         }
         loaded = true;
     }

@@ -8,8 +8,8 @@ of gym_guided_vision/gym_guided_vision/__init__.py:4-101, so callers written aga
 kernels; this file only holds host-side glue (action/observation packing, object-pose sampling).
 
 Differences a caller can see (DESIGN.md lists them): the `pixels` observations and `render()` are drawn by the library's
-own triangle rasteriser over the decimated visual meshes (robot, frame, textured table, task objects; flat Lambert shading, no
-shadows / specular terms), not by MuJoCo's OpenGL renderer; `render_depth()` returns float32 depth images of the same cameras (BASELINE config 5); envs can be batched
+own triangle rasteriser over the decimated visual meshes (robot, frame, textured table, task objects; flat shading per triangle with the
+scene's lights, the directional light's shadows and specular term, 2 x 2 multisampling), not by MuJoCo's OpenGL renderer; `render_depth()` returns float32 depth images of the same cameras (BASELINE config 5); envs can be batched
 with `num_envs > 1` (every array gains a leading axis).
 """
 from __future__ import annotations

@@ -173,7 +173,8 @@ int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height,
  * "render_shadows" 1 -- the scene's directional light (scene.xml:48) casts shadows inside its shadow box (<statistic center extent>,
  * scene.xml:6), from a 512 x 512 depth map rendered from the light per env; "render_samples" 4 -- 2 x 2 supersampling (MuJoCo's offscreen
  * buffer is multisampled, offsamples default 4 [EXT]).  Both are off at the C-ABI and on in the gym facades.  "render_cam_major" 1 -- out is
- * uint8[ncam][N][height][width][3] (every camera's batch contiguous: the facades hand out one array per camera without copying).  No specular terms, haze or
+ * uint8[ncam][N][height][width][3] (every camera's batch contiguous: the facades hand out one array per camera without copying).  The directional light's specular
+ * term (MJCF defaults: light 0.3 x material 0.5, exponent 64) is part of the shade.  No per-vertex lighting or
  * transparency: a stand-in for MuJoCo's OpenGL output, not a pixel match.  A view that runs out of triangle
  * records or tile-list entries sets the overflow flags of avsim_visual_info (the image then lacks triangles).  Pointer conventions
  * as avsim_render_depth. */

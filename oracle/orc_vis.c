@@ -166,6 +166,18 @@ int orc_vis_render_ex(const orc_data* d, int cam, int nvert, const double* vert,
                     }
                     double lum = amb + hd * ch + ld * (cl > 0 ? cl : 0);
                     if (lum > 1) lum = 1;
+                    /* the light's specular term (render_light[16] = light specular x material specular, [17] the exponent): Blinn's half vector with
+                     * the viewer at infinity along the optical axis, as fixed-function GL has it [EXT]; white, added to every channel; gone in shadow */
+                    double spec = 0;
+                    if (cl > 0 && L[16] > 0) {
+                        double h[3] = {-lc[0], -lc[1], -lc[2] + 1.0};
+                        const double hn = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+                        if (hn > 1e-12) {
+                            double sgn = ch >= 0 ? 1.0 : -1.0;          /* the normal turned towards the camera */
+                            const double nh = sgn * (n[0] * h[0] + n[1] * h[1] + n[2] * h[2]) / (nn * hn);
+                            if (nh > 0) spec = L[16] * pow(nh, L[17]);
+                        }
+                    }
                     if (tex[bt]) {
                         const double* w = uv + 6 * bt;
                         const double tu = w[0] + bu * (w[2] - w[0]) + bv * (w[4] - w[0]), tv = w[1] + bu * (w[3] - w[1]) + bv * (w[5] - w[1]);
@@ -173,9 +185,9 @@ int orc_vis_render_ex(const orc_data* d, int cam, int nvert, const double* vert,
                         int xi = (int)(fu * texn), yi = (int)((1.0 - fv) * texn);
                         xi = xi > texn - 1 ? texn - 1 : xi; yi = yi > texn - 1 ? texn - 1 : yi;
                         const unsigned px = (unsigned)texel[yi * texn + xi];
-                        col[0] = (px & 255u) / 255.0 * lum; col[1] = ((px >> 8) & 255u) / 255.0 * lum; col[2] = ((px >> 16) & 255u) / 255.0 * lum;
+                        col[0] = (px & 255u) / 255.0 * lum + spec; col[1] = ((px >> 8) & 255u) / 255.0 * lum + spec; col[2] = ((px >> 16) & 255u) / 255.0 * lum + spec;
                     } else
-                        for (int k = 0; k < 3; k++) col[k] = rgb[3 * bt + k] * lum;
+                        for (int k = 0; k < 3; k++) col[k] = rgb[3 * bt + k] * lum + spec;
                 } else {
                     const double idn = 1.0 / sqrt(dir[0] * dir[0] + dir[1] * dir[1] + 1.0);
                     const double w = 0.5 + 0.5 * (up[0] * dir[0] + up[1] * dir[1] - up[2]) * idn;
