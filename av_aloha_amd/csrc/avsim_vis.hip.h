@@ -136,11 +136,11 @@ __device__ inline void vis_sload12x4(const void* p0, const void* p1, const void*
 }
 
 // Tile lists.  Records are taken 64 at a time by a wavefront, one per lane.  A triangle whose box covers a few tiles is walked by its
-// own lane.  A big one (the table top covers every tile of the overhead view, a frame bar crosses the image) goes to a queue that the whole
-// workgroup then works through: chunks of 64 tiles of a queued triangle's box, dealt round-robin over the wavefronts, lane k of a chunk taking
-// its k-th tile -- the big triangles come in runs of one mesh (the table's 92), which as the work of whichever wavefront took that run of
-// records were a third of the view's time once sixteen wavefronts shared a view.  The queue is built by the counting pass and reused by
-// the fill pass.  FILL = false counts (cnt[tile]++), FILL = true appends the record index at cur[tile]++.
+// own lane.  A big one (the table top covers every tile of the overhead view, a frame bar crosses the image) goes to a queue that the
+// workgroup then works through: the entries dealt round-robin over the wavefronts (the big triangles come in runs of one mesh: the table's
+// 92), a queued triangle's tile ROWS over the lanes, the row's span of tiles from the three edge functions -- a thin bar across the image has a
+// box of thousands of tiles and touches a hundred.  The queue is built by the counting pass and reused by the fill pass.
+// FILL = false counts (cnt[tile]++), FILL = true appends the record index at cur[tile]++.
 template <bool FILL>
 __device__ inline void vis_bin(const float4* __restrict__ rec, const int* __restrict__ bbox, int nrec, int* cnt, int* __restrict__ list, int listcap, int tw, int lane, int wave,
                                int& flag, int* __restrict__ bigq, int* bign) {
