@@ -55,12 +55,13 @@ struct VisScene {
     const float *cam_pos, *cam_mat, *cam_fovy;   // cam_fovy: tan(fovy / 2)
     const float* light;     // as RenderModel::light; [3] half extent of the light's shadow box (0: none), [7] [11] [15] its centre (world)
     float znear;
-    const unsigned* shmap;  // shadow maps [N][VIS_SM][VIS_SM]: ordered keys of the largest height towards the light (null: no shadows)
+    int shn;                // texels per side of a shadow map (option "render_shadow_size": 512 default, 1024, 2048)
+    const unsigned* shmap;  // shadow maps [N][shn][shn]: ordered keys of the largest height towards the light (null: no shadows)
     float le1[3], le2[3], lw[3];   // light frame: e1, e2 span the plane normal to the unit light direction lw (oracle/orc_vis.c light_frame)
     float sh_s0, sh_t0, sh_itex;   // light-space corner of the shadow box, texels per metre
     float spec_k, spec_n;          // the directional light's specular term: light specular x material specular, exponent (render_light[16], [17]; 0: none)
 };
-constexpr int VIS_SM = 512;
+constexpr int VIS_SM = 512;       // default side of the shadow map
 __device__ __host__ inline unsigned vis_hkey(float f) { unsigned b; memcpy(&b, &f, 4); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }      // order-preserving
 __device__ inline float vis_hval(unsigned k) { const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; return __uint_as_float(b); }
 
@@ -218,8 +219,9 @@ __global__ void __launch_bounds__(VIS_SHADOW_THREADS) k_vis_shadow(VisScene S, c
     __shared__ int nq;
     const int env = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (env >= N) return;
-    unsigned* map = shmap + (size_t)env * VIS_SM * VIS_SM;
-    for (int i = tid; i < VIS_SM * VIS_SM / 4; i += VIS_SHADOW_THREADS) ((uint4*)map)[i] = make_uint4(0u, 0u, 0u, 0u);
+    const int SM = S.shn;
+    unsigned* map = shmap + (size_t)env * SM * SM;
+    for (int i = tid; i < SM * SM / 4; i += VIS_SHADOW_THREADS) ((uint4*)map)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) nq = 0;
     __threadfence_block();
     __syncthreads();
@@ -229,8 +231,8 @@ __global__ void __launch_bounds__(VIS_SHADOW_THREADS) k_vis_shadow(VisScene S, c
         const float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
         if (!(fabsf(area) > 1e-12f)) return;
         const float ia = 1.0f / area;
-        const int ix0 = max(0, (int)ceilf(fminf(x0, fminf(x1, x2)) - 0.5f)), ix1 = min(VIS_SM - 1, (int)floorf(fmaxf(x0, fmaxf(x1, x2)) - 0.5f));
-        const int iy0 = max(0, (int)ceilf(fminf(y0, fminf(y1, y2)) - 0.5f)), iy1 = min(VIS_SM - 1, (int)floorf(fmaxf(y0, fmaxf(y1, y2)) - 0.5f));
+        const int ix0 = max(0, (int)ceilf(fminf(x0, fminf(x1, x2)) - 0.5f)), ix1 = min(SM - 1, (int)floorf(fmaxf(x0, fmaxf(x1, x2)) - 0.5f));
+        const int iy0 = max(0, (int)ceilf(fminf(y0, fminf(y1, y2)) - 0.5f)), iy1 = min(SM - 1, (int)floorf(fmaxf(y0, fmaxf(y1, y2)) - 0.5f));
         if (ix0 > ix1 || iy0 > iy1) return;
         const int bw = ix1 - ix0 + 1, n = bw * (iy1 - iy0 + 1);
         // barycentrics and the height as functions affine in the texel centre
@@ -239,10 +241,11 @@ __global__ void __launch_bounds__(VIS_SHADOW_THREADS) k_vis_shadow(VisScene S, c
         const float h0 = P[2], h1 = P[5], h2 = P[8];
         const float ibw = 1.0f / (float)bw;
         for (int k = first; k < n; k += stride) {
-            const int ry = (int)(((float)k + 0.5f) * ibw), rx = k - ry * bw;      // (k / bw, k % bw: exact for the boxes of a 512 x 512 map)
+            int ry = (int)(((float)k + 0.5f) * ibw), rx = k - ry * bw;            // k / bw, k % bw through the reciprocal, put right where it rounded across a row
+            if (rx < 0) { ry--; rx += bw; } else if (rx >= bw) { ry++; rx -= bw; }
             const float fx = (float)(ix0 + rx) + 0.5f, fy = (float)(iy0 + ry) + 0.5f;
             const float l0 = a0 * fx + (b0 * fy + c0), l1 = a1 * fx + (b1 * fy + c1), l2 = 1.0f - l0 - l1;
-            if (fminf(fminf(l0, l1), l2) >= 0.0f) atomicMax(&map[(iy0 + ry) * VIS_SM + ix0 + rx], vis_hkey(l0 * h0 + l1 * h1 + l2 * h2));
+            if (fminf(fminf(l0, l1), l2) >= 0.0f) atomicMax(&map[(iy0 + ry) * SM + ix0 + rx], vis_hkey(l0 * h0 + l1 * h1 + l2 * h2));
         }
     };
     for (int t0 = 0; t0 < S.ntri; t0 += VIS_SHADOW_THREADS) {
@@ -521,7 +524,7 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
         const long long tc4 = __builtin_readcyclecounter();
         // 4. tiles: one wavefront each, lane = pixel
         unsigned char* img = out + (size_t)(cam_major ? cs * N + env : view) * H * W * 3;      // [N][cam] or (option render_cam_major) [cam][N]
-        const unsigned* shenv = SH ? S.shmap + (size_t)env * VIS_SM * VIS_SM : nullptr;
+        const unsigned* shenv = SH ? S.shmap + (size_t)env * S.shn * S.shn : nullptr;
         // (records and lists were written with vector stores: the barrier above made them visible in L2, this drops what the scalar cache
         // still holds of the slot's previous view)
         __builtin_amdgcn_s_dcache_inv();
@@ -613,8 +616,8 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                             const float wx = cam[9] + cam[0] * px + cam[1] * py + cam[2] * pz, wy = cam[10] + cam[3] * px + cam[4] * py + cam[5] * pz, wz = cam[11] + cam[6] * px + cam[7] * py + cam[8] * pz;
                             const float su = (wx * cam[19] + wy * cam[20] + wz * cam[21] - cam[28]) * cam[30], sv = (wx * cam[22] + wy * cam[23] + wz * cam[24] - cam[29]) * cam[30];
                             const float hh = -(wx * cam[25] + wy * cam[26] + wz * cam[27]);
-                            if (su >= 0.0f && sv >= 0.0f && su < (float)VIS_SM && sv < (float)VIS_SM) {
-                                const unsigned key = shenv[(unsigned)((int)sv * VIS_SM + (int)su)];
+                            if (su >= 0.0f && sv >= 0.0f && su < (float)S.shn && sv < (float)S.shn) {
+                                const unsigned key = shenv[(unsigned)((int)sv * S.shn + (int)su)];
                                 if (key != 0u && vis_hval(key) > hh + r3.w) col = __float_as_uint(r3.z);
                             }
                         }
@@ -691,6 +694,7 @@ struct VisHost {
     int* d_cam_ids = nullptr;
     int samples = 1;                 // option "render_samples": 1, or 4 = 2 x 2 supersampling
     bool cam_major = false;          // option "render_cam_major": the images as [cam][N][H][W][3] (every camera's batch contiguous) instead of [N][cam][H][W][3]
+    int shadow_size = VIS_SM;        // option "render_shadow_size": 512 | 1024 | 2048 texels per side (MuJoCo's own map is 8192 wide, scene.xml:12; 2.3 mm texels at 512)
     bool shadows = false;            // option "render_shadows": the directional light casts shadows (depth map from the light, one per env)
     unsigned* d_shmap = nullptr;
     int shmap_envs = 0;
@@ -765,7 +769,8 @@ struct VisHost {
             const double half = L[3] > 0 ? L[3] : 1.0, c[3] = {L[7], L[11], L[15]};
             S.sh_s0 = (float)(c[0] * e1[0] + c[1] * e1[1] + c[2] * e1[2] - half);
             S.sh_t0 = (float)(c[0] * e2[0] + c[1] * e2[1] + c[2] * e2[2] - half);
-            S.sh_itex = (float)(VIS_SM / (2.0 * half));
+            S.shn = shadow_size;
+            S.sh_itex = (float)(shadow_size / (2.0 * half));
             S.shmap = nullptr;
             S.spec_k = (float)L[16]; S.spec_n = (float)L[17];
         }
@@ -831,12 +836,17 @@ struct VisHost {
         }
         S.shmap = nullptr;
         if (shadows && light_host[3] > 0) {
-            // one depth map from the light per env (shared by the env's cameras): VIS_SM^2 keys, 1 MB an env
+            // one depth map from the light per env (shared by the env's cameras): shadow_size^2 keys, 1 MB an env at 512
+            if (S.shn != shadow_size) {        // (option changed since the scene was loaded: the texel scale with it)
+                S.sh_itex *= (float)shadow_size / (float)S.shn;
+                S.shn = shadow_size;
+                shmap_envs = 0;                // reallocate
+            }
             if (N > shmap_envs) {
                 if (hipStreamSynchronize(st) != hipSuccess) { err = "visual render: stream synchronisation failed"; return -3; }
                 if (d_shmap) (void)hipFree(d_shmap);
                 d_shmap = nullptr; shmap_envs = 0;
-                if (hipMalloc((void**)&d_shmap, (size_t)N * VIS_SM * VIS_SM * sizeof(unsigned)) != hipSuccess) { err = "hipMalloc(shadow maps) failed"; return -3; }
+                if (hipMalloc((void**)&d_shmap, (size_t)N * shadow_size * shadow_size * sizeof(unsigned)) != hipSuccess) { err = "hipMalloc(shadow maps) failed"; return -3; }
                 shmap_envs = N;
                 shmap_ver = 0;
             }

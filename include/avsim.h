@@ -171,7 +171,7 @@ int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height,
  * light :48, table texture, skybox gradient :34).  Without a loaded visual scene, or with option "render_proxies" 1, the collision
  * proxies are drawn in their flat material colours instead (the depth rasteriser's colour variant).  Options of the visual image (round 5):
  * "render_shadows" 1 -- the scene's directional light (scene.xml:48) casts shadows inside its shadow box (<statistic center extent>,
- * scene.xml:6), from a 512 x 512 depth map rendered from the light per env; "render_samples" 4 -- 2 x 2 supersampling (MuJoCo's offscreen
+ * scene.xml:6), from a 512 x 512 depth map rendered from the light per env ("render_shadow_size" 1024 | 2048: a finer one, 4 / 16 MB per env); "render_samples" 4 -- 2 x 2 supersampling (MuJoCo's offscreen
  * buffer is multisampled, offsamples default 4 [EXT]).  Both are off at the C-ABI and on in the gym facades.  "render_cam_major" 1 -- out is
  * uint8[ncam][N][height][width][3] (every camera's batch contiguous: the facades hand out one array per camera without copying).  The directional light's specular
  * term (MJCF defaults: light 0.3 x material 0.5, exponent 64) is part of the shade.  No per-vertex lighting or

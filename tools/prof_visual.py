@@ -16,7 +16,7 @@ h = _ffi.Handle(blob, N, 0, _ffi.AVSIM_IO_DEVICE)
 L = h.L
 lib = open(os.path.join(MODEL_DIR, "visual_meshes.avv"), "rb").read()
 h.check(L.avsim_load_visual(h.h, lib, len(lib)))
-for opt, env in (("render_shadows", "SHADOWS"), ("render_samples", "SAMPLES")):      # SHADOWS=1 SAMPLES=4: the facades' defaults
+for opt, env in (("render_shadows", "SHADOWS"), ("render_samples", "SAMPLES"), ("render_shadow_size", "SHSIZE")):      # SHADOWS=1 SAMPLES=4: the facades' defaults
     if os.environ.get(env):
         h.check(L.avsim_set_option(h.h, opt.encode(), float(os.environ[env])))
 obj = torch.tensor(np.repeat(OBJ[None], N, 0).reshape(N, -1), dtype=torch.float64, device="cuda")
@@ -25,6 +25,8 @@ cams = ["zed_cam_left", "wrist_cam_left", "wrist_cam_right", "overhead_cam"]
 ids = np.array([man["camera_names"].index(c) for c in cams], dtype=np.int32)
 out = torch.empty((N, len(ids), H, W, 3), dtype=torch.uint8, device="cuda")
 for rep in range(3):
+    h.check(L.avsim_reset(h.h, None, obj.data_ptr()))        # (a new state version: the call below renders its shadow maps, as a call after a step does)
+    h.check(L.avsim_sync(h.h))
     torch.cuda.synchronize(); t = time.time()
     h.check(L.avsim_render_rgb(h.h, ids.ctypes.data, len(ids), H, W, out.data_ptr()))
     h.check(L.avsim_sync(h.h)); torch.cuda.synchronize()
