@@ -221,7 +221,9 @@ __global__ void __launch_bounds__(VIS_SHADOW_THREADS) k_vis_shadow(VisScene S, c
     if (env >= N) return;
     const int SM = S.shn;
     unsigned* map = shmap + (size_t)env * SM * SM;
-    for (int i = tid; i < SM * SM / 4; i += VIS_SHADOW_THREADS) ((uint4*)map)[i] = make_uint4(0u, 0u, 0u, 0u);
+    // (a launch of few envs splits every map into bands of rows, one workgroup each: blockIdx.y; every band walks all triangles)
+    const int rows = SM / (int)gridDim.y, yb0 = (int)blockIdx.y * rows, yb1 = yb0 + rows - 1;
+    for (int i = tid; i < rows * SM / 4; i += VIS_SHADOW_THREADS) ((uint4*)(map + (size_t)yb0 * SM))[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) nq = 0;
     __threadfence_block();
     __syncthreads();
@@ -232,7 +234,7 @@ __global__ void __launch_bounds__(VIS_SHADOW_THREADS) k_vis_shadow(VisScene S, c
         if (!(fabsf(area) > 1e-12f)) return;
         const float ia = 1.0f / area;
         const int ix0 = max(0, (int)ceilf(fminf(x0, fminf(x1, x2)) - 0.5f)), ix1 = min(SM - 1, (int)floorf(fmaxf(x0, fmaxf(x1, x2)) - 0.5f));
-        const int iy0 = max(0, (int)ceilf(fminf(y0, fminf(y1, y2)) - 0.5f)), iy1 = min(SM - 1, (int)floorf(fmaxf(y0, fmaxf(y1, y2)) - 0.5f));
+        const int iy0 = max(yb0, (int)ceilf(fminf(y0, fminf(y1, y2)) - 0.5f)), iy1 = min(yb1, (int)floorf(fmaxf(y0, fmaxf(y1, y2)) - 0.5f));
         if (ix0 > ix1 || iy0 > iy1) return;
         const int bw = ix1 - ix0 + 1, n = bw * (iy1 - iy0 + 1);
         // barycentrics and the height as functions affine in the texel centre
@@ -261,11 +263,14 @@ __global__ void __launch_bounds__(VIS_SHADOW_THREADS) k_vis_shadow(VisScene S, c
                 P[3 * c + 1] = (w[0] * S.le2[0] + w[1] * S.le2[1] + w[2] * S.le2[2] - S.sh_t0) * S.sh_itex;
                 P[3 * c + 2] = -(w[0] * S.lw[0] + w[1] * S.lw[1] + w[2] * S.lw[2]);
             }
-            const float bx = fmaxf(P[0], fmaxf(P[3], P[6])) - fminf(P[0], fminf(P[3], P[6])), by = fmaxf(P[1], fmaxf(P[4], P[7])) - fminf(P[1], fminf(P[4], P[7]));
-            if ((bx + 1.0f) * (by + 1.0f) > 64.0f) {
-                const int slot = atomicAdd(&nq, 1);          // (< VIS_SHQ: the queue is emptied while a pass of the workgroup still fits)
-                for (int c = 0; c < 9; c++) Q[9 * slot + c] = P[c];
-            } else raster(P, 0, 1);
+            const float ylo = fmaxf(fminf(P[1], fminf(P[4], P[7])), (float)yb0), yhi = fminf(fmaxf(P[1], fmaxf(P[4], P[7])), (float)(yb1 + 1));      // (the box inside this band)
+            const float bx = fmaxf(P[0], fmaxf(P[3], P[6])) - fminf(P[0], fminf(P[3], P[6])), by = yhi - ylo;
+            if (by >= 0.0f) {              // (else: the triangle lies outside this band)
+                if ((bx + 1.0f) * (by + 1.0f) > 64.0f) {
+                    const int slot = atomicAdd(&nq, 1);          // (< VIS_SHQ: the queue is emptied while a pass of the workgroup still fits)
+                    for (int c = 0; c < 9; c++) Q[9 * slot + c] = P[c];
+                } else raster(P, 0, 1);
+            }
         }
         __syncthreads();
         const int n = nq;
@@ -852,7 +857,10 @@ struct VisHost {
             }
             S.shmap = d_shmap;
             if (state_ver == 0 || shmap_ver != state_ver) {      // (the maps of this state may be there already: an earlier call for other cameras)
-                hipLaunchKernelGGL(k_vis_shadow, dim3(N), dim3(VIS_SHADOW_THREADS), 0, st, S, d_xpose, d_shmap, N);
+                // few envs: the maps in bands of rows (a workgroup each), so that one env's map is not one workgroup's work (16 bands for one env)
+                int bands = 1;
+                while (bands < 16 && N * bands < 256) bands *= 2;
+                hipLaunchKernelGGL(k_vis_shadow, dim3(N, bands), dim3(VIS_SHADOW_THREADS), 0, st, S, d_xpose, d_shmap, N);
                 shmap_ver = state_ver;
             }
         }
