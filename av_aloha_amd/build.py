@@ -43,9 +43,11 @@ def _build_hip_locked(verbose):
         # cross-lane sums from folding into their adds (config 2: 972 k -> 1009 k env-steps/s, private segment 592 -> 464 B)
         # -O2, no loop vectoriser, no atomic optimiser (the LDS atomics of a wave go to distinct addresses by construction): measured
         # together 1006 k -> 1023 k (tools/exp_flags_multi.sh, profiles/r03_experiments.txt); -O3 was the setting until then
+        # -amdgpu-sched-strategy=max-ilp: the machine scheduler orders for instruction-level parallelism instead of for occupancy, which the kernels fix
+        # themselves (waves_per_eu): config 2 1 028 -> 1 039 k, f64 428 -> 436 k on one box (tools/exp_flags_ab.sh, profiles/r05_experiments.txt 7b)
         ("avsim_api", ["-O2", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero", "-fno-slp-vectorize", "-fno-vectorize",
-                       "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"] + (["-DAVSIM_RENDER_STATS"] if os.environ.get("AVSIM_RENDER_STATS") else []) + os.environ.get("AVSIM_EXTRA_FLAGS", "").split()),
-        ("avsim_phys_f64", ["-O3", "-ffp-contract=off"] + os.environ.get("AVSIM_EXTRA_FLAGS_F64", "").split()),
+                       "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-mllvm", "-amdgpu-sched-strategy=max-ilp"] + (["-DAVSIM_RENDER_STATS"] if os.environ.get("AVSIM_RENDER_STATS") else []) + os.environ.get("AVSIM_EXTRA_FLAGS", "").split()),
+        ("avsim_phys_f64", ["-O3", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp"] + os.environ.get("AVSIM_EXTRA_FLAGS_F64", "").split()),
     ]
     procs = []
     for name, extra in units:
