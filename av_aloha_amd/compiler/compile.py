@@ -181,10 +181,10 @@ def read_blob(path):
     return out
 
 
-def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbose=False, vis_ids=None, kmax_collision=128):
+def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbose=False, vis_ids=None, kmax_collision=128, xml_path=None):
     xml, task_id = TASKS[task]
-    m = parse(os.path.join(assets, xml))
-    if num_arms == 2:
+    m = parse(xml_path if xml_path is not None else os.path.join(assets, xml))
+    if num_arms == 2 and xml_path is None:
         # env.py:60-62, 394-395: hide_middle_arm() rewrites the base body position
         for b in m.bodies:
             if b["name"] == "middle_base_link":
@@ -291,8 +291,12 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
             continue
         if b["inertial"] is not None:
             it = b["inertial"]
-            R = quat_to_mat(it["quat"])
-            I3 = R @ np.diag(it["diaginertia"]) @ R.T
+            if "fullinertia" in it:
+                f = it["fullinertia"]
+                I3 = np.array([[f[0], f[3], f[4]], [f[3], f[1], f[5]], [f[4], f[5], f[2]]])
+            else:
+                R = quat_to_mat(it["quat"])
+                I3 = R @ np.diag(it["diaginertia"]) @ R.T
             mass[i], ipos[i] = it["mass"], it["pos"]
         else:
             # inertiafromgeom (auto): combine all geoms of the body [EXT]
@@ -391,6 +395,9 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
             return hull_info[name]
         me = m.meshes[name]
         key = me["file"]
+        if key is None:                      # inline vertex set (emit_mjcf.py's restatement of a compiled model)
+            key = "inline:" + name
+            mesh_cache[key] = me["vertex"]
         if key not in mesh_cache:
             mesh_cache[key] = hullmod.read_stl(key)
         pts = mesh_cache[key] * me["scale"]
@@ -649,6 +656,15 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
         p_gap[i] = max(g_gap[a], g_gap[b])
     md.update(npair=npair, pair_geom=p_geom, pair_condim=p_condim, pair_friction=p_fric,
               pair_solref=p_solref, pair_solimp=p_solimp, pair_margin=p_margin, pair_gap=p_gap)
+    # what the pair list was made FROM (round 6): the contact filter's inputs, so that compiler/emit_mjcf.py can restate the model as a
+    # self-contained MJCF for the MuJoCo pin (tests/test_mujoco_pin.py) without the reference's XML.  The library and the oracle read
+    # the blob by name and never look at these.
+    md["geom_contype"], md["geom_conaffinity"], md["geom_priority"], md["geom_solmix"] = g_contype, g_conaff, g_prio, g_solmix
+    md["exclude_body"] = np.array([(body_id[a], body_id[b]) for a, b in m.excludes], dtype=np.int32).reshape(-1, 2)
+    md["site_body"] = np.array([t["body"] for t in m.sites], dtype=np.int32)
+    md["site_pos"] = np.array([t["pos"] for t in m.sites]).reshape(-1, 3)
+    md["site_quat"] = np.array([t["quat"] for t in m.sites]).reshape(-1, 4)
+    md["opt_multiccd"] = np.array([1 if m.option.get("flag_multiccd", "disable") == "enable" else 0], dtype=np.int32)
 
     # ---- options -------------------------------------------------------------------------
     md["opt"] = np.array([
@@ -737,6 +753,7 @@ def compile_task(assets, task, num_arms, kmax_default=20, kmax_finger=32, verbos
         "actuator_names": [a["name"] for a in m.actuators],
         "geom_names": names,
         "camera_names": [c["name"] for c in m.cameras],
+        "site_names": [t["name"] for t in m.sites],
         "hulls": report,
         "total_mass": float(mass.sum()),
     }

@@ -198,9 +198,12 @@ def parse(path):
 
     for node in root.findall("asset"):
         for me in node.findall("mesh"):
+            scale = _floats(me.attrib.get("scale", "1 1 1"), 3)
+            if "vertex" in me.attrib:        # inline vertex set (compiler/emit_mjcf.py writes the collision hulls that way)
+                m.meshes[me.attrib["name"]] = {"file": None, "scale": scale, "vertex": _floats(me.attrib["vertex"]).reshape(-1, 3)}
+                continue
             f = me.attrib["file"]
             name = me.attrib.get("name", os.path.splitext(os.path.basename(f))[0])
-            scale = _floats(me.attrib.get("scale", "1 1 1"), 3)
             m.meshes[name] = {"file": os.path.join(meshdir, f), "scale": scale}
         for ma in node.findall("material"):
             m.materials[ma.attrib["name"]] = _floats(ma.attrib["rgba"], 4) if "rgba" in ma.attrib else None
@@ -229,8 +232,11 @@ def parse(path):
                     "pos": _floats(ch.attrib["pos"], 3),
                     "quat": orientation(ch.attrib, eulerseq),
                     "mass": float(ch.attrib["mass"]),
-                    "diaginertia": _floats(ch.attrib["diaginertia"], 3),
                 }
+                if "fullinertia" in ch.attrib:   # Ixx Iyy Izz Ixy Ixz Iyz in the frame at `pos` aligned with the body (emit_mjcf.py)
+                    body["inertial"]["fullinertia"] = _floats(ch.attrib["fullinertia"], 6)
+                else:
+                    body["inertial"]["diaginertia"] = _floats(ch.attrib["diaginertia"], 3)
             elif ch.tag in ("joint", "freejoint"):
                 a = elem_attrs("joint", ch, cc)
                 jtype = "free" if ch.tag == "freejoint" else a.get("type", "hinge")

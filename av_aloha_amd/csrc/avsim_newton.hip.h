@@ -76,6 +76,7 @@ struct NewtonArgs {
     LDS_PTR(int) prof;           // optional cycle counters (8 ints) or null
     int nv, nefc, ncon, nlead, ntree, iters;
     real tol, scale, ls_tol;
+    int ls_iters;                // option "ls_iterations": evaluations of phi' after the one at alpha = 0
     int early_exit;              // option "newton_early_exit": leave without the confirming gradient after an exact step of a quadratic piece
     // this lane's dof (lane < nv <= 64): first dof and size of its tree, offset of its row in the tree's block of M
     int k_a0, k_n, k_mb;
@@ -720,7 +721,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         A.nv = __builtin_amdgcn_readfirstlane(ka->m.nv); A.ntree = __builtin_amdgcn_readfirstlane(ka->m.ntree);
         A.nefc = __builtin_amdgcn_readfirstlane(nefc); A.ncon = __builtin_amdgcn_readfirstlane(ncon);
         A.nlead = __builtin_amdgcn_readfirstlane(nlead); A.iters = __builtin_amdgcn_readfirstlane(iters);
-        A.tol = tol; A.scale = scale; A.ls_tol = sizeof(real) == 8 ? real(1e-10) : real(1e-4);
+        A.tol = tol; A.scale = scale; A.ls_tol = ka->m.ls_tolerance; A.ls_iters = __builtin_amdgcn_readfirstlane(ka->m.ls_iterations);
         A.early_exit = __builtin_amdgcn_readfirstlane(ka->m.newton_early_exit);
     }
     const int nv = A.nv, ne = A.nefc;
@@ -956,7 +957,7 @@ __device__ __attribute__((always_inline)) int newton_solve(KPtr<real> ka, GLB_PT
         // be four times larger in the middle than at its ends, and plain Newton then cycles between the two flat ends of the bracket (the
         // two-arm grasp of HookPackage: 100 stalled Newton iterations; oracle/orc_newton.c has the story and the same rule)
         real alpha = 0, lo = 0, hi = -1, dphi0 = 0, dxold = 0, dx = 0;
-        for (int ls = 0; ls < 51; ls++) {
+        for (int ls = 0; ls <= A.ls_iters; ls++) {
             real gsum = 0, hsum = 0;
             for (int i = lane; i < A.nlead; i += 64) {
                 real f, h;

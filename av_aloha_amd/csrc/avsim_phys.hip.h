@@ -49,6 +49,8 @@ struct DevModel {
     int noslip_per_tree;          // 1: the dry-friction rows of the noslip pass go per kinematic tree (needs <= 8 trees); option "noslip_per_tree"
     int solver, newton_iters;     // 0 = PGS (dual), 1 = Newton (primal, the reference's default solver)
     real newton_tol, nscale;      // MuJoCo tolerance and 1/(meaninertia*nv) scaling of the termination tests
+    real ls_tolerance;            // Newton's line search stops at |phi'(alpha)| < ls_tolerance |phi'(0)| (option "ls_tolerance"; default 1e-10 in f64, 1e-4 in f32 -- MuJoCo's mjOption.ls_tolerance is 0.01 of another scale [EXT])
+    int ls_iterations;            // ... after at most this many evaluations beyond phi'(0) (option "ls_iterations"; default 50 = MuJoCo's mjOption.ls_iterations [EXT])
     // bodies
     GLB_PTR(const int) body_parent;
     GLB_PTR(const int) body_jntadr;
@@ -3614,7 +3616,7 @@ struct PhysHost {
         auto opt = F("opt");
         m.timestep = (real)opt[0]; m.gravity[0] = (real)opt[1]; m.gravity[1] = (real)opt[2]; m.gravity[2] = (real)opt[3];
         m.impratio = (real)opt[4]; m.noslip_iters = (int)opt[5]; m.noslip_per_tree = 1; m.noslip_trees = 1; m.newton_component = 1; m.newton_early_exit = 1; m.qcqp_tridiag = sizeof(real) == 4 ? 2 : 0;
-        m.solver = 1; m.newton_iters = 100; m.newton_tol = sizeof(real) == 8 ? (real)1e-8 : (real)1e-6;     // MuJoCo defaults: iterations 100, tolerance 1e-8
+        m.solver = 1; m.newton_iters = 100; m.newton_tol = sizeof(real) == 8 ? (real)1e-8 : (real)1e-6; m.ls_tolerance = sizeof(real) == 8 ? (real)1e-10 : (real)1e-4; m.ls_iterations = 50;     // MuJoCo defaults: iterations 100, tolerance 1e-8
         m.nscale = (real)(1.0 / ((opt.size() > 7 && opt[7] > 0 ? opt[7] : 1.0) * std::max(1, m.nv)));
         auto gr = F("grip_range");
         m.grip_lo = (real)gr[0]; m.grip_hi = (real)gr[1];
@@ -3955,6 +3957,8 @@ struct PhysHost {
         if (n == "solver") { if (v != 0 && v != 1) return false; mf.solver = md.solver = (int)v; return true; }
         if (n == "newton_iters") { if (v < 1 || v > 100) return false; mf.newton_iters = md.newton_iters = (int)v; return true; }
         if (n == "newton_tol") { if (v < 0) return false; mf.newton_tol = (float)v; md.newton_tol = v; return true; }
+        if (n == "ls_tolerance") { if (!(v > 0) || v >= 1) return false; mf.ls_tolerance = (float)v; md.ls_tolerance = v; return true; }
+        if (n == "ls_iterations") { if (v < 1 || v > 1000) return false; mf.ls_iterations = md.ls_iterations = (int)v; return true; }
         if (n == "export_contacts") { export_contacts = v != 0; return true; }
         if (n == "num_joints") { if (v != 14 && v != 21) return false; mf.nj = md.nj = (int)v; return true; }
         if (n == "order_envs") { order_envs = v != 0; return true; }
@@ -4034,6 +4038,10 @@ struct PhysHost {
             if (hipMemcpy(d_kargs, &ka, sizeof(ka), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_kargs2, &ka2, sizeof(ka2), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy(kernel arguments) failed"; return -3; }
             kargs_dirty = false;
         }
+        // (checked BEFORE anything is enqueued: set_option admits 16 .. 1000, so this cannot fire through the API)
+        // the second pass gets the first tier's capacities in two 10-bit fields of retry_mode, above the three mode bits and the pairing bit
+        static_assert((8 | 7) < (1 << 8), "retry_mode: mode bits and pairing flag below bit 8");
+        if (two && (maxcon1 >= 1024 || maxefc1 >= 1024 || maxcon1 < 0 || maxefc1 < 0)) { err = "first-tier capacities do not fit the 10-bit fields of retry_mode (maxcon_first / maxefc_first < 1024)"; return -1; }
         // launch order from the previous step's per-env cost
         const int* order = nullptr;
         if (order_envs && have_cost && nsub > 0 && N > wpb) {
@@ -4052,9 +4060,6 @@ struct PhysHost {
                                d_cpairs, d_cdist, d_diag, max_reward, export_contacts, d_prof, d_xpose, order, order_envs ? d_cost : (int*)nullptr, head, next,
                                d_retry, two ? (1 + 2 * par) | pairing : 0, (KPtr<real>)d_kargs2);
         }
-        // the second pass gets the first tier's capacities in two 10-bit fields of retry_mode, above the three mode bits and the pairing bit
-        static_assert((8 | 7) < (1 << 8), "retry_mode: mode bits and pairing flag below bit 8");
-        if (two && (maxcon1 >= 1024 || maxefc1 >= 1024 || maxcon1 < 0 || maxefc1 < 0)) { err = "first-tier capacities do not fit the 10-bit fields of retry_mode (maxcon_first / maxefc_first < 1024)"; return -1; }
         if (two) {
             // second pass: the envs the first one gave up on, with the full capacities; one workgroup per CU is plenty for the few there
             // are (the workgroups loop over the list), and a launch that finds the list empty returns at once

@@ -776,7 +776,7 @@ struct RenderHost {
     float* d_sedge = nullptr;       // [N][ncam][nedge][4] silhouette edges (lines in the image, positive inside), compacted per polyhedron
     float* d_camaux = nullptr;      // [N][16][8] light direction and world up axis in the camera frame
     int* d_cam_ids = nullptr;
-    size_t recs_cap = 0;
+    size_t recs_cap = 0, counts_cap = 0;
     int N = 0;
     // option "kernel_timing": HIP events around every k_render_depth launch on the launch stream (avsim_render_kernel_time)
     bool timing = false;
@@ -906,7 +906,7 @@ struct RenderHost {
         if (d_fbox) (void)hipFree(d_fbox);
         if (d_sedge) (void)hipFree(d_sedge);
         if (d_cam_ids) (void)hipFree(d_cam_ids);
-        d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; d_fbox = nullptr; d_sedge = nullptr; d_cam_ids = nullptr; recs_cap = 0;
+        d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; d_fbox = nullptr; d_sedge = nullptr; d_cam_ids = nullptr; recs_cap = 0; counts_cap = 0;
     }
     // d_out: device float[N][ncam_sel][H][W], or (rgb) u8[N][ncam_sel][H][W][3]; body poses must already be in d_xpose (same stream)
     int launch(hipStream_t st, const int* cam_ids_host, int ncam_sel, int H, int W, void* d_out, bool rgb, std::string& err) {
@@ -919,14 +919,16 @@ struct RenderHost {
         // 17.1 in sixteen -- k_render_depth is not waiting for those reads, and every pass has a tail.)
         const int chunk = N < env_chunk ? N : env_chunk;
         const size_t need = (size_t)chunk * ncam_sel * m.ngeom * REC_W;
-        if (need > recs_cap) {
+        // d_counts is sized by the chunk alone (16 camera slots per env), the other buffers by chunk x cameras: a larger chunk with fewer cameras can
+        // leave `need` where it was, so the chunk size that was allocated for is tracked on its own
+        if (need > recs_cap || (size_t)chunk > counts_cap) {
             if (d_recs) (void)hipFree(d_recs);
             if (d_counts) (void)hipFree(d_counts);
             if (d_order) (void)hipFree(d_order);
             if (d_tplanes) (void)hipFree(d_tplanes);
             if (d_fbox) (void)hipFree(d_fbox);
             if (d_sedge) (void)hipFree(d_sedge);
-            d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; d_fbox = nullptr; d_sedge = nullptr; recs_cap = 0;
+            d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; d_fbox = nullptr; d_sedge = nullptr; recs_cap = 0; counts_cap = 0;
             if (hipMalloc((void**)&d_recs, need * sizeof(float)) != hipSuccess || hipMalloc((void**)&d_counts, (size_t)chunk * 16 * sizeof(int)) != hipSuccess ||
                 hipMalloc((void**)&d_order, (size_t)chunk * ncam_sel * m.ngeom * sizeof(int)) != hipSuccess ||
                 hipMalloc((void**)&d_tplanes, (size_t)chunk * ncam_sel * (m.nplane + 1) * 4 * sizeof(float)) != hipSuccess ||
@@ -936,6 +938,7 @@ struct RenderHost {
                 return -3;
             }
             recs_cap = need;
+            counts_cap = (size_t)chunk;
         }
         if (!d_cam_ids && hipMalloc((void**)&d_cam_ids, 16 * sizeof(int)) != hipSuccess) { err = "hipMalloc(camera ids) failed"; return -3; }
         if (hipMemcpyAsync(d_cam_ids, cam_ids_host, ncam_sel * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { err = "camera id copy failed"; return -3; }

@@ -267,14 +267,19 @@ class StreamWriter:
             sb += struct.pack("<QQII", 0, root_oh, 1, 0) + struct.pack("<QQ", root_bt, root_hp)
             assert len(sb) == 96
             f.patch(0, sb)
-        finally:
-            self.done = True
-            f.close()
+        except BaseException:
+            self.abort()                 # no truncated file with a zeroed superblock behind a failed finish (bad name, dtype, disk full)
+            raise
+        self.done = True
+        f.close()
 
 
 def write(path: str, datasets: dict, attrs: dict | None = None, chunks: dict | None = None) -> None:
     """datasets: "/a/b/name" -> array; attrs: attributes of the root group; chunks: name -> chunk shape (first axis split only)."""
-    StreamWriter(path).finish(datasets, attrs, chunks)
+    # written next to the destination and renamed over it: a failure leaves an existing (good) file at `path` as it was
+    part = path + ".part"
+    StreamWriter(part).finish(datasets, attrs, chunks)
+    os.replace(part, path)
 
 
 # ---- reader ------------------------------------------------------------------------------------------------------------------

@@ -91,6 +91,51 @@ def kernel_flops(cfg_id, f64):
         return {}
 
 
+N_SIMD, CLOCK_HZ = 1024, 2.4e9          # 256 CUs x 4 SIMDs, peak engine clock (MI355X_MICROARCH.md)
+
+
+def valu_issue_frac(cfg_id, f64, k_avg_ms):
+    """How busy the VALU issue ports are: VALU wave-instructions per launch (SQ_INSTS_VALU, profiles/kernel_flops.json) x 2 cycles per
+    wave64 instruction on a 32-lane-wide SIMD [guide: cdna_hip_programming.md] / (SIMDs x launch time x clock).  1 - this is what
+    better latency hiding could still return; only recorded for the configuration whose instruction mix was profiled (config 2, f32)."""
+    if f64 or cfg_id not in (2, 5) or k_avg_ms <= 0:
+        return None
+    try:
+        mix = json.load(open(os.path.join(ROOT, "profiles", "kernel_flops.json"))).get("config2_instruction_mix_per_launch", {})
+        return mix["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * k_avg_ms * 1e-3 * CLOCK_HZ)
+    except Exception:
+        return None
+
+
+def mujoco_row(cfg_id, home, budget_s=20.0):
+    """SURVEY 8(d)(ii) "MuJoCo CPU (optional)": if and only if `import mujoco` works on this host, real mj_step x 20 per env-step on the
+    model rebuilt from the build's own blob (av_aloha_amd/compiler/emit_mjcf.py -> tests/mj_env.py; no reference file), one thread, the
+    joint-space home action, a bounded sample.  -> (importable, row or None)."""
+    try:
+        import mujoco  # noqa: F401
+    except Exception:
+        return False, None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from av_aloha_amd import workloads as W
+        from mj_env import MjEnv
+        cfg = W.CONFIGS[cfg_id]
+        e = MjEnv(cfg["task"], cfg["arms"], hulls="full")
+        e.reset(W.object_poses(cfg["task"], [0], cfg["seed"])[0])
+        a = np.concatenate([e.blob["ctrl_home"][:6], [1.0], e.blob["ctrl_home"][7:13], [1.0], e.blob["ctrl_home"][14:21]])
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s and n < 3000:
+            a[0] = e.blob["ctrl_home"][0] + 0.1 * np.sin(0.05 * n)
+            e.step(a)
+            n += 1
+        wall = time.perf_counter() - t0
+        return True, {"value": n / wall, "unit": "env-steps/s", "cores": 1, "kind": "reference-engine", "mujoco_version": mujoco.__version__,
+                      "sample": f"{n} env-steps of ONE env ({cfg['task']}, full mesh hulls, joint-space sway of one joint), mj_step x 20 + mj_step1 per env-step, {wall:.1f} s",
+                      "note": "real MuJoCo on the MJCF emitted from the build's own model blob; x host cores for a process-per-core figure"}
+    except Exception as ex:            # importable but the emitted model did not load / step: say so, do not hide it
+        return True, {"error": repr(ex)[:300]}
+
+
 def valu_roofline(cfg_id, f64, N, k_avg_ms, k_n, abytes):
     """roofline block of a k_phys run: the kernel's own flops per launch / mean launch time against the vector peak of the dtype, the
     HBM view next to it; `frac` stays numeric (the HBM fraction) when profiles/kernel_flops.json lacks the configuration."""
@@ -109,7 +154,7 @@ def valu_roofline(cfg_id, f64, N, k_avg_ms, k_n, abytes):
             "hbm_achieved": hbm, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": hbm / HBM_PEAK_GBS,
             "kernel": f"k_phys<{'double' if f64 else 'float'}>", "kernel_avg_ms": k_avg_ms, "kernel_launches": int(k_n),
             "algorithmic_bytes_per_launch": abytes * N, "valu_flops_per_env_step_kernel": kflops,
-            "valu_lane_utilisation": kf.get("lane_utilisation"), "kernel_flops_source": kf.get("source"),
+            "valu_lane_utilisation": kf.get("lane_utilisation"), "valu_issue_frac": valu_issue_frac(cfg_id, f64, k_avg_ms), "kernel_flops_source": kf.get("source"),
             "peak_source": "FP64 vector 78.6 TF / FP32 vector 157.3 TF (AMD MI355X specification; MI355X_MICROARCH.md lists the matrix peaks only)"}
 
 
@@ -559,27 +604,21 @@ def main():
             # what bounds k_phys is the issue rate and latency of one wave's dependent VALU / LDS chain (neither HBM nor
             # MFMA): `frac` is the kernel's own floating-point work against the vector peak; the HBM view the contract asks for
             # (algorithmic bytes per launch / launch time against 8 TB/s) is kept next to it as hbm_*
-            "roofline": {"bound": "valu+latency", "achieved": valu_k_tflops, "peak": VALU_PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-                         "frac": valu_k_tflops / VALU_PEAK_TFLOPS[dtype] if valu_k_tflops is not None else achieved / HBM_PEAK_GBS,
-                         "hbm_achieved": achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": achieved / HBM_PEAK_GBS,
+            "roofline": {**valu_roofline(args.config, args.f64, N, k_avg_s * 1e3, k_n, abytes),
                          "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_over_algorithmic": traffic / (abytes * N) if traffic else None,
-                         "kernel": f"k_phys<{'double' if args.f64 else 'float'}>", "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": int(k_n),
-                         "algorithmic_bytes_per_launch": abytes * N,
                          "valu_flops_per_env_step_counted": flops_step,
                          "valu_achieved_tflops": flops_step * N / k_avg_s / 1e12 if (flops_step and k_avg_s > 0) else None,
                          "valu_peak_tflops": VALU_PEAK_TFLOPS[dtype],
                          "valu_frac": flops_step * N / k_avg_s / 1e12 / VALU_PEAK_TFLOPS[dtype] if (flops_step and k_avg_s > 0) else None,
                          # the kernel's OWN arithmetic (its sparse row windows and per-tree solves, not the oracle's dense rows):
                          # floating-point VALU instructions the SQ counted for k_phys x lanes active, per env-step
-                         "valu_flops_per_env_step_kernel": kflops_step,
                          "valu_frac_kernel": valu_k_tflops / VALU_PEAK_TFLOPS[dtype] if valu_k_tflops is not None else None,
-                         "valu_lane_utilisation": kf.get("lane_utilisation"),
-                         "kernel_flops_source": kf.get("source"),
                          "note": "state stays in LDS across the 20 substeps, so HBM sees ~1 KB per env-step; the kernel is "
-                                 "VALU/LDS-latency bound (SURVEY 8d): frac = valu_frac_kernel; hbm_frac is reported because the contract asks for it; "
-                                 "valu_frac uses the flops counted in the oracle's instrumented dense build (profiles/flop_counts.json), "
-                                 "valu_frac_kernel the kernel's own floating-point instruction counts (profiles/kernel_flops.json)"},
+                                 "VALU/LDS-latency bound (SURVEY 8d): frac = valu_frac_kernel = achieved / peak with achieved from kernel_flops_source (a profile of this "
+                                 "command, not a count made in this run) / this run's HIP-event launch time; hbm_frac is reported because the contract asks for it; "
+                                 "valu_frac uses the flops counted in the oracle's instrumented dense build (profiles/flop_counts.json); "
+                                 "valu_issue_frac = VALU wave-instructions x 2 cycles / (1024 SIMDs x launch time x 2.4 GHz): the share of issue slots in use"},
         }
         if w.depth is not None:
             r_ms = sum(a.elapsed_time(b) for a, b in w.r_events) / max(1, len(w.r_events))
@@ -626,6 +665,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.config, n_total, home, 1 if args.solver == "newton" else 0)
         elif world > 1:
             out["cpu_baseline"] = None
+        importable, mj = mujoco_row(args.config, home) if world == 1 else (None, None)
+        out["mujoco_importable"] = importable
+        if mj is not None:
+            out["mujoco_cpu"] = mj
+        # the driver keeps the line's last 2000 characters: the figures that matter once more, compactly, as the LAST key
+        r4 = lambda x: None if x is None else float(f"{x:.4g}")
+        out["summary"] = {k: r4(out.get(k)) for k in ("value", "f64_value", "value_1024", "latency_ms_1env", "value_episode300", "config3_value", "config4_value", "config5_value")}
+        out["summary"].update({"k_phys_ms": r4(out.get("roofline_physics", out["roofline"]).get("kernel_avg_ms")), "frac": r4(out.get("roofline_physics", out["roofline"]).get("frac")),
+                               "valu_issue_frac": r4(out.get("roofline_physics", out["roofline"]).get("valu_issue_frac")),
+                               "k_render_depth_ms": r4((out.get("config5") or {}).get("k_render_depth_ms")),
+                               "allgather_ms": r4(out["multi_rank"]["allgather_ms"]), "cpu_baseline": r4((out.get("cpu_baseline") or {}).get("value")),
+                               "mujoco_importable": importable, "mujoco_cpu": r4((mj or {}).get("value"))})
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

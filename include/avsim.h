@@ -63,6 +63,10 @@ int avsim_dims(const avsim_t* h, int32_t dims[AVSIM_NDIMS]);
 /* Solver / capacity / debug knobs (returns AVSIM_EINVAL for an unknown name or a value out of range):
  *   "solver"            0 PGS (BASELINE north_star), 1 Newton (MuJoCo's default, what the reference runs; default)
  *   "pgs_iters"         Gauss-Seidel sweeps of the PGS solver (default 20); "newton_iters" cap (default 100 = MuJoCo), "newton_tol" (1e-8 in f64 = MuJoCo, 1e-6 in f32)
+ *   "ls_tolerance", "ls_iterations"   Newton's exact line search: stop when |phi'(alpha)| < ls_tolerance x |phi'(0)|, at most ls_iterations evaluations
+ *                       after the one at alpha = 0.  Defaults 1e-10 (f64) / 1e-4 (f32) and 50.  MuJoCo's mjOption.ls_iterations is 50 and its
+ *                       ls_tolerance 0.01, applied to a differently scaled derivative [EXT]: the default here searches much further than MuJoCo
+ *                       does (the whole-episode parity tests need both sides to take the same step to rounding) -- a listed deviation, DESIGN.md 2
  *   "maxefc", "maxcon"  constraint rows / contacts an env can hold (per-task defaults 176-480 / 48-96): the stride of the contact export
  *                       and of the global row scratch; setting one makes it the capacity of a single tier (one pass)
  *   "maxefc_first", "maxcon_first"   the FIRST tier of the two-tier capacities (defaults: SewNeedle 224 / 56 of 336 / 72, TubeTransfer

@@ -117,6 +117,11 @@ typedef struct {
     int overflow; /* set when ORC_MAXCON / ORC_MAXEFC was hit */
     long stat_narrow; /* narrow-phase calls, for the flop/pair accounting */
     int stat_noslip;  /* noslip sweeps used by the last solve */
+    /* Newton's exact line search: stop when |phi'(alpha)| < ls_tol |phi'(0)|, at most ls_iters evaluations after phi'(0).  MuJoCo's own
+     * search [EXT mjOption.ls_tolerance = 0.01, ls_iterations = 50] stops at a derivative of tolerance x ls_tolerance x |search vector| /
+     * scale; this restatement searches to 1e-10 RELATIVE by default (both sides then take the same step to rounding, which the whole-episode
+     * parity tests need) -- a listed deviation; the device's twin options are "ls_tolerance" / "ls_iterations" */
+    double ls_tol; int ls_iters;
 } orc_data;
 
 /* model / data */

@@ -68,6 +68,8 @@ orc_data* orc_data_new(const orc_model* m) {
     d->solver = 0;
     d->newton_iters = 100; /* MuJoCo default opt.iterations */
     d->newton_tol = 1e-8;
+    d->ls_tol = 1e-10;
+    d->ls_iters = 50;
     d->pgs_scale = 1.0 / (m->meaninertia * (m->nv > 1 ? m->nv : 1));
     memcpy(d->qpos, m->qpos0, sizeof(double) * m->nq);
     return d;

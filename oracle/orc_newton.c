@@ -241,10 +241,10 @@ void orc_solve_newton(orc_data* d) {
          * a lucky parity of the evaluation count in this oracle.  (Rounds 1-4 had the first rule only.)  Same rule, same numbers in
          * avsim_newton.hip.h. */
         double lo = 0, hi = -1, alpha = -dphi0 / ddphi0, glo = dphi0, dxold = alpha, dx = alpha;
-        for (int ls = 0; ls < 50; ls++) {
+        for (int ls = 0; ls < d->ls_iters; ls++) {
             ls_eval(d, jar, jv, alpha, q1, q2, &dphi, &ddphi, jar2, force, hd, zone);
             if (dbg && it == 2) fprintf(stderr, "         orc ls %d: alpha %.12e dphi %.6e ddphi %.6e lo %.6e hi %.6e (ddphi0 %.6e)\n", ls + 1, alpha, dphi, ddphi, lo, hi, ddphi0);
-            if (fabs(dphi) < 1e-10 * fabs(dphi0) + 1e-300) break;
+            if (fabs(dphi) < d->ls_tol * fabs(dphi0) + 1e-300) break;
             if (dphi < 0) { lo = alpha; glo = dphi; } else hi = alpha;
             double nx = alpha - dphi / ddphi;
             if (hi < 0) { if (!(nx > lo)) nx = 2 * alpha + 1e-12; }

@@ -31,7 +31,7 @@ class Data(C.Structure):
                 [("efc_KBIP", C.c_double * (4 * MAXEFC)), ("efc_type", C.c_int * MAXEFC), ("efc_id", C.c_int * MAXEFC),
                  ("pgs_iters", C.c_int), ("pgs_tol", C.c_double), ("pgs_scale", C.c_double), ("stat_sweeps", C.c_int),
                  ("solver", C.c_int), ("newton_iters", C.c_int), ("newton_tol", C.c_double),
-                 ("overflow", C.c_int), ("stat_narrow", C.c_long), ("stat_noslip", C.c_int)])
+                 ("overflow", C.c_int), ("stat_narrow", C.c_long), ("stat_noslip", C.c_int), ("ls_tol", C.c_double), ("ls_iters", C.c_int)])
 
 
 class OrcEnv:

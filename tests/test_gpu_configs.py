@@ -379,3 +379,42 @@ def test_noslip_per_tree_equals_the_wave_wide_pass():
         assert out[0][2].max() >= 6
         np.testing.assert_allclose(out[1][0], out[0][0], atol=1e-9, err_msg=task)
         np.testing.assert_allclose(out[1][1], out[0][1], atol=1e-7, err_msg=task)
+
+
+def test_newton_early_exit_in_f32_stays_within_the_solver_tolerance():
+    """Option newton_early_exit (default 1) returns from Newton without the gradient evaluation that would confirm the minimiser when a step
+    ended in the active set it started from.  The argument is exact-arithmetic; the f32 product mode's Cholesky solve and its line search
+    (ls_tolerance 1e-4) are not.  So: HookPackage random walk in f32 (arms dragged over the table, contacts coming and
+    going: 4 - 8 Newton iterations), the early-exit build teacher-forced along the run WITHOUT it -- every env-step both handles start from
+    the same state, warm start included, and step the same action -- must land within the f32 solver tolerance of it: one env-step (20
+    substeps) apart by less than 2e-5 rad / m in the median env and 5e-4 in the worst (an env whose arm sticks and slips amplifies the
+    solver's 1e-6 inside the step), contact counts equal in >= 99 % of the (env, step) pairs, rewards equal in all."""
+    from av_aloha_amd.sim import BatchedSim
+    task, na, n, T = "hook_package", 2, 128, 16
+    md = model_dict(task, na)
+    gids = np.arange(n)
+    acts = walk_actions(md, gids, T, 14, 3000)
+    a = BatchedSim(task, na, n, options={"newton_early_exit": 0})
+    b = BatchedSim(task, na, n, options={"newton_early_exit": 1})
+    a.reset(poses_for(task, gids, 3000))
+    b.reset(poses_for(task, gids, 3000))
+    dq, ncon_same, rew_same, iters = [], 0, 0, []
+    for t in range(T):
+        q, v, c, w = a.get_state()
+        b.set_state(q, v, c, w)
+        _, ra, _ = a.step(acts[t])
+        _, rb, _ = b.step(acts[t])
+        qa = a.get_state()[0]
+        qb = b.get_state()[0]
+        dq.append(np.abs(qa - qb).max(1))
+        ncon_same += int((a.diag()[:, 0] == b.diag()[:, 0]).sum())
+        rew_same += int((ra == rb).sum())
+        iters.append(((a.diag()[:, 3] >> 16) & 0xfff).mean() / 20.0)
+    dq = np.stack(dq)
+    print("newton_early_exit 0 vs 1, f32, one env-step from the same state: |dq| median %.2e p99 %.2e max %.2e; ncon equal %.4f; Newton iterations per substep %.2f" %
+          (np.median(dq), np.percentile(dq, 99), dq.max(), ncon_same / (n * T), np.mean(iters)))
+    assert a.diag()[:, 0].max() >= 8                       # arms on the table
+    assert np.median(dq) < 2e-5 and dq.max() < 5e-4, (np.median(dq), dq.max())
+    assert ncon_same >= 0.99 * n * T and rew_same == n * T
+    a.close()
+    b.close()

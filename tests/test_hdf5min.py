@@ -221,3 +221,18 @@ def test_streamed_episode_equals_the_one_written_at_once(tmp_path):
         finally:
             w2.abort()
     assert not (tmp_path / "x.hdf5").exists()
+
+
+def test_a_failed_write_leaves_the_existing_file_alone(tmp_path):
+    """write() goes through <path>.part and a rename: a data set name that passes through another data set makes finish() fail, the good
+    file at the destination is untouched and no partial file stays behind."""
+    import os
+    from av_aloha_amd import hdf5min
+    p = str(tmp_path / "episode_0.hdf5")
+    hdf5min.write(p, {"/action": np.arange(6, dtype=np.float32).reshape(2, 3)}, {"sim": True})
+    good = open(p, "rb").read()
+    with pytest.raises(AssertionError):
+        hdf5min.write(p, {"/a": np.zeros(3, dtype=np.float32), "/a/b": np.zeros(3, dtype=np.float32)})
+    assert open(p, "rb").read() == good
+    assert sorted(os.listdir(tmp_path)) == ["episode_0.hdf5"]
+    np.testing.assert_array_equal(hdf5min.read(p)[0]["/action"], np.arange(6, dtype=np.float32).reshape(2, 3))

@@ -4,7 +4,18 @@
 The build image has no MuJoCo, so the files do not exist yet and every test here SKIPS with that reason: the physics half of the
 oracle is "parity unpinned" until a machine with mujoco + dm_control + /root/reference runs the generator once.  The tolerances
 are the ones SURVEY.md Appendix B proposes for build vs MuJoCo: joint angles 1e-3 rad over the first 10 env-steps in contact-free
-motion of the arms, contact counts equal, rewards and is_success exact over the whole script."""
+motion of the arms, contact counts equal, rewards and is_success exact over the whole script.
+
+Round 6: a second, SELF-CONTAINED route that needs no reference file and no recorded trajectory.  av_aloha_amd/compiler/emit_mjcf.py
+restates a compiled model (models/*.avm + *.json) as one MJCF text -- explicit inertials, the collision hulls as inline vertex sets,
+aloha_sim.xml:2-6's options -- and tests/mj_env.py steps it under `import mujoco` with the reference env's semantics (env.py:203-249).
+  * `test_emitted_mjcf_is_the_compiled_model` (CPU, always runs): the text goes back through the build's own reader and compiler
+    (compiler/mjcf.py, compile.py) and must give the blob back -- every dynamics, contact-filter, pair-parameter, support-table and IK
+    array identical (orientations to 2e-16: the reader re-normalises quaternions), so the text carries the model and nothing else.
+  * `test_oracle_follows_mujoco_on_the_emitted_model` / `test_device_follows_mujoco_on_the_emitted_model`: `pytest.importorskip("mujoco")`,
+    then the action script of tests/mj_actions.py on MuJoCo, the oracle and the device side by side with the tolerances above.
+`import mujoco` fails in the build image AND on the GPU box (probed through gpurun in round 6: profiles/r06_mujoco_probe.txt), so the
+last two skip there too; bench.py reports `mujoco_importable` in its line and times MuJoCo next to the oracle where it exists."""
 import glob
 import os
 
@@ -78,4 +89,119 @@ def test_device_follows_mujoco(path):
         assert int(rw[0]) == int(d["reward"][t]) and bool(su[0]) == bool(d["success"][t]), (t, rw[0], d["reward"][t])
         if t < 10:
             np.testing.assert_allclose(ap[0], d["agent_pos"][t][:ap.shape[1]], atol=1e-3, err_msg=f"{task} agent_pos step {t}")
+    sim.close()
+
+
+# ---- round 6: the self-contained route (emitted MJCF; no reference file, no recorded trajectory) ------------------------------------------
+
+import json
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# derived from the 20 / 32-vertex depth-image polyhedra of the STL files, which an emitted model does not carry (it holds the collision
+# hulls); the colour renderer's instance table likewise
+NOT_IN_MJCF = ("hull_vert", "hull_face_vadr", "hull_face_vnum", "hull_face_vidx", "hull_edge", "hull_plane", "geom_hull", "geom_hedge", "geom_hplane")
+
+
+@pytest.mark.parametrize("task,arms,prefix", [("slot_insertion", 3, ""), ("tube_transfer", 2, ""), ("hook_package", 3, "dc_")])
+def test_emitted_mjcf_is_the_compiled_model(task, arms, prefix):
+    from av_aloha_amd.compiler import compile as CC
+    from av_aloha_amd.compiler import emit_mjcf
+    txt = emit_mjcf.emit_files(os.path.join(ROOT, "models"), task, arms, prefix=prefix)
+    assert "file=" not in txt and "/root" not in txt                # self-contained: no mesh, texture or include files
+    with tempfile.NamedTemporaryFile("w", suffix=".xml", delete=False) as f:
+        f.write(txt)
+    try:
+        arr, man = CC.compile_task(None, task, arms, xml_path=f.name)
+    finally:
+        os.unlink(f.name)
+    blob = CC.read_blob(os.path.join(ROOT, "models", f"{prefix}{task}_{arms}arms.avm"))
+    man0 = json.load(open(os.path.join(ROOT, "models", f"{prefix}{task}_{arms}arms.json")))
+    for k in ("body_names", "joint_names", "actuator_names", "geom_names", "camera_names", "site_names", "nq", "nv", "nu", "npair", "total_mass"):
+        assert man[k] == man0[k], k
+    checked = 0
+    for k, b in blob.items():
+        if k.startswith("vis_inst") or k in NOT_IN_MJCF:
+            continue
+        a = np.atleast_1d(np.asarray(arr[k]))
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        if b.dtype.kind == "f":
+            np.testing.assert_allclose(a, b, rtol=0, atol=2e-15, err_msg=k)
+        else:
+            assert np.array_equal(a, b), k
+        checked += 1
+    assert checked > 110          # inertias, joints, actuators, equalities, filter inputs, pair table, hulls + support tables, IK constants ...
+    for k in ("chull_vert", "chull_cells", "chull_cand", "pair_geom", "pair_friction", "pair_solref", "pair_margin", "pair_gap", "body_inertia",
+              "dof_invweight0", "body_invweight0", "exclude_body", "geom_contype"):
+        assert np.array_equal(np.atleast_1d(np.asarray(arr[k])), blob[k]), k       # bit for bit
+
+
+def test_emitted_mjcf_full_hulls_and_options():
+    """hulls="full": the mesh assets are the full qhull vertex sets (what MuJoCo builds from the STL files); the option block is aloha_sim.xml:2-6's."""
+    import xml.etree.ElementTree as ET
+    from av_aloha_amd.compiler import emit_mjcf
+    root = ET.fromstring(emit_mjcf.emit_files(os.path.join(ROOT, "models"), "hook_package", 2, hulls="full"))
+    opt = root.find("option")
+    assert (opt.get("noslip_iterations"), opt.get("cone"), float(opt.get("impratio")), float(opt.get("timestep"))) == ("3", "elliptic", 100.0, 0.002)
+    assert opt.find("flag").get("multiccd") == "enable"
+    fh = json.load(open(os.path.join(ROOT, "models", "oracle_full_hulls.json")))
+    n = {m.get("name"): len(m.get("vertex").split()) // 3 for m in root.find("asset").findall("mesh")}
+    for name, cnt in n.items():
+        assert cnt == fh["nvert"][fh["mesh_names"].index(name)]
+    assert max(n.values()) > 1000 and len(root.find("contact").findall("exclude")) == 3        # aloha_sim.xml:370-374
+
+
+def _emitted_cases():
+    import mj_actions as A
+    return [(key, arms) for _, key in A.TASKS for arms in (2, 3)]
+
+
+def _poses(task, arms):
+    from av_aloha_amd.env import sample_object_poses
+    import mj_actions as A
+    np.random.seed(A.SEED)                    # the reference samples from the global RNG (env.py:482 ...)
+    return sample_object_poses(task)
+
+
+@pytest.mark.parametrize("task,arms", _emitted_cases())
+def test_oracle_follows_mujoco_on_the_emitted_model(task, arms):
+    pytest.importorskip("mujoco", reason="real MuJoCo is importable neither in the build image nor on the GPU box (profiles/r06_mujoco_probe.txt)")
+    import mj_actions as A
+    from mj_env import MjEnv
+    pose = _poses(task, arms)
+    mj = MjEnv(task, arms)
+    mj.reset(pose)
+    e = OrcEnv(task, arms)
+    e.d.solver = 1
+    e.reset(pose)
+    np.testing.assert_allclose(e.qpos, mj.qpos, atol=1e-12)
+    for t, a in enumerate(A.actions(arms)):
+        ap, r, s = e.env_step(a.astype(np.float64))
+        ap_m, r_m, s_m = mj.step(a)
+        assert (r, s) == (r_m, s_m), (task, t, r, r_m)
+        if t < 10:
+            np.testing.assert_allclose(ap, ap_m, atol=1e-3, err_msg=f"{task} agent_pos step {t}")
+            np.testing.assert_allclose(e.qpos[23:], mj.qpos[23:], atol=2e-3, err_msg=f"{task} objects step {t}")
+            assert e.d.ncon == mj.ncon, (task, t, e.d.ncon, mj.ncon)
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,arms", _emitted_cases())
+def test_device_follows_mujoco_on_the_emitted_model(task, arms):
+    pytest.importorskip("mujoco", reason="real MuJoCo is importable neither in the build image nor on the GPU box (profiles/r06_mujoco_probe.txt)")
+    import mj_actions as A
+    from av_aloha_amd.sim import BatchedSim
+    from mj_env import MjEnv
+    pose = _poses(task, arms)
+    mj = MjEnv(task, arms)
+    mj.reset(pose)
+    sim = BatchedSim(task, arms, 1, options={"solver": 1})
+    sim.reset(np.asarray(pose).reshape(1, -1, 7))
+    for t, a in enumerate(A.actions(arms)):
+        ap, rw, su = sim.step(a[None])
+        ap_m, r_m, s_m = mj.step(a)
+        assert (int(rw[0]), bool(su[0])) == (r_m, s_m), (task, t, rw[0], r_m)
+        if t < 10:
+            np.testing.assert_allclose(ap[0], ap_m[:ap.shape[1]], atol=1e-3, err_msg=f"{task} agent_pos step {t}")
     sim.close()
