@@ -8,14 +8,16 @@
 // oracle/orc_render.c draws.
 //
 // Two kernels.  k_render_geoms: one wavefront per (env, camera) moves every visible geom into the camera frame, projects its
-// vertices to a screen-space box, drops the geoms outside the view and compacts the survivors (ordered ballot) into 28-float
-// records plus a front-to-back order (rank sort on the nearest vertex depth).  k_render_depth: one
-// wavefront per 32 x 8 pixel tile; the tile first culls the camera's records against its own pyramid (screen boxes, one
-// record per lane, ballot masks; then a separating-face test with one hull plane per lane) and walks the survivors front to back, stopping as soon as every pixel of the tile is
-// nearer than the next geom can be; every lane casts its 4 horizontally adjacent rays: the
-// geom record and the hull planes are wave-uniform (scalar loads), the rays differ only in one coordinate, and the result
-// leaves as one 16-byte store per lane (8 lanes = one 128-byte line of the image).  HBM-write bound by construction:
-// 4 B per pixel out, the records (<= 8 KB per camera) come from L2.
+// vertices to a screen-space octagon, drops the geoms outside the view, writes every polyhedron's faces in camera-ray form, their screen
+// boxes and its silhouette edges, ranks the survivors front to back and leaves one 64-byte LIST HEADER per survivor in that order
+// (octagon, nearest depth, packed counts, scratch offsets, and the set of image bins that none of its silhouette edges excludes).
+// k_render_depth: a block of four wavefronts per bin of 10 x 2 tiles of 32 x 16 pixels: (A) the camera's headers, one per lane, coalesced,
+// octagon + bin-mask test, ordered compaction into LDS; (B) the listed polyhedra's faces -- in INVERSE-depth form: 1 / t of a pixel ray
+// is affine in the pixel --, face boxes and silhouette edges into an LDS arena, two candidates per wave in flight; (C) the waves take the
+// bin's tiles from an LDS counter and cast each against the list, front to back, reading LDS only: per record one face / one edge per
+// lane for the tile tests, then two faces per round (v_readlane, v_pk_fma_f32 per pixel pair, v_min3 per pixel), one rcp per pixel at
+// the end, one 16-byte non-temporal store per lane and row (8 lanes = one 128-byte line of the image).  HBM-write bound by
+// construction: 4 B per pixel out; measured: profiles/r06_experiments.txt.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -81,8 +83,8 @@ __device__ inline void mul33(const float* A, const float* B, float* C) {   // C 
 // grid (ncam_sel, N), block 64
 __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float* __restrict__ xpose, const int* __restrict__ cam_ids, int ncam_sel,
                                                      int H, int W, float* __restrict__ recs, int* __restrict__ counts, int* __restrict__ order, float* __restrict__ tplanes,
-                                                     float* __restrict__ camaux, float* __restrict__ fbox, float* __restrict__ sedge) {
-    __shared__ float keys[128];
+                                                     float* __restrict__ camaux, float* __restrict__ fbox, float* __restrict__ sedge, float4* __restrict__ heads, const int bin_tx) {
+    __shared__ float hs[16][128];      // the kept records' list headers (k_render_depth's hA / hB / hC + the bin mask), until their front-to-back ranks are known
     __shared__ float vcx[RVERT_MAX][64], vcy[RVERT_MAX][64], vcz[RVERT_MAX][64];      // the lane's polyhedron in the camera frame (vertex major: no bank conflicts)
     const int lane = threadIdx.x, cs = blockIdx.x, env = blockIdx.y, cam = cam_ids[cs];
     const float* xb = xpose + (size_t)env * m.nbody * 12;
@@ -106,6 +108,15 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
     const float scale = 2.0f * m.cam_fovy[cam] / (float)H;       // cam_fovy holds tan(fovy / 2)
     const float tx = 0.5f * W * scale, ty = 0.5f * H * scale, sx = sqrtf(1 + tx * tx), sy = sqrtf(1 + ty * ty);
     float* out = recs + ((size_t)env * ncam_sel + cs) * m.ngeom * REC_W;
+    // k_render_depth's bins (bin_tx x BIN_TY tiles of TILE_W x TILE_H pixels, numbered row by row): every record gets the set of bins
+    // that none of its silhouette edges excludes, 128 bits (an image with more bins gets all ones: the tiles still test the edges)
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+    const int nbx = (tiles_x + bin_tx - 1) / bin_tx, nby = (tiles_y + BIN_TY - 1) / BIN_TY;
+#if defined(AVSIM_RDBG) && AVSIM_RDBG == 4
+    const bool binmask = false;      // (experiment: no bin masks)
+#else
+    const bool binmask = nbx * nby <= 128;
+#endif
     int base = 0;
     for (int g0 = 0; g0 < m.ngeom; g0 += 64) {
         const int g = g0 + lane;
@@ -259,19 +270,93 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
             const int k = base + __popcll(bal & ((1ull << lane) - 1ull));
 #pragma unroll
             for (int q = 0; q < REC_W; q++) out[k * REC_W + q] = rec[q];
-            keys[k] = rec[23];
+            // list header: octagon, nearest depth, packed word (type | general path << 4 | faces << 6 | silhouette edges << 13; k_render_depth adds
+            // the staging bits), record index, face / edge offsets into the camera's scratch, bin mask
+            const int ty_ = __float_as_int(rec[19]);
+            const int gen = ty_ == 7 && __float_as_int(rec[18]) != 0 ? 1 : 0;
+            const int np_ = ty_ == 7 ? __float_as_int(rec[21]) : 0, ns_ = ty_ == 7 && !gen ? __float_as_int(rec[17]) : 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) hs[q][k] = rec[24 + q];
+            hs[8][k] = rec[23];
+            hs[9][k] = __int_as_float((ty_ & 15) | (gen << 4) | ((np_ > 127 ? 127 : np_) << 6) | ((ns_ > 127 ? 127 : ns_) << 13));
+            hs[10][k] = __int_as_float(k);
+            hs[11][k] = __int_as_float(ty_ == 7 ? (__float_as_int(rec[20]) | (__float_as_int(rec[16]) << 16)) : 0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) hs[12 + q][k] = __int_as_float(-1);        // bin mask: all bins until the pass below has looked at the silhouette
         }
         base += __popcll(bal);
     }
     if (lane == 0) counts[(size_t)env * ncam_sel + cs] = base;
     __syncthreads();
+    if (binmask) {
+        // Bin masks: lane = bin (two rounds for 65 .. 128 bins).  A bin whose four corner rays lie outside some silhouette edge cannot see the
+        // polyhedron.  The record's edges (written above by the lane that owns the geom: visible after the barrier) are loaded one per lane,
+        // the next record's while this one is tested, and handed round by v_readlane.
+        const size_t cbase = (size_t)env * ncam_sel + cs;
+        const float4* SEb = reinterpret_cast<const float4*>(sedge) + cbase * m.nedge;
+        const int nb = nbx * nby;
+        float cxl[2], cxr[2], cyt[2], cyb[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int b = lane + 64 * h, bx = b % nbx, by = b / nbx;
+            const int px0 = bx * bin_tx * TILE_W, px1 = px0 + bin_tx * TILE_W < W ? px0 + bin_tx * TILE_W : W;
+            const int py0 = by * BIN_TY * TILE_H, py1 = py0 + BIN_TY * TILE_H < H ? py0 + BIN_TY * TILE_H : H;
+            cxl[h] = (px0 - 0.5f * W) * scale; cxr[h] = (px1 - 0.5f * W) * scale; cyt[h] = -(py0 - 0.5f * H) * scale; cyb[h] = -(py1 - 0.5f * H) * scale;
+        }
+        auto edges_of = [&](int i, int& ns) -> float4 {
+            ns = 0;
+            if (i >= base) return make_float4(0.f, 0.f, 1.f, 0.f);
+            const int pk = __float_as_int(hs[9][i]), pe = __float_as_int(hs[11][i]);
+            if ((pk & 15) != 7 || ((pk >> 4) & 1)) return make_float4(0.f, 0.f, 1.f, 0.f);
+            ns = (pk >> 13) & 127;
+            if (ns > 64) ns = 64;          // (a polyhedron of <= 32 vertices has <= 32 silhouette edges; more are left to the tiles)
+            {   // only records whose octagon's box meets more than three bins are worth the pass (the long frame bars that cross the image at an angle:
+                // 17.7 octagon candidates per bin against 4.3 with the masks); the small ones stay candidates of their one to three bins
+                const float bw = bin_tx * TILE_W * scale, bh = BIN_TY * TILE_H * scale, x0 = -0.5f * W * scale, y0 = 0.5f * H * scale;
+                const int c0 = max(0, (int)floorf((hs[0][i] - x0) / bw)), c1 = min(nbx - 1, (int)floorf((hs[1][i] - x0) / bw));
+                const int r0 = max(0, (int)floorf((y0 - hs[3][i]) / bh)), r1 = min(nby - 1, (int)floorf((y0 - hs[2][i]) / bh));
+                if ((c1 - c0 + 1) * (r1 - r0 + 1) <= 3) { ns = 0; return make_float4(0.f, 0.f, 1.f, 0.f); }
+            }
+            return SEb[((pe >> 16) & 0xffff) + (lane < ns ? lane : 0)];
+        };
+        auto test = [&](int i, const float4 eg, const int ns) {
+            if (ns == 0) return;
+            bool out0 = false, out1 = false;
+            for (int e = 0; e < ns; e++) {
+                const float ea = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.x), e));
+                const float eb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.y), e));
+                const float ec = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.z), e));
+                out0 = out0 || (fmaxf(ea * cxl[0], ea * cxr[0]) + fmaxf(eb * cyt[0], eb * cyb[0]) + ec < 0);
+                if (nb > 64) out1 = out1 || (fmaxf(ea * cxl[1], ea * cxr[1]) + fmaxf(eb * cyt[1], eb * cyb[1]) + ec < 0);
+            }
+            const unsigned long long m0 = __ballot(!out0), m1 = nb > 64 ? __ballot(!out1) : ~0ull;
+            if (lane == 0) {
+                hs[12][i] = __int_as_float((int)(unsigned)m0); hs[13][i] = __int_as_float((int)(unsigned)(m0 >> 32));
+                hs[14][i] = __int_as_float((int)(unsigned)m1); hs[15][i] = __int_as_float((int)(unsigned)(m1 >> 32));
+            }
+        };
+        // four records' edges in flight while the four before them are tested (one record per round trip made this pass the kernel's longest)
+        int nA0, nA1, nA2, nA3;
+        float4 eA0 = edges_of(0, nA0), eA1 = edges_of(1, nA1), eA2 = edges_of(2, nA2), eA3 = edges_of(3, nA3);
+        for (int i = 0; i < base; i += 4) {
+            const float4 c0 = eA0, c1 = eA1, c2 = eA2, c3 = eA3;
+            const int m0 = nA0, m1 = nA1, m2 = nA2, m3 = nA3;
+            eA0 = edges_of(i + 4, nA0); eA1 = edges_of(i + 5, nA1); eA2 = edges_of(i + 6, nA2); eA3 = edges_of(i + 7, nA3);
+            test(i, c0, m0); test(i + 1, c1, m1); test(i + 2, c2, m2); test(i + 3, c3, m3);
+        }
+        __syncthreads();
+    }
     // front-to-back order by rank sort on the nearest depth (ties by index)
     int* ord = order + ((size_t)env * ncam_sel + cs) * m.ngeom;
     for (int i = lane; i < base; i += 64) {
-        const float ki = keys[i];
+        const float ki = hs[8][i];
         int rank = 0;
-        for (int j = 0; j < base; j++) { const float kj = keys[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
+        for (int j = 0; j < base; j++) { const float kj = hs[8][j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
         ord[rank] = i;
+        // the headers in front-to-back order, four float4 each: a bin reads its camera's list in one coalesced pass
+        float4* hd = heads + (((size_t)env * ncam_sel + cs) * m.ngeom + rank) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) hd[q] = make_float4(hs[4 * q][i], hs[4 * q + 1][i], hs[4 * q + 2][i], hs[4 * q + 3][i]);
     }
 }
 
@@ -280,6 +365,8 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
 // of signalling NaNs, which the compiler cannot rule out for a phi); none of the depths and edge values here is a NaN that matters
 __device__ __forceinline__ float vmax1(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmin1(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+typedef float v2f __attribute__((ext_vector_type(2)));      // two pixels per v_pk_fma_f32
 
 __device__ inline float wave_max(float x) {
 #define AVS_DPP_MAX(ctrl) x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true)))
@@ -337,8 +424,13 @@ __device__ inline bool ray_prim(int type, const float* sz, const float* o, const
 // front-to-back order (LDS, built by k_render_depth).  RGB: the cast also remembers which record (and hull face) each pixel sees,
 // and an epilogue shades it (flat material colour, Lambert terms of the headlight along the ray and of the scene's directional
 // light, sky gradient where nothing is hit) into u8[H][W][3]
+// The bin's list lives in LDS (k_render_depth): per entry the screen octagon (hA: box, hB: x + y / x - y extents), hC = (nearest depth, packed
+// word, record index, -), and -- polyhedra -- the faces in camera-ray form, their screen boxes and the silhouette edges in `arena`.  packed:
+// bits 0-3 type, 4 general path, 5 staged, 6-12 faces, 13-19 silhouette edges, 20-31 arena offset (float4 slots).
+constexpr int BL_MAX = 128;      // list entries per bin (the models have <= 91 collision geoms; RenderHost::launch refuses more)
+constexpr int ARENA4 = 1600;     // float4 slots of a bin's staging arena: 25 KB (with the headers 31.3 KB per block: five blocks = five waves per SIMD at 82 VGPRs)
 template <bool RGB>
-__device__ __forceinline__ void render_tile(const int lane, const int tx0, const int ty0, const int cs, const int env, const unsigned short* blist, const int cnt,
+__device__ __forceinline__ void render_tile(const int lane, const int tx0, const int ty0, const int cs, const int env, const float4* hA, const float4* hB, const float4* hC, const float4* arena, const int cnt,
                                             const float* __restrict__ R, const float4* __restrict__ tplanes, const float4* __restrict__ fboxes, const float4* __restrict__ sedges, int nplane, int nedge, const float scale, int ncam_sel, int H,
                                             int W, float znear, float zfar, float* __restrict__ out, const float* __restrict__ geom_rgba, const float* __restrict__ light,
                                             const float* __restrict__ camaux, unsigned char* __restrict__ out_rgb) {
@@ -347,35 +439,42 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
     // tile pyramid: x in [xl, xr], y in [yb, yt] at z = -1
     const int x1 = tx0 + TILE_W < W ? tx0 + TILE_W : W, y1 = ty0 + TILE_H < H ? ty0 + TILE_H : H;
     const float xl = (tx0 - 0.5f * W) * scale, xr = (x1 - 0.5f * W) * scale, yt = -(ty0 - 0.5f * H) * scale, yb = -(y1 - 0.5f * H) * scale;
-    float dyr[TILE_R], dx[4], best[NPX];
+    // The tile works in INVERSE depth s = 1 / t: for a face (a, b, c, no) the crossing of the pixel ray (x, y, -1) is t = no / (a x + b y - c), so
+    // s = (a / no) x + (b / no) y - c / no is affine in the pixel -- one fma per pixel and face instead of fma + rcp + mul, the nearest surface
+    // is the LARGEST s, the entry face of a polyhedron the one with the SMALLEST s, and one rcp per pixel at the very end gives the depth.
+    float dyr[TILE_R], dx[4], best[NPX];      // best: inverse depth of what the pixel sees so far (1 / zfar: nothing; off-image pixels hold a value no surface beats)
     int win[NPX];     // RGB: record index | entry face << 8 of what the pixel sees; pixel q = 4 * row + column
+    const float sfar0 = 1.0f / zfar, sznear = 1.0f / znear;
 #pragma unroll
     for (int r = 0; r < TILE_R; r++) dyr[r] = -(py0 + 8 * r + 0.5f - 0.5f * H) * scale;
 #pragma unroll
     for (int q = 0; q < 4; q++) dx[q] = (px + q + 0.5f - 0.5f * W) * scale;
 #pragma unroll
-    for (int q = 0; q < NPX; q++) { best[q] = (px + (q & 3) < W && py0 + 8 * (q >> 2) < H) ? zfar : 0.0f; win[q] = -1; }
-    float far = zfar;    // farthest current depth over the tile's pixels (off-image pixels count as 0)
+    for (int q = 0; q < NPX; q++) { best[q] = (px + (q & 3) < W && py0 + 8 * (q >> 2) < H) ? sfar0 : 1e30f; win[q] = -1; }
+    const v2f dxa = {dx[0], dx[1]}, dxb = {dx[2], dx[3]};
+    float far = zfar, sfar = sfar0;    // farthest current depth over the tile's pixels and its inverse (off-image pixels do not count)
     RSTAT(0, 1); RSTAT(1, cnt);
     for (int k0 = 0; k0 < cnt; k0 += 64) {
         bool hit = false;
-        int mine = 0;
+        float zmine = 0;
+        int pmine = 0, kmine = 0;
         if (k0 + lane < cnt) {
-            mine = blist[k0 + lane];
-            const float* bb = R + (size_t)mine * REC_W + 24;
-            hit = bb[0] <= xr && bb[1] >= xl && bb[2] <= yt && bb[3] >= yb && bb[4] <= xr + yt && bb[5] >= xl + yb && bb[6] <= xr - yb && bb[7] >= xl - yt;
+            // one entry per lane, from LDS: the octagon test, and what the tile needs to know of the entry should it be hit (a dropped entry
+            // carries an empty box)
+            const float4 ba = hA[k0 + lane], bo = hB[k0 + lane], hc = hC[k0 + lane];
+            hit = ba.x <= xr && ba.y >= xl && ba.z <= yt && ba.w >= yb && bo.x <= xr + yt && bo.y >= xl + yb && bo.z <= xr - yb && bo.w >= xl - yt;
+            zmine = hc.x; pmine = __float_as_int(hc.y); kmine = __float_as_int(hc.z);
         }
         unsigned long long mask = __ballot(hit);
         RSTAT(2, __popcll(mask));
         while (mask) {
             const int pos = __builtin_ctzll(mask);
             mask &= mask - 1;
-            const int k = __builtin_amdgcn_readlane(mine, pos);
-            const float* rec = R + (size_t)k * REC_W;    // wave-uniform: scalar loads
             // front to back: nothing behind this geom's nearest vertex can win once every pixel of the tile is nearer
-            if (rec[23] >= far) { mask = 0; k0 = cnt; break; }
-            const float o[3] = {rec[0], rec[1], rec[2]};
-            const int type = __float_as_int(rec[19]);
+            if (__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zmine), pos)) >= far) { mask = 0; k0 = cnt; break; }
+            const int pk = __builtin_amdgcn_readlane(pmine, pos), k = __builtin_amdgcn_readlane(kmine, pos);
+            const float* rec = R + (size_t)k * REC_W;    // wave-uniform: scalar loads (primitives and unstaged polyhedra only)
+            const int type = pk & 15;
             if (type == 7) {
                 // A convex polyhedron (mesh hull or box), rasterised from what k_render_geoms projected once per camera:
                 //  * every face seen from outside has a screen box; only those whose box meets the tile can cover one of its pixels
@@ -387,66 +486,92 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                 //    inside needs no per-pixel test, the (few) others are evaluated per pixel.
                 // One face and one edge per lane for the tile tests; the kept ones are fetched from those lanes' registers.
                 const size_t cb = (size_t)env * ncam_sel + cs;
-                const int poff = __float_as_int(rec[20]), np = __float_as_int(rec[21]);
-                const float4* P = tplanes + cb * nplane + poff;
-                float lo[NPX];
+                const bool staged = (pk >> 5) & 1;
+                const int np = staged ? (pk >> 6) & 127 : __float_as_int(rec[21]), aoff = (pk >> 20) & 4095;
+                const float4* P = tplanes + cb * nplane + (staged ? 0 : __float_as_int(rec[20]));      // (read when the entry is not staged)
+                float lo[NPX];    // fast path: the polyhedron's inverse depth at the pixel (smallest over its faces seen from outside); general path: entry depth
                 float em[NPX];    // the smallest silhouette-edge value of the pixel so far (negative: outside the polyhedron); a float,
                                   // not a flag: an array of bools is packed into bytes by the compiler and unpacked again in every round
                 int face[NPX];
+                const bool genp = (pk >> 4) & 1;
 #pragma unroll
-                for (int q = 0; q < NPX; q++) { lo[q] = -1e30f; em[q] = 1e30f; face[q] = 0; }
-                if (__float_as_int(rec[18]) == 0) {
-                    const float4* FB = fboxes + cb * nplane + poff;
-                    const float4* SE = sedges + cb * nedge + __float_as_int(rec[16]);
-                    const int nsil = __float_as_int(rec[17]);
+                for (int q = 0; q < NPX; q++) { lo[q] = genp ? -1e30f : 1e30f; em[q] = 1e30f; face[q] = 0; }
+                if (!genp) {
+                    const int nsil = staged ? (pk >> 13) & 127 : __float_as_int(rec[17]);
                     const bool onf = lane < np, one = lane < nsil;
-                    const float4 fl = P[onf ? lane : 0], bb = FB[onf ? lane : 0], eg = SE[one ? lane : 0];
+                    float4 fl, bb, eg;
+                    if (staged) {          // one LDS round trip: the bin staged this polyhedron's faces (inverse-depth form), face boxes and silhouette edges
+                        fl = arena[aoff + (onf ? lane : 0)]; bb = arena[aoff + np + (onf ? lane : 0)]; eg = arena[aoff + 2 * np + (one ? lane : 0)];
+                    } else {
+                        const float4* FB = fboxes + cb * nplane + __float_as_int(rec[20]);
+                        const float4* SE = sedges + cb * nedge + __float_as_int(rec[16]);
+                        fl = P[onf ? lane : 0]; bb = FB[onf ? lane : 0]; eg = SE[one ? lane : 0];
+                        const float iw = __builtin_amdgcn_rcpf(fl.w);
+                        fl = make_float4(fl.x * iw, fl.y * iw, -fl.z * iw, fl.w);
+                    }
                     const bool keepF = onf && bb.x <= xr && bb.y >= xl && bb.z <= yt && bb.w >= yb;
                     const float e00 = eg.x * xl + eg.y * yb + eg.z, e10 = eg.x * xr + eg.y * yb + eg.z, e01 = eg.x * xl + eg.y * yt + eg.z, e11 = eg.x * xr + eg.y * yt + eg.z;
                     const bool allout = e00 < 0 && e10 < 0 && e01 < 0 && e11 < 0, allin = e00 >= 0 && e10 >= 0 && e01 >= 0 && e11 >= 0;
                     if (__any(one && allout)) continue;
                     unsigned long long mF = __ballot(keepF), mS = __ballot(one && !allin);
                     if (!mF) continue;
-                    {   // nothing of this polyhedron is nearer in this tile than what the tile already shows: a pixel's depth is the
-                        // crossing of its covering face, a ratio of affine functions of the pixel, so over the tile it is not below the
-                        // smallest corner value of the candidate faces (a face some corner ray does not approach gives no bound)
-                        const float n00 = fl.x * xl + fl.y * yb - fl.z, n10 = fl.x * xr + fl.y * yb - fl.z, n01 = fl.x * xl + fl.y * yt - fl.z, n11 = fl.x * xr + fl.y * yt - fl.z;
-                        const float t00 = fl.w * __builtin_amdgcn_rcpf(n00), t10 = fl.w * __builtin_amdgcn_rcpf(n10), t01 = fl.w * __builtin_amdgcn_rcpf(n01), t11 = fl.w * __builtin_amdgcn_rcpf(n11);
-                        const bool allneg = n00 < 0 && n10 < 0 && n01 < 0 && n11 < 0;
-                        const float tmn = keepF ? (allneg ? fminf(fminf(t00, t10), fminf(t01, t11)) : -1e30f) : 1e30f;
-                        if (!__any(tmn < far)) continue;
+                    {   // nothing of this polyhedron is nearer in this tile than what the tile already shows: a pixel's inverse depth is that of its
+                        // covering face, affine in the pixel, so over the tile it is not above the largest corner value of the candidate faces
+                        // (a face some corner ray does not approach -- s <= 0 there -- gives no bound)
+                        const float s00 = fl.x * xl + fl.y * yb + fl.z, s10 = fl.x * xr + fl.y * yb + fl.z, s01 = fl.x * xl + fl.y * yt + fl.z, s11 = fl.x * xr + fl.y * yt + fl.z;
+                        const bool allpos = s00 > 0 && s10 > 0 && s01 > 0 && s11 > 0;
+                        if (!__any(keepF && (!allpos || fmaxf(fmaxf(s00, s10), fmaxf(s01, s11)) > sfar))) continue;
                     }
                     RSTAT(3, 1); RSTAT(4, __popcll(mF)); RSTAT(5, __popcll(mS));
+                    // two faces per round: six readlanes, a packed fma per pixel pair and face, one v_min3 per pixel
                     while (mF) {
-                        const int p = __builtin_ctzll(mF);
+                        const int p0 = __builtin_ctzll(mF);
                         mF &= mF - 1;
-                        const float fa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.x), p));
-                        const float fb_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.y), p));
-                        const float fc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.z), p));
-                        const float fw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.w), p));
-                        float nb[TILE_R];
+                        int p1 = p0;
+                        if (!RGB && mF) { p1 = __builtin_ctzll(mF); mF &= mF - 1; }
+                        const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.x), p0));
+                        const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.y), p0));
+                        const float c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.z), p0));
+                        const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.x), p1));
+                        const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.y), p1));
+                        const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl.z), p1));
+                        const v2f a0v = {a0, a0}, a1v = {a1, a1};
 #pragma unroll
-                        for (int r = 0; r < TILE_R; r++) nb[r] = fb_ * dyr[r] - fc;
-#pragma unroll
-                        for (int q = 0; q < NPX; q++) {
-                            const float nv = nb[q >> 2] + fa * dx[q & 3];
-                            // (a pixel inside the silhouette approaches every face seen from outside: nv < 0 there; elsewhere the value is unused)
-                            const float t = fw * __builtin_amdgcn_rcpf(nv);
-                            if (RGB) { if (t > lo[q]) face[q] = p; }
-                            lo[q] = vmax1(lo[q], t);
+                        for (int r = 0; r < TILE_R; r++) {
+                            const float n0 = b0 * dyr[r] + c0, n1 = b1 * dyr[r] + c1;
+                            const v2f n0v = {n0, n0}, n1v = {n1, n1};
+                            const v2f s0a = a0v * dxa + n0v, s0b = a0v * dxb + n0v, s1a = a1v * dxa + n1v, s1b = a1v * dxb + n1v;
+                            // (a pixel inside the silhouette approaches every face seen from outside: s > 0 there; elsewhere the value is unused)
+                            if (RGB) {
+                                if (s0a.x < lo[4 * r]) face[4 * r] = p0;
+                                if (s0a.y < lo[4 * r + 1]) face[4 * r + 1] = p0;
+                                if (s0b.x < lo[4 * r + 2]) face[4 * r + 2] = p0;
+                                if (s0b.y < lo[4 * r + 3]) face[4 * r + 3] = p0;
+                            }
+                            lo[4 * r] = vmin3(lo[4 * r], s0a.x, s1a.x); lo[4 * r + 1] = vmin3(lo[4 * r + 1], s0a.y, s1a.y);
+                            lo[4 * r + 2] = vmin3(lo[4 * r + 2], s0b.x, s1b.x); lo[4 * r + 3] = vmin3(lo[4 * r + 3], s0b.y, s1b.y);
                         }
                     }
                     while (mS) {
-                        const int e = __builtin_ctzll(mS);
+                        const int e0 = __builtin_ctzll(mS);
                         mS &= mS - 1;
-                        const float ea = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.x), e));
-                        const float eb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.y), e));
-                        const float ec = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.z), e));
-                        float nb[TILE_R];
+                        int e1 = e0;
+                        if (mS) { e1 = __builtin_ctzll(mS); mS &= mS - 1; }
+                        const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.x), e0));
+                        const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.y), e0));
+                        const float c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.z), e0));
+                        const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.x), e1));
+                        const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.y), e1));
+                        const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.z), e1));
+                        const v2f a0v = {a0, a0}, a1v = {a1, a1};
 #pragma unroll
-                        for (int r = 0; r < TILE_R; r++) nb[r] = eb * dyr[r] + ec;
-#pragma unroll
-                        for (int q = 0; q < NPX; q++) em[q] = vmin1(em[q], nb[q >> 2] + ea * dx[q & 3]);
+                        for (int r = 0; r < TILE_R; r++) {
+                            const float n0 = b0 * dyr[r] + c0, n1 = b1 * dyr[r] + c1;
+                            const v2f n0v = {n0, n0}, n1v = {n1, n1};
+                            const v2f s0a = a0v * dxa + n0v, s0b = a0v * dxb + n0v, s1a = a1v * dxa + n1v, s1b = a1v * dxb + n1v;
+                            em[4 * r] = vmin3(em[4 * r], s0a.x, s1a.x); em[4 * r + 1] = vmin3(em[4 * r + 1], s0a.y, s1a.y);
+                            em[4 * r + 2] = vmin3(em[4 * r + 2], s0b.x, s1b.x); em[4 * r + 3] = vmin3(em[4 * r + 3], s0b.y, s1b.y);
+                        }
                     }
                 } else {
                     // general path (a vertex behind the near plane -- the links around the camera itself --, or more faces / vertices
@@ -462,7 +587,7 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                 float4 fl = make_float4(0.f, 0.f, 0.f, 0.f);      // this lane's face: the casting loops fetch the kept faces from here (v_readlane)
                 if (np <= 64) {
                     const bool on = lane < np;
-                    const float4 f = P[on ? lane : 0];
+                    const float4 f = staged ? arena[aoff + (on ? lane : 0)] : P[on ? lane : 0];
                     fl = f;
                     const float n00 = f.x * xl + f.y * yb - f.z, n10 = f.x * xr + f.y * yb - f.z, n01 = f.x * xl + f.y * yt - f.z, n11 = f.x * xr + f.y * yt - f.z;
                     const bool front = on && f.w < 0;
@@ -541,7 +666,7 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                 {
                     bool need = false;
 #pragma unroll
-                    for (int q = 0; q < NPX; q++) need = need || (em[q] >= 0 && lo[q] >= znear && lo[q] < best[q]);
+                    for (int q = 0; q < NPX; q++) need = need || (em[q] >= 0 && lo[q] >= znear && lo[q] * best[q] < 1.0f);      // (best holds inverse depths)
                     if (!__any(need)) continue;
                 }
                 if (np <= 64) {
@@ -570,20 +695,25 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                         for (int q = 0; q < NPX; q++) if (!(lo[q] * (nb[q >> 2] + f.x * dx[q & 3]) <= f.w)) em[q] = -1.0f;
                     }
                 }
+#pragma unroll
+                for (int q = 0; q < NPX; q++) lo[q] = lo[q] > 0 ? __builtin_amdgcn_rcpf(lo[q]) : 1e30f;      // entry depth -> inverse depth
                 }
+                // the pixel sees the polyhedron (inside every silhouette edge), beyond the near plane, nearer than what it has
                 bool any_new = false;
 #pragma unroll
                 for (int q = 0; q < NPX; q++)
-                    if (em[q] >= 0 && lo[q] >= znear && lo[q] < best[q]) { best[q] = lo[q]; any_new = true; if (RGB) win[q] = k | (face[q] << 8); }
+                    if (em[q] >= 0 && lo[q] <= sznear && lo[q] > best[q]) { best[q] = lo[q]; any_new = true; if (RGB) win[q] = k | (face[q] << 8); }
                 if (__any(any_new)) {
                     float bm = best[0];
 #pragma unroll
-                    for (int q = 1; q < NPX; q++) bm = fmaxf(bm, best[q]);
-                    far = wave_max(bm);
+                    for (int q = 1; q < NPX; q++) bm = fminf(bm, best[q]);
+                    sfar = -wave_max(-bm);
+                    far = __builtin_amdgcn_rcpf(sfar);
                 }
             } else {
                 // direction in the geom frame: A (dx, dy, -1)
                 RSTAT(6, 1);
+                const float o[3] = {rec[0], rec[1], rec[2]};
                 float va[3];
 #pragma unroll
                 for (int i = 0; i < 3; i++) va[i] = rec[3 + 3 * i];
@@ -593,24 +723,36 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                     const float dyq = dyr[q >> 2], dxq = dx[q & 3];
                     const float v[3] = {rec[4] * dyq - rec[5] + va[0] * dxq, rec[7] * dyq - rec[8] + va[1] * dxq, rec[10] * dyq - rec[11] + va[2] * dxq};
                     float t0;
-                    if (ray_prim(type, sz, o, v, &t0) && t0 >= znear && t0 < best[q]) { best[q] = t0; if (RGB) win[q] = k; }
+                    if (ray_prim(type, sz, o, v, &t0) && t0 >= znear && t0 * best[q] < 1.0f) { best[q] = 1.0f / t0; if (RGB) win[q] = k; }
                 }
                 {
                     float bm = best[0];
 #pragma unroll
-                    for (int q = 1; q < NPX; q++) bm = fmaxf(bm, best[q]);
-                    far = wave_max(bm);
+                    for (int q = 1; q < NPX; q++) bm = fminf(bm, best[q]);
+                    sfar = -wave_max(-bm);
+                    far = __builtin_amdgcn_rcpf(sfar);
                 }
             }
         }
     }
+#pragma unroll
+    for (int q = 0; q < NPX; q++) best[q] = best[q] == sfar0 ? zfar : __builtin_amdgcn_rcpf(best[q]);      // (the far plane itself where nothing was hit)
     if (!RGB) {
 #pragma unroll
         for (int r = 0; r < TILE_R; r++) {
             const int py = py0 + 8 * r;
             if (py < H) {
                 float* dst = out + (((size_t)env * ncam_sel + cs) * H + py) * W + px;
-                if (px + 3 < W && (W & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(best[4 * r], best[4 * r + 1], best[4 * r + 2], best[4 * r + 3]);
+                if (px + 3 < W && (W & 3) == 0) {
+#ifndef AVSIM_RD_NO_NT
+                    // streamed out (non-temporal; round 6: 11.21 -> 11.04 ms): the image is written once and not read by this kernel; keeping its 20 GB out of the L2 leaves the headers and faces there
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const v4f v = {best[4 * r], best[4 * r + 1], best[4 * r + 2], best[4 * r + 3]};
+                    __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst));
+#else
+                    *reinterpret_cast<float4*>(dst) = make_float4(best[4 * r], best[4 * r + 1], best[4 * r + 2], best[4 * r + 3]);
+#endif
+                }
                 else {
 #pragma unroll
                     for (int q = 0; q < 4; q++) if (px + q < W) dst[q] = best[4 * r + q];
@@ -687,79 +829,135 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
 }
 
 // grid (bins_x * bins_y, ncam_sel, N), block 256 = 4 wavefronts.  A block owns a bin of bin_tx x BIN_TY tiles (bin_width: equally wide columns of at most BIN_TX tiles).
-// Wave 0 first makes the bin's record list: one record per lane in front-to-back order, kept if its screen octagon (box + the
-// extents of x + y and x - y) meets the bin's rectangle and -- hulls -- no face seen from outside has all four corner rays of the
-// bin on its outer side; ordered ballot compaction into LDS.  The four waves then cast the bin's
-// 32 tiles, each against this short list instead of every record of the camera.
-
+// Round 6: the bin's list and everything the tiles read of its polyhedra live in LDS.  Until round 5 a tile read, per list entry, the record's
+// octagon from global memory, and per entry it then cast the record through scalar loads and -- dependent on those -- one face, one face box and one
+// silhouette edge per lane: five to seven dependent L2 round trips per tile, with the VALU busy 40 % of the time at four waves per SIMD.
+//   A  wave 0: one record per lane in front-to-back order, kept if its screen octagon (box + the extents of x + y and x - y) meets the bin's
+//      rectangle; ordered ballot compaction -> cand[].
+//   B  all four waves, a candidate each: the record's header (octagon, nearest depth, a packed word) into hA / hB / hC; a polyhedron's faces in
+//      camera-ray form, the faces' screen boxes and its silhouette edges (one per lane: at most 64 faces, 32 vertices) into a slice of `arena`
+//      (an LDS atomic hands out the slices; a polyhedron that does not fit stays in global memory and the tiles read it from there as before),
+//      and the bin-level rejection on the values just loaded: a silhouette edge with the bin's four corner rays outside (general path: a face seen
+//      from outside with the four corner rays on its outer side) drops the entry -- its header gets an empty box.
+//   C  the waves take the bin's tiles from an LDS counter (a tile under the arm costs several times an empty one) and cast each against the list.
 template <bool RGB>
-__global__ void __launch_bounds__(256) k_render_depth(const float* __restrict__ recs, const int* __restrict__ counts, const int* __restrict__ order,
+__global__ void __launch_bounds__(256) k_render_depth(const float* __restrict__ recs, const int* __restrict__ counts, const float4* __restrict__ heads,
                                                       const float4* __restrict__ tplanes, const float4* __restrict__ fboxes, const float4* __restrict__ sedges, int nplane, int nedge,
                                                       const float* __restrict__ cam_fovy, const int* __restrict__ cam_ids, int ncam_sel, int ngeom, int H,
                                                       int W, float znear, float zfar, float* __restrict__ out, const float* __restrict__ geom_rgba, const float* __restrict__ light,
                                                       const float* __restrict__ camaux, unsigned char* __restrict__ out_rgb, const int bin_tx) {
-    __shared__ unsigned short blist[512];
-    __shared__ int bcount;
+    __shared__ float4 hA[BL_MAX], hB[BL_MAX], hC[BL_MAX];
+    __shared__ float4 arena[ARENA4];
+    __shared__ int ncand, arena_top, next_tile;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cs = blockIdx.y, env = blockIdx.z;
-    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H, bins_x = (tiles_x + bin_tx - 1) / bin_tx;
-    const int btx = (blockIdx.x % bins_x) * bin_tx, bty = (blockIdx.x / bins_x) * BIN_TY;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H, bins_x = (tiles_x + bin_tx - 1) / bin_tx, bins_y = (tiles_y + BIN_TY - 1) / BIN_TY;
+    // One block per bin.  (Persistent blocks that walk the bins with the grid's stride were tried in round 6 and are SLOWER, 15.1 against 11.1 ms per
+    // 4096 envs x 4 cameras: on gfx9 stores and loads share vmcnt, so the next bin's first dependent load waits for the previous bin's tile stores
+    // to drain -- with a block per bin that drain overlaps with the other blocks of the CU.)
+    const int gbin = blockIdx.x;
+    const int bin = gbin % (bins_x * bins_y), view = gbin / (bins_x * bins_y), cs = view % ncam_sel, env = view / ncam_sel;
+    const int btx = (bin % bins_x) * bin_tx, bty = (bin / bins_x) * BIN_TY;
     const float scale = 2.0f * cam_fovy[cam_ids[cs]] / (float)H;     // cam_fovy holds tan(fovy / 2)
     const float* R = recs + ((size_t)env * ncam_sel + cs) * ngeom * REC_W;
+    const size_t cb = (size_t)env * ncam_sel + cs;
     if (wave == 0) {
-        const int cnt = counts[(size_t)env * ncam_sel + cs];
-        const int* ord = order + ((size_t)env * ncam_sel + cs) * ngeom;
-        const int px0 = btx * TILE_W, py0 = bty * TILE_H;
-        const int px1 = px0 + bin_tx * TILE_W < W ? px0 + bin_tx * TILE_W : W, py1 = py0 + BIN_TY * TILE_H < H ? py0 + BIN_TY * TILE_H : H;
-        const float xl = (px0 - 0.5f * W) * scale, xr = (px1 - 0.5f * W) * scale, yt = -(py0 - 0.5f * H) * scale, yb = -(py1 - 0.5f * H) * scale;
+        // A: the camera's list headers, front to back, one per lane (coalesced: 64 B each); kept when the octagon meets the bin's rectangle and
+        // the record's bin mask (k_render_geoms: no silhouette edge has the bin's four corner rays outside) has this bin's bit
+        const int bpx0 = btx * TILE_W, bpy0 = bty * TILE_H;
+        const int bpx1 = bpx0 + bin_tx * TILE_W < W ? bpx0 + bin_tx * TILE_W : W, bpy1 = bpy0 + BIN_TY * TILE_H < H ? bpy0 + BIN_TY * TILE_H : H;
+        const float xl = (bpx0 - 0.5f * W) * scale, xr = (bpx1 - 0.5f * W) * scale, yt = -(bpy0 - 0.5f * H) * scale, yb = -(bpy1 - 0.5f * H) * scale;
+#if defined(AVSIM_RDBG) && AVSIM_RDBG == 1
+        const int cnt = 0;          // (experiment: no list at all -- the far plane is stored)
+#else
+        const int cnt = counts[cb];
+#endif
+        const float4* HD = heads + cb * ngeom * 4;
+        const int mbit = bins_x * bins_y <= 128 ? bin : -1;
         int n = 0;
         for (int k0 = 0; k0 < cnt; k0 += 64) {
             bool keep = false;
-            int mine = 0;
+            float4 ba, bo, hc;
             if (k0 + lane < cnt) {
-                mine = ord[k0 + lane];
-                const float* rec = R + (size_t)mine * REC_W;
-                keep = rec[24] <= xr && rec[25] >= xl && rec[26] <= yt && rec[27] >= yb && rec[28] <= xr + yt && rec[29] >= xl + yb && rec[30] <= xr - yb && rec[31] >= xl - yt;
-                if (keep && __float_as_int(rec[19]) == 7 && __float_as_int(rec[18]) != 0) {
-                    // (general path) no face seen from outside may have all four corner rays of the bin on its outer side
-                    const float4* P = tplanes + ((size_t)env * ncam_sel + cs) * nplane + __float_as_int(rec[20]);
-                    const int np = __float_as_int(rec[21]);
-                    for (int p = 0; p < np; p++) {
-                        const float4 f = P[p];
-                        if (f.w < 0 && f.x * xl + f.y * yt - f.z >= 0 && f.x * xr + f.y * yt - f.z >= 0 && f.x * xl + f.y * yb - f.z >= 0 && f.x * xr + f.y * yb - f.z >= 0) {
-                            keep = false;
-                            break;
-                        }
-                    }
-                } else if (keep && __float_as_int(rec[19]) == 7) {
-                    // polyhedra: no silhouette edge may have all four corners of the bin on its outer side.  Four edges per round trip
-                    // to memory (a loop that stops at the first such edge waits for every load in turn)
-                    const float4* SE = sedges + ((size_t)env * ncam_sel + cs) * nedge + __float_as_int(rec[16]);
-                    const int nsil = __float_as_int(rec[17]);
-                    bool out = false;
-                    for (int e = 0; e < nsil; e += 4) {
-                        float4 g[4];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) g[j] = SE[e + j < nsil ? e + j : e];
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            out = out || (g[j].x * xl + g[j].y * yt + g[j].z < 0 && g[j].x * xr + g[j].y * yt + g[j].z < 0 && g[j].x * xl + g[j].y * yb + g[j].z < 0 && g[j].x * xr + g[j].y * yb + g[j].z < 0);
-                    }
-                    keep = !out;
-                }
+                const float4* hd = HD + (size_t)(k0 + lane) * 4;
+                ba = hd[0]; bo = hd[1]; hc = hd[2];
+                const float4 mk = hd[3];
+                const int w = mbit < 0 ? -1 : __float_as_int(mbit < 32 ? mk.x : (mbit < 64 ? mk.y : (mbit < 96 ? mk.z : mk.w)));
+                keep = ba.x <= xr && ba.y >= xl && ba.z <= yt && ba.w >= yb && bo.x <= xr + yt && bo.y >= xl + yb && bo.z <= xr - yb && bo.w >= xl - yt && ((w >> (mbit & 31)) & 1);
             }
             const unsigned long long bal = __ballot(keep);
-            if (keep) { const int at = n + __popcll(bal & ((1ull << lane) - 1ull)); if (at < 512) blist[at] = (unsigned short)mine; }
+            if (keep) { const int at = n + __popcll(bal & ((1ull << lane) - 1ull)); if (at < BL_MAX) { hA[at] = ba; hB[at] = bo; hC[at] = hc; } }
             n += __popcll(bal);
         }
-        if (lane == 0) bcount = n < 512 ? n : 512;
+        if (lane == 0) { ncand = n < BL_MAX ? n : BL_MAX; arena_top = 0; next_tile = 0; }
     }
     __syncthreads();
-    const int cnt = bcount;
-    for (int t = wave; t < bin_tx * BIN_TY; t += 4) {
+#if defined(AVSIM_RDBG) && AVSIM_RDBG == 2
+    const int cnt = 0;              // (experiment: list made, nothing staged or cast)
+#else
+    const int cnt = ncand;
+#endif
+    // B: the listed polyhedra into LDS, a candidate per wave and two at a time, so that the loads of both are in flight together: the faces in
+    // inverse-depth form (1 / t of a pixel ray is AFFINE in the pixel: s = (a x + b y - c) / no), their screen boxes, the silhouette edges
+    for (int i0 = wave; i0 < cnt; i0 += 8) {
+        // (two candidates spelled out: arrays indexed by the unrolled loop variable went to scratch)
+#define AVS_STAGE_LOAD(I, FL, BB, EG, ST, OFF, NP, NS)                                                                                          \
+        float4 FL = make_float4(0.f, 0.f, 0.f, 1.f), BB = FL, EG = FL;                                                                          \
+        bool ST = false;                                                                                                                       \
+        int OFF = 0, NP = 0, NS = 0;                                                                                                           \
+        if ((I) < cnt) {                                                                                                                       \
+            const float4 hc = hC[I];                                                                                                           \
+            const int pk = __builtin_amdgcn_readfirstlane(__float_as_int(hc.y)), pe = __builtin_amdgcn_readfirstlane(__float_as_int(hc.w));    \
+            NP = (pk >> 6) & 127; NS = (pk >> 13) & 127;                                                                                       \
+            if ((pk & 15) == 7 && ((pk >> 4) & 1) == 0 && NP <= 64 && NS <= 64) {                                                              \
+                int o = 0;                                                                                                                     \
+                if (lane == 0) o = atomicAdd(&arena_top, 2 * NP + NS);                                                                         \
+                OFF = __builtin_amdgcn_readfirstlane(o);                                                                                       \
+                ST = OFF + 2 * NP + NS <= ARENA4;                                                                                              \
+                if (ST) {                                                                                                                      \
+                    const int poff = pe & 0xffff, eoff = (pe >> 16) & 0xffff;                                                                  \
+                    FL = (tplanes + cb * nplane + poff)[lane < NP ? lane : 0];                                                                 \
+                    BB = (fboxes + cb * nplane + poff)[lane < NP ? lane : 0];                                                                  \
+                    EG = (sedges + cb * nedge + eoff)[lane < NS ? lane : 0];                                                                   \
+                }                                                                                                                              \
+            }                                                                                                                                  \
+        }
+#define AVS_STAGE_STORE(I, FL, BB, EG, ST, OFF, NP, NS)                                                                                         \
+        if (ST) {                                                                                                                              \
+            if (lane < NP) {                                                                                                                   \
+                const float iw = __builtin_amdgcn_rcpf(FL.w);                                                                                  \
+                arena[OFF + lane] = make_float4(FL.x * iw, FL.y * iw, -FL.z * iw, FL.w);                                                       \
+                arena[OFF + NP + lane] = BB;                                                                                                   \
+            }                                                                                                                                  \
+            if (lane < NS) arena[OFF + 2 * NP + lane] = EG;                                                                                    \
+            if (lane == 0) {                                                                                                                   \
+                float4 hc = hC[I];                                                                                                             \
+                hc.y = __int_as_float(__float_as_int(hc.y) | (1 << 5) | (OFF << 20));                                                          \
+                hC[I] = hc;                                                                                                                    \
+            }                                                                                                                                  \
+        }
+        AVS_STAGE_LOAD(i0, flA, bbA, egA, stA, offA, npA, nsA)
+        AVS_STAGE_LOAD(i0 + 4, flB, bbB, egB, stB, offB, npB, nsB)
+        AVS_STAGE_STORE(i0, flA, bbA, egA, stA, offA, npA, nsA)
+        AVS_STAGE_STORE(i0 + 4, flB, bbB, egB, stB, offB, npB, nsB)
+#undef AVS_STAGE_LOAD
+#undef AVS_STAGE_STORE
+    }
+    __syncthreads();
+    const int ntile = bin_tx * BIN_TY;
+    for (;;) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(&next_tile, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= ntile) break;
         const int tix = btx + (t % bin_tx), tiy = bty + (t / bin_tx);
         if (tix >= tiles_x || tiy >= tiles_y) continue;
-        render_tile<RGB>(lane, tix * TILE_W, tiy * TILE_H, cs, env, blist, cnt, R, tplanes, fboxes, sedges, nplane, nedge, scale, ncam_sel, H, W, znear, zfar, out, geom_rgba, light, camaux, out_rgb);
+#if defined(AVSIM_RDBG) && AVSIM_RDBG == 3
+        const int cast_cnt = 0;            // (experiment: list and staging made, nothing cast)
+#else
+        const int cast_cnt = cnt;
+#endif
+        render_tile<RGB>(lane, tix * TILE_W, tiy * TILE_H, cs, env, hA, hB, hC, arena, cast_cnt, R, tplanes, fboxes, sedges, nplane, nedge, scale, ncam_sel, H, W, znear, zfar, out, geom_rgba, light, camaux, out_rgb);
     }
 }
 
@@ -774,6 +972,7 @@ struct RenderHost {
     float* d_tplanes = nullptr;     // [N][ncam][nplane][4] faces of the polyhedra in camera-ray form
     float* d_fbox = nullptr;        // [N][ncam][nplane][4] screen boxes of the faces seen from outside
     float* d_sedge = nullptr;       // [N][ncam][nedge][4] silhouette edges (lines in the image, positive inside), compacted per polyhedron
+    float* d_heads = nullptr;       // [N][ncam][ngeom][16] the kept records' list headers in front-to-back order (octagon, nearest depth, packed word, record, offsets, bin mask)
     float* d_camaux = nullptr;      // [N][16][8] light direction and world up axis in the camera frame
     int* d_cam_ids = nullptr;
     size_t recs_cap = 0, counts_cap = 0;
@@ -905,14 +1104,16 @@ struct RenderHost {
         if (d_tplanes) (void)hipFree(d_tplanes);
         if (d_fbox) (void)hipFree(d_fbox);
         if (d_sedge) (void)hipFree(d_sedge);
+        if (d_heads) (void)hipFree(d_heads);
         if (d_cam_ids) (void)hipFree(d_cam_ids);
-        d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; d_fbox = nullptr; d_sedge = nullptr; d_cam_ids = nullptr; recs_cap = 0; counts_cap = 0;
+        d_heads = nullptr; d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; d_fbox = nullptr; d_sedge = nullptr; d_cam_ids = nullptr; recs_cap = 0; counts_cap = 0;
     }
     // d_out: device float[N][ncam_sel][H][W], or (rgb) u8[N][ncam_sel][H][W][3]; body poses must already be in d_xpose (same stream)
     int launch(hipStream_t st, const int* cam_ids_host, int ncam_sel, int H, int W, void* d_out, bool rgb, std::string& err) {
         if (ncam_sel < 1 || ncam_sel > 16 || H < 1 || W < 1 || H > 4096 || W > 4096) { err = "avsim_render_depth: bad camera count or image size"; return -1; }
         for (int c = 0; c < ncam_sel; c++)
             if (cam_ids_host[c] < 0 || cam_ids_host[c] >= m.ncam) { err = "avsim_render_depth: camera index out of range"; return -1; }
+        if (m.ngeom > BL_MAX || m.nplane >= 65536 || m.nedge >= 65536) { err = "avsim_render_depth: the model has more geoms than a bin's list holds (BL_MAX), or more faces / edges than the list header's 16-bit offsets"; return -1; }
         // The envs go through the two kernels in chunks of at most env_chunk (4096): a view's records, face planes, face boxes and silhouette
         // edges are ~100 KB -- 1.6 GB of scratch per 4096 envs x 4 cameras -- and the allocation is the chunk's, not the batch's.  (Smaller chunks,
         // whose scratch would stay in the Infinity Cache between the two kernels, are SLOWER: 15.5 ms per 4096 envs in one pass, 15.9 in four,
@@ -928,12 +1129,14 @@ struct RenderHost {
             if (d_tplanes) (void)hipFree(d_tplanes);
             if (d_fbox) (void)hipFree(d_fbox);
             if (d_sedge) (void)hipFree(d_sedge);
-            d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; d_fbox = nullptr; d_sedge = nullptr; recs_cap = 0; counts_cap = 0;
+            if (d_heads) (void)hipFree(d_heads);
+            d_heads = nullptr; d_recs = nullptr; d_counts = nullptr; d_order = nullptr; d_tplanes = nullptr; d_fbox = nullptr; d_sedge = nullptr; recs_cap = 0; counts_cap = 0;
             if (hipMalloc((void**)&d_recs, need * sizeof(float)) != hipSuccess || hipMalloc((void**)&d_counts, (size_t)chunk * 16 * sizeof(int)) != hipSuccess ||
                 hipMalloc((void**)&d_order, (size_t)chunk * ncam_sel * m.ngeom * sizeof(int)) != hipSuccess ||
                 hipMalloc((void**)&d_tplanes, (size_t)chunk * ncam_sel * (m.nplane + 1) * 4 * sizeof(float)) != hipSuccess ||
                 hipMalloc((void**)&d_fbox, (size_t)chunk * ncam_sel * (m.nplane + 1) * 4 * sizeof(float)) != hipSuccess ||
-                hipMalloc((void**)&d_sedge, (size_t)chunk * ncam_sel * (m.nedge + 1) * 4 * sizeof(float)) != hipSuccess) {
+                hipMalloc((void**)&d_sedge, (size_t)chunk * ncam_sel * (m.nedge + 1) * 4 * sizeof(float)) != hipSuccess ||
+                hipMalloc((void**)&d_heads, (size_t)chunk * ncam_sel * m.ngeom * 16 * sizeof(float)) != hipSuccess) {
                 err = "hipMalloc(render records) failed";
                 return -3;
             }
@@ -958,16 +1161,19 @@ struct RenderHost {
         }
         for (int e0 = 0; e0 < N; e0 += chunk) {
             const int n = N - e0 < chunk ? N - e0 : chunk;
+            const long long total_ll = (long long)tiles * ncam_sel * n;
+            if (total_ll > 0x7fffffffLL) { err = "avsim_render_depth: too many bins in one pass (lower render_chunk)"; return -1; }
+            const int nblk = (int)total_ll;
             const float* xp = (const float*)d_xpose + (size_t)e0 * m.nbody * 12;
             float* aux = d_camaux + (size_t)e0 * 16 * 8;
-            hipLaunchKernelGGL(k_render_geoms, dim3(ncam_sel, n), dim3(64), 0, st, m, xp, (const int*)d_cam_ids, ncam_sel, H, W, d_recs, d_counts, d_order, d_tplanes, aux, d_fbox, d_sedge);
+            hipLaunchKernelGGL(k_render_geoms, dim3(ncam_sel, n), dim3(64), 0, st, m, xp, (const int*)d_cam_ids, ncam_sel, H, W, d_recs, d_counts, d_order, d_tplanes, aux, d_fbox, d_sedge, (float4*)d_heads, bin_tx);
             if (timing && e0 == 0) (void)hipEventRecord(tev[tev_used], st);       // (the image kernel's time; with more than one chunk the later chunks' set-up kernels are inside)
             const size_t px = (size_t)e0 * ncam_sel * H * W;
             if (rgb)
-                hipLaunchKernelGGL(k_render_depth<true>, dim3(tiles, ncam_sel, n), dim3(256), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, (const float4*)d_fbox, (const float4*)d_sedge, m.nplane, m.nedge,
+                hipLaunchKernelGGL(k_render_depth<true>, dim3(nblk), dim3(256), 0, st, (const float*)d_recs, (const int*)d_counts, (const float4*)d_heads, (const float4*)d_tplanes, (const float4*)d_fbox, (const float4*)d_sedge, m.nplane, m.nedge,
                                    m.cam_fovy, (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, (float*)nullptr, m.geom_rgba, m.light, (const float*)aux, (unsigned char*)d_out + px * 3, bin_tx);
             else
-                hipLaunchKernelGGL(k_render_depth<false>, dim3(tiles, ncam_sel, n), dim3(256), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_tplanes, (const float4*)d_fbox, (const float4*)d_sedge, m.nplane, m.nedge,
+                hipLaunchKernelGGL(k_render_depth<false>, dim3(nblk), dim3(256), 0, st, (const float*)d_recs, (const int*)d_counts, (const float4*)d_heads, (const float4*)d_tplanes, (const float4*)d_fbox, (const float4*)d_sedge, m.nplane, m.nedge,
                                    m.cam_fovy, (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, m.znear, m.zfar, (float*)d_out + px, m.geom_rgba, m.light, (const float*)aux, (unsigned char*)nullptr, bin_tx);
         }
         hipError_t e = hipGetLastError();

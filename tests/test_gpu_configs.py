@@ -387,8 +387,8 @@ def test_newton_early_exit_in_f32_stays_within_the_solver_tolerance():
     (ls_tolerance 1e-4) are not.  So: HookPackage random walk in f32 (arms dragged over the table, contacts coming and
     going: 4 - 8 Newton iterations), the early-exit build teacher-forced along the run WITHOUT it -- every env-step both handles start from
     the same state, warm start included, and step the same action -- must land within the f32 solver tolerance of it: one env-step (20
-    substeps) apart by less than 2e-5 rad / m in the median env and 5e-4 in the worst (an env whose arm sticks and slips amplifies the
-    solver's 1e-6 inside the step), contact counts equal in >= 99 % of the (env, step) pairs, rewards equal in all."""
+    substeps) apart by less than 1e-7 rad / m in the median (env, step) and 2e-5 in the worst (observed 1.7e-9 / 1.8e-6: an arm that sticks and
+    slips amplifies the solver's 1e-6 inside the step), contact counts equal in >= 99 % of the (env, step) pairs, rewards equal in all."""
     from av_aloha_amd.sim import BatchedSim
     task, na, n, T = "hook_package", 2, 128, 16
     md = model_dict(task, na)
@@ -414,7 +414,7 @@ def test_newton_early_exit_in_f32_stays_within_the_solver_tolerance():
     print("newton_early_exit 0 vs 1, f32, one env-step from the same state: |dq| median %.2e p99 %.2e max %.2e; ncon equal %.4f; Newton iterations per substep %.2f" %
           (np.median(dq), np.percentile(dq, 99), dq.max(), ncon_same / (n * T), np.mean(iters)))
     assert a.diag()[:, 0].max() >= 8                       # arms on the table
-    assert np.median(dq) < 2e-5 and dq.max() < 5e-4, (np.median(dq), dq.max())
+    assert np.median(dq) < 1e-7 and dq.max() < 2e-5, (np.median(dq), dq.max())
     assert ncon_same >= 0.99 * n * T and rew_same == n * T
     a.close()
     b.close()
