@@ -3254,6 +3254,9 @@ struct Env {
 // a global counter (most expensive first when env_order is given), runs the env's whole step out of its own LDS record, and comes
 // back for another.  A slow env therefore holds up one wave's slot, not its block's LDS (static block -> env maps made a block
 // wait for the slowest of its eight).  No block barrier after the table copy.
+#ifndef AVSIM_PHYS_MAXW
+#define AVSIM_PHYS_MAXW 8
+#endif
 template <typename real, int G, int MAXW, bool RETRY>
 #ifndef AVSIM_PHYS_ATTR
 #ifdef AVSIM_TU_F64
@@ -3969,7 +3972,7 @@ struct PhysHost {
         if (n == "newton_component") { mf.newton_component = md.newton_component = v != 0; return true; }
         if (n == "newton_early_exit") { mf.newton_early_exit = md.newton_early_exit = v != 0; return true; }
         if (n == "persist_blocks") { int x = (int)v; if (x >= 1 && x <= 64) { persist_over = x; return true; } return false; }
-        if (n == "waves_per_block") { int x = (int)v; if (x >= 0 && x <= 8) { wpb_override = x; return true; } return false; }
+        if (n == "waves_per_block") { int x = (int)v; if (x >= 0 && x <= AVSIM_PHYS_MAXW) { wpb_override = x; return true; } return false; }
         if (n == "profile_phases") {
             if (v != 0 && !d_prof) d_prof = up(std::vector<long long>((size_t)N * PROF_W, 0));
             if (v == 0) d_prof = nullptr;
@@ -4086,8 +4089,11 @@ struct PhysHost {
         (void)N_; (void)nj;
         // the double-precision kernel lives in its own translation unit (avsim_phys_f64.hip), compiled without FMA contraction
         if (f64) return phys_launch_f64(*this, st, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
-        // as many envs (wavefronts) per block as fit next to one copy of the tables in 160 KiB, at most 8 (two per SIMD)
-        return launch_t<float, 64, 8>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
+        // as many envs (wavefronts) per block as fit next to one copy of the tables in 160 KiB, at most 8 (two per SIMD).
+        // Build option (round 6, profiles/r06_experiments.txt 3): -DAVSIM_PHYS_MAXW=12 "-DAVSIM_PHYS_ATTR=__attribute__((amdgpu_waves_per_eu(3)))" compiles
+        // the f32 kernel for three waves per SIMD (168 VGPRs) and lets a workgroup hold up to twelve envs where the LDS record allows
+        // (options maxefc_first / maxcon_first shrink it: 96 rows / 24 contacts = 14.6 KB = ten envs per CU for SlotInsertion)
+        return launch_t<float, 64, AVSIM_PHYS_MAXW>(st, mf, nsub, action, qpos, qvel, ctrl, warm, latch, agent, reward, success, err);
     }
 #endif
 };
