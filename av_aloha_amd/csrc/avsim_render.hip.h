@@ -83,8 +83,8 @@ __device__ inline void mul33(const float* A, const float* B, float* C) {   // C 
 // grid (ncam_sel, N), block 64
 __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float* __restrict__ xpose, const int* __restrict__ cam_ids, int ncam_sel,
                                                      int H, int W, float* __restrict__ recs, int* __restrict__ counts, int* __restrict__ order, float* __restrict__ tplanes,
-                                                     float* __restrict__ camaux, float* __restrict__ fbox, float* __restrict__ sedge, float4* __restrict__ heads, const int bin_tx) {
-    __shared__ float hs[16][128];      // the kept records' list headers (k_render_depth's hA / hB / hC + the bin mask), until their front-to-back ranks are known
+                                                     float* __restrict__ camaux, float* __restrict__ fbox, float* __restrict__ sedge) {
+    __shared__ float keys[128];
     __shared__ float vcx[RVERT_MAX][64], vcy[RVERT_MAX][64], vcz[RVERT_MAX][64];      // the lane's polyhedron in the camera frame (vertex major: no bank conflicts)
     const int lane = threadIdx.x, cs = blockIdx.x, env = blockIdx.y, cam = cam_ids[cs];
     const float* xb = xpose + (size_t)env * m.nbody * 12;
@@ -108,15 +108,6 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
     const float scale = 2.0f * m.cam_fovy[cam] / (float)H;       // cam_fovy holds tan(fovy / 2)
     const float tx = 0.5f * W * scale, ty = 0.5f * H * scale, sx = sqrtf(1 + tx * tx), sy = sqrtf(1 + ty * ty);
     float* out = recs + ((size_t)env * ncam_sel + cs) * m.ngeom * REC_W;
-    // k_render_depth's bins (bin_tx x BIN_TY tiles of TILE_W x TILE_H pixels, numbered row by row): every record gets the set of bins
-    // that none of its silhouette edges excludes, 128 bits (an image with more bins gets all ones: the tiles still test the edges)
-    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
-    const int nbx = (tiles_x + bin_tx - 1) / bin_tx, nby = (tiles_y + BIN_TY - 1) / BIN_TY;
-#if defined(AVSIM_RDBG) && AVSIM_RDBG == 4
-    const bool binmask = false;      // (experiment: no bin masks)
-#else
-    const bool binmask = nbx * nby <= 128;
-#endif
     int base = 0;
     for (int g0 = 0; g0 < m.ngeom; g0 += 64) {
         const int g = g0 + lane;
@@ -270,93 +261,89 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
             const int k = base + __popcll(bal & ((1ull << lane) - 1ull));
 #pragma unroll
             for (int q = 0; q < REC_W; q++) out[k * REC_W + q] = rec[q];
-            // list header: octagon, nearest depth, packed word (type | general path << 4 | faces << 6 | silhouette edges << 13; k_render_depth adds
-            // the staging bits), record index, face / edge offsets into the camera's scratch, bin mask
-            const int ty_ = __float_as_int(rec[19]);
-            const int gen = ty_ == 7 && __float_as_int(rec[18]) != 0 ? 1 : 0;
-            const int np_ = ty_ == 7 ? __float_as_int(rec[21]) : 0, ns_ = ty_ == 7 && !gen ? __float_as_int(rec[17]) : 0;
-#pragma unroll
-            for (int q = 0; q < 8; q++) hs[q][k] = rec[24 + q];
-            hs[8][k] = rec[23];
-            hs[9][k] = __int_as_float((ty_ & 15) | (gen << 4) | ((np_ > 127 ? 127 : np_) << 6) | ((ns_ > 127 ? 127 : ns_) << 13));
-            hs[10][k] = __int_as_float(k);
-            hs[11][k] = __int_as_float(ty_ == 7 ? (__float_as_int(rec[20]) | (__float_as_int(rec[16]) << 16)) : 0);
-#pragma unroll
-            for (int q = 0; q < 4; q++) hs[12 + q][k] = __int_as_float(-1);        // bin mask: all bins until the pass below has looked at the silhouette
+            keys[k] = rec[23];
         }
         base += __popcll(bal);
     }
     if (lane == 0) counts[(size_t)env * ncam_sel + cs] = base;
     __syncthreads();
-    if (binmask) {
-        // Bin masks: lane = bin (two rounds for 65 .. 128 bins).  A bin whose four corner rays lie outside some silhouette edge cannot see the
-        // polyhedron.  The record's edges (written above by the lane that owns the geom: visible after the barrier) are loaded one per lane,
-        // the next record's while this one is tested, and handed round by v_readlane.
-        const size_t cbase = (size_t)env * ncam_sel + cs;
-        const float4* SEb = reinterpret_cast<const float4*>(sedge) + cbase * m.nedge;
-        const int nb = nbx * nby;
-        float cxl[2], cxr[2], cyt[2], cyb[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int b = lane + 64 * h, bx = b % nbx, by = b / nbx;
-            const int px0 = bx * bin_tx * TILE_W, px1 = px0 + bin_tx * TILE_W < W ? px0 + bin_tx * TILE_W : W;
-            const int py0 = by * BIN_TY * TILE_H, py1 = py0 + BIN_TY * TILE_H < H ? py0 + BIN_TY * TILE_H : H;
-            cxl[h] = (px0 - 0.5f * W) * scale; cxr[h] = (px1 - 0.5f * W) * scale; cyt[h] = -(py0 - 0.5f * H) * scale; cyb[h] = -(py1 - 0.5f * H) * scale;
-        }
-        auto edges_of = [&](int i, int& ns) -> float4 {
-            ns = 0;
-            if (i >= base) return make_float4(0.f, 0.f, 1.f, 0.f);
-            const int pk = __float_as_int(hs[9][i]), pe = __float_as_int(hs[11][i]);
-            if ((pk & 15) != 7 || ((pk >> 4) & 1)) return make_float4(0.f, 0.f, 1.f, 0.f);
-            ns = (pk >> 13) & 127;
-            if (ns > 64) ns = 64;          // (a polyhedron of <= 32 vertices has <= 32 silhouette edges; more are left to the tiles)
-            {   // only records whose octagon's box meets more than three bins are worth the pass (the long frame bars that cross the image at an angle:
-                // 17.7 octagon candidates per bin against 4.3 with the masks); the small ones stay candidates of their one to three bins
-                const float bw = bin_tx * TILE_W * scale, bh = BIN_TY * TILE_H * scale, x0 = -0.5f * W * scale, y0 = 0.5f * H * scale;
-                const int c0 = max(0, (int)floorf((hs[0][i] - x0) / bw)), c1 = min(nbx - 1, (int)floorf((hs[1][i] - x0) / bw));
-                const int r0 = max(0, (int)floorf((y0 - hs[3][i]) / bh)), r1 = min(nby - 1, (int)floorf((y0 - hs[2][i]) / bh));
-                if ((c1 - c0 + 1) * (r1 - r0 + 1) <= 3) { ns = 0; return make_float4(0.f, 0.f, 1.f, 0.f); }
-            }
-            return SEb[((pe >> 16) & 0xffff) + (lane < ns ? lane : 0)];
-        };
-        auto test = [&](int i, const float4 eg, const int ns) {
-            if (ns == 0) return;
-            bool out0 = false, out1 = false;
-            for (int e = 0; e < ns; e++) {
-                const float ea = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.x), e));
-                const float eb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.y), e));
-                const float ec = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.z), e));
-                out0 = out0 || (fmaxf(ea * cxl[0], ea * cxr[0]) + fmaxf(eb * cyt[0], eb * cyb[0]) + ec < 0);
-                if (nb > 64) out1 = out1 || (fmaxf(ea * cxl[1], ea * cxr[1]) + fmaxf(eb * cyt[1], eb * cyb[1]) + ec < 0);
-            }
-            const unsigned long long m0 = __ballot(!out0), m1 = nb > 64 ? __ballot(!out1) : ~0ull;
-            if (lane == 0) {
-                hs[12][i] = __int_as_float((int)(unsigned)m0); hs[13][i] = __int_as_float((int)(unsigned)(m0 >> 32));
-                hs[14][i] = __int_as_float((int)(unsigned)m1); hs[15][i] = __int_as_float((int)(unsigned)(m1 >> 32));
-            }
-        };
-        // four records' edges in flight while the four before them are tested (one record per round trip made this pass the kernel's longest)
-        int nA0, nA1, nA2, nA3;
-        float4 eA0 = edges_of(0, nA0), eA1 = edges_of(1, nA1), eA2 = edges_of(2, nA2), eA3 = edges_of(3, nA3);
-        for (int i = 0; i < base; i += 4) {
-            const float4 c0 = eA0, c1 = eA1, c2 = eA2, c3 = eA3;
-            const int m0 = nA0, m1 = nA1, m2 = nA2, m3 = nA3;
-            eA0 = edges_of(i + 4, nA0); eA1 = edges_of(i + 5, nA1); eA2 = edges_of(i + 6, nA2); eA3 = edges_of(i + 7, nA3);
-            test(i, c0, m0); test(i + 1, c1, m1); test(i + 2, c2, m2); test(i + 3, c3, m3);
-        }
-        __syncthreads();
-    }
     // front-to-back order by rank sort on the nearest depth (ties by index)
     int* ord = order + ((size_t)env * ncam_sel + cs) * m.ngeom;
     for (int i = lane; i < base; i += 64) {
-        const float ki = hs[8][i];
+        const float ki = keys[i];
         int rank = 0;
-        for (int j = 0; j < base; j++) { const float kj = hs[8][j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
+        for (int j = 0; j < base; j++) { const float kj = keys[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
         ord[rank] = i;
-        // the headers in front-to-back order, four float4 each: a bin reads its camera's list in one coalesced pass
-        float4* hd = heads + (((size_t)env * ncam_sel + cs) * m.ngeom + rank) * 4;
+    }
+}
+
+// grid (views of the pass), block 256.  The list headers k_render_depth reads: one 64-byte header per kept record in FRONT-TO-BACK order -- the screen
+// octagon, the nearest depth, a packed word (type | general path << 4 | faces << 6 | silhouette edges << 13; k_render_depth adds the staging bits),
+// the record index, the face / edge offsets into the camera's scratch -- and the record's BIN MASK: the set of k_render_depth's bins (bin_tx x
+// BIN_TY tiles, numbered row by row; 128 bits, all ones for an image with more bins) that none of its silhouette edges excludes.  The octagon
+// alone leaves 17.7 candidates per bin (the long frame bars cross the image at an angle), the mask 4.3.  A wave per record, lane = bin: the
+// record's edges are loaded one per lane and handed round by v_readlane; only records whose octagon's box meets more than three bins are tested.
+// (Inside k_render_geoms -- one wave per view, LDS-bound at five waves per CU -- the same pass cost 0.8 ms per 16384 views; here it hides behind
+// the other waves: profiles/r06_experiments.txt 1.)
+__global__ void __launch_bounds__(256) k_render_heads(const float* __restrict__ recs, const int* __restrict__ counts, const int* __restrict__ order,
+                                                      const float4* __restrict__ sedges, int nedge, const float* __restrict__ cam_fovy, const int* __restrict__ cam_ids,
+                                                      int ncam_sel, int ngeom, int H, int W, float4* __restrict__ heads, const int bin_tx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t cb = blockIdx.x;
+    const int cs = (int)(cb % ncam_sel);
+    const float scale = 2.0f * cam_fovy[cam_ids[cs]] / (float)H;
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+    const int nbx = (tiles_x + bin_tx - 1) / bin_tx, nby = (tiles_y + BIN_TY - 1) / BIN_TY, nb = nbx * nby;
+#if defined(AVSIM_RDBG) && AVSIM_RDBG == 4
+    const bool binmask = false;      // (experiment: no bin masks)
+#else
+    const bool binmask = nb <= 128;
+#endif
+    float cxl[2], cxr[2], cyt[2], cyb[2];
 #pragma unroll
-        for (int q = 0; q < 4; q++) hd[q] = make_float4(hs[4 * q][i], hs[4 * q + 1][i], hs[4 * q + 2][i], hs[4 * q + 3][i]);
+    for (int h = 0; h < 2; h++) {
+        const int b = lane + 64 * h, bx = b % nbx, by = b / nbx;
+        const int px0 = bx * bin_tx * TILE_W, px1 = px0 + bin_tx * TILE_W < W ? px0 + bin_tx * TILE_W : W;
+        const int py0 = by * BIN_TY * TILE_H, py1 = py0 + BIN_TY * TILE_H < H ? py0 + BIN_TY * TILE_H : H;
+        cxl[h] = (px0 - 0.5f * W) * scale; cxr[h] = (px1 - 0.5f * W) * scale; cyt[h] = -(py0 - 0.5f * H) * scale; cyb[h] = -(py1 - 0.5f * H) * scale;
+    }
+    const int cnt = counts[cb];
+    const float* R = recs + cb * ngeom * REC_W;
+    const float bw = bin_tx * TILE_W * scale, bh = BIN_TY * TILE_H * scale, x0 = -0.5f * W * scale, y0 = 0.5f * H * scale;
+    for (int r = wave; r < cnt; r += 4) {
+        const int i = __builtin_amdgcn_readfirstlane(order[cb * ngeom + r]);
+        const float* rec = R + (size_t)i * REC_W;                 // wave-uniform: scalar loads
+        const int ty_ = __float_as_int(rec[19]);
+        const int gen = ty_ == 7 && __float_as_int(rec[18]) != 0 ? 1 : 0;
+        const int np_ = ty_ == 7 ? __float_as_int(rec[21]) : 0, ns_ = ty_ == 7 && !gen ? __float_as_int(rec[17]) : 0;
+        unsigned long long m0 = ~0ull, m1 = ~0ull;
+        if (binmask && ty_ == 7 && !gen && ns_ > 0) {
+            const int c0 = max(0, (int)floorf((rec[24] - x0) / bw)), c1 = min(nbx - 1, (int)floorf((rec[25] - x0) / bw));
+            const int r0 = max(0, (int)floorf((y0 - rec[27]) / bh)), r1 = min(nby - 1, (int)floorf((y0 - rec[26]) / bh));
+            if ((c1 - c0 + 1) * (r1 - r0 + 1) > 3) {
+                const int ns = ns_ > 64 ? 64 : ns_;          // (a polyhedron of <= 32 vertices has <= 32 silhouette edges; more are left to the tiles)
+                const float4 eg = (sedges + cb * nedge + __float_as_int(rec[16]))[lane < ns ? lane : 0];
+                bool out0 = false, out1 = false;
+                for (int e = 0; e < ns; e++) {
+                    const float ea = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.x), e));
+                    const float eb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.y), e));
+                    const float ec = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eg.z), e));
+                    // the bin's four corner rays all outside this edge (its largest corner value is negative): the bin cannot see the polyhedron
+                    out0 = out0 || (fmaxf(ea * cxl[0], ea * cxr[0]) + fmaxf(eb * cyt[0], eb * cyb[0]) + ec < 0);
+                    if (nb > 64) out1 = out1 || (fmaxf(ea * cxl[1], ea * cxr[1]) + fmaxf(eb * cyt[1], eb * cyb[1]) + ec < 0);
+                }
+                m0 = __ballot(!out0);
+                if (nb > 64) m1 = __ballot(!out1);
+            }
+        }
+        if (lane == 0) {
+            float4* hd = heads + (cb * ngeom + r) * 4;
+            hd[0] = make_float4(rec[24], rec[25], rec[26], rec[27]);
+            hd[1] = make_float4(rec[28], rec[29], rec[30], rec[31]);
+            hd[2] = make_float4(rec[23], __int_as_float((ty_ & 15) | (gen << 4) | ((np_ > 127 ? 127 : np_) << 6) | ((ns_ > 127 ? 127 : ns_) << 13)), __int_as_float(i),
+                                __int_as_float(ty_ == 7 ? (__float_as_int(rec[20]) | (__float_as_int(rec[16]) << 16)) : 0));
+            hd[3] = make_float4(__int_as_float((int)(unsigned)m0), __int_as_float((int)(unsigned)(m0 >> 32)), __int_as_float((int)(unsigned)m1), __int_as_float((int)(unsigned)(m1 >> 32)));
+        }
     }
 }
 
@@ -366,6 +353,7 @@ __global__ void __launch_bounds__(64) k_render_geoms(RenderModel m, const float*
 __device__ __forceinline__ float vmax1(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmin1(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 typedef float v2f __attribute__((ext_vector_type(2)));      // two pixels per v_pk_fma_f32
 
 __device__ inline float wave_max(float x) {
@@ -428,7 +416,10 @@ __device__ inline bool ray_prim(int type, const float* sz, const float* o, const
 // word, record index, -), and -- polyhedra -- the faces in camera-ray form, their screen boxes and the silhouette edges in `arena`.  packed:
 // bits 0-3 type, 4 general path, 5 staged, 6-12 faces, 13-19 silhouette edges, 20-31 arena offset (float4 slots).
 constexpr int BL_MAX = 128;      // list entries per bin (the models have <= 91 collision geoms; RenderHost::launch refuses more)
-constexpr int ARENA4 = 1600;     // float4 slots of a bin's staging arena: 25 KB (with the headers 31.3 KB per block: five blocks = five waves per SIMD at 82 VGPRs)
+#ifndef AVSIM_RD_ARENA4
+#define AVSIM_RD_ARENA4 1600
+#endif
+constexpr int ARENA4 = AVSIM_RD_ARENA4;     // float4 slots of a bin's staging arena: 25 KB (with the headers 31.3 KB per block: five blocks = five waves per SIMD at 82 VGPRs)
 template <bool RGB>
 __device__ __forceinline__ void render_tile(const int lane, const int tx0, const int ty0, const int cs, const int env, const float4* hA, const float4* hB, const float4* hC, const float4* arena, const int cnt,
                                             const float* __restrict__ R, const float4* __restrict__ tplanes, const float4* __restrict__ fboxes, const float4* __restrict__ sedges, int nplane, int nedge, const float scale, int ncam_sel, int H,
@@ -462,7 +453,9 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
             // one entry per lane, from LDS: the octagon test, and what the tile needs to know of the entry should it be hit (a dropped entry
             // carries an empty box)
             const float4 ba = hA[k0 + lane], bo = hB[k0 + lane], hc = hC[k0 + lane];
-            hit = ba.x <= xr && ba.y >= xl && ba.z <= yt && ba.w >= yb && bo.x <= xr + yt && bo.y >= xl + yb && bo.z <= xr - yb && bo.w >= xl - yt;
+            // (one compare of the largest violation instead of eight compares and seven mask ANDs: the scalar unit's share of the tile -- mask logic,
+            // loop control, readlane targets: 374 SALU next to 636 VALU instructions per tile -- was as long as the vector unit's)
+            hit = vmax3(vmax3(ba.x - xr, xl - ba.y, ba.z - yt), vmax3(yb - ba.w, bo.x - (xr + yt), (xl + yb) - bo.y), fmaxf(bo.z - (xr - yb), (xl - yt) - bo.w)) <= 0.0f;
             zmine = hc.x; pmine = __float_as_int(hc.y); kmine = __float_as_int(hc.z);
         }
         unsigned long long mask = __ballot(hit);
@@ -509,18 +502,20 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                         const float iw = __builtin_amdgcn_rcpf(fl.w);
                         fl = make_float4(fl.x * iw, fl.y * iw, -fl.z * iw, fl.w);
                     }
-                    const bool keepF = onf && bb.x <= xr && bb.y >= xl && bb.z <= yt && bb.w >= yb;
-                    const float e00 = eg.x * xl + eg.y * yb + eg.z, e10 = eg.x * xr + eg.y * yb + eg.z, e01 = eg.x * xl + eg.y * yt + eg.z, e11 = eg.x * xr + eg.y * yt + eg.z;
-                    const bool allout = e00 < 0 && e10 < 0 && e01 < 0 && e11 < 0, allin = e00 >= 0 && e10 >= 0 && e01 >= 0 && e11 >= 0;
+                    const bool keepF = onf && fmaxf(fmaxf(bb.x - xr, xl - bb.y), fmaxf(bb.z - yt, yb - bb.w)) <= 0.0f;
+                    // the edge function over the tile's four corners: its largest and smallest value (affine: max / min of the x part + of the y part)
+                    const float exa = eg.x * xl, exb = eg.x * xr, eya = eg.y * yb + eg.z, eyb = eg.y * yt + eg.z;
+                    const float emax = fmaxf(exa, exb) + fmaxf(eya, eyb), emin = fminf(exa, exb) + fminf(eya, eyb);
+                    const bool allout = emax < 0, allin = emin >= 0;
                     if (__any(one && allout)) continue;
                     unsigned long long mF = __ballot(keepF), mS = __ballot(one && !allin);
                     if (!mF) continue;
                     {   // nothing of this polyhedron is nearer in this tile than what the tile already shows: a pixel's inverse depth is that of its
                         // covering face, affine in the pixel, so over the tile it is not above the largest corner value of the candidate faces
                         // (a face some corner ray does not approach -- s <= 0 there -- gives no bound)
-                        const float s00 = fl.x * xl + fl.y * yb + fl.z, s10 = fl.x * xr + fl.y * yb + fl.z, s01 = fl.x * xl + fl.y * yt + fl.z, s11 = fl.x * xr + fl.y * yt + fl.z;
-                        const bool allpos = s00 > 0 && s10 > 0 && s01 > 0 && s11 > 0;
-                        if (!__any(keepF && (!allpos || fmaxf(fmaxf(s00, s10), fmaxf(s01, s11)) > sfar))) continue;
+                        const float sxa = fl.x * xl, sxb = fl.x * xr, sya = fl.y * yb + fl.z, syb = fl.y * yt + fl.z;
+                        const float smax = fmaxf(sxa, sxb) + fmaxf(sya, syb), smin = fminf(sxa, sxb) + fminf(sya, syb);
+                        if (!__any(keepF && (!(smin > 0) || smax > sfar))) continue;
                     }
                     RSTAT(3, 1); RSTAT(4, __popcll(mF)); RSTAT(5, __popcll(mS));
                     // two faces per round: six readlanes, a packed fma per pixel pair and face, one v_min3 per pixel
@@ -699,16 +694,24 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
                 for (int q = 0; q < NPX; q++) lo[q] = lo[q] > 0 ? __builtin_amdgcn_rcpf(lo[q]) : 1e30f;      // entry depth -> inverse depth
                 }
                 // the pixel sees the polyhedron (inside every silhouette edge), beyond the near plane, nearer than what it has
-                bool any_new = false;
+                float bm0 = best[0];
 #pragma unroll
-                for (int q = 0; q < NPX; q++)
-                    if (em[q] >= 0 && lo[q] <= sznear && lo[q] > best[q]) { best[q] = lo[q]; any_new = true; if (RGB) win[q] = k | (face[q] << 8); }
-                if (__any(any_new)) {
+                for (int q = 1; q < NPX; q++) bm0 = fminf(bm0, best[q]);
+#pragma unroll
+                for (int q = 0; q < NPX; q++) {
+                    float c = em[q] >= 0 ? lo[q] : 0.0f;      // (two selects and a max per pixel: no mask logic on the scalar unit)
+                    c = lo[q] <= sznear ? c : 0.0f;
+                    if (RGB) { if (c > best[q]) win[q] = k | (face[q] << 8); }
+                    best[q] = vmax1(best[q], c);
+                }
+                {
                     float bm = best[0];
 #pragma unroll
                     for (int q = 1; q < NPX; q++) bm = fminf(bm, best[q]);
-                    sfar = -wave_max(-bm);
-                    far = __builtin_amdgcn_rcpf(sfar);
+                    if (__any(bm != bm0)) {      // some pixel of the tile came nearer: the tile's farthest depth may have
+                        sfar = -wave_max(-bm);
+                        far = __builtin_amdgcn_rcpf(sfar);
+                    }
                 }
             } else {
                 // direction in the geom frame: A (dx, dy, -1)
@@ -840,8 +843,11 @@ __device__ __forceinline__ void render_tile(const int lane, const int tx0, const
 //      and the bin-level rejection on the values just loaded: a silhouette edge with the bin's four corner rays outside (general path: a face seen
 //      from outside with the four corner rays on its outer side) drops the entry -- its header gets an empty box.
 //   C  the waves take the bin's tiles from an LDS counter (a tile under the arm costs several times an empty one) and cast each against the list.
+#ifndef AVSIM_RD_WAVES
+#define AVSIM_RD_WAVES 1
+#endif
 template <bool RGB>
-__global__ void __launch_bounds__(256) k_render_depth(const float* __restrict__ recs, const int* __restrict__ counts, const float4* __restrict__ heads,
+__global__ void __launch_bounds__(256, RGB ? 1 : AVSIM_RD_WAVES) k_render_depth(const float* __restrict__ recs, const int* __restrict__ counts, const float4* __restrict__ heads,
                                                       const float4* __restrict__ tplanes, const float4* __restrict__ fboxes, const float4* __restrict__ sedges, int nplane, int nedge,
                                                       const float* __restrict__ cam_fovy, const int* __restrict__ cam_ids, int ncam_sel, int ngeom, int H,
                                                       int W, float znear, float zfar, float* __restrict__ out, const float* __restrict__ geom_rgba, const float* __restrict__ light,
@@ -1166,7 +1172,9 @@ struct RenderHost {
             const int nblk = (int)total_ll;
             const float* xp = (const float*)d_xpose + (size_t)e0 * m.nbody * 12;
             float* aux = d_camaux + (size_t)e0 * 16 * 8;
-            hipLaunchKernelGGL(k_render_geoms, dim3(ncam_sel, n), dim3(64), 0, st, m, xp, (const int*)d_cam_ids, ncam_sel, H, W, d_recs, d_counts, d_order, d_tplanes, aux, d_fbox, d_sedge, (float4*)d_heads, bin_tx);
+            hipLaunchKernelGGL(k_render_geoms, dim3(ncam_sel, n), dim3(64), 0, st, m, xp, (const int*)d_cam_ids, ncam_sel, H, W, d_recs, d_counts, d_order, d_tplanes, aux, d_fbox, d_sedge);
+            hipLaunchKernelGGL(k_render_heads, dim3(ncam_sel * n), dim3(256), 0, st, (const float*)d_recs, (const int*)d_counts, (const int*)d_order, (const float4*)d_sedge, m.nedge, m.cam_fovy,
+                               (const int*)d_cam_ids, ncam_sel, m.ngeom, H, W, (float4*)d_heads, bin_tx);
             if (timing && e0 == 0) (void)hipEventRecord(tev[tev_used], st);       // (the image kernel's time; with more than one chunk the later chunks' set-up kernels are inside)
             const size_t px = (size_t)e0 * ncam_sel * H * W;
             if (rgb)

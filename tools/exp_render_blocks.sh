@@ -11,7 +11,7 @@ for v in ${LIST:-10,2 20,2 20,4 10,4}; do
 import csv,glob
 for f in glob.glob("gpurun_out/rdbg/prof/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_render_depth<false>" in r["Name"] or "k_render_geoms" in r["Name"]:
+        if "k_render_" in r["Name"] and "<true>" not in r["Name"]:
             print("   ", r["Name"][:40], r["Calls"], "avg ms %.3f" % (float(r["AverageNs"]) / 1e6))
 PY
 done
