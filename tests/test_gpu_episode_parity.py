@@ -18,12 +18,12 @@ the device's IK produced at every step is recorded and the oracle steps the SAME
       - teacher-forced (`lockstep`): at every env-step the oracle is put into the device's f32 state and steps the device's ctrl once.
         Per-step reward and success flags without the divergence of two chaotic trajectories in between: a differing flag needs a
         contact within f32 rounding of its margin in that step.  Observed (profiles/r04_episode_parity.json): 0 differing success
-        flags in 224 000 env-steps of SlotInsertion / InsertPeg / SewNeedle / TubeTransfer and 0 - 11 differing rewards per task
-        (< 0.02 %); HookPackage 0.15 % while the released package is knocked about in 4 of the 128 envs.
+        flags in 224 000 env-steps of SlotInsertion / InsertPeg / SewNeedle / TubeTransfer and 0 - 15 differing rewards per task
+        (< 0.03 %; round 6: one differing flag-step in SewNeedle); HookPackage 23 flag-steps of 52 480 (0.04 %) while the released package is knocked about.
       - open-loop replay of the whole ctrl sequence: the final is_success per env.  The f64 replay of controls that were computed
         in closed loop on the f32 trajectory has no feedback: a millimetre of difference in how the object sits in the gripper, and
         the replayed peg meets the tube's rim (clearance 8 mm).  The mismatch count is stated and bounded per task
-        (observed 0 / 1 / 1 / 0 / 5 of 128 for SlotInsertion / InsertPeg / SewNeedle / HookPackage / TubeTransfer).
+        (observed 0 / 0 / 3 / 0 / 0 of 128 for SlotInsertion / InsertPeg / SewNeedle / HookPackage / TubeTransfer in round 6; 0 / 1 / 1 / 0 / 5 in round 5).
 """
 import numpy as np
 import pytest
@@ -64,8 +64,9 @@ def test_f64_full_episode_rewards_and_success_identical(task, n, max_reward, pos
         assert r["dev_final_reward"] == r["orc_final_reward"], r
         assert r["held_reward_diff"] == 0, r                       # (the steps before the script lets go / pours)
     if task == "tube_transfer":
-        assert len(differing) <= n // 4 and all(r["n_reward_diff"] <= 10 for r in differing), differing        # observed: 0 of 16 envs
-        assert all(r["held_max_qpos_err"] < 3e-3 and r["arm_max_qpos_err"] < 2e-2 for r in rows), rows          # observed: 2.9e-4, 1.8e-3
+        # (round 6: bounds at three times the observed maxima -- n // 4 envs, 3e-3 and 2e-2 until then)
+        assert len(differing) <= 1 and all(r["n_reward_diff"] <= 10 for r in differing), differing               # observed: 0 of 16 envs
+        assert all(r["held_max_qpos_err"] < 1e-3 and r["arm_max_qpos_err"] < 6e-3 for r in rows), rows          # observed: 2.9e-4 up to the pour, 1.8e-3 for the arms over the whole episode
         assert np.median([r["max_qpos_err"] for r in rows]) < 1e-6                                              # observed: 4e-10
     else:
         assert not differing, f"{task}: reward sequences differ: {differing}"
@@ -102,13 +103,15 @@ def test_f64_whole_episodes_agree_to_1e7_when_the_solver_converges(task, n):
 
 
 # task: (open-loop replay: bound on final-flag mismatches of 128; lockstep: bounds on differing success-flag steps, differing reward
-# steps (fraction of all env-steps), final-flag mismatches).  Observed at the end of round 4 in the comments.
+# steps (fraction of all env-steps), final-flag mismatches).  Round 6: the bounds are the maxima observed on the driver's kind of box (in the
+# comments: replay mismatches; success-flag steps, reward-step fraction, final flags) times three, at least observed + 1 -- they were 2 / 4 / 4 / 2 / 10
+# replay mismatches and 160 HookPackage flag-steps until round 5.
 F32_CASES = {
-    "slot_insertion":    dict(replay_mismatch=2, ls_success_steps=2, ls_reward_frac=1e-3, ls_final=0, min_success=0.9),     # 0; 0, 1.1e-4, 0
-    "insert_peg":        dict(replay_mismatch=4, ls_success_steps=2, ls_reward_frac=1e-3, ls_final=0, min_success=0.95),    # 1; 0, 2e-5, 0
-    "sew_needle_thread": dict(replay_mismatch=4, ls_success_steps=2, ls_reward_frac=1e-3, ls_final=0, min_success=0.95),    # 1; 0, 1.2e-4, 0
-    "hook_package":      dict(replay_mismatch=2, ls_success_steps=160, ls_reward_frac=4e-3, ls_final=4, min_success=0.9),   # 0; 77, 1.5e-3, 3
-    "tube_transfer":     dict(replay_mismatch=10, ls_success_steps=2, ls_reward_frac=1e-3, ls_final=0, min_success=0.93),   # 5 (the ball's billiard in the carried tube); 0, 0, 0
+    "slot_insertion":    dict(replay_mismatch=1, ls_success_steps=2, ls_reward_frac=5e-4, ls_final=0, min_success=0.9),     # 0; 0, 0, 0
+    "insert_peg":        dict(replay_mismatch=1, ls_success_steps=2, ls_reward_frac=5e-4, ls_final=0, min_success=0.95),    # 0; 0, 0, 0
+    "sew_needle_thread": dict(replay_mismatch=4, ls_success_steps=3, ls_reward_frac=7e-4, ls_final=0, min_success=0.95),    # 3; 1, 2.2e-4, 0
+    "hook_package":      dict(replay_mismatch=1, ls_success_steps=70, ls_reward_frac=4e-3, ls_final=1, min_success=0.9),    # 0; 23, 1.3e-3, 0
+    "tube_transfer":     dict(replay_mismatch=2, ls_success_steps=2, ls_reward_frac=5e-4, ls_final=0, min_success=0.93),    # 0 (5 in round 5: the ball's billiard in the carried tube); 0, 0, 0
 }
 
 
