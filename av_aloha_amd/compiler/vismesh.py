@@ -150,6 +150,38 @@ def cluster_decimate(V, F, cell):
     return V2, F2
 
 
+CREASE_COS = 0.8
+
+
+def corner_normals(V, F, cos_thr=CREASE_COS):
+    """Per triangle and corner, the normal the lighting uses there (unit, mesh frame, [nt, 3, 3]): the area-weighted mean of the normals of
+    the faces around that vertex whose own normal lies within the crease angle (cos >= 0.8) of THIS face's -- smooth over curved surfaces,
+    faceted across hard edges.  MuJoCo's compiler generates vertex normals for meshes that bring none (the STL files here) by area-weighted
+    averaging and, with <compiler smoothnormal="false"> (the default), leaves large-angle faces out of a vertex's average [EXT: from the
+    documentation and memory of user_mesh.cc; the 0.8 is the uncertain part]; its fixed-function GL pipeline then lights per VERTEX and
+    interpolates (Gouraud)."""
+    V = np.asarray(V, dtype=np.float64)
+    F = np.asarray(F, dtype=np.int64)
+    cr = np.cross(V[F[:, 1]] - V[F[:, 0]], V[F[:, 2]] - V[F[:, 0]])          # 2 x area x unit normal
+    ln = np.linalg.norm(cr, axis=1)
+    fn = cr / np.maximum(ln, 1e-300)[:, None]
+    order = np.argsort(F.reshape(-1), kind="stable")
+    vs = F.reshape(-1)[order]
+    fs = order // 3
+    start = np.searchsorted(vs, np.arange(len(V)))
+    end = np.searchsorted(vs, np.arange(len(V)), side="right")
+    out = np.zeros((len(F), 3, 3))
+    for f in range(len(F)):
+        for c in range(3):
+            v = F[f, c]
+            adj = fs[start[v]:end[v]]
+            keep = adj[fn[adj] @ fn[f] >= cos_thr]
+            n = cr[keep].sum(0)
+            l = np.linalg.norm(n)
+            out[f, c] = n / l if l > 1e-300 else (fn[f] if ln[f] > 0 else np.array([0.0, 0.0, 1.0]))      # (a degenerate triangle is never drawn)
+    return out
+
+
 def unit_box():
     V = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], dtype=np.float64)
     quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
@@ -261,7 +293,7 @@ def build_library(models, texture_png, budget=20000, verbose=False):
     dec = decimate_all(hi)
     names = list(prim) + files
     ids = {n: i for i, n in enumerate(names)}
-    vadr, vnum, tadr, tnum, Vs, Fs, UVs = [], [], [], [], [], [], []
+    vadr, vnum, tadr, tnum, Vs, Fs, UVs, TNs = [], [], [], [], [], [], [], []
     for n in names:
         if n in prim:
             V, F = prim[n]
@@ -273,7 +305,7 @@ def build_library(models, texture_png, budget=20000, verbose=False):
             if T is not None and len(T):
                 uv = T[np.maximum(FT, 0)].reshape(len(F), 6)
         vadr.append(sum(len(v) for v in Vs)); vnum.append(len(V)); tadr.append(sum(len(f) for f in Fs)); tnum.append(len(F))
-        Vs.append(V); Fs.append(F); UVs.append(uv)
+        Vs.append(V); Fs.append(F); UVs.append(uv); TNs.append(corner_normals(V, F).reshape(len(F), 9))
         if verbose:
             print(f"  {os.path.basename(n):40s} {len(raw[n][1]) if n in raw else len(F):7d} -> {len(F):6d} triangles")
     img = read_png_rgb8(texture_png).astype(np.float64)
@@ -285,6 +317,7 @@ def build_library(models, texture_png, budget=20000, verbose=False):
         "lib_vadr": np.array(vadr, dtype=np.int32), "lib_vnum": np.array(vnum, dtype=np.int32),
         "lib_tadr": np.array(tadr, dtype=np.int32), "lib_tnum": np.array(tnum, dtype=np.int32),
         "lib_vert": np.concatenate(Vs), "lib_tri": np.concatenate(Fs).astype(np.int32), "lib_uv": np.concatenate(UVs),
+        "lib_tnorm": np.concatenate(TNs),       # per triangle the three corners' lighting normals, mesh frame (corner_normals; round 6: smooth shading)
         "lib_tex": (lambda t: (t[:, 0] | (t[:, 1] << 8) | (t[:, 2] << 16)).astype(np.int32))(np.round(tex).astype(np.int64).reshape(-1, 3)),   # r | g << 8 | b << 16, row-major from the top
     }
     info = {"cell_m": hi, "meshes": {os.path.basename(n): int(t) for n, t in zip(names, tnum)},
@@ -294,8 +327,8 @@ def build_library(models, texture_png, budget=20000, verbose=False):
 
 def expand_instances(lib, inst):
     """Instances x library -> the scene's triangles in body frames (what the device's loader and the oracle draw):
-    vert (nv, 3), vbody (nv,), tri (nt, 3), rgb (nt, 3), uv (nt, 6), tex (nt,)."""
-    Vs, Bs, Fs, Cs, Us, Ts = [], [], [], [], [], []
+    vert (nv, 3), vbody (nv,), tri (nt, 3), rgb (nt, 3), uv (nt, 6), tex (nt,), tnorm (nt, 9): the corners' lighting normals, body frame."""
+    Vs, Bs, Fs, Cs, Us, Ts, Ns = [], [], [], [], [], [], []
     nv = 0
     for k in range(len(inst["vis_inst_mesh"])):
         mid = int(inst["vis_inst_mesh"][k])
@@ -303,11 +336,16 @@ def expand_instances(lib, inst):
         V = lib["lib_vert"][va:va + vn] * inst["vis_inst_scale"][k]
         V = V @ inst["vis_inst_mat"][k].reshape(3, 3).T + inst["vis_inst_pos"][k]
         F = lib["lib_tri"][ta:ta + tn]
+        # normals go with the inverse transpose: n / scale, then the instance's rotation
+        TN = lib["lib_tnorm"][ta:ta + tn].reshape(tn, 3, 3) / inst["vis_inst_scale"][k]
+        TN = TN @ inst["vis_inst_mat"][k].reshape(3, 3).T
+        TN = TN / np.maximum(np.linalg.norm(TN, axis=2, keepdims=True), 1e-300)
         if np.prod(inst["vis_inst_scale"][k]) < 0:
             F = F[:, ::-1]
+            TN = TN[:, ::-1]
         Vs.append(V); Bs.append(np.full(vn, int(inst["vis_inst_body"][k]), dtype=np.int32)); Fs.append(F + nv)
         Cs.append(np.repeat(inst["vis_inst_rgba"][k][None, :3], tn, 0)); Us.append(lib["lib_uv"][ta:ta + tn])
-        Ts.append(np.full(tn, int(inst["vis_inst_tex"][k]), dtype=np.int32))
+        Ts.append(np.full(tn, int(inst["vis_inst_tex"][k]), dtype=np.int32)); Ns.append(TN.reshape(tn, 9))
         nv += vn
     return (np.concatenate(Vs), np.concatenate(Bs), np.concatenate(Fs).astype(np.int32), np.concatenate(Cs), np.concatenate(Us),
-            np.concatenate(Ts))
+            np.concatenate(Ts), np.concatenate(Ns))

@@ -497,6 +497,7 @@ int avsim_set_option(avsim_t* h, const char* name, double value) {
     if (!std::strcmp(name, "render_proxies")) { h->render_proxies = value != 0; return AVSIM_OK; }
     if (!std::strcmp(name, "render_samples")) { if (value != 1 && value != 4) { h->set_error("render_samples is 1 or 4"); return AVSIM_EINVAL; } h->vis.samples = (int)value; return AVSIM_OK; }
     if (!std::strcmp(name, "render_shadows")) { h->vis.shadows = value != 0; return AVSIM_OK; }
+    if (!std::strcmp(name, "render_smooth")) { h->vis.smooth_opt = value != 0; h->vis.S.smooth = value != 0 ? 1 : 0; return AVSIM_OK; }
     if (!std::strcmp(name, "render_shadow_size")) { if (value != 512 && value != 1024 && value != 2048) { h->set_error("render_shadow_size is 512, 1024 or 2048"); return AVSIM_EINVAL; } h->vis.shadow_size = (int)value; return AVSIM_OK; }
     if (!std::strcmp(name, "render_cam_major")) { h->vis.cam_major = value != 0; return AVSIM_OK; }
     if (!std::strcmp(name, "render_chunk")) { if (value < 1) { h->set_error("render_chunk is a number of envs >= 1"); return AVSIM_EINVAL; } h->render.env_chunk = (int)value; return AVSIM_OK; }

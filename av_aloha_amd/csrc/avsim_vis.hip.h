@@ -49,6 +49,8 @@ struct VisScene {
     const float* rgb;       // [ntri][3]
     const float* uv;        // [ntri][6]
     const int* tex;         // [ntri]
+    const float* tnorm;     // [ntri][9] the corners' lighting normals, body frame (compiler/vismesh.py corner_normals); null: a library without them
+    int smooth;             // option "render_smooth" (default 1 where the library has the normals): light the corners and interpolate (Gouraud, as MuJoCo's fixed-function GL [EXT]); 0: one shade per triangle
     const unsigned* texel;  // [VIS_TEX][VIS_TEX] r | g << 8 | b << 16, row 0 = top
     int texn;
     const int* cam_body;
@@ -72,6 +74,7 @@ struct VisScratch {
     int* bbox;        // [slots][reccap][4] tile ranges
     int* list;        // [slots][listcap]
     int* bigq;        // [slots][reccap]: the records whose boxes cover more than 16 tiles (vis_bin)
+    float4* grec;     // [slots][reccap][3]: smooth shading: per record the planes of shade x w, shade-without-the-light x w, specular x w over the image (w = 1 / depth): value at a sample = plane / w
     float4* trec;     // [slots][VIS_TEXCAP][3]: per textured triangle the planes U, V, D over the image: texture coordinate = U / D, V / D at a sample
     int* flags;       // [nviews][8]: overflow bits (0: records, 1: lists), shader-clock cycles / 1024 of the five stages, records, list entries
     int reccap, listcap;
@@ -288,7 +291,8 @@ __global__ void __launch_bounds__(VIS_SHADOW_THREADS) k_vis_shadow(VisScene S, c
 #else
 #define VIS_OCC_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))      // 128 VGPRs: sixteen wavefronts per CU
 #endif
-template <int SS, bool SH>       // SS x SS samples per pixel; SH: shadows of the directional light (S.shmap)
+template <int SS, bool SH, bool SM>       // SS x SS samples per pixel; SH: shadows of the directional light (S.shmap); SM: smooth shading (a template flag: as a run-time one it
+                                         // cost the flat path 16 % -- registers of both paths live in the tile loop at the 128-VGPR cap)
 __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScene S, VisScratch X, const float* __restrict__ xpose, const int* __restrict__ cam_ids, int ncam_sel,
                                                             int N, int H, int W, unsigned char* __restrict__ out, int cam_major) {
     __shared__ float Rcb[VIS_MAXBODY * 12];
@@ -308,6 +312,8 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
     int* bbox = X.bbox + (size_t)slot * X.reccap * 4;
     int* list = X.list + (size_t)slot * X.listcap;
     float4* trec = X.trec + (size_t)slot * VIS_TEXCAP * 3;
+    float4* grec = X.grec + (size_t)slot * X.reccap * 3;
+    constexpr bool smooth = SM;
     int* bigq = X.bigq + (size_t)slot * X.reccap;
     for (int view = blockIdx.x; view < nviews; view += gridDim.x) {
         const int env = view / ncam_sel, cs = view - env * ncam_sel, cid = cam_ids[cs];
@@ -365,6 +371,7 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
             const int t = t0 + tid;
             int nout = 0;
             float px[4], py[4], pw[4];
+            float att[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};      // smooth shading: shade, shade without the light's term, specular at the (clipped) corners
             unsigned colour = 0, colour2 = 0;
             float sbias = -1.0f;
             int tag = t;               // word 13 of the record: the triangle, or for a textured one its slot in trec
@@ -377,13 +384,37 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                     const float D[3] = {da, db, dc};
                     float Q[4][3];
                     int nq = 0;
+                    float A3[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+                    if (smooth) {
+                        // the three corners lit with their own normals (body frame -> camera frame through the body's rotation), as the flat shade below
+                        // lights the centroid: headlight term along the ray to the corner, the light's diffuse and specular terms
+                        const float* o = Rcb + 12 * S.vbody[S.tri[3 * t]];
+                        const float* tn = S.tnorm + 9 * (size_t)t;
+#pragma unroll
+                        for (int i = 0; i < 3; i++) {
+                            const float nx = o[0] * tn[3 * i] + o[1] * tn[3 * i + 1] + o[2] * tn[3 * i + 2], ny = o[3] * tn[3 * i] + o[4] * tn[3 * i + 1] + o[5] * tn[3 * i + 2],
+                                        nz = o[6] * tn[3 * i] + o[7] * tn[3 * i + 1] + o[8] * tn[3 * i + 2];
+                            const float ig = rsqrtf(fmaxf(P[i][0] * P[i][0] + P[i][1] * P[i][1] + P[i][2] * P[i][2], 1e-30f));
+                            const float chv = fmaxf(-(nx * P[i][0] + ny * P[i][1] + nz * P[i][2]) * ig, 0.0f), clv = -(nx * cam[12] + ny * cam[13] + nz * cam[14]);
+                            A3[i][0] = fminf(1.0f, amb + hd * chv + ld * fmaxf(clv, 0.0f));
+                            A3[i][1] = fminf(1.0f, amb + hd * chv);
+                            float sp = 0.0f;
+                            if (clv > 0.0f && S.spec_k > 0.0f) {
+                                const float nh = nx * cam[31] + ny * cam[32] + nz * cam[33];
+                                if (nh > 0.0f) sp = S.spec_k * exp2f(S.spec_n * log2f(nh));
+                            }
+                            A3[i][2] = sp;
+                        }
+                    }
                     for (int i = 0; i < 3; i++) {
                         const int j = i == 2 ? 0 : i + 1;
                         const bool in_i = D[i] >= znear, in_j = D[j] >= znear;
-                        if (in_i) { Q[nq][0] = P[i][0]; Q[nq][1] = P[i][1]; Q[nq][2] = P[i][2]; nq++; }
+                        if (in_i) { Q[nq][0] = P[i][0]; Q[nq][1] = P[i][1]; Q[nq][2] = P[i][2]; for (int l = 0; l < 3; l++) att[nq][l] = A3[i][l]; nq++; }
                         if (in_i != in_j) {
                             const float s = (znear - D[i]) / (D[j] - D[i]);
-                            Q[nq][0] = P[i][0] + s * (P[j][0] - P[i][0]); Q[nq][1] = P[i][1] + s * (P[j][1] - P[i][1]); Q[nq][2] = -znear; nq++;
+                            Q[nq][0] = P[i][0] + s * (P[j][0] - P[i][0]); Q[nq][1] = P[i][1] + s * (P[j][1] - P[i][1]); Q[nq][2] = -znear;
+                            for (int l = 0; l < 3; l++) att[nq][l] = A3[i][l] + s * (A3[j][l] - A3[i][l]);
+                            nq++;
                         }
                     }
                     for (int i = 0; i < nq; i++) {
@@ -438,16 +469,18 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                                 } else { tag = VIS_TEXCAP - 1; flag |= 1; }
                             }
                         }
+                        else if (smooth) colour = vis_pack(S.rgb[3 * t], S.rgb[3 * t + 1], S.rgb[3 * t + 2]);      // (the material's colour: the shade comes from the record's planes at the sample)
                         else { colour = vis_pack(S.rgb[3 * t] * lum + spec, S.rgb[3 * t + 1] * lum + spec, S.rgb[3 * t + 2] * lum + spec); colour2 = vis_pack(S.rgb[3 * t] * lum2, S.rgb[3 * t + 1] * lum2, S.rgb[3 * t + 2] * lum2); }
                         // in the light's shadow the light's term goes (colour2); the depth map's texels are S.sh_itex^-1 wide, so a lit surface
                         // tilted by theta against the light lies up to texel x tan(theta) below its own texel's height: slope-scaled bias.
                         // A surface that faces away from the light has no such term to lose: bias < 0 = no look-up
+                        if (smooth) colour2 = (A3[0][2] > 0.0f || A3[1][2] > 0.0f || A3[2][2] > 0.0f) ? 1u : 0u;      // (smooth mode: word 14 says whether the record has a specular plane worth fetching)
                         sbias = cl > 0.0f ? 1e-3f + 1.5f * sqrtf(fmaxf(0.0f, 1.0f - cl * cl)) / fmaxf(cl, 0.05f) / S.sh_itex : -1.0f;
                     }
                 }
             }
             // the (at most two) records of this thread's triangle
-            float4 R[2][4];
+            float4 R[2][4], G[2][3];
             int4 B[2];
             bool keep[2];
 #pragma unroll
@@ -476,6 +509,12 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                         R[k][1] = make_float4(b1, c1, a2, b2);
                         R[k][2] = make_float4(c2, a0 * w0 + a1 * w1 + a2 * w2, b0 * w0 + b1 * w1 + b2 * w2, c0 * w0 + c1 * w1 + c2 * w2);
                         R[k][3] = make_float4(__uint_as_float(colour), __int_as_float(tag), __uint_as_float(colour2), sbias);
+                        // smooth shading: a corner attribute q interpolates perspective-correctly as sum(lambda_i q_i w_i) / sum(lambda_i w_i): the numerator's plane
+#pragma unroll
+                        for (int l = 0; l < 3; l++) {
+                            const float q0 = att[i0][l] * w0, q1 = att[i1][l] * w1, q2 = att[i2][l] * w2;
+                            G[k][l] = make_float4(a0 * q0 + a1 * q1 + a2 * q2, b0 * q0 + b1 * q1 + b2 * q2, c0 * q0 + c1 * q1 + c2 * q2, 0.0f);
+                        }
                         B[k] = make_int4(ix0 / VIS_TILE, ix1 / VIS_TILE, iy0 / VIS_TILE, iy1 / VIS_TILE);
                     }
                 }
@@ -494,6 +533,7 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                 if (keep[k]) {
                     if (idx < X.reccap) {
                         rec[4 * idx] = R[k][0]; rec[4 * idx + 1] = R[k][1]; rec[4 * idx + 2] = R[k][2]; rec[4 * idx + 3] = R[k][3];
+                        if (smooth) { grec[3 * idx] = G[k][0]; grec[3 * idx + 1] = G[k][1]; grec[3 * idx + 2] = G[k][2]; }
                         ((int4*)bbox)[idx] = B[k];
                     } else flag |= 1;
                     idx++;
@@ -615,6 +655,7 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                     if (bi[q] != 0x7fffffff) {
                         const float4 r3 = rec[4u * (unsigned)bi[q] + 3u];      // colour, triangle or texture slot, colour without the light's term, shadow bias
                         col = __float_as_uint(r3.x);
+                        bool shadowed = false;
                         if (SH && r3.w >= 0.0f) {
                             // the sample's surface point in the world: depth 1 / w along the optical axis; its place and height in the light's frame
                             const float depth = __builtin_amdgcn_rcpf(bw[q]), px = dx * depth, py = dy * depth, pz = -depth;
@@ -623,12 +664,21 @@ __global__ void __launch_bounds__(VIS_THREADS) VIS_OCC_ATTR k_vis_render(VisScen
                             const float hh = -(wx * cam[25] + wy * cam[26] + wz * cam[27]);
                             if (su >= 0.0f && sv >= 0.0f && su < (float)S.shn && sv < (float)S.shn) {
                                 const unsigned key = shenv[(unsigned)((int)sv * S.shn + (int)su)];
-                                if (key != 0u && vis_hval(key) > hh + r3.w) col = __float_as_uint(r3.z);
+                                if (key != 0u && vis_hval(key) > hh + r3.w) { if (!smooth) col = __float_as_uint(r3.z); shadowed = true; }
                             }
+                        }
+                        float glum = 0.0f, gspec = 0.0f;
+                        if (smooth) {      // the shade at THIS sample from the record's planes (lit corners, interpolated): plane / w
+                            const float4* gp = grec + 3u * (unsigned)bi[q];
+                            const float4 g0 = gp[shadowed ? 1 : 0];
+                            const float dep = __builtin_amdgcn_rcpf(bw[q]);
+                            glum = fminf(fmaxf((g0.x * sx + (g0.y * sy + g0.z)) * dep, 0.0f), 1.0f);
+                            if (!shadowed && __float_as_uint(r3.z) != 0u) { const float4 g2 = gp[2]; gspec = fmaxf((g2.x * sx + (g2.y * sy + g2.z)) * dep, 0.0f); }
+                            if (!(col & 0x80000000u)) col = vis_pack((float)(col & 255u) * (glum / 255.0f) + gspec, (float)((col >> 8) & 255u) * (glum / 255.0f) + gspec, (float)((col >> 16) & 255u) * (glum / 255.0f) + gspec);
                         }
                         if (col & 0x80000000u) {
                             // textured: (u, v) = (U, V) / D with the triangle's three planes over the image (set-up), then the texel
-                            const float lum = (float)(col & 0xffffu) * (1.0f / 65535.0f), spc = (float)((col >> 16) & 0x7fffu) * (1.0f / 32767.0f);
+                            const float lum = smooth ? glum : (float)(col & 0xffffu) * (1.0f / 65535.0f), spc = smooth ? gspec : (float)((col >> 16) & 0x7fffu) * (1.0f / 32767.0f);
                             const float4* tp = trec + 3 * __float_as_int(r3.y);
                             const float4 pu = tp[0], pv = tp[1], pd = tp[2];
                             const float den = pd.x * sx + (pd.y * sy + pd.z);
@@ -700,6 +750,7 @@ struct VisHost {
     int samples = 1;                 // option "render_samples": 1, or 4 = 2 x 2 supersampling
     bool cam_major = false;          // option "render_cam_major": the images as [cam][N][H][W][3] (every camera's batch contiguous) instead of [N][cam][H][W][3]
     int shadow_size = VIS_SM;        // option "render_shadow_size": 512 | 1024 | 2048 texels per side (MuJoCo's own map is 8192 wide, scene.xml:12; 2.3 mm texels at 512)
+    bool smooth_opt = false;         // option "render_smooth": corners lit with their own normals and interpolated (needs a library with lib_tnorm); on in the gym / Cartesian facades, off in a bare handle (like shadows and multisampling: the raw kernel timings stay comparable)
     bool shadows = false;            // option "render_shadows": the directional light casts shadows (depth map from the light, one per env)
     unsigned* d_shmap = nullptr;
     int shmap_envs = 0;
@@ -728,7 +779,9 @@ struct VisHost {
         if (loaded) return;
         auto vadr = lib.i("lib_vadr"), vnum = lib.i("lib_vnum"), tadr = lib.i("lib_tadr"), tnum = lib.i("lib_tnum"), ltri = lib.i("lib_tri"), ltex = lib.i("lib_tex");
         auto lvert = lib.f("lib_vert"), luv = lib.f("lib_uv");
-        std::vector<float> vert, rgb, uv;
+        std::vector<double> ltn;
+        try { ltn = lib.f("lib_tnorm"); } catch (const std::exception&) { ltn.clear(); }      // (a library from before round 6: flat shading only)
+        std::vector<float> vert, rgb, uv, tnorm;
         std::vector<int> vbody, tri, tex;
         const int ninst = (int)inst_mesh.size();
         for (int k = 0; k < ninst; k++) {
@@ -749,12 +802,23 @@ struct VisHost {
                 const int o[3] = {0, flip ? 2 : 1, flip ? 1 : 2};
                 for (int c = 0; c < 3; c++) { tri.push_back(v0 + f[o[c]]); uv.push_back((float)u[2 * o[c]]); uv.push_back((float)u[2 * o[c] + 1]); }
                 for (int c = 0; c < 3; c++) rgb.push_back((float)inst_rgba[4 * k + c]);
+                if (!ltn.empty())
+                    for (int c = 0; c < 3; c++) {      // normals go with the inverse transpose: n / scale, then the instance's rotation
+                        const double* n = &ltn[9 * (size_t)(tadr[mid] + t) + 3 * o[c]];
+                        const double m[3] = {n[0] / sc[0], n[1] / sc[1], n[2] / sc[2]};
+                        double r[3];
+                        for (int i = 0; i < 3; i++) r[i] = R[3 * i] * m[0] + R[3 * i + 1] * m[1] + R[3 * i + 2] * m[2];
+                        const double l = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+                        for (int i = 0; i < 3; i++) tnorm.push_back((float)(l > 0 ? r[i] / l : (i == 2 ? 1.0 : 0.0)));
+                    }
                 tex.push_back(inst_tex[k]);
             }
         }
         if (nbody > VIS_MAXBODY) throw std::runtime_error("visual renderer: more than 64 bodies");
         S.nvert = (int)vbody.size(); S.ntri = (int)tex.size(); S.nbody = nbody;
         S.vert = up(vert); S.vbody = up(vbody); S.tri = up(tri); S.rgb = up(rgb); S.uv = up(uv); S.tex = up(tex);
+        S.tnorm = tnorm.empty() ? nullptr : up(tnorm);
+        S.smooth = smooth_opt ? 1 : 0;
         std::vector<unsigned> texel(ltex.begin(), ltex.end());
         S.texel = up(texel);
         S.texn = (int)std::lround(std::sqrt((double)texel.size()));
@@ -784,7 +848,7 @@ struct VisHost {
     void destroy() {
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
-        for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.trec, (void*)X.bigq, (void*)X.flags, (void*)d_cam_ids, (void*)d_shmap}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.trec, (void*)X.grec, (void*)X.bigq, (void*)X.flags, (void*)d_cam_ids, (void*)d_shmap}) if (p) (void)hipFree(p);
         X = VisScratch{}; d_cam_ids = nullptr; d_shmap = nullptr; shmap_envs = 0; shmap_ver = 0; loaded = false; slots = 0; max_slots = 0; nviews_cap = 0; last_nviews = 0;
     }
     // overflow flags of the last launch, OR over the views (bit 0: triangle records, bit 1: tile lists); synchronises the stream
@@ -811,13 +875,13 @@ struct VisHost {
         const int want = nviews < max_slots ? nviews : max_slots;
         if (want > slots) {
             if (hipStreamSynchronize(st) != hipSuccess) { err = "visual render: stream synchronisation failed"; return -3; }
-            for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.trec, (void*)X.bigq}) if (p) (void)hipFree(p);
-            X.vcam = nullptr; X.rec = nullptr; X.bbox = nullptr; X.list = nullptr; X.trec = nullptr; X.bigq = nullptr; slots = 0;
+            for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.trec, (void*)X.grec, (void*)X.bigq}) if (p) (void)hipFree(p);
+            X.vcam = nullptr; X.rec = nullptr; X.bbox = nullptr; X.list = nullptr; X.trec = nullptr; X.grec = nullptr; X.bigq = nullptr; slots = 0;
             if (hipMalloc((void**)&X.vcam, (size_t)want * S.nvert * sizeof(float4)) != hipSuccess || hipMalloc((void**)&X.rec, (size_t)want * X.reccap * 4 * sizeof(float4)) != hipSuccess ||
                 hipMalloc((void**)&X.bbox, (size_t)want * X.reccap * 4 * sizeof(int)) != hipSuccess || hipMalloc((void**)&X.list, ((size_t)want * X.listcap + 16) * sizeof(int)) != hipSuccess ||      // (+ 16: the tile stage reads its list four entries at a time)
-                hipMalloc((void**)&X.trec, (size_t)want * VIS_TEXCAP * 3 * sizeof(float4)) != hipSuccess || hipMalloc((void**)&X.bigq, (size_t)want * X.reccap * sizeof(int)) != hipSuccess) {
-                for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.trec, (void*)X.bigq}) if (p) (void)hipFree(p);
-                X.vcam = nullptr; X.rec = nullptr; X.bbox = nullptr; X.list = nullptr; X.trec = nullptr; X.bigq = nullptr;
+                hipMalloc((void**)&X.trec, (size_t)want * VIS_TEXCAP * 3 * sizeof(float4)) != hipSuccess || hipMalloc((void**)&X.grec, (size_t)want * X.reccap * 3 * sizeof(float4)) != hipSuccess || hipMalloc((void**)&X.bigq, (size_t)want * X.reccap * sizeof(int)) != hipSuccess) {
+                for (void* p : {(void*)X.vcam, (void*)X.rec, (void*)X.bbox, (void*)X.list, (void*)X.trec, (void*)X.grec, (void*)X.bigq}) if (p) (void)hipFree(p);
+                X.vcam = nullptr; X.rec = nullptr; X.bbox = nullptr; X.list = nullptr; X.trec = nullptr; X.grec = nullptr; X.bigq = nullptr;
                 err = "hipMalloc(visual render scratch) failed"; return -3;
             }
             slots = want;
@@ -833,10 +897,12 @@ struct VisHost {
         const int grid = nviews < slots ? nviews : slots;
         const size_t shmem = (size_t)(2 * ntile + 1) * sizeof(int);
         if (!attr_done) {
-            if (hipFuncSetAttribute((const void*)k_vis_render<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_vis_render<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_vis_render<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_vis_render<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) { err = "hipFuncSetAttribute(visual render) failed"; return -3; }
+            bool ok = true;
+#define VIS_ATTR(SS_, SH_, SM_) ok = ok && hipFuncSetAttribute((const void*)k_vis_render<SS_, SH_, SM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) == hipSuccess
+            VIS_ATTR(1, false, false); VIS_ATTR(2, false, false); VIS_ATTR(1, true, false); VIS_ATTR(2, true, false);
+            VIS_ATTR(1, false, true); VIS_ATTR(2, false, true); VIS_ATTR(1, true, true); VIS_ATTR(2, true, true);
+#undef VIS_ATTR
+            if (!ok) { err = "hipFuncSetAttribute(visual render) failed"; return -3; }
             attr_done = true;
         }
         S.shmap = nullptr;
@@ -865,7 +931,9 @@ struct VisHost {
             }
         }
         const bool sh = S.shmap != nullptr;
-#define VIS_LAUNCH(SS_, SH_) hipLaunchKernelGGL((k_vis_render<SS_, SH_>), dim3(grid), dim3(VIS_THREADS), shmem, st, S, X, d_xpose, (const int*)d_cam_ids, ncam_sel, N, H, W, (unsigned char*)d_out, cam_major ? 1 : 0)
+        const bool sm = S.smooth != 0 && S.tnorm != nullptr;
+#define VIS_LAUNCH(SS_, SH_) do { if (sm) hipLaunchKernelGGL((k_vis_render<SS_, SH_, true>), dim3(grid), dim3(VIS_THREADS), shmem, st, S, X, d_xpose, (const int*)d_cam_ids, ncam_sel, N, H, W, (unsigned char*)d_out, cam_major ? 1 : 0); \
+                                  else hipLaunchKernelGGL((k_vis_render<SS_, SH_, false>), dim3(grid), dim3(VIS_THREADS), shmem, st, S, X, d_xpose, (const int*)d_cam_ids, ncam_sel, N, H, W, (unsigned char*)d_out, cam_major ? 1 : 0); } while (0)
         if (samples > 1) { if (sh) VIS_LAUNCH(2, true); else VIS_LAUNCH(2, false); }
         else { if (sh) VIS_LAUNCH(1, true); else VIS_LAUNCH(1, false); }
 #undef VIS_LAUNCH

@@ -115,7 +115,7 @@ class GuidedVisionEnv(_EnvBase):
         self.num_joints = 14 if num_arms == 2 else 21
         # the colour images as MuJoCo's renderer makes them by default [EXT]: the directional light casts shadows, the offscreen buffer is
         # multisampled (4 samples); options={"render_shadows": 0, "render_samples": 1} gives the plain image
-        options = {"render_shadows": 1, "render_samples": 4, **(options or {})}
+        options = {"render_shadows": 1, "render_samples": 4, "render_smooth": 1, **(options or {})}
         self._device, self._f64, self._options, self._model_arms = device, f64, options, num_arms
         self.sim = BatchedSim(self.task, num_arms, self.num_envs, device=device, f64=f64, options=options)
         self.max_reward = self.sim.max_reward

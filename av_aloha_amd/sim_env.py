@@ -59,7 +59,7 @@ class GuidedVisionEnv:
         # and the peg have MuJoCo's default solref there (task_sew_needle.xml:17, task_insert_peg.xml:7) and the ZED cameras fovy 90
         # (aloha_sim.xml:357-358); variant="gym" runs the Cartesian env on the gym assets' model instead
         self.variant = variant
-        options = {"render_shadows": 1, "render_samples": 4, **(options or {})}       # (MuJoCo's defaults: shadows on, 4 offscreen samples [EXT])
+        options = {"render_shadows": 1, "render_samples": 4, "render_smooth": 1, **(options or {})}       # (MuJoCo's defaults: shadows on, 4 offscreen samples [EXT])
         self.sim = BatchedSim(self.task, 3, self.num_envs, device=device, f64=f64, options=options, variant=variant)
         from .compiler.compile import read_blob
         from .constants import MODEL_DIR

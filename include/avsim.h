@@ -178,8 +178,11 @@ int avsim_render_depth(avsim_t* h, const int32_t* cam_ids, int ncam, int height,
  * scene.xml:6), from a 512 x 512 depth map rendered from the light per env ("render_shadow_size" 1024 | 2048: a finer one, 4 / 16 MB per env); "render_samples" 4 -- 2 x 2 supersampling (MuJoCo's offscreen
  * buffer is multisampled, offsamples default 4 [EXT]).  Both are off at the C-ABI and on in the gym facades.  "render_cam_major" 1 -- out is
  * uint8[ncam][N][height][width][3] (every camera's batch contiguous: the facades hand out one array per camera without copying).  The directional light's specular
- * term (MJCF defaults: light 0.3 x material 0.5, exponent 64) is part of the shade.  No per-vertex lighting or
- * transparency: a stand-in for MuJoCo's OpenGL output, not a pixel match.  A view that runs out of triangle
+ * term (MJCF defaults: light 0.3 x material 0.5, exponent 64) is part of the shade.  "render_smooth" 1 (round 6; on in the gym / Cartesian facades, off
+ * at the C-ABI) -- the three corners of a triangle are lit with their own normals (the library's lib_tnorm: area-weighted means over the faces
+ * within the crease angle, as MuJoCo generates vertex normals with smoothnormal="false" [EXT]) and the shade is interpolated perspective-correctly
+ * over the triangle, as fixed-function GL lights per vertex; 0: one shade per triangle.  No transparency: a stand-in for MuJoCo's OpenGL output,
+ * not a pixel match.  A view that runs out of triangle
  * records or tile-list entries sets the overflow flags of avsim_visual_info (the image then lacks triangles).  Pointer conventions
  * as avsim_render_depth. */
 int avsim_render_rgb(avsim_t* h, const int32_t* cam_ids, int ncam, int height, int width, uint8_t* out);

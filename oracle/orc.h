@@ -142,6 +142,9 @@ int orc_vis_render(const orc_data* d, int cam, int nvert, const double* vert, co
 
 int orc_vis_render_ex(const orc_data* d, int cam, int nvert, const double* vert, const int* vbody, int ntri, const int* tri, const double* rgb,
                       const double* uv, const int* tex, const int* texel, int texn, int H, int W, int ss, int shadows, unsigned char* out, int* tri_out, double* depth_out);
+/* the same with per-corner lighting normals [ntri][9] (body frame): smooth shading; tnorm NULL = orc_vis_render_ex */
+int orc_vis_render_sm(const orc_data* d, int cam, int nvert, const double* vert, const int* vbody, int ntri, const int* tri, const double* rgb,
+                      const double* uv, const int* tex, const int* texel, int texn, const double* tnorm, int H, int W, int ss, int shadows, unsigned char* out, int* tri_out, double* depth_out);
 
 /* env-level (env.py:203-249): reset to home pose with given object free-joint poses (nobj x 7) */
 void orc_reset(orc_data* d, const double* obj_qpos);

@@ -40,8 +40,12 @@ static void light_frame(const double* lw, double* e1, double* e2) {
  * <statistic center extent>, scene.xml:6: render_light[7], [11], [15] and [3]) loses the light's diffuse term when another triangle lies
  * between it and the light -- one exact ray per sample where the device looks up a depth map rendered from the light.  tri_out /
  * depth_out hold the pixel-centre ray's answers. */
-int orc_vis_render_ex(const orc_data* d, int cam, int nvert, const double* vert, const int* vbody, int ntri, const int* tri, const double* rgb,
-                      const double* uv, const int* tex, const int* texel, int texn, int H, int W, int ss, int shadows, unsigned char* out, int* tri_out, double* depth_out) {
+/* tnorm (orc_vis_render_sm; NULL = flat): per triangle the three corners' lighting normals in the body frame (compiler/vismesh.py corner_normals).  With
+ * them every corner is lit with its own normal -- headlight term along the ray to the corner, the directional light's diffuse and specular terms, each
+ * clamped as fixed-function GL clamps a vertex colour [EXT] -- and the three terms (shade, shade without the light's part, specular) are interpolated with
+ * the hit point's barycentrics, which are perspective-correct by construction here. */
+static int vis_render(const orc_data* d, int cam, int nvert, const double* vert, const int* vbody, int ntri, const int* tri, const double* rgb,
+                      const double* uv, const int* tex, const int* texel, int texn, int H, int W, int ss, int shadows, const double* tnorm, unsigned char* out, int* tri_out, double* depth_out) {
     const orc_model* m = d->m;
     if (cam < 0 || cam >= m->ncam || !m->render_light || (ss != 1 && ss != 2)) return -1;
     int b = m->cam_body[cam];
@@ -164,6 +168,7 @@ int orc_vis_render_ex(const orc_data* d, int cam, int nvert, const double* vert,
                             }
                         }
                     }
+                    const int in_shadow = cl == 0;      /* (set by the shadow ray above; a face turned away from the light has cl < 0) */
                     double lum = amb + hd * ch + ld * (cl > 0 ? cl : 0);
                     if (lum > 1) lum = 1;
                     /* the light's specular term (render_light[16] = light specular x material specular, [17] the exponent): Blinn's half vector with
@@ -177,6 +182,38 @@ int orc_vis_render_ex(const orc_data* d, int cam, int nvert, const double* vert,
                             const double nh = sgn * (n[0] * h[0] + n[1] * h[1] + n[2] * h[2]) / (nn * hn);
                             if (nh > 0) spec = L[16] * pow(nh, L[17]);
                         }
+                    }
+                    if (tnorm) {
+                        /* smooth shading: the corners' own shades, interpolated at the hit point (1 - u - v, u, v) */
+                        const double* Rbd = d->xmat + 9 * vbody[tri[3 * bt]];
+                        const double* P3[3] = {a, bb, c};
+                        double at[3][3];
+                        for (int k = 0; k < 3; k++) {
+                            const double* tn = tnorm + 9 * (size_t)bt + 3 * k;
+                            double nw[3], nc[3];
+                            for (int i = 0; i < 3; i++) nw[i] = Rbd[3 * i] * tn[0] + Rbd[3 * i + 1] * tn[1] + Rbd[3 * i + 2] * tn[2];
+                            for (int j = 0; j < 3; j++) nc[j] = Rc[j] * nw[0] + Rc[3 + j] * nw[1] + Rc[6 + j] * nw[2];
+                            const double* p = P3[k];
+                            const double pl = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+                            double chv = -(nc[0] * p[0] + nc[1] * p[1] + nc[2] * p[2]) / (pl > 1e-300 ? pl : 1e-300);
+                            if (chv < 0) chv = 0;
+                            const double clv = -(nc[0] * lc[0] + nc[1] * lc[1] + nc[2] * lc[2]);
+                            at[k][0] = amb + hd * chv + ld * (clv > 0 ? clv : 0); if (at[k][0] > 1) at[k][0] = 1;
+                            at[k][1] = amb + hd * chv; if (at[k][1] > 1) at[k][1] = 1;
+                            at[k][2] = 0;
+                            if (clv > 0 && L[16] > 0) {
+                                double h[3] = {-lc[0], -lc[1], -lc[2] + 1.0};
+                                const double hn = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+                                const double nh = hn > 1e-12 ? (nc[0] * h[0] + nc[1] * h[1] + nc[2] * h[2]) / hn : 0;
+                                if (nh > 0) at[k][2] = L[16] * pow(nh, L[17]);
+                            }
+                        }
+                        const double b0 = 1.0 - bu - bv;
+                        lum = b0 * at[0][in_shadow ? 1 : 0] + bu * at[1][in_shadow ? 1 : 0] + bv * at[2][in_shadow ? 1 : 0];
+                        spec = in_shadow ? 0.0 : b0 * at[0][2] + bu * at[1][2] + bv * at[2][2];
+                        if (lum < 0) lum = 0;
+                        if (lum > 1) lum = 1;
+                        if (spec < 0) spec = 0;
                     }
                     if (tex[bt]) {
                         const double* w = uv + 6 * bt;
@@ -206,6 +243,16 @@ int orc_vis_render_ex(const orc_data* d, int cam, int nvert, const double* vert,
     free(vc);
     free(front);
     return hits;
+}
+
+int orc_vis_render_ex(const orc_data* d, int cam, int nvert, const double* vert, const int* vbody, int ntri, const int* tri, const double* rgb,
+                      const double* uv, const int* tex, const int* texel, int texn, int H, int W, int ss, int shadows, unsigned char* out, int* tri_out, double* depth_out) {
+    return vis_render(d, cam, nvert, vert, vbody, ntri, tri, rgb, uv, tex, texel, texn, H, W, ss, shadows, NULL, out, tri_out, depth_out);
+}
+
+int orc_vis_render_sm(const orc_data* d, int cam, int nvert, const double* vert, const int* vbody, int ntri, const int* tri, const double* rgb,
+                      const double* uv, const int* tex, const int* texel, int texn, const double* tnorm, int H, int W, int ss, int shadows, unsigned char* out, int* tri_out, double* depth_out) {
+    return vis_render(d, cam, nvert, vert, vbody, ntri, tri, rgb, uv, tex, texel, texn, H, W, ss, shadows, tnorm, out, tri_out, depth_out);
 }
 
 int orc_vis_render(const orc_data* d, int cam, int nvert, const double* vert, const int* vbody, int ntri, const int* tri, const double* rgb,

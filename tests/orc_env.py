@@ -111,23 +111,29 @@ class OrcEnv:
         assert hits >= 0
         return out, dep
 
-    def render_visual(self, cam, H, W, scene, ss=1, shadows=False):
-        """Colour image uint8 [H, W, 3] of the visual scene (scene = vismesh.expand_instances(library, model blob)), the index of the
-        triangle every pixel sees (-1: sky) and its depth: oracle/orc_vis.c, one ray per pixel against every triangle."""
+    def render_visual(self, cam, H, W, scene, ss=1, shadows=False, smooth=False):
+        """Colour image uint8 [H, W, 3] of the visual scene (scene = vismesh.expand_instances(library, model blob) + (texels,)), the index of the
+        triangle every pixel sees (-1: sky) and its depth: oracle/orc_vis.c, one ray per pixel against every triangle.  smooth (the device's
+        option render_smooth, on in the gym / Cartesian facades): the corners lit with their own normals (the scene's tnorm) and interpolated; False: one shade per triangle."""
         ci = self.man["camera_names"].index(cam) if isinstance(cam, str) else int(cam)
-        vert, vbody, tri, rgb, uv, tex, texel = scene
+        if len(scene) == 8:
+            vert, vbody, tri, rgb, uv, tex, tnorm, texel = scene
+        else:                                   # (a scene without corner normals: flat shading)
+            vert, vbody, tri, rgb, uv, tex, texel = scene
+            tnorm = None
         vert = np.ascontiguousarray(vert, dtype=np.float64); vbody = np.ascontiguousarray(vbody, dtype=np.int32)
         tri = np.ascontiguousarray(tri, dtype=np.int32); rgb = np.ascontiguousarray(rgb, dtype=np.float64)
         uv = np.ascontiguousarray(uv, dtype=np.float64); tex = np.ascontiguousarray(tex, dtype=np.int32)
         texel = np.ascontiguousarray(texel, dtype=np.int32)
+        tn = np.ascontiguousarray(tnorm, dtype=np.float64) if (tnorm is not None and smooth) else None
         out = np.empty((H, W, 3), dtype=np.uint8)
         tid = np.empty((H, W), dtype=np.int32)
         dep = np.empty((H, W), dtype=np.float64)
-        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
         # ss = 2: the four samples 1/4 pixel off the centre averaged; shadows: an exact ray towards the scene's directional light per sample
-        self.L.orc_vis_render_ex.restype = C.c_int
-        hits = self.L.orc_vis_render_ex(self.dptr, ci, len(vbody), vp(vert), vp(vbody), len(tex), vp(tri), vp(rgb), vp(uv), vp(tex), vp(texel),
-                                        int(round(len(texel) ** 0.5)), H, W, int(ss), int(bool(shadows)), vp(out), vp(tid), vp(dep))
+        self.L.orc_vis_render_sm.restype = C.c_int
+        hits = self.L.orc_vis_render_sm(self.dptr, ci, len(vbody), vp(vert), vp(vbody), len(tex), vp(tri), vp(rgb), vp(uv), vp(tex), vp(texel),
+                                        int(round(len(texel) ** 0.5)), vp(tn), H, W, int(ss), int(bool(shadows)), vp(out), vp(tid), vp(dep))
         assert hits >= 0
         return out, tid, dep
 

@@ -46,6 +46,7 @@ def test_visual_images_match_the_oracle_after_motion():
     for a in acts:
         sim.step(np.repeat(a[None], 3, 0))
         e.env_step(a)
+    sim.set_option("render_smooth", 1)          # (on in the gym / Cartesian facades, off in a bare handle, like shadows and multisampling)
     img = sim.render_rgb(CAMS, H, W)
     info = sim.visual_info()
     assert info["triangles"] > 15000 and info["overflow"] == 0, info
@@ -53,7 +54,7 @@ def test_visual_images_match_the_oracle_after_motion():
     assert np.array_equal(img[0], img[1]) and np.array_equal(img[0], img[2])       # identical envs, identical images
     scene = scene_of("slot_insertion", 3)
     for ci, cam in enumerate(CAMS):
-        ref, tid, dep = e.render_visual(cam, H, W, scene)
+        ref, tid, dep = e.render_visual(cam, H, W, scene, smooth=True)
         agree(img[0, ci], ref, 0.02)
         assert (tid >= 0).mean() > 0.3                                             # the scene fills the view
     # known answers in the overhead view: the stick is green (task_slot_insertion.xml rgba), the table shows its wood texture
@@ -66,6 +67,13 @@ def test_visual_images_match_the_oracle_after_motion():
     assert table_px.mean() > 0.2
     wood = o[table_px].mean(0)
     assert wood[0] > wood[1] > wood[2] and wood[0] > 60, wood                      # small_meta_table_diffuse.png is brown
+    # option render_smooth = 0: one shade per triangle (rounds 3-5), against the oracle's flat mode; and smooth shading changes the picture
+    sim.set_option("render_smooth", 0)
+    flat = sim.render_rgb(CAMS[:2], H, W)
+    for ci, cam in enumerate(CAMS[:2]):
+        agree(flat[0, ci], e.render_visual(cam, H, W, scene, smooth=False)[0], 0.02)
+    assert (np.abs(flat[0, 0].astype(int) - img[0, 0].astype(int)).max(-1) > 2).mean() > 0.005       # (6 % of the pixels by more than 4 levels at 480 x 640)
+    sim.set_option("render_smooth", 1)
     # the proxy image is still there, and it is a different picture (hull proxies in flat colours)
     prox = sim.render_rgb(CAMS[:1], H, W, visual=False)
     assert prox.shape == (3, 1, H, W, 3) and not np.array_equal(prox[0, 0], img[0, 0])

@@ -237,6 +237,6 @@ def test_rerender_replay_of_a_recorded_episode_for_another_camera_configuration(
     for t in (0, 4, 9):
         e.set_qpos(ep["/observations/all_qpos"][t].astype(np.float64))
         for cam in ("zed_cam_left", "overhead_cam", "wrist_cam_left"):
-            ref, tid, dep = e.render_visual(cam, H, W, scene, ss=2, shadows=True)          # (the gym facade's defaults: shadows, 4 samples)
+            ref, tid, dep = e.render_visual(cam, H, W, scene, ss=2, shadows=True, smooth=True)          # (the gym facade's defaults: shadows, 4 samples, smooth shading)
             agree(out3[f"/observations/images/{cam}"][t], ref, 0.06)                          # (shadow edges: a depth map of 2.3 mm texels against exact rays)
     e.close()

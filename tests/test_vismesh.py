@@ -45,7 +45,7 @@ def test_library_and_instances_of_every_model():
     for task in ("insert_peg", "slot_insertion", "sew_needle", "tube_transfer", "hook_package"):
         for arms in (2, 3):
             mdl = read_blob(os.path.join(ROOT, "models", f"{task}_{arms}arms.avm"))
-            V, B, F, C, U, T = vismesh.expand_instances(lib, mdl)
+            V, B, F, C, U, T, TN = vismesh.expand_instances(lib, mdl)
             assert len(F) <= 20000 and F.max() < len(V) and B.max() < int(mdl["nbody"][0] if "nbody" in mdl else 64)
             assert T.sum() == 220                        # tabletop.obj + tablelegs.obj carry the texture
             assert np.isfinite(V).all() and np.abs(V).max() < 3.0
@@ -75,3 +75,36 @@ def test_oracle_image_known_answers():
     top = sky[0].astype(int)
     assert (tid2[0] < 0).mean() > 0.5 and (top[tid2[0] < 0][:, 2] >= top[tid2[0] < 0][:, 0]).all()
     e.close()
+
+
+def test_corner_normals_known_answers():
+    """compiler/vismesh.py corner_normals (round 6: smooth shading): a sphere's corner normals are its radii, a box stays faceted (its 90-degree
+    edges are beyond the crease angle), a cylinder is smooth round its side and flat on its caps; the library carries unit normals for every triangle
+    and an instance's rotation and scale carry them into the body frame."""
+    V, F = vismesh.unit_sphere()
+    N = vismesh.corner_normals(V, F)
+    assert np.abs(N - V[F]).max() < 0.05                       # (area-weighted facet mean against the exact radius)
+    V, F = vismesh.unit_box()
+    N = vismesh.corner_normals(V, F)
+    fn = np.cross(V[F[:, 1]] - V[F[:, 0]], V[F[:, 2]] - V[F[:, 0]])
+    fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+    assert np.abs(N - fn[:, None, :]).max() < 1e-12
+    V, F = vismesh.unit_cylinder()
+    N = vismesh.corner_normals(V, F)
+    fn = np.cross(V[F[:, 1]] - V[F[:, 0]], V[F[:, 2]] - V[F[:, 0]])
+    fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+    side = np.abs(fn[:, 2]) < 0.5
+    radial = V[F[side]] * np.array([1.0, 1.0, 0.0])
+    # (a ring vertex sits in two triangles of one facet and one of the other: the area-weighted mean leans 2.5 degrees towards the first)
+    assert np.abs(N[side] - radial).max() < 0.05 and np.abs(N[side][..., 2]).max() < 1e-12 and np.abs(N[~side] - fn[~side][:, None, :]).max() < 1e-12
+    lib = read_blob(LIB)
+    assert lib["lib_tnorm"].shape == (len(lib["lib_tri"]), 9)
+    assert np.abs(np.linalg.norm(lib["lib_tnorm"].reshape(-1, 3), axis=1) - 1).max() < 1e-9
+    mdl = read_blob(os.path.join(ROOT, "models", "slot_insertion_3arms.avm"))
+    V, B, F, C, U, T, TN = vismesh.expand_instances(lib, mdl)
+    assert TN.shape == (len(F), 9) and np.abs(np.linalg.norm(TN.reshape(-1, 3), axis=1) - 1).max() < 1e-9
+    # the corner normals lie on their own face's side (within the crease angle of it)
+    fn = np.cross(V[F[:, 1]] - V[F[:, 0]], V[F[:, 2]] - V[F[:, 0]])
+    ok = np.linalg.norm(fn, axis=1) > 1e-12
+    fn = fn[ok] / np.linalg.norm(fn[ok], axis=1, keepdims=True)
+    assert (np.einsum("tcj,tj->tc", TN.reshape(-1, 3, 3)[ok], fn) > 0.75).mean() > 0.999

@@ -16,7 +16,7 @@ h = _ffi.Handle(blob, N, 0, _ffi.AVSIM_IO_DEVICE)
 L = h.L
 lib = open(os.path.join(MODEL_DIR, "visual_meshes.avv"), "rb").read()
 h.check(L.avsim_load_visual(h.h, lib, len(lib)))
-for opt, env in (("render_shadows", "SHADOWS"), ("render_samples", "SAMPLES"), ("render_shadow_size", "SHSIZE")):      # SHADOWS=1 SAMPLES=4: the facades' defaults
+for opt, env in (("render_shadows", "SHADOWS"), ("render_samples", "SAMPLES"), ("render_shadow_size", "SHSIZE"), ("render_smooth", "SMOOTH")):      # SHADOWS=1 SAMPLES=4 SMOOTH=1: the facades' defaults
     if os.environ.get(env):
         h.check(L.avsim_set_option(h.h, opt.encode(), float(os.environ[env])))
 obj = torch.tensor(np.repeat(OBJ[None], N, 0).reshape(N, -1), dtype=torch.float64, device="cuda")
