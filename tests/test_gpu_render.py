@@ -83,6 +83,30 @@ def test_depth_full_size_properties_and_ragged_width():
     e2.close()
 
 
+@pytest.mark.parametrize("hw", [(720, 1280), (1080, 1920)])
+def test_depth_large_images_bin_masks_and_their_fallback(hw):
+    """Round 6: k_render_depth lists a record in a bin only when the record's BIN MASK (k_render_heads: 128 bits, no silhouette edge excludes the
+    bin) has the bin's bit.  720 x 1280 (the Cartesian env's ZED images are 720 high) has 4 x 23 = 92 bins -- the second mask word pair is in
+    use --, 1080 x 1920 has 6 x 34 = 204 > 128: every mask is all ones and the tiles' own silhouette tests do the work.  A strided subset of
+    rows of two cameras against the oracle's rays; the wrist camera sits among the gripper's links (polyhedra that reach behind the near plane)."""
+    from av_aloha_amd.sim import BatchedSim
+    H, W = hw
+    sim = BatchedSim("slot_insertion", 3, 1)
+    sim.reset(OBJ[None])
+    e = OrcEnv()
+    e.reset(OBJ)
+    cams = ["zed_cam_left", "wrist_cam_right"]
+    img = sim.render_depth(cams, H, W)
+    assert img.shape == (1, 2, H, W) and np.isfinite(img).all() and img.min() >= 0.03 and img.max() <= 30.0
+    step = H // 12
+    for ci, cam in enumerate(cams):
+        rows = e.render_depth_rows(cam, H, W, 7, step, 12)
+        assert (rows < 30).mean() > 0.2
+        compare(img[0, ci, 7::step][:12], rows)
+    sim.close()
+    e.close()
+
+
 def compare_rgb(img, ref, frac=0.01):
     """u8 colour images: +-1 level where both see the same surface; silhouette rays and rays along a box edge / hull
     ridge may pick the neighbouring face in f32, so up to `frac` of the pixels may differ by more."""
