@@ -62,3 +62,24 @@ print("  greedy, this step's true order %.2f" % (r[:, 2].mean() / 1e6))
 print("  sum / 2048 slots               %.2f" % (r[:, 3].mean() / 1e6))
 print("  slowest env                    %.2f" % (r[:, 4].mean() / 1e6))
 print("  corr(prev cost, cost) %.3f; of this step's slowest 1 %% of envs, fraction that was in the previous step's slowest 1 %%: %.2f" % (r[:, 5].mean(), r[:, 6].mean()))
+
+# ---- what a ROLLOUT launch (every wave steps its env through all K steps before it takes another) would be as long as: list scheduling of the per-env TOTALS over K steps ----
+K = int(os.environ.get("ROLLOUT_K", "0"))
+if K:
+    sim.reset(W.object_poses(task, np.arange(N), seed))
+    acts = W.walk_actions(md["qpos_home"], md["act_ctrlrange"], np.arange(N), K, nj, seed)
+    per = np.zeros((K, N))
+    launch = np.zeros(K)
+    for t in range(K):
+        sim.step(acts[t])
+        out = np.zeros((N, 26), dtype=np.int64)
+        sim.h.check(sim.h.L.avsim_get_phase_cycles(sim.h.h, out.ctypes.data))
+        per[t] = out[:, :8].sum(1)
+        launch[t] = ktime() * 1e-3 * 2.4e9
+    tot = per.sum(0)
+    print(f"rollout of {K} steps from the reset: sum of the per-step launches {launch.sum() / 1e6:.1f} M cycles; per-env totals: mean {tot.mean() / 1e6:.1f} max {tot.max() / 1e6:.1f} M;")
+    print(f"  list scheduling of the totals on {S} slots (most expensive first): {greedy(tot, np.argsort(-tot), S) / 1e6:.1f} M; in index order: {greedy(tot, np.arange(N), S) / 1e6:.1f} M; balanced {tot.sum() / S / 1e6:.1f} M")
+    for kk in (10, 25, 50):
+        if kk < K:
+            c = per[:K // kk * kk].reshape(-1, kk, N).sum(1)
+            print(f"  chunks of {kk} steps: sum over chunks of greedy (previous chunk's order) {sum(greedy(c[i], np.argsort(-c[max(i - 1, 0)]), S) for i in range(len(c))) / 1e6:.1f} M")
