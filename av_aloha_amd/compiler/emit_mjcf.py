@@ -81,7 +81,7 @@ def emit(blob, manifest, hulls="device", full_hulls=None, model_name=None):
 
     def geom_xml(k, ind):
         t = int(blob["geom_type"][k])
-        a = [f'name="{gn[k]}"', f'type="{GEOM_NAME[t]}"', f'pos="{_f(blob["geom_pos"][k])}"', f'quat="{_f(blob["geom_quat"][k])}"']
+        a = ([f'name="{gn[k]}"'] if gn[k] else []) + [f'type="{GEOM_NAME[t]}"', f'pos="{_f(blob["geom_pos"][k])}"', f'quat="{_f(blob["geom_quat"][k])}"']      # (most collision geoms of the assets are unnamed)
         if t == 7:
             a.append(f'mesh="{mesh_of[int(blob["geom_chull"][k][0])]}"')
         else:

@@ -41,9 +41,14 @@ class MjEnv:
         b = self.blob
         assert (self.model.nq, self.model.nv, self.model.nu, self.model.nbody) == (int(b["nq"][0]), int(b["nv"][0]), int(b["nu"][0]), int(b["nbody"][0]))
         self.nj = 21 if num_arms == 3 else 14
-        # MuJoCo numbers geoms body by body; the blob in document order: map by name
+        # MuJoCo numbers geoms body by body, in the order they appear inside a body [EXT]; the blob numbers them in document order and most of them
+        # carry no name: MuJoCo's geom g is the g-th blob geom in a stable sort by body (emit_mjcf.py keeps a body's geoms in the blob's order)
+        self.geom_of = np.argsort(np.asarray(b["geom_body"]), kind="stable").astype(np.int32)
+        assert self.model.ngeom == len(self.geom_of)
         names = self.man["geom_names"]
-        self.geom_of = np.array([names.index(mujoco.mj_id2name(self.model, mujoco.mjtObj.mjOBJ_GEOM, g)) for g in range(self.model.ngeom)], dtype=np.int32)
+        for g in range(self.model.ngeom):
+            nm = mujoco.mj_id2name(self.model, mujoco.mjtObj.mjOBJ_GEOM, g)
+            assert (nm or "") == names[self.geom_of[g]], (g, nm, names[self.geom_of[g]])
         self.orc_model = load_model(task, num_arms, variant)
         self.latch = C.c_int(0)
         self.max_reward = lib().orc_max_reward(self.orc_model)
