@@ -19,7 +19,7 @@ def _stale(target, sources):
 def build_hip(force=False, verbose=False):
     """hipcc --offload-arch=gfx950: avsim_api.hip (C-ABI, f32 product kernels, IK, render) and avsim_phys_f64.hip (the f64 parity
     kernel, -ffp-contract=off so that it rounds like the oracle) compiled side by side, linked into libavsim.so."""
-    srcs = [os.path.join(SRC, f) for f in sorted(os.listdir(SRC)) if not f.endswith(".o") and not f.startswith(".")] + [os.path.join(ROOT, "include", "avsim.h")]
+    srcs = [os.path.join(SRC, f) for f in sorted(os.listdir(SRC)) if not f.endswith(".o") and not f.startswith(".")] + [os.path.join(ROOT, "include", "avsim.h"), os.path.abspath(__file__)]       # (this file holds the flags: a library built with other flags is stale too)
     if not force and not _stale(LIB, srcs):
         return LIB
     # one builder at a time (pytest next to bench.py, several ranks): the objects go to fixed paths
