@@ -145,6 +145,52 @@ def test_newton_f64_parity_and_f32_tolerance():
         sim.close()
 
 
+def test_line_search_options_are_the_same_rule_on_both_sides():
+    """Options ls_tolerance / ls_iterations (round 6; MuJoCo's mjOption.ls_tolerance 0.01 / ls_iterations 50 [EXT]) and the oracle's ls_tol /
+    ls_iters are one rule.  HookPackage-2Arms under the random walk (arms dragged over the table: contacts in the cone's middle zone, where the
+    cost along the search line is not quadratic and the search really iterates): with a LOOSE search on both sides (1e-2 relative -- MuJoCo's
+    figure --, at most 8 evaluations) the f64 device still follows the oracle at rounding level over 10 env-steps (tools/dbg_ls_options.py: 1e-16 for
+    every setting from 1e-10 / 50 to 1e-2 / 8); that the options reach the kernel shows with a cap of 3 evaluations, which is another trajectory
+    altogether (the unevaluated doubling step of an unbracketed search); bad values are refused."""
+    from av_aloha_amd.workloads import object_poses, walk_actions
+    task, na, T = "hook_package", 2, 10
+    md = model_dict(task, na)
+    gid = np.array([5])
+    pose = object_poses(task, gid, 3000)[0]
+    acts = walk_actions(md["qpos_home"], md["act_ctrlrange"], gid, T, 14, 3000)[:, 0].astype(np.float64)
+
+    def oracle(ls_tol, ls_iters):
+        e = OrcEnv(task, na)
+        e.d.solver = 1
+        e.d.ls_tol, e.d.ls_iters = ls_tol, ls_iters
+        e.reset(pose)
+        out = []
+        for a in acts:
+            e.env_step(a)
+            out.append((e.qpos.copy(), e.d.ncon))
+        e.close()
+        return out
+    ref_loose = oracle(1e-2, 8)
+    sim = make(task, na, f64=True, solver=1, ls_tolerance=1e-2, ls_iterations=8)
+    sim.reset(pose[None])
+    for t, a in enumerate(acts):
+        sim.step(a[None])
+        qpos = sim.get_state()[0]
+        np.testing.assert_allclose(qpos[0], ref_loose[t][0], atol=1e-8, err_msg=f"qpos step {t}")
+        assert int(sim.contacts()[0][0]) == ref_loose[t][1]
+    assert max(r[1] for r in ref_loose) >= 6                                     # the arms are on the table
+    q8 = sim.get_state()[0][0].copy()
+    sim.set_option("ls_iterations", 3)
+    sim.reset(pose[None])
+    for a in acts:
+        sim.step(a[None])
+    assert np.abs(sim.get_state()[0][0] - q8).max() > 1e-6                       # the cap reaches the kernel
+    for name, bad in (("ls_tolerance", 0.0), ("ls_tolerance", 1.5), ("ls_iterations", 0)):
+        with pytest.raises(Exception):
+            sim.set_option(name, bad)
+    sim.close()
+
+
 @pytest.mark.parametrize("task", ["insert_peg", "sew_needle", "hook_package", "tube_transfer"])
 def test_newton_f64_parity_other_tasks(task):
     md = model_dict(task)
